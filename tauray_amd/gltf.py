@@ -1,0 +1,363 @@
+"""Minimal GLB (binary glTF 2.0) reader -> SceneDesc.
+
+Host mirror of the reference's loader for the subset the path tracer needs
+(src/gltf.cc:199-280 materials, :330-505 nodes/lights/cameras, :510-798
+meshes), followed by the instance flattening of scene_stage
+(src/scene_stage.cc:664-819: one instance per (model, vertex group), in node
+traversal order).  Supports KHR_lights_punctual, KHR_materials_transmission,
+KHR_materials_ior, KHR_materials_emissive_strength and Tauray's TR_data.
+"""
+from __future__ import annotations
+
+import json
+import math
+import struct
+import zlib
+from typing import List
+
+import numpy as np
+
+from . import scene as S
+
+_COMP = {5120: ("i1", 1), 5121: ("u1", 1), 5122: ("<i2", 2), 5123: ("<u2", 2), 5125: ("<u4", 4), 5126: ("<f4", 4)}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """PNG -> HxWx4 uint8.  Uses Pillow when importable, otherwise a tiny pure
+    zlib+numpy decoder (8-bit, non-interlaced; gray/gray+alpha/RGB/RGBA)."""
+    try:
+        import io
+        from PIL import Image
+        return np.array(Image.open(io.BytesIO(data)).convert("RGBA"), dtype=np.uint8)
+    except ImportError:
+        return _decode_png_pure(data)
+
+
+def _decode_png_pure(data: bytes) -> np.ndarray:
+    assert data[:8] == b"\x89PNG\r\n\x1a\n", "not a PNG"
+    pos = 8
+    idat = []
+    w = h = depth = ctype = interlace = None
+    while pos < len(data):
+        (length,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + length]
+        pos += 12 + length
+        if tag == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+    if depth != 8 or interlace != 0 or ctype not in (0, 2, 4, 6):
+        raise ValueError(f"unsupported PNG (depth={depth}, color type={ctype}, interlace={interlace})")
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8)
+    stride = w * ch
+    raw = raw.reshape(h, stride + 1)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:
+            cur = line.reshape(w, ch).copy()
+            np.cumsum(cur, axis=0, out=cur)
+            cur = cur.reshape(-1) & 255
+        else:
+            cur = np.zeros(stride, dtype=np.int32)
+            for x in range(stride):
+                a = cur[x - ch] if x >= ch else 0
+                b = prev[x]
+                c = prev[x - ch] if x >= ch else 0
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[x] = (line[x] + pred) & 255
+        out[y] = cur
+        prev = cur
+    img = out.reshape(h, w, ch)
+    rgba = np.full((h, w, 4), 255, dtype=np.uint8)
+    if ch == 1:
+        rgba[..., :3] = img
+    elif ch == 2:
+        rgba[..., :3] = img[..., :1]
+        rgba[..., 3] = img[..., 1]
+    elif ch == 3:
+        rgba[..., :3] = img
+    else:
+        rgba = img.copy()
+    return rgba
+
+
+class _Glb:
+    def __init__(self, path):
+        d = open(path, "rb").read()
+        magic, version, _ = struct.unpack("<4sII", d[:12])
+        if magic != b"glTF":
+            raise ValueError("not a GLB file")
+        off = 12
+        self.json = None
+        self.bin = b""
+        while off < len(d):
+            clen, ctype = struct.unpack("<II", d[off:off + 8])
+            body = d[off + 8:off + 8 + clen]
+            if ctype == 0x4E4F534A:
+                self.json = json.loads(body)
+            elif ctype == 0x004E4942:
+                self.bin = body
+            off += 8 + clen
+
+    def view(self, idx) -> bytes:
+        bv = self.json["bufferViews"][idx]
+        o = bv.get("byteOffset", 0)
+        return self.bin[o:o + bv["byteLength"]]
+
+    def accessor(self, idx) -> np.ndarray:
+        a = self.json["accessors"][idx]
+        bv = self.json["bufferViews"][a["bufferView"]]
+        dt, sz = _COMP[a["componentType"]]
+        nc = _NCOMP[a["type"]]
+        base = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0) or sz * nc
+        count = a["count"]
+        if stride == sz * nc:
+            arr = np.frombuffer(self.bin, dtype=dt, count=count * nc, offset=base).reshape(count, nc)
+        else:
+            arr = np.stack([np.frombuffer(self.bin, dtype=dt, count=nc, offset=base + i * stride) for i in range(count)])
+        return arr
+
+
+def _calculate_normals(vertices, indices):
+    """mesh::calculate_normals (src/mesh.cc:113-143)."""
+    pos = vertices["pos"].astype(np.float32)
+    tri = indices.reshape(-1, 3)
+    hn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]]).astype(np.float32)
+    ln = np.linalg.norm(hn, axis=1)
+    hn[ln > 1e-6] /= ln[ln > 1e-6, None]
+    n = np.zeros_like(pos)
+    for k in range(3):
+        np.add.at(n, tri[:, k], hn)
+    ln = np.linalg.norm(n, axis=1)
+    n[ln > 1e-6] /= ln[ln > 1e-6, None]
+    vertices["normal"] = n
+
+
+def _calculate_tangents(vertices, indices):
+    """mesh::calculate_tangents (src/mesh.cc:145-185); note only v0 accumulates."""
+    pos = vertices["pos"].astype(np.float32)
+    uv = vertices["uv"].astype(np.float32)
+    nrm = vertices["normal"].astype(np.float32)
+    tri = indices.reshape(-1, 3)
+    d0 = pos[tri[:, 1]] - pos[tri[:, 0]]
+    d1 = pos[tri[:, 2]] - pos[tri[:, 0]]
+    hn = np.cross(d0, d1)
+    ln = np.linalg.norm(hn, axis=1)
+    hn[ln > 1e-6] /= ln[ln > 1e-6, None]
+    uv0 = uv[tri[:, 1]] - uv[tri[:, 0]]
+    uv1 = uv[tri[:, 2]] - uv[tri[:, 0]]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ht = uv1[:, 1:2] * d0 - uv0[:, 1:2] * d1
+        ht = ht / np.linalg.norm(ht, axis=1, keepdims=True)
+        hb = uv1[:, 0:1] * d1 - uv0[:, 0:1] * d0
+        hb = hb / np.linalg.norm(hb, axis=1, keepdims=True)
+        sign = np.where(np.einsum("ij,ij->i", np.cross(hn, ht), hb) < 0, -1.0, 1.0).astype(np.float32)
+        t = np.zeros((len(pos), 4), dtype=np.float32)
+        np.add.at(t, tri[:, 0], np.concatenate([ht, sign[:, None]], axis=1).astype(np.float32))
+        t3 = t[:, :3] - nrm * np.einsum("ij,ij->i", nrm, t[:, :3])[:, None]
+        t3 = t3 / np.linalg.norm(t3, axis=1, keepdims=True)
+    vertices["tangent"][:, :3] = t3
+    vertices["tangent"][:, 3] = np.where(t[:, 3] < 0, -1.0, 1.0)
+
+
+def _create_material(g: _Glb, mat: dict) -> np.ndarray:
+    """create_material (src/gltf.cc:199-280)."""
+    pbr = mat.get("pbrMetallicRoughness", {})
+
+    def tex_source(info):
+        if not info or info.get("index", -1) < 0:
+            return -1
+        return int(g.json["textures"][info["index"]]["source"])
+
+    albedo = list(pbr.get("baseColorFactor", [1, 1, 1, 1]))
+    emission = list(mat.get("emissiveFactor", [0, 0, 0]))
+    transmittance = 0.0
+    ior = 1.45
+    ext = mat.get("extensions", {})
+    discard_tr_emission = False
+    if "KHR_materials_emissive_strength" in ext and "emissiveStrength" in ext["KHR_materials_emissive_strength"]:
+        k = float(ext["KHR_materials_emissive_strength"]["emissiveStrength"])
+        emission = [e * k for e in emission]
+        discard_tr_emission = True
+    tr = pbr.get("extensions", {}).get("TR_data")
+    if tr is not None:
+        if "transmission" in tr:
+            transmittance = float(tr["transmission"])
+        if "ior" in tr:
+            ior = float(tr["ior"])
+        if not discard_tr_emission and "emission" in tr:
+            emission = [float(v) for v in tr["emission"][:3]]
+    if "transmissionFactor" in ext.get("KHR_materials_transmission", {}):
+        transmittance = float(ext["KHR_materials_transmission"]["transmissionFactor"])
+    if "ior" in ext.get("KHR_materials_ior", {}):
+        ior = float(ext["KHR_materials_ior"]["ior"])
+    return S.make_material(
+        albedo=albedo, metallic=pbr.get("metallicFactor", 1.0), roughness=pbr.get("roughnessFactor", 1.0),
+        emission=emission, transmittance=transmittance, ior=ior, normal_factor=1.0,
+        double_sided=bool(mat.get("doubleSided", False)),
+        albedo_tex=tex_source(pbr.get("baseColorTexture")),
+        mr_tex=tex_source(pbr.get("metallicRoughnessTexture")),
+        normal_tex=tex_source(mat.get("normalTexture")),
+        emission_tex=tex_source(mat.get("emissiveTexture")))
+
+
+def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float = 0.0,
+             force_single_sided: bool = False, force_double_sided: bool = False,
+             gather_emissive_triangles: bool = True) -> S.SceneDesc:
+    """load_gltf + scene flattening.  `width/height` drive set_camera_params
+    (src/tauray.cc:68-110): the camera aspect is forced to width/height."""
+    g = _Glb(path)
+    j = g.json
+
+    # The reference loads images flipped (stbi flag) and flips them back
+    # (src/gltf.cc:525,557): net effect is row 0 = top row of the file.
+    textures: List[np.ndarray] = []
+    for img in j.get("images", []):
+        if "bufferView" not in img:
+            raise ValueError("only embedded images are supported")
+        if img.get("mimeType") != "image/png":
+            raise ValueError("only PNG images are supported")
+        textures.append(decode_png(g.view(img["bufferView"])))
+
+    # meshes -> list of vertex groups (material, vertices, indices)
+    models = []
+    for mesh in j.get("meshes", []):
+        groups = []
+        for p in mesh["primitives"]:
+            if "material" in p and p["material"] >= 0:
+                mat = _create_material(g, j["materials"][p["material"]])
+                if force_single_sided and mat["transmittance"] == 0:
+                    mat["flags"] &= ~np.uint32(S.MATERIAL_FLAG_DOUBLE_SIDED)
+                if force_double_sided:
+                    mat["flags"] |= np.uint32(S.MATERIAL_FLAG_DOUBLE_SIDED)
+            else:
+                mat = S.make_material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0)
+            at = p["attributes"]
+            pos = g.accessor(at["POSITION"]).astype(np.float32)
+            v = np.zeros(len(pos), dtype=S.VERTEX)
+            v["pos"] = pos[:, :3]
+            if "NORMAL" in at:
+                v["normal"] = g.accessor(at["NORMAL"]).astype(np.float32)[:, :3]
+            if "TEXCOORD_0" in at:
+                uv = g.accessor(at["TEXCOORD_0"])
+                v["uv"] = uv.astype(np.float32)[:, :2]
+            if "TANGENT" in at:
+                v["tangent"] = g.accessor(at["TANGENT"]).astype(np.float32)[:, :4]
+            if "indices" in p:
+                idx = g.accessor(p["indices"]).astype(np.uint32).reshape(-1)
+            else:
+                idx = np.arange(len(pos), dtype=np.uint32)
+            if "NORMAL" not in at:
+                _calculate_normals(v, idx)
+            if "TANGENT" not in at:
+                _calculate_tangents(v, idx)
+            groups.append((mat, v, idx))
+        models.append(groups)
+
+    inst_list, span_list, vert_list, idx_list = [], [], [], []
+    point_lights, spot_lights, dir_lights, cameras = [], [], [], []
+    voff = ioff = 0
+    light_meta = {"angle": 0.0, "radius": 0.0}
+
+    def visit(node_index, parent):
+        nonlocal voff, ioff
+        node = j["nodes"][node_index]
+        tr = node.get("extensions", {}).get("TR_data")
+        if tr and "light" in tr:
+            if "angle" in tr["light"]:
+                light_meta["angle"] = float(tr["light"]["angle"])
+            if "radius" in tr["light"]:
+                light_meta["radius"] = float(tr["light"]["radius"])
+        if "matrix" in node:
+            local = np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T
+        else:
+            local = S.trs_matrix(node.get("translation", (0, 0, 0)), node.get("rotation", (0, 0, 0, 1)),
+                                 node.get("scale", (1, 1, 1)))
+        glob = parent @ local
+
+        if "mesh" in node:
+            sto = 0.0
+            if tr and "mesh" in tr:
+                sto = float(tr["mesh"].get("shadow_terminator_offset", 0.0))
+            for mat, v, idx in models[node["mesh"]]:
+                inst_list.append(S.make_instance(glob, mat, sto))
+                span_list.append((voff, len(v), ioff, len(idx) // 3))
+                vert_list.append(v)
+                idx_list.append(idx)
+                voff += len(v)
+                ioff += len(idx)
+
+        if "camera" in node:
+            c = j["cameras"][node["camera"]]
+            cam = S.Camera(transform=glob)
+            if c["type"] == "perspective":
+                pp = c["perspective"]
+                cam.projection = S.PROJ_PERSPECTIVE
+                cam.fov = math.degrees(pp["yfov"])
+                cam.aspect = pp.get("aspectRatio", 1.0)
+                cam.near = pp["znear"]
+                cam.far = pp.get("zfar", math.inf)
+            else:
+                o = c["orthographic"]
+                cam.projection = S.PROJ_ORTHOGRAPHIC
+                cam.ortho = (-0.5 * o["xmag"], 0.5 * o["xmag"], -0.5 * o["ymag"], 0.5 * o["ymag"], o["znear"], o["zfar"])
+            cameras.append(cam)
+
+        kl = node.get("extensions", {}).get("KHR_lights_punctual")
+        if kl is not None:
+            l = j["extensions"]["KHR_lights_punctual"]["lights"][kl["light"]]
+            color = np.array(l.get("color", [1, 1, 1]), dtype=np.float64) * float(l.get("intensity", 1.0))
+            # get_global_direction: normalize(global orientation * (0,0,-1))
+            rot = glob[:3, :3] / np.linalg.norm(glob[:3, :3], axis=0, keepdims=True)
+            direction = rot @ np.array([0, 0, -1.0])
+            position = glob[:3, 3]
+            if l["type"] == "directional":
+                dir_lights.append(S.make_directional_light(color, direction, math.degrees(light_meta["angle"])))
+            elif l["type"] == "point":
+                point_lights.append(S.make_point_light(color / (4 * math.pi), position, light_meta["radius"]))
+            elif l["type"] == "spot":
+                outer = math.degrees(l["spot"].get("outerConeAngle", math.pi / 4))
+                inner = math.degrees(l["spot"].get("innerConeAngle", 0.0))
+                fall = S.spotlight_falloff_from_inner_angle(inner, outer, 4 / 255.0)
+                spot_lights.append(S.make_spotlight(color / (4 * math.pi), position, direction,
+                                                    light_meta["radius"], outer, fall))
+        for ch in node.get("children", []):
+            visit(ch, glob)
+
+    for sc in j.get("scenes", []):
+        for n in sc["nodes"]:
+            visit(n, np.eye(4))
+
+    aspect = aspect_ratio if aspect_ratio > 0 else width / float(height)
+    for cam in cameras:
+        cam.set_aspect(aspect)
+
+    # point lights first, then spotlights (src/scene_stage.cc:1287-1317)
+    pls = point_lights + spot_lights
+    desc = S.SceneDesc(
+        instances=np.concatenate(inst_list) if inst_list else np.zeros(0, dtype=S.INSTANCE),
+        spans=np.array(span_list, dtype=S.MESH_SPAN),
+        vertices=np.concatenate(vert_list) if vert_list else np.zeros(0, dtype=S.VERTEX),
+        indices=np.concatenate(idx_list).astype(np.uint32) if idx_list else np.zeros(0, dtype=np.uint32),
+        point_lights=np.concatenate(pls) if pls else np.zeros(0, dtype=S.POINT_LIGHT),
+        directional_lights=np.concatenate(dir_lights) if dir_lights else np.zeros(0, dtype=S.DIRECTIONAL_LIGHT),
+        textures=textures, envmap=None, environment_factor=(0, 0, 0, 0), cameras=cameras,
+        name=path.split("/")[-1])
+    return desc.finalize(gather_emissive_triangles)
