@@ -1,0 +1,169 @@
+/* trhip - C ABI of the MI355X-native path-tracing core.
+ *
+ * This is the drop-in boundary for Tauray's path_tracer_stage hot path.  The
+ * reference has no FFI: its extension point is C++ subclassing
+ * (docs/DEVELOPERS.md:3-27; rt_renderer<Pipeline> in src/rt_renderer.hh:28-77).
+ * Each entry point below names the reference interface it replaces; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: one opaque trhip_device per HIP device, all calls from one host
+ * thread, work is enqueued on the caller's hipStream_t (passed as void*; NULL =
+ * the default stream) and is asynchronous unless stated.  Every function
+ * returns 0 on success, non-zero on failure with a message available from
+ * trhip_last_error() (the reference throws std::runtime_error instead).
+ * All POD layouts are the reference's GPU-side structs.
+ */
+#ifndef TRHIP_H
+#define TRHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trhip_device trhip_device;
+typedef struct trhip_pt trhip_pt;
+
+/* ---- device / memory (replaces tr::context + tr::device, src/context.hh, src/device.hh) */
+int trhip_device_create(int hip_device, trhip_device** out);
+void trhip_device_destroy(trhip_device* dev);
+const char* trhip_last_error(void);
+int trhip_malloc(trhip_device* dev, size_t bytes, void** out);           /* gpu_buffer (src/gpu_buffer.hh) */
+int trhip_free(trhip_device* dev, void* ptr);
+int trhip_upload(trhip_device* dev, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int trhip_download(trhip_device* dev, void* dst_host, const void* src_dev, size_t bytes, void* stream); /* headless readback, src/headless.cc:292-303 */
+int trhip_memset(trhip_device* dev, void* dst_dev, int value, size_t bytes, void* stream);
+int trhip_sync(trhip_device* dev, void* stream);
+
+/* ---- scene (replaces scene_stage::update's uploads, src/scene_stage.cc:1026-1496) */
+typedef struct trhip_scene_desc {
+    const void* instances;            /* 288-byte `instance` records (shader/scene.glsl:43-53) */
+    const void* spans;                /* u32x4 per instance: vertex_offset, vertex_count, index_offset, triangle_count */
+    uint32_t instance_count;
+    const void* vertices;             /* 48-byte `vertex` records, model space (src/mesh.hh:19-25) */
+    uint32_t vertex_count;
+    const uint32_t* indices;          /* per-instance, relative to the instance's vertex span */
+    uint32_t index_count;
+    const void* point_lights;         /* 64 B (shader/light.glsl:15-27); point lights first, then spotlights */
+    uint32_t point_light_count;
+    const void* directional_lights;   /* 32 B (shader/light.glsl:7-13) */
+    uint32_t directional_light_count;
+    const void* texture_infos;        /* u32x4 per texture: width, height, texel_offset (in texels), pad */
+    uint32_t texture_count;
+    const uint8_t* texels;            /* RGBA8, row 0 first */
+    const float* envmap;              /* RGBA32F lat-long, or NULL (then environment_factor is ignored, proj = -1) */
+    uint32_t envmap_width, envmap_height;
+    const void* alias_table;          /* 16 B entries (src/environment_map.hh:37-43), one per envmap texel */
+    float environment_factor[4];
+    const void* cameras;              /* 320-byte camera_data (shader/camera.glsl:13-23), one per viewport */
+    uint32_t camera_count;
+    const uint8_t* non_opaque;        /* per instance: material::potentially_transparent (src/material.cc:7-11) */
+    uint32_t gather_emissive_triangles; /* scene_stage::options::gather_emissive_triangles (src/tauray.cc:384) */
+} trhip_scene_desc;
+
+typedef struct trhip_accel_info {
+    uint32_t triangle_count;
+    uint32_t node_count;
+    uint32_t tri_light_count;
+    float build_ms;                   /* device time of the whole build */
+    float bounds_min[3], bounds_max[3];
+} trhip_accel_info;
+
+int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
+int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
+/* Replaces vkCmdBuildAccelerationStructuresKHR (src/acceleration_structure.cc:198,266,421) with an
+ * on-device LBVH (pre-transform -> bounds -> Morton -> radix sort -> Karras hierarchy -> refit) and
+ * runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).  Synchronous. */
+int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out);
+/* copies the 64-byte tri_light records back to the host (test hook) */
+int trhip_scene_get_tri_lights(trhip_device* dev, void* out_host, uint32_t max_count);
+
+/* ---- path_tracer_stage (src/path_tracer_stage.{hh,cc}, src/rt_camera_stage.{hh,cc}, src/rt_stage.{hh,cc}) */
+typedef struct trhip_pt_options {     /* == path_tracer_stage::options flattened (src/path_tracer_stage.hh:13-30) */
+    int32_t max_bounces;              /* rt_stage::options::max_ray_depth -> MAX_BOUNCES */
+    float min_ray_dist;
+    uint32_t rng_seed;                /* raw option; pcg() applied if non-zero (src/rt_stage.cc:82) */
+    int32_t sampler;                  /* rt_stage::sampler_type: 0 uniform-random, 1 sobol-owen, 2 sobol-z 2D, 3 sobol-z 3D */
+    int32_t samples_per_pixel;
+    int32_t samples_per_pass;
+    int32_t projection;               /* camera::projection_type: 0 perspective, 1 orthographic, 2 equirectangular */
+    int32_t film;                     /* film_filter: 0 point, 1 box, 2 blackman-harris */
+    float film_radius;
+    int32_t mis_mode;                 /* 0 disabled, 1 balance, 2 power */
+    float russian_roulette_delta;
+    float indirect_clamping;
+    float regularization_gamma;
+    int32_t depth_of_field;
+    float nee_point, nee_directional, nee_envmap, nee_triangles;  /* light_sampling_weights; 0 disables the class */
+    int32_t bounce_mode;              /* bounce_sampling_mode: 0 hemisphere, 1 cosine hemisphere, 2 material */
+    int32_t tri_light_mode;           /* tri_light_sampling_mode: 0 area, 1 solid angle, 2 hybrid */
+    int32_t hide_lights;
+    int32_t use_white_albedo_on_first_bounce;
+    int32_t transparent_background;
+    int32_t pre_transformed_vertices; /* must be 0 in this build (the reference default) */
+} trhip_pt_options;
+
+typedef struct trhip_distribution {   /* == distribution_params (src/distribution_strategy.hh:21-28) */
+    uint32_t size_x, size_y;
+    int32_t strategy;                 /* 0 duplicate, 1 scanline, 2 shuffled strips */
+    uint32_t index, count;
+    uint32_t primary;
+} trhip_distribution;
+
+typedef struct trhip_counters {       /* per trhip_pt, cumulative since the last reset */
+    uint64_t closest_rays, shadow_rays;           /* rays actually traced (-> Mray/s) */
+    uint64_t node_visits, tri_tests, alpha_tests, surface_hits;   /* only counted when counting is enabled */
+    uint64_t stack_overflows;
+} trhip_counters;
+
+typedef struct trhip_timings {        /* hipEvent timers with the reference's stage names (src/timer.cc) */
+    float path_tracing_ms;            /* "path tracing (N viewports)" of the last trhip_pt_render */
+    float trace_closest_ms, trace_shadow_ms, shade_ms, raygen_ms, resolve_ms;   /* valid when detailed timing is on */
+} trhip_timings;
+
+int trhip_pt_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out);   /* path_tracer_stage ctor */
+void trhip_pt_destroy(trhip_pt* pt);
+int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist);  /* rt_camera_stage::reset_distribution_params */
+int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /* reset_accumulated_samples / reset_sample_counter */
+/* One frame: update() + every pass of record_command_buffer_pass (src/path_tracer_stage.cc:118-147).
+ * `color` is the device RGBA32F image2DArray [viewports][target_h][target_w] where target size is
+ * get_distribution_target_size(dist) (src/distribution_strategy.cc:6-19). */
+int trhip_pt_render(trhip_pt* pt, void* color_dev, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
+int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
+int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */
+int trhip_pt_reset_counters(trhip_pt* pt);
+int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out);       /* synchronises the stream */
+
+/* ---- feature_stage (src/feature_stage.cc:22-104): 0 albedo, 1 world normal, 2 view normal, 3 world pos,
+ *      4 view pos, 5 distance, 9 instance id */
+int trhip_feature_render(trhip_device* dev, int feature, const trhip_distribution* dist, int projection,
+                         uint32_t viewport, float min_ray_dist, const float default_value[4],
+                         void* color_dev, uint32_t target_w, uint32_t target_h, void* stream);
+
+/* ---- ray-level queries (parity hooks for traceRayEXT, shader/path_tracer.glsl:38-50,387-403).
+ * rays: 8 floats each {ox, oy, oz, tmin, dx, dy, dz, tmax}; hits: {i32 instance, i32 primitive, f32 u, f32 v, f32 t}.
+ * seeds == NULL selects the feature renderer's fixed alpha cutoff (shader/rt_feature.rahit:17). */
+int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, const void* seeds_dev,
+                        int include_lights, void* hits_dev, void* stream);
+int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void* visibility_dev, void* stream);
+
+/* ---- stitch_stage (src/stitch_stage.cc:128-196, shader/stitch_scanline.comp, stitch_shuffled_strips.comp).
+ * Scatters one non-primary device's partial image into the primary (full-size) image. */
+int trhip_stitch(trhip_device* dev, const trhip_distribution* partial_dist, const void* partial_dev,
+                 uint32_t partial_w, uint32_t partial_h, void* primary_dev, uint32_t viewports,
+                 float blend_ratio, void* stream);
+
+/* ---- tonemap_stage (src/tonemap_stage.cc:139-164, shader/tonemap*.comp) */
+typedef struct trhip_tonemap_info {
+    int32_t op;                       /* tonemap_stage::operator_type: 0 linear, 1 gamma, 2 filmic, 3 reinhard, 4 reinhard luminance */
+    float exposure, gamma;
+    int32_t alpha_grid_background;    /* 0 or grid size (16 when not headless) */
+} trhip_tonemap_info;
+int trhip_tonemap(trhip_device* dev, const void* in_dev, void* out_dev, uint32_t width, uint32_t height,
+                  uint32_t layers, const trhip_tonemap_info* info, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,413 @@
+// C ABI of libtrhip.so (include/trhip.h) + the small kernels around the path tracer:
+// feature_stage, ray-level query hooks, stitch_stage and tonemap_stage.
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt.h"
+#include "trace.h"
+
+namespace tr {
+
+static thread_local std::string g_error;
+int set_error(const std::string& msg) { g_error = msg; return 1; }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+
+constexpr int KB = TR_BLOCK;
+
+// ---------------------------------------------------------------------------------------------------
+// feature_stage: shader/rt_feature.rgen:21-45 + rt_feature.rchit:16-27 with FEATURE of src/feature_stage.cc:33-65
+__global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int feature, int projection, uint viewport, float min_ray_dist,
+                                                f4 default_value, f4* target, uint target_w, uint target_h, uint* overflow_flag) {
+    __shared__ int s_stack[TR_LDS_STACK * KB];
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= L.launch_w * L.launch_h) return;
+    uint lx = i % L.launch_w, ly = i / L.launch_w;
+    int px, py, wx, wy;
+    if (!get_pixel_pos(L, lx, ly, px, py) || !get_write_pixel_pos(L, lx, ly, wx, wy)) return;
+    const CameraData cam = sv.cameras[viewport];
+    f3 origin, dir;
+    get_screen_camera_ray(L, px, py, cam, projection, false, F2(0), F2(0.5f), origin, dir);
+    f3 ray_origin = projection == 2 ? origin : F3(cam.origin);   // rt_feature.rgen:35 traces from cam.origin
+    HitRecord hit;
+    TraceStats st = {0, 0, 0};
+    bool overflow = false;
+    trace_closest<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
+    if (overflow) *overflow_flag = 1;
+    f4 data = default_value;
+    if (hit.instance_id >= 0) {
+        SurfacePoint v;
+        SampledMaterial mat;
+        shade_surface(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v, dir, ray_origin, false, 0, v, mat);
+        switch (feature) {
+            default:
+            case 0: data = mat.albedo; break;
+            case 1: data = F4(v.mapped_normal, 1); break;
+            case 2: data = F4(F3(mul(cam.view, F4(v.mapped_normal, 0))), 1); break;
+            case 3: data = F4(v.pos, 1); break;
+            case 4: data = mul(cam.view, F4(v.pos, 1)); break;
+            case 5: data = F4(hit.t, hit.t, hit.t, 1); break;
+            case 9: data = F4((float)hit.instance_id, (float)hit.primitive_id, 0, 1); break;
+        }
+    }
+    if ((uint)wx >= target_w || (uint)wy >= target_h) return;
+    target[(size_t)wy * target_w + (uint)wx] = data;
+}
+
+// ray-level hooks
+__global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
+                                                      HitRecord* out, uint* overflow_flag) {
+    __shared__ int s_stack[TR_LDS_STACK * KB];
+    bool overflow = false;
+    TraceStats st = {0, 0, 0};
+    for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
+        const float* r = rays + (size_t)i * 8;
+        HitRecord hit;
+        if (seeds) trace_closest<0, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seeds[i], s_stack + threadIdx.x, hit, st, overflow);
+        else trace_closest<1, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, s_stack + threadIdx.x, hit, st, overflow);
+        out[i] = hit;
+    }
+    if (overflow) *overflow_flag = 1;
+}
+__global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
+    __shared__ int s_stack[TR_LDS_STACK * KB];
+    bool overflow = false;
+    TraceStats st = {0, 0, 0};
+    for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
+        const float* r = rays + (size_t)i * 8;
+        out[i] = trace_shadow<false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow);
+    }
+    if (overflow) *overflow_flag = 1;
+}
+
+// stitch_stage: shader/stitch_scanline.comp:20-50 and shader/stitch_shuffled_strips.comp:20-63 for ONE partial image
+__global__ __launch_bounds__(KB) void k_stitch(LaunchCtx L, const f4* partial, uint pw, uint ph, f4* primary, uint viewports, float blend_ratio) {
+    uint per_view = L.strategy == 2 ? L.launch_w : pw * ph;
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= per_view * viewports) return;
+    uint z = i / per_view, p = i % per_view;
+    uint sx, sy, ox, oy;
+    if (L.strategy == 2) {
+        uint j = permute_region_id(L.index + p, L.size_x, L.size_y, L.count);
+        if (j >= L.size_x * L.size_y) return;
+        sx = p % L.size_x; sy = p / L.size_x;
+        ox = j % L.size_x; oy = j / L.size_x;
+    } else {
+        sx = p % pw; sy = p / pw;
+        ox = sx; oy = sy * L.count + L.index;
+        if (oy >= L.size_y) return;
+    }
+    f4 c = partial[((size_t)z * ph + sy) * pw + sx];
+    size_t o = ((size_t)z * L.size_y + oy) * L.size_x + ox;
+    if (blend_ratio < 1.0f) c = mix4(primary[o], c, blend_ratio);
+    primary[o] = c;
+}
+
+// tonemap_stage: shader/tonemap.glsl:35-55 + tonemap_{gamma,filmic,reinhard,reinhard_luminance}.comp
+__global__ __launch_bounds__(KB) void k_tonemap(const f4* in, f4* out, uint w, uint h, uint layers, int op, float exposure, float gamma, int grid) {
+    size_t i = (size_t)blockIdx.x * KB + threadIdx.x;
+    size_t n = (size_t)w * h * layers;
+    if (i >= n) return;
+    f4 col = in[i];
+    f3 c;
+    if (op <= 1) c = F3(col) * exposure;
+    else if (op == 2) {
+        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
+        c = max3(F3(0.0f), c - 0.004f);
+        f3 q = (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
+        c = F3(powf(q.x, 2.2f), powf(q.y, 2.2f), powf(q.z, 2.2f));
+    } else if (op == 3) {
+        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
+        c = c / (F3(1.0f) + c);
+    } else {
+        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
+        float lum = rgb_to_luminance(c);
+        float new_lum = lum / (1.0f + lum);
+        c = c / fmax2(lum, 1e-4f) * new_lum;
+    }
+    if (gamma != 1.0f) { float ig = 1.0f / gamma; c = F3(powf(c.x, ig), powf(c.y, ig), powf(c.z, ig)); }
+    if (grid != 0) {
+        uint x = (uint)(i % w), y = (uint)((i / w) % h);
+        int gx = (int)(x / (uint)grid) & 1, gy = (int)(y / (uint)grid) & 1;
+        f3 ac = (gx ^ gy) == 0 ? F3(0.4f) : F3(0.6f);
+        c = mix3(ac, c, col.w);
+    }
+    out[i] = F4(c, col.w);
+}
+
+template <typename T>
+int upload_array(T*& dst, const void* src, size_t count) {
+    dst = nullptr;
+    if (count == 0 || !src) return 0;
+    HIPCHK(hipMalloc(&dst, count * sizeof(T)));
+    HIPCHK(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+}  // namespace tr
+
+using namespace tr;
+
+struct trhip_device {
+    int hip_device = 0;
+    DeviceScene scene;
+    uint* overflow_flag = nullptr;
+};
+struct trhip_pt {
+    trhip_device* dev;
+    PtStage* stage;
+};
+
+#define DEVCHK(dev) do { if (!(dev)) return set_error("null trhip_device"); hipError_t e_ = hipSetDevice((dev)->hip_device); \
+    if (e_ != hipSuccess) return set_error(std::string("hipSetDevice: ") + hipGetErrorString(e_)); } while (0)
+
+extern "C" {
+
+const char* trhip_last_error(void) { return g_error.c_str(); }
+
+int trhip_device_create(int hip_device, trhip_device** out) {
+    if (!out) return set_error("trhip_device_create: null out");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return set_error(std::string("trhip_device_create: no HIP device available (") + hipGetErrorString(e) + ")");
+    if (hip_device < 0 || hip_device >= count) return set_error("trhip_device_create: device index out of range");
+    HIPCHK(hipSetDevice(hip_device));
+    trhip_device* d = new trhip_device();
+    d->hip_device = hip_device;
+    HIPCHK(hipMalloc(&d->overflow_flag, 4));
+    HIPCHK(hipMemset(d->overflow_flag, 0, 4));
+    *out = d;
+    return 0;
+}
+void trhip_device_destroy(trhip_device* dev) {
+    if (!dev) return;
+    (void)hipSetDevice(dev->hip_device);
+    (void)hipDeviceSynchronize();
+    dev->scene.free_all();
+    if (dev->overflow_flag) (void)hipFree(dev->overflow_flag);
+    delete dev;
+}
+int trhip_malloc(trhip_device* dev, size_t bytes, void** out) { DEVCHK(dev); HIPCHK(hipMalloc(out, bytes ? bytes : 16)); return 0; }
+int trhip_free(trhip_device* dev, void* ptr) { DEVCHK(dev); if (ptr) HIPCHK(hipFree(ptr)); return 0; }
+int trhip_upload(trhip_device* dev, void* dst, const void* src, size_t bytes, void* stream) {
+    DEVCHK(dev); HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0;
+}
+int trhip_download(trhip_device* dev, void* dst, const void* src, size_t bytes, void* stream) {
+    DEVCHK(dev); HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0;
+}
+int trhip_memset(trhip_device* dev, void* dst, int value, size_t bytes, void* stream) { DEVCHK(dev); HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream)); return 0; }
+int trhip_sync(trhip_device* dev, void* stream) { DEVCHK(dev); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
+    DEVCHK(dev);
+    if (!d) return set_error("trhip_scene_upload: null desc");
+    HIPCHK(hipDeviceSynchronize());
+    DeviceScene& s = dev->scene;
+    s.free_all();
+    if (d->instance_count && (!d->instances || !d->spans || !d->non_opaque)) return set_error("trhip_scene_upload: missing instance arrays");
+    // validate spans against the vertex / index arrays (the reference trusts its own loader; a C ABI cannot)
+    std::vector<uint> prefix(d->instance_count + 1, 0);
+    const MeshSpan* spans = (const MeshSpan*)d->spans;
+    const Instance* insts = (const Instance*)d->instances;
+    uint tri_lights = 0;
+    for (uint i = 0; i < d->instance_count; ++i) {
+        const MeshSpan& sp = spans[i];
+        if ((uint64_t)sp.vertex_offset + sp.vertex_count > d->vertex_count || (uint64_t)sp.index_offset + 3ull * sp.triangle_count > d->index_count)
+            return set_error("trhip_scene_upload: instance span out of range");
+        for (uint k = 0; k < 3 * sp.triangle_count; ++k)
+            if (d->indices[sp.index_offset + k] >= sp.vertex_count) return set_error("trhip_scene_upload: vertex index out of range");
+        prefix[i + 1] = prefix[i] + sp.triangle_count;
+        const Material& m = insts[i].mat;
+        int texs[4] = {m.albedo_tex_id, m.metallic_roughness_tex_id, m.normal_tex_id, m.emission_tex_id};
+        for (int t : texs) if (t >= (int)d->texture_count) return set_error("trhip_scene_upload: texture id out of range");
+        if (insts[i].light_base_id >= 0) tri_lights = std::max(tri_lights, (uint)insts[i].light_base_id + sp.triangle_count);
+    }
+    if (upload_array(s.instances, d->instances, d->instance_count)) return 1;
+    if (upload_array(s.spans, d->spans, d->instance_count)) return 1;
+    if (upload_array(s.vertices, d->vertices, d->vertex_count)) return 1;
+    if (upload_array(s.indices, d->indices, d->index_count)) return 1;
+    if (upload_array(s.point_lights, d->point_lights, d->point_light_count)) return 1;
+    if (upload_array(s.directional_lights, d->directional_lights, d->directional_light_count)) return 1;
+    if (upload_array(s.tex_infos, d->texture_infos, d->texture_count)) return 1;
+    size_t texel_count = 0;
+    const TextureInfo* ti = (const TextureInfo*)d->texture_infos;
+    for (uint i = 0; i < d->texture_count; ++i) {
+        if (ti[i].width == 0 || ti[i].height == 0) return set_error("trhip_scene_upload: empty texture");
+        texel_count = std::max(texel_count, (size_t)ti[i].texel_offset + (size_t)ti[i].width * ti[i].height);
+    }
+    if (upload_array(s.texels, d->texels, texel_count * 4)) return 1;
+    if (upload_array(s.cameras, d->cameras, d->camera_count)) return 1;
+    if (upload_array(s.non_opaque, d->non_opaque, d->instance_count)) return 1;
+    if (upload_array(s.tri_prefix, prefix.data(), prefix.size())) return 1;
+    s.environment_proj = -1;
+    s.environment_factor = F4(0);
+    if (d->envmap && d->envmap_width && d->envmap_height) {
+        if (!d->alias_table) return set_error("trhip_scene_upload: envmap without alias table");
+        size_t n = (size_t)d->envmap_width * d->envmap_height;
+        if (upload_array(s.envmap, d->envmap, n)) return 1;          // f4 elements
+        if (upload_array(s.alias_table, d->alias_table, n)) return 1;
+        s.env_w = d->envmap_width; s.env_h = d->envmap_height;
+        s.environment_proj = 0;
+        s.environment_factor = F4(d->environment_factor[0], d->environment_factor[1], d->environment_factor[2], d->environment_factor[3]);
+    }
+    s.instance_count = d->instance_count; s.point_light_count = d->point_light_count;
+    s.directional_light_count = d->directional_light_count; s.camera_count = d->camera_count; s.texture_count = d->texture_count;
+    s.vertex_count = d->vertex_count; s.index_count = d->index_count; s.tri_count = prefix.back();
+    s.gather_emissive_triangles = d->gather_emissive_triangles;
+    s.host_tri_light_count = d->gather_emissive_triangles ? tri_lights : 0;
+    return 0;
+}
+
+int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    HIPCHK(hipDeviceSynchronize());
+    if (count > s.camera_count) {
+        if (s.cameras) (void)hipFree(s.cameras);
+        s.cameras = nullptr;
+        HIPCHK(hipMalloc(&s.cameras, (size_t)count * sizeof(CameraData)));
+    }
+    if (count) HIPCHK(hipMemcpy(s.cameras, camera_data, (size_t)count * sizeof(CameraData), hipMemcpyHostToDevice));
+    s.camera_count = count;
+    return 0;
+}
+
+int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
+    DEVCHK(dev);
+    return build_accel(dev->scene, nullptr, out);
+}
+
+int trhip_scene_get_tri_lights(trhip_device* dev, void* out_host, uint32_t max_count) {
+    DEVCHK(dev);
+    uint n = std::min(max_count, dev->scene.tri_light_count);
+    if (n) HIPCHK(hipMemcpy(out_host, dev->scene.tri_lights, (size_t)n * sizeof(TriLight), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trhip_pt_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out) {
+    DEVCHK(dev);
+    if (!opt || !out) return set_error("trhip_pt_create: null argument");
+    if (opt->max_bounces < 1) return set_error("trhip_pt_create: max_bounces must be >= 1");
+    if (opt->sampler < 0 || opt->sampler > 3) return set_error("trhip_pt_create: unknown sampler");
+    if (opt->samples_per_pass < 1 || opt->samples_per_pixel < 1) return set_error("trhip_pt_create: sample counts must be >= 1");
+    trhip_pt* p = new trhip_pt();
+    p->dev = dev;
+    p->stage = new PtStage(&dev->scene, *opt);
+    *out = p;
+    return 0;
+}
+void trhip_pt_destroy(trhip_pt* pt) {
+    if (!pt) return;
+    (void)hipSetDevice(pt->dev->hip_device);
+    (void)hipDeviceSynchronize();
+    delete pt->stage;
+    delete pt;
+}
+int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist) {
+    if (!pt || !dist) return set_error("trhip_pt_set_distribution: null argument");
+    if (dist->strategy < 0 || dist->strategy > 2) return set_error("trhip_pt_set_distribution: unknown strategy");
+    if (dist->strategy == 1 && (dist->count == 0 || dist->index >= dist->count)) return set_error("trhip_pt_set_distribution: bad scanline index/count");
+    pt->stage->dist = *dist;
+    return 0;
+}
+int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter) {
+    if (!pt) return set_error("null trhip_pt");
+    pt->stage->accumulated_samples = 0;
+    if (reset_sample_counter) pt->stage->frame_counter = 0;
+    return 0;
+}
+int trhip_pt_render(trhip_pt* pt, void* color_dev, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream) {
+    if (!pt) return set_error("null trhip_pt");
+    DEVCHK(pt->dev);
+    pt->stage->last_stream = (hipStream_t)stream;
+    return pt->stage->render(color_dev, target_w, target_h, viewports, (hipStream_t)stream);
+}
+int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
+    if (!pt) return set_error("null trhip_pt");
+    pt->stage->count_work = count_work; pt->stage->detailed_timing = detailed_timing;
+    return 0;
+}
+int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_counters(out, pt->stage->last_stream); }
+int trhip_pt_reset_counters(trhip_pt* pt) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); HIPCHK(hipStreamSynchronize(pt->stage->last_stream)); return pt->stage->reset_counters(); }
+int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_timings(out); }
+
+static LaunchCtx make_launch(const trhip_distribution& d) {
+    LaunchCtx L;
+    uint lw, lh;
+    get_ray_count(d, lw, lh);
+    L.size_x = d.size_x; L.size_y = d.size_y; L.strategy = d.strategy; L.index = d.index; L.primary = d.primary;
+    L.count = d.count;
+    if (d.strategy == 2) { uint n = d.size_x * d.size_y, b = 31; while ((n >> b) < 128 && b > 0) b--; L.count = b; }
+    L.launch_w = lw; L.launch_h = lh;
+    return L;
+}
+
+int trhip_feature_render(trhip_device* dev, int feature, const trhip_distribution* dist, int projection, uint32_t viewport,
+                         float min_ray_dist, const float default_value[4], void* color_dev, uint32_t target_w, uint32_t target_h, void* stream) {
+    DEVCHK(dev);
+    if (!dev->scene.accel_built) return set_error("trhip_feature_render: call trhip_scene_build_accel first");
+    if (viewport >= dev->scene.camera_count) return set_error("trhip_feature_render: viewport out of range");
+    LaunchCtx L = make_launch(*dist);
+    size_t n = (size_t)L.launch_w * L.launch_h;
+    if (n == 0) return 0;
+    f4 dv = F4(default_value[0], default_value[1], default_value[2], default_value[3]);
+    hipLaunchKernelGGL(k_feature, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), L, feature, projection,
+                       viewport, min_ray_dist, dv, (f4*)color_dev, target_w, target_h, dev->overflow_flag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, const void* seeds_dev, int include_lights, void* hits_dev, void* stream) {
+    DEVCHK(dev);
+    if (!dev->scene.accel_built) return set_error("trhip_trace_closest: call trhip_scene_build_accel first");
+    if (n == 0) return 0;
+    uint blocks = std::min((n + KB - 1) / KB, 2048u);
+    hipLaunchKernelGGL(k_query_closest, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+                       (const uint*)seeds_dev, include_lights, (HitRecord*)hits_dev, dev->overflow_flag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void* visibility_dev, void* stream) {
+    DEVCHK(dev);
+    if (!dev->scene.accel_built) return set_error("trhip_trace_shadow: call trhip_scene_build_accel first");
+    if (n == 0) return 0;
+    uint blocks = std::min((n + KB - 1) / KB, 2048u);
+    hipLaunchKernelGGL(k_query_shadow, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+                       (float*)visibility_dev, dev->overflow_flag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int trhip_stitch(trhip_device* dev, const trhip_distribution* pd, const void* partial_dev, uint32_t pw, uint32_t ph, void* primary_dev,
+                 uint32_t viewports, float blend_ratio, void* stream) {
+    DEVCHK(dev);
+    if (!pd || pd->strategy == 0) return set_error("trhip_stitch: needs a scanline or shuffled-strips partial");
+    LaunchCtx L = make_launch(*pd);
+    size_t per_view = pd->strategy == 2 ? L.launch_w : (size_t)pw * ph;
+    size_t n = per_view * viewports;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_stitch, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, L, (const f4*)partial_dev, pw, ph,
+                       (f4*)primary_dev, viewports, blend_ratio);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int trhip_tonemap(trhip_device* dev, const void* in_dev, void* out_dev, uint32_t width, uint32_t height, uint32_t layers,
+                  const trhip_tonemap_info* info, void* stream) {
+    DEVCHK(dev);
+    if (!info) return set_error("trhip_tonemap: null info");
+    size_t n = (size_t)width * height * layers;
+    if (n == 0) return 0;
+    float gamma = info->op == 0 ? 1.0f : info->gamma;   // src/tonemap_stage.cc:159
+    hipLaunchKernelGGL(k_tonemap, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, (const f4*)in_dev, (f4*)out_dev, width,
+                       height, layers, info->op, info->exposure, gamma, info->alpha_grid_background);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

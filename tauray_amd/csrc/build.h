@@ -1,0 +1,68 @@
+// Host-side device scene container shared by the API and the BVH builder.
+#pragma once
+#include <string>
+
+#include "common.h"
+#include "shading.h"
+
+namespace tr {
+
+int set_error(const std::string& msg);   // records trhip_last_error(); returns 1
+
+struct DeviceScene {
+    // uploaded by trhip_scene_upload
+    Instance* instances = nullptr;
+    MeshSpan* spans = nullptr;
+    Vertex* vertices = nullptr;
+    uint* indices = nullptr;
+    PointLight* point_lights = nullptr;
+    DirectionalLight* directional_lights = nullptr;
+    TextureInfo* tex_infos = nullptr;
+    uint8_t* texels = nullptr;
+    f4* envmap = nullptr;
+    AliasEntry* alias_table = nullptr;
+    CameraData* cameras = nullptr;
+    uint8_t* non_opaque = nullptr;
+    uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
+    f4 environment_factor = {0, 0, 0, 0};
+    int environment_proj = -1;
+    uint instance_count = 0, point_light_count = 0, directional_light_count = 0, camera_count = 0, texture_count = 0;
+    uint env_w = 0, env_h = 0, tri_count = 0, vertex_count = 0, index_count = 0;
+    uint gather_emissive_triangles = 0, host_tri_light_count = 0;
+    // built by trhip_scene_build_accel
+    BvhNode* nodes = nullptr;
+    TriRecord* tris = nullptr;
+    TriLight* tri_lights = nullptr;
+    uint node_count = 0, tri_light_count = 0;
+    bool accel_built = false;
+
+    SceneView view() const {
+        SceneView v;
+        v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
+        v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
+        v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
+        v.cameras = cameras; v.nodes = nodes; v.tris = tris;
+        v.environment_factor = environment_factor; v.environment_proj = environment_proj;
+        v.instance_count = instance_count; v.point_light_count = point_light_count;
+        v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
+        v.env_w = env_w; v.env_h = env_h; v.tri_count = accel_built ? tri_count : 0; v.node_count = node_count;
+        return v;
+    }
+    void free_accel() {
+        if (nodes) (void)hipFree(nodes);
+        if (tris) (void)hipFree(tris);
+        if (tri_lights) (void)hipFree(tri_lights);
+        nodes = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;
+    }
+    void free_all() {
+        free_accel();
+        void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
+                        alias_table, cameras, non_opaque, tri_prefix};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        *this = DeviceScene();
+    }
+};
+
+int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);
+
+}  // namespace tr

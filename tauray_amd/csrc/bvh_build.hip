@@ -1,0 +1,317 @@
+// On-device LBVH build: the software replacement for the driver's BLAS/TLAS build
+// (reference call sites src/acceleration_structure.cc:198,266,421; recorded by
+// src/scene_stage.cc:1620-1662).  Pipeline:
+//   pre-transform (shader/pre_transform.comp:26-42, positions only) -> centroid bounds ->
+//   63-bit Morton keys -> radix sort (rocPRIM) -> Karras 2012 hierarchy -> atomic bottom-up refit ->
+//   64-byte BVH2 nodes + 48-byte triangle records in Morton order.
+// Also runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).
+#include "build.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace tr {
+
+namespace {
+
+constexpr int BT = 256;
+
+// order-preserving float <-> uint map for atomicMin/Max on bounds
+TR_DEV uint float_flip(float f) { uint u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+TR_HD float float_unflip(uint u) {
+    uint v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(v);
+#else
+    memcpy(&f, &v, 4);
+#endif
+    return f;
+}
+
+// instance/primitive of a global triangle id via binary search over the per-instance prefix sums
+TR_DEV void locate_triangle(const uint* tri_prefix, uint instance_count, uint gid, uint& inst, uint& prim) {
+    uint lo = 0, hi = instance_count;   // prefix has instance_count + 1 entries
+    while (hi - lo > 1) {
+        uint mid = (lo + hi) >> 1;
+        if (tri_prefix[mid] <= gid) lo = mid; else hi = mid;
+    }
+    inst = lo;
+    prim = gid - tri_prefix[lo];
+}
+
+// world-space triangle = (model * vec4(pos, 1)).xyz in the GLSL evaluation order; also accumulates the
+// centroid bounds used to quantise Morton codes.
+__global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* tri_prefix, const uint8_t* non_opaque,
+                                                     TriRecord* tris_unsorted, uint* cbounds /*6 flipped uints*/) {
+    uint gid = blockIdx.x * BT + threadIdx.x;
+    float cmin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float cmax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    if (gid < sv.tri_count) {
+        uint inst, prim;
+        locate_triangle(tri_prefix, sv.instance_count, gid, inst, prim);
+        const MeshSpan sp = sv.spans[inst];
+        const uint* ix = sv.indices + sp.index_offset + 3u * prim;
+        const Vertex* vb = sv.vertices + sp.vertex_offset;
+        const m4 model = sv.instances[inst].model;
+        f3 p0 = transform_point(model, vb[ix[0]].pos);
+        f3 p1 = transform_point(model, vb[ix[1]].pos);
+        f3 p2 = transform_point(model, vb[ix[2]].pos);
+        TriRecord t;
+        t.v0[0] = p0.x; t.v0[1] = p0.y; t.v0[2] = p0.z;
+        t.v1[0] = p1.x; t.v1[1] = p1.y; t.v1[2] = p1.z;
+        t.v2[0] = p2.x; t.v2[1] = p2.y; t.v2[2] = p2.z;
+        t.inst_flags = inst | (non_opaque[inst] ? 0x80000000u : 0u);
+        t.prim = prim;
+        t.pad = 0;
+        tris_unsorted[gid] = t;
+        f3 lo = min3(min3(p0, p1), p2), hi = max3(max3(p0, p1), p2);
+        f3 c = (lo + hi) * 0.5f;
+        cmin[0] = cmax[0] = c.x; cmin[1] = cmax[1] = c.y; cmin[2] = cmax[2] = c.z;
+    }
+    // wave reduce, then one atomic per wave
+    for (int k = 0; k < 3; ++k) {
+        float mn = cmin[k], mx = cmax[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if ((threadIdx.x & 63) == 0 && mn <= mx) {
+            atomicMin(&cbounds[k], float_flip(mn));
+            atomicMax(&cbounds[3 + k], float_flip(mx));
+        }
+    }
+}
+
+TR_DEV unsigned long long expand21(uint v) {   // spread 21 bits to every third bit
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(BT) void k_morton(uint n, const TriRecord* tris, const uint* cbounds, unsigned long long* keys, uint* vals) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], inv[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = float_unflip(cbounds[k]);
+        float ext = float_unflip(cbounds[3 + k]) - lo[k];
+        inv[k] = ext > 0 ? 2097151.0f / ext : 0.0f;
+    }
+    const TriRecord t = tris[i];
+    float c[3];
+    for (int k = 0; k < 3; ++k) {
+        float mn = fminf(fminf(t.v0[k], t.v1[k]), t.v2[k]), mx = fmaxf(fmaxf(t.v0[k], t.v1[k]), t.v2[k]);
+        c[k] = (mn + mx) * 0.5f;
+    }
+    uint q[3];
+    for (int k = 0; k < 3; ++k) {
+        float f = (c[k] - lo[k]) * inv[k];
+        q[k] = (uint)fminf(fmaxf(f, 0.0f), 2097151.0f);
+    }
+    keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    vals[i] = i;
+}
+
+// Karras 2012: common-prefix length between sorted keys i and j, ties broken by index
+TR_DEV int delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint)i ^ (uint)j);
+    return __clzll((long long)(a ^ b));
+}
+
+// one thread per internal node i in [0, n-1): children + parent links.
+// refs: >= 0 internal node, < 0 leaf ~leaf_index (leaf_index = position in sorted order)
+__global__ __launch_bounds__(BT) void k_hierarchy(int n, const unsigned long long* keys, int2* children, int* parent_internal, int* parent_leaf) {
+    int i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int left = (min(i, j) == gamma) ? ~gamma : gamma;
+    int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+    children[i] = make_int2(left, right);
+    if (left >= 0) parent_internal[left] = i; else parent_leaf[~left] = i;
+    if (right >= 0) parent_internal[right] = i; else parent_leaf[~right] = i;
+    if (i == 0) parent_internal[0] = -1;
+}
+
+// gather triangles into Morton order and emit leaf boxes
+__global__ __launch_bounds__(BT) void k_gather_leaves(uint n, const TriRecord* unsorted, const uint* sorted_vals, TriRecord* sorted, float* leaf_box /*6 per leaf*/) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n) return;
+    const TriRecord t = unsorted[sorted_vals[i]];
+    sorted[i] = t;
+    for (int k = 0; k < 3; ++k) {
+        leaf_box[6 * i + k] = fminf(fminf(t.v0[k], t.v1[k]), t.v2[k]);
+        leaf_box[6 * i + 3 + k] = fmaxf(fmaxf(t.v0[k], t.v1[k]), t.v2[k]);
+    }
+}
+
+// bottom-up refit: the second thread to reach a node owns it.  Agent-scope release/acquire around the
+// arrival counter makes the first child's box (written by another CU, possibly another XCD) visible.
+__global__ __launch_bounds__(BT) void k_refit(int n, const int2* children, const int* parent_internal, const int* parent_leaf,
+                                              const float* leaf_box, float* node_box /*6 per internal*/, uint* arrive, BvhNode* nodes) {
+    int leaf = blockIdx.x * BT + threadIdx.x;
+    if (leaf >= n) return;
+    int node = parent_leaf[leaf];
+    while (node >= 0) {
+        __threadfence();   // release: our child's box is published before we announce arrival
+        uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) return;            // sibling subtree not finished: the other thread continues
+        __threadfence();   // acquire
+        const int2 ch = children[node];
+        BvhNode out;
+        float lo[3], hi[3];
+        {
+            const float* b0 = ch.x >= 0 ? node_box + 6 * (size_t)ch.x : leaf_box + 6 * (size_t)(~ch.x);
+            const float* b1 = ch.y >= 0 ? node_box + 6 * (size_t)ch.y : leaf_box + 6 * (size_t)(~ch.y);
+            for (int k = 0; k < 3; ++k) {
+                float l0 = __hip_atomic_load(&b0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float h0 = __hip_atomic_load(&b0[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float l1 = __hip_atomic_load(&b1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float h1 = __hip_atomic_load(&b1[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.lo0[k] = l0; out.hi0[k] = h0; out.lo1[k] = l1; out.hi1[k] = h1;
+                lo[k] = fminf(l0, l1); hi[k] = fmaxf(h0, h1);
+            }
+        }
+        out.child0 = ch.x; out.child1 = ch.y; out.pad0 = 0; out.pad1 = 0;
+        nodes[node] = out;
+        for (int k = 0; k < 3; ++k) {
+            __hip_atomic_store(&node_box[6 * (size_t)node + k], lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&node_box[6 * (size_t)node + 3 + k], hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        node = parent_internal[node];
+    }
+}
+
+// shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
+__global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const uint* tri_prefix, TriLight* out) {
+    uint gid = blockIdx.x * BT + threadIdx.x;
+    if (gid >= sv.tri_count) return;
+    uint inst, prim;
+    locate_triangle(tri_prefix, sv.instance_count, gid, inst, prim);
+    const Instance& o = sv.instances[inst];
+    if (o.light_base_id < 0) return;
+    const MeshSpan sp = sv.spans[inst];
+    const uint* ix = sv.indices + sp.index_offset + 3u * prim;
+    const Vertex* vb = sv.vertices + sp.vertex_offset;
+    const Vertex v0 = vb[ix[0]], v1 = vb[ix[1]], v2 = vb[ix[2]];
+    TriLight l;
+    l.emission_tex_id = o.mat.emission_tex_id;
+    l.emission_factor = rgb_to_r9g9b9e5(F3(o.mat.emission_factor));
+    l.instance_id = inst;
+    l.primitive_id = prim;
+    l.pos[0] = transform_point(o.model, v0.pos);
+    l.pos[1] = transform_point(o.model, v1.pos);
+    l.pos[2] = transform_point(o.model, v2.pos);
+    l.uv[0] = pack_half2x16(v0.uv); l.uv[1] = pack_half2x16(v1.uv); l.uv[2] = pack_half2x16(v2.uv);
+    out[(uint)o.light_base_id + prim] = l;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+}  // namespace
+
+int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
+    const uint n = ds.tri_count;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, stream));
+    ds.free_accel();
+    SceneView sv = ds.view();
+    sv.tri_count = n;
+    uint* cbounds = nullptr;
+    HIPCHK(hipMalloc(&cbounds, 6 * sizeof(uint)));
+    {
+        uint init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(cbounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    if (n > 0) {
+        TriRecord* unsorted = nullptr;
+        unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+        uint *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
+        int2* children = nullptr;
+        int *parent_internal = nullptr, *parent_leaf = nullptr;
+        float *leaf_box = nullptr, *node_box = nullptr;
+        HIPCHK(hipMalloc(&unsorted, (size_t)n * sizeof(TriRecord)));
+        HIPCHK(hipMalloc(&ds.tris, (size_t)n * sizeof(TriRecord)));
+        HIPCHK(hipMalloc(&keys, (size_t)n * 8)); HIPCHK(hipMalloc(&keys_sorted, (size_t)n * 8));
+        HIPCHK(hipMalloc(&vals, (size_t)n * 4)); HIPCHK(hipMalloc(&vals_sorted, (size_t)n * 4));
+        HIPCHK(hipMalloc(&leaf_box, (size_t)n * 24));
+        const uint blocks = (n + BT - 1) / BT;
+        hipLaunchKernelGGL(k_pretransform, dim3(blocks), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
+        hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
+        size_t temp_bytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+        void* temp = nullptr;
+        HIPCHK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+        HIPCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+        hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
+        ds.node_count = n > 1 ? n - 1 : 0;
+        if (n > 1) {
+            HIPCHK(hipMalloc(&ds.nodes, (size_t)(n - 1) * sizeof(BvhNode)));
+            HIPCHK(hipMalloc(&children, (size_t)(n - 1) * sizeof(int2)));
+            HIPCHK(hipMalloc(&parent_internal, (size_t)(n - 1) * 4));
+            HIPCHK(hipMalloc(&parent_leaf, (size_t)n * 4));
+            HIPCHK(hipMalloc(&node_box, (size_t)(n - 1) * 24));
+            HIPCHK(hipMalloc(&arrive, (size_t)(n - 1) * 4));
+            HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
+            const uint iblocks = (n - 1 + BT - 1) / BT;
+            hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(BT), 0, stream, (int)n, keys_sorted, children, parent_internal, parent_leaf);
+            hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BT), 0, stream, (int)n, children, parent_internal, parent_leaf, leaf_box,
+                               node_box, arrive, ds.nodes);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        (void)hipFree(unsorted); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted); (void)hipFree(leaf_box);
+        (void)hipFree(temp); (void)hipFree(children); (void)hipFree(parent_internal); (void)hipFree(parent_leaf); (void)hipFree(node_box); (void)hipFree(arrive);
+    }
+    ds.accel_built = true;
+    // tri lights
+    ds.tri_light_count = 0;
+    if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0) {
+        HIPCHK(hipMalloc(&ds.tri_lights, (size_t)ds.host_tri_light_count * sizeof(TriLight)));
+        HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
+        ds.tri_light_count = ds.host_tri_light_count;
+        SceneView sv2 = ds.view();
+        hipLaunchKernelGGL(k_extract_tri_lights, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(e1, stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint hb[6];
+    HIPCHK(hipMemcpy(hb, cbounds, sizeof(hb), hipMemcpyDeviceToHost));
+    (void)hipFree(cbounds);
+    if (info) {
+        info->triangle_count = n;
+        info->node_count = ds.node_count;
+        info->tri_light_count = ds.tri_light_count;
+        info->build_ms = ms;
+        for (int k = 0; k < 3; ++k) { info->bounds_min[k] = float_unflip(hb[k]); info->bounds_max[k] = float_unflip(hb[3 + k]); }
+    }
+    return 0;
+}
+
+}  // namespace tr

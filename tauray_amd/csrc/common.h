@@ -1,0 +1,169 @@
+// Shared device/host definitions for the trhip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string.h>
+#include <cstring>
+
+#include "../../include/trhip.h"
+
+#define TR_DEV __device__ __forceinline__
+#define TR_HD __host__ __device__ __forceinline__
+
+namespace tr {
+
+typedef uint32_t uint;
+
+// ---------------------------------------------------------------------------
+// small vector layer (explicit evaluation order; see DESIGN.md "fp contract")
+// ---------------------------------------------------------------------------
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct u4 { uint x, y, z, w; };
+struct u2 { uint x, y; };
+
+TR_HD f2 F2(float a, float b) { return {a, b}; }
+TR_HD f2 F2(float a) { return {a, a}; }
+TR_HD f3 F3(float a, float b, float c) { return {a, b, c}; }
+TR_HD f3 F3(float a) { return {a, a, a}; }
+TR_HD f3 F3(const f4& v) { return {v.x, v.y, v.z}; }
+TR_HD f4 F4(float a, float b, float c, float d) { return {a, b, c, d}; }
+TR_HD f4 F4(const f3& v, float w) { return {v.x, v.y, v.z, w}; }
+TR_HD f4 F4(float a) { return {a, a, a, a}; }
+
+TR_HD f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+TR_HD f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+TR_HD f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
+TR_HD f2 operator/(f2 a, f2 b) { return {a.x / b.x, a.y / b.y}; }
+TR_HD f2 operator*(f2 a, float s) { return {a.x * s, a.y * s}; }
+TR_HD f2 operator*(float s, f2 a) { return {a.x * s, a.y * s}; }
+TR_HD f2 operator/(f2 a, float s) { return {a.x / s, a.y / s}; }
+TR_HD f2 operator+(f2 a, float s) { return {a.x + s, a.y + s}; }
+TR_HD f2 operator-(f2 a, float s) { return {a.x - s, a.y - s}; }
+TR_HD f2 operator-(float s, f2 a) { return {s - a.x, s - a.y}; }
+TR_HD float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+
+TR_HD f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+TR_HD f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+TR_HD f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+TR_HD f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+TR_HD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+TR_HD f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
+TR_HD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+TR_HD f3 operator+(f3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+TR_HD f3 operator-(f3 a, float s) { return {a.x - s, a.y - s, a.z - s}; }
+TR_HD f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+TR_HD f3& operator+=(f3& a, f3 b) { a = a + b; return a; }
+TR_HD f3& operator*=(f3& a, f3 b) { a = a * b; return a; }
+TR_HD f3& operator*=(f3& a, float s) { a = a * s; return a; }
+TR_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+TR_HD f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+TR_HD float length(f3 a) { return sqrtf(dot(a, a)); }
+TR_HD f3 normalize(f3 a) { float l = length(a); return {a.x / l, a.y / l, a.z / l}; }
+TR_HD float comp(const f3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+TR_HD f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+TR_HD f4 operator-(f4 a, f4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+TR_HD f4 operator*(f4 a, f4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+TR_HD f4 operator*(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+TR_HD f4 operator*(float s, f4 a) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+TR_HD float fmin2(float a, float b) { return b < a ? b : a; }   // GLSL min
+TR_HD float fmax2(float a, float b) { return a < b ? b : a; }   // GLSL max
+TR_HD float clampf(float x, float lo, float hi) { return fmin2(fmax2(x, lo), hi); }
+TR_HD int clampi(int x, int lo, int hi) { int t = x < lo ? lo : x; return t > hi ? hi : t; }
+TR_HD uint clampu(uint x, uint lo, uint hi) { uint t = x < lo ? lo : x; return t > hi ? hi : t; }
+TR_HD float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+TR_HD f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+TR_HD f4 mix4(f4 a, f4 b, float t) { return a * (1.0f - t) + b * t; }
+TR_HD float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+TR_HD f3 max3(f3 a, f3 b) { return {fmax2(a.x, b.x), fmax2(a.y, b.y), fmax2(a.z, b.z)}; }
+TR_HD f3 min3(f3 a, f3 b) { return {fmin2(a.x, b.x), fmin2(a.y, b.y), fmin2(a.z, b.z)}; }
+TR_HD bool any_nan(f3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
+
+// column-major matrices, as glm / GLSL
+struct m3 { f3 c[3]; };
+struct m4 { f4 c[4]; };
+TR_HD f3 mul(const m3& m, f3 v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; }          // M * v
+TR_HD f3 mulT(f3 v, const m3& m) { return {dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])}; }   // v * M
+TR_HD f4 mul(const m4& m, f4 v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z + m.c[3] * v.w; }
+TR_HD m3 upper3(const m4& m) { return {{F3(m.c[0]), F3(m.c[1]), F3(m.c[2])}}; }
+TR_HD f3 transform_point(const m4& m, f3 p) { return F3(mul(m, F4(p, 1.0f))); }
+
+// ---------------------------------------------------------------------------
+// POD layouts shared with the host
+// ---------------------------------------------------------------------------
+#pragma pack(push, 4)
+struct Vertex { f3 pos; f3 normal; f2 uv; f4 tangent; };
+struct Material {
+    f4 albedo_factor, metallic_roughness_factor, emission_factor;
+    float transmittance, ior, normal_factor; uint flags;
+    int albedo_tex_id, metallic_roughness_tex_id, normal_tex_id, emission_tex_id;
+};
+struct Instance {
+    int light_base_id, sh_grid_index; uint pad; float shadow_terminator_mul;
+    m4 model, model_normal, model_prev; Material mat;
+};
+struct DirectionalLight { f3 color; int shadow_map_index; f3 dir; float dir_cutoff; };
+struct PointLight {
+    f3 color, dir, pos; float radius, dir_cutoff, dir_falloff, cutoff_radius, spot_radius;
+    int shadow_map_index, padding;
+};
+struct TriLight { f3 pos[3]; uint emission_factor, instance_id, primitive_id; uint uv[3]; int emission_tex_id; };
+struct AliasEntry { uint alias_id, probability; float pdf, alias_pdf; };
+struct CameraData { m4 view, view_inverse, view_proj, proj_inverse; f4 origin, dof_params, projection_info, pan; };
+struct MeshSpan { uint vertex_offset, vertex_count, index_offset, triangle_count; };
+struct TextureInfo { uint width, height, texel_offset, pad; };
+#pragma pack(pop)
+static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288, "layout");
+static_assert(sizeof(DirectionalLight) == 32 && sizeof(PointLight) == 64 && sizeof(TriLight) == 64, "layout");
+static_assert(sizeof(CameraData) == 320 && sizeof(AliasEntry) == 16, "layout");
+
+// ---------------------------------------------------------------------------
+// Acceleration structure in HBM
+// ---------------------------------------------------------------------------
+// 64-byte BVH2 node: both child boxes + child references.
+//   child >= 0 : internal node index;  child < 0 : leaf, triangle index = ~child
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int child0, child1;
+    uint pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "node layout");
+
+// 48-byte world-space triangle record, stored in Morton (leaf) order.
+//   inst_flags: bits 0..30 instance id, bit 31 = non-opaque (runs the any-hit path)
+struct alignas(16) TriRecord {
+    float v0[3], v1[3], v2[3];
+    uint inst_flags, prim, pad;
+};
+static_assert(sizeof(TriRecord) == 48, "tri layout");
+
+struct HitRecord { int instance_id, primitive_id; float u, v, t; };
+
+// Everything a kernel needs to see the scene (passed by value).
+struct SceneView {
+    const Instance* instances;
+    const MeshSpan* spans;
+    const Vertex* vertices;
+    const uint* indices;
+    const PointLight* point_lights;
+    const DirectionalLight* directional_lights;
+    const TriLight* tri_lights;
+    const TextureInfo* tex_infos;
+    const uint8_t* texels;
+    const f4* envmap;
+    const AliasEntry* alias_table;
+    const CameraData* cameras;
+    const BvhNode* nodes;
+    const TriRecord* tris;
+    f4 environment_factor;
+    int environment_proj;
+    uint instance_count, point_light_count, directional_light_count, tri_light_count;
+    uint env_w, env_h;
+    uint tri_count, node_count;
+};
+
+}  // namespace tr

@@ -1,0 +1,721 @@
+// Wavefront path tracer for gfx950: the MI355X-native replacement of Tauray's path_tracer_stage
+// dispatch (src/path_tracer_stage.cc:118-147 -> shader/path_tracer.rgen + hit/miss shader table).
+//
+// One vkCmdTraceRaysKHR pass becomes, per sample:
+//   k_raygen -> for bounce in 0..MAX_BOUNCES-1: k_trace_closest -> k_shade -> k_trace_shadow
+// and k_resolve at the end of the pass.  Path state lives in HBM as float4/uint4 SoA streams; live paths
+// are compacted with wave ballots into id queues between bounces so later bounces launch dense waves.
+// Kernel launches are sized for the worst case and read the live count from device memory: there is no
+// host round trip inside a frame.
+#include "pt.h"
+#include "trace.h"
+
+namespace tr {
+
+namespace {
+
+constexpr int KB = TR_BLOCK;
+
+struct PathBuffers {
+    f4* org_pdf;      // origin.xyz, bsdf_pdf
+    f4* dir_reg;      // direction.xyz, regularization
+    f4* atten_alpha;  // attenuation.rgb, first-hit albedo.a
+    f4* color;        // accumulated colour of the current sample (folded demodulated colour), w unused
+    f4* wp;           // per-path colour weight after bounce 0: Wd*pd + Wr*pr
+    u4* rng;          // random_sampler.seed
+    u4* misc;         // payload.random_seed, sobol_index, launch linear id, flags (bit0 = dead)
+    int4* hit;        // instance, primitive, bary.u bits, bary.v bits (u carries t for sphere lights)
+    f4* sum_color;    // sum over the samples of one pass (+ alpha of the last sample)
+    // shadow rays of the current bounce (compact)
+    f4* sh_org_tmax;  // origin.xyz, tmax
+    f4* sh_dir_id;    // direction.xyz, path id bits
+    f4* sh_contrib;   // rgb contribution if visible
+    uint* queue[2];
+    uint* counters;   // [0] next-queue count, [1] shadow count, [2] overflow flag, [4..] work counters
+};
+
+enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
+       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_WORDS = 16 };
+
+struct PtParams {
+    trhip_pt_options opt;
+    LaunchCtx L;
+    uint viewports;
+    uint n_launch;                // launch_w * launch_h * viewports
+    uint max_sobol_bounces;
+    uint sample_counter, rng_seed;
+    uint previous_samples;        // control.previous_samples of the pass
+    uint sample_in_pass;
+    uint samples_accumulated;
+    uint target_w, target_h;
+    float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
+    int nee_point, nee_tri, nee_dir, nee_env;
+    int count_work;
+};
+
+TR_DEV void add64(uint* counters, int idx, uint v) {
+    if (v) atomicAdd(reinterpret_cast<unsigned long long*>(counters + idx), (unsigned long long)v);
+}
+
+// wave-aggregated append: one atomic per wave, slots handed out in lane order
+TR_DEV uint wave_append(uint* counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    uint n = __popcll(mask);
+    uint base = 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    if (pred && lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    uint rank = __popcll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
+__global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= P.n_launch) return;
+    uint lx = i % P.L.launch_w;
+    uint ly = (i / P.L.launch_w) % P.L.launch_h;
+    uint lz = i / (P.L.launch_w * P.L.launch_h);
+    int px, py;
+    bool valid = get_pixel_pos(P.L, lx, ly, px, py);
+    u4 misc = {0, 0, i, valid ? 0u : 1u};
+    if (P.sample_in_pass == 0) pb.sum_color[i] = F4(0, 0, 0, 1);
+    if (!valid) { pb.misc[i] = misc; return; }
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, lz, P.previous_samples + P.sample_in_pass}, P.sample_counter,
+                                         P.rng_seed, P.opt.sampler);
+    f2 cam_offset = F2(0.0f);
+    if (P.opt.film != 0) {   // control.antialiasing == 1
+        f4 r = u4_to_unit(pcg4d(ls.rs));   // generate_film_sample
+        if (P.opt.film == 1) cam_offset = F2(r.x, r.y) * 2.0f - 1.0f;
+        else cam_offset = sample_blackman_harris_concentric_disk(F2(r.x, r.y)) * 2.0f;
+        cam_offset = cam_offset * (2.0f * P.opt.film_radius);
+    }
+    f2 dof_u = F2(0.5f);
+    if (P.opt.depth_of_field) { f4 r = u4_to_unit(pcg4d(ls.rs)); dof_u = F2(r.x, r.y); }
+    f3 origin, dir;
+    get_screen_camera_ray(P.L, px, py, sv.cameras[lz], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
+    misc.x = pcg4d(ls.rs).x;      // payload.random_seed = pcg4d(lsampler.rs.seed).x  (path_tracer.glsl:384)
+    misc.y = ls.sobol_index;
+    pb.org_pdf[i] = F4(origin, 0.0f);            // bsdf_pdf = 0
+    pb.dir_reg[i] = F4(dir, 1.0f);               // regularization = 1
+    pb.atten_alpha[i] = F4(1, 1, 1, 1);          // attenuation = 1
+    pb.color[i] = F4(0);
+    pb.wp[i] = F4(0);
+    pb.rng[i] = ls.rs;
+    pb.misc[i] = misc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+                                                      const uint* count_ptr) {
+    __shared__ int s_stack[TR_LDS_STACK * KB];
+    const uint n = queue ? *count_ptr : P.n_launch;
+    TraceStats st = {0, 0, 0};
+    uint rays = 0;
+    bool overflow = false;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
+        uint id = queue ? queue[qi] : qi;
+        u4 misc = pb.misc[id];
+        if (misc.w & 1u) continue;
+        f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
+        HitRecord hit;
+        bool include_lights = !(P.opt.hide_lights && bounce == 0);
+        trace_closest<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                misc.x, s_stack + threadIdx.x, hit, st, overflow);
+        pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+        rays++;
+    }
+    if (overflow) pb.counters[CNT_OVERFLOW] = 1;
+    if (P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_xor(rays, off);
+            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            add64(pb.counters, CNT_CLOSEST, rays);
+            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
+        }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
+    __shared__ int s_stack[TR_LDS_STACK * KB];
+    const uint n = pb.counters[CNT_SHADOW];
+    TraceStats st = {0, 0, 0};
+    uint rays = 0;
+    bool overflow = false;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
+        f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
+        float vis = trace_shadow<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
+        uint id = __float_as_uint(d.w);
+        if (vis != 0.0f) {
+            // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
+            float m = c.w * vis;
+            if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
+            f4 col = pb.color[id];
+            col.x += c.x * vis; col.y += c.y * vis; col.z += c.z * vis;
+            pb.color[id] = col;
+        }
+        rays++;
+    }
+    if (overflow) pb.counters[CNT_OVERFLOW] = 1;
+    if (P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_xor(rays, off);
+            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            add64(pb.counters, CNT_SHADOWRAYS, rays);
+            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MIS (path_tracer.glsl:54-89)
+TR_DEV float bsdf_mis_pdf(const SceneView& sv, const PtParams& P, float pl_pdf, float dl_pdf, float tri_pdf, float env_pdf, float bsdf_pdf) {
+    if (bsdf_pdf == 0.0f) return 1.0f;
+    float avg_nee_pdf =
+        dl_pdf * P.prob_dir / (float)max(sv.directional_light_count, 1u) +
+        tri_pdf * P.prob_tri / (float)max(sv.tri_light_count, 1u) +
+        env_pdf * P.prob_env +
+        pl_pdf * P.prob_point / (float)max(sv.point_light_count, 1u);
+    if (P.opt.mis_mode == 2) return (avg_nee_pdf * avg_nee_pdf + bsdf_pdf * bsdf_pdf) / bsdf_pdf;
+    if (P.opt.mis_mode == 1) return avg_nee_pdf + bsdf_pdf;
+    return avg_nee_pdf > 0 ? __builtin_huge_valf() : bsdf_pdf;
+}
+TR_DEV float nee_mis_pdf(const PtParams& P, float nee_pdf, float bsdf_pdf) {
+    if (nee_pdf <= 0.0f) return -nee_pdf;
+    if (P.opt.mis_mode == 2) return (nee_pdf * nee_pdf + bsdf_pdf * bsdf_pdf) / nee_pdf;
+    if (P.opt.mis_mode == 1) return nee_pdf + bsdf_pdf;
+    return nee_pdf;
+}
+TR_DEV float clamp_contribution_mul(const PtParams& P, f3 contrib) {   // path_tracer.glsl:356-365
+    if (P.opt.indirect_clamping > 0.0f) {
+        float m = rgb_to_luminance(contrib);
+        if (m > P.opt.indirect_clamping) return P.opt.indirect_clamping / m;
+    }
+    return 1;
+}
+
+// sample_environment_map (rt.glsl:251-285)
+TR_DEV f3 sample_environment_map(const SceneView& sv, u4 rnd, f3& dir, float& length, float& pdf) {
+    f3 color = F3(sv.environment_factor);
+    if (sv.environment_proj >= 0) {
+        uint sx = sv.env_w, sy = sv.env_h;
+        const uint pixel_count = sx * sy;
+        uint ipx = clampu(rnd.x / (0xFFFFFFFFu / sx), 0u, sx - 1u), ipy = clampu(rnd.y / (0xFFFFFFFFu / sy), 0u, sy - 1u);
+        int i = (int)(ipx + ipy * sx);
+        AliasEntry at = sv.alias_table[i];
+        pdf = at.pdf;
+        if (rnd.z > at.probability) { i = (int)at.alias_id; pdf = at.alias_pdf; }
+        int ppx = (int)((uint)i % sx), ppy = (int)((uint)i / sx);
+        f2 off = F2((float)(uint)(rnd.x * pixel_count), (float)(uint)(rnd.y * pixel_count)) * TR_INV_UINT32_MAX;
+        f2 uv = (F2((float)ppx, (float)ppy) + off) / F2((float)sx, (float)sy);
+        dir = uv_to_latlong_direction(uv);
+        color = color * F3(sample_envmap(sv, uv));
+    } else {
+        pdf = 1.0f / (4.0f * TR_PI);
+        dir = sample_sphere(F2((float)rnd.x, (float)rnd.y) * TR_INV_UINT32_MAX);
+    }
+    length = __builtin_huge_valf();
+    return color;
+}
+TR_DEV float sample_environment_map_pdf(const SceneView& sv, f3 dir) {   // rt.glsl:287-299
+    if (sv.environment_proj >= 0) {
+        uint i = (uint)latlong_direction_to_pixel_id(dir, (int)sv.env_w, (int)sv.env_h);
+        uint n = sv.env_w * sv.env_h;
+        if (i >= n) i = n - 1;   // the GLSL read is out of bounds for the last half texel row/column
+        return sv.alias_table[i].pdf;
+    }
+    return 1.0f / (4.0f * TR_PI);
+}
+
+// sample_explicit_light (path_tracer.glsl:203-289)
+TR_DEV f3 sample_explicit_light(const SceneView& sv, const PtParams& P, u4 rnd, f3 pos, f3& out_dir, float& out_length, float& pdf) {
+    f4 u = u4_to_unit(rnd);
+    if (P.nee_point && (u.w -= P.prob_point) < 0) {
+        const int light_count = (int)sv.point_light_count;
+        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);   // random_sample_point_light
+        float weight = (float)max(light_count, 1);
+        const PointLight pl = sv.point_lights[light_index];
+        f3 color;
+        sample_point_light(pl, F2(u.x, u.y), pos, out_dir, out_length, color, pdf);
+        pdf *= P.prob_point / weight;
+        return color;
+    }
+    if (P.nee_tri && (u.w -= P.prob_tri) < 0) {
+        const int light_count = (int)sv.tri_light_count;
+        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
+        const TriLight tl = sv.tri_lights[light_index];
+        f3 A = tl.pos[0] - pos, B = tl.pos[1] - pos, C = tl.pos[2] - pos;
+        f3 color = r9g9b9e5_to_rgb(tl.emission_factor);
+        float tri_pdf = 0.0f;
+        out_dir = sample_triangle_light(P.opt.tri_light_mode, F2(u.x, u.y), A, B, C, tri_pdf);
+        out_length = ray_plane_intersection_dist(out_dir, A, B, C);
+        if (isinf(tri_pdf) || tri_pdf <= 0 || out_length <= P.opt.min_ray_dist || any_nan(out_dir)) {
+            pdf = 1.0f; out_dir = F3(0);
+            return F3(0);
+        }
+        if (tl.emission_tex_id >= 0) {
+            f3 bary = get_barycentric_coords(out_dir * out_length, A, B, C);
+            f2 uv = bary.x * unpack_half2x16(tl.uv[0]) + bary.y * unpack_half2x16(tl.uv[1]) + bary.z * unpack_half2x16(tl.uv[2]);
+            color = color * F3(sample_texture(sv, tl.emission_tex_id, uv));
+        }
+        out_length -= P.opt.min_ray_dist;
+        pdf = P.prob_tri * tri_pdf / light_count;
+        return color;
+    }
+    if (P.nee_env && (u.w -= P.prob_env) < 0) {
+        f3 color = sample_environment_map(sv, rnd, out_dir, out_length, pdf);
+        pdf *= P.prob_env;
+        return color;
+    }
+    if (P.nee_dir && (u.w -= P.prob_dir) < 0) {
+        const int light_count = (int)sv.directional_light_count;
+        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
+        const DirectionalLight dl = sv.directional_lights[light_index];
+        out_length = __builtin_huge_valf();
+        out_dir = sample_cone(F2(u.x, u.y), -dl.dir, dl.dir_cutoff);   // sample_directional_light (light.glsl:119-129)
+        pdf = dl.dir_cutoff >= 1.0f ? -1.0f : 1.0f / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
+        f3 color = pdf > 0 ? dl.color * pdf : dl.color;
+        pdf *= P.prob_dir / light_count;
+        return color;
+    }
+    out_dir = F3(0); out_length = 0; pdf = 1.0f;
+    return F3(0);
+}
+
+TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lobes& l) {   // path_tracer.glsl:291-300
+    if (dot(geometric_normal, sample_dir) < 0) { l.diffuse = 0; l.dielectric_reflection = 0; l.metallic_reflection = 0; }
+    else l.transmission = 0;
+}
+
+// One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
+template <bool COUNT>
+__global__ __launch_bounds__(KB) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+                                              const uint* count_ptr, uint* next_queue) {
+    const uint n = queue ? *count_ptr : P.n_launch;
+    const uint n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
+    uint surf = 0;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
+        bool active = qi < n;
+        uint id = 0;
+        u4 misc = {0, 0, 0, 1};
+        if (active) { id = queue ? queue[qi] : qi; misc = pb.misc[id]; active = !(misc.w & 1u); }
+        bool alive = false;        // continues to the next bounce
+        bool want_shadow = false;
+        f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
+        float sh_tmax = 0, sh_lum = 0;
+        if (active) {
+            const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id], a4 = pb.atten_alpha[id];
+            const int4 h = pb.hit[id];
+            f3 pos = F3(o4), view = F3(d4);
+            float bsdf_pdf = o4.w, regularization = d4.w;
+            f3 attenuation = F3(a4);
+            float first_alpha = a4.w;
+            f4 color = pb.color[id];
+            f3 wp = F3(pb.wp[id]);
+            u4 rs = pb.rng[id];
+            pcg(misc.x);   // the any-hit seed advances once per closest-hit trace
+
+            // ---- get_intersection_info (path_tracer.glsl:91-201)
+            SampledMaterial mat;
+            mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
+            mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
+            SurfacePoint v;
+            v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
+            float pl_pdf = 0, dl_pdf = 0, tri_pdf = 0, env_pdf = 0;
+            f3 light = F3(0);
+            bool surface = false;
+            if (h.x >= 0) {
+                surface = true;
+                if (COUNT) surf++;
+                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, v, mat);
+                mat.albedo.w = 1.0f;
+                if (P.nee_tri) {
+                    tri_pdf = v.tri_light_pdf;
+                    light = mat.emission;
+                    mat.emission = F3(0);
+                }
+            } else if (h.y >= 0) {
+                const PointLight pl = sv.point_lights[h.y];
+                f3 c = get_spotlight_intensity(pl, view) * pl.color / (pl.radius * pl.radius * TR_PI);
+                if (P.nee_point) { light = c; pl_pdf = sample_point_light_pdf(pl, pos); }
+                else mat.emission = c;
+                v.pos = pos + __int_as_float(h.z) * view;
+                v.mapped_normal = normalize(v.pos - pl.pos);
+                mat.albedo = F4(0, 0, 0, 1);
+            } else {
+                f4 c = sv.environment_factor;
+                if (sv.environment_proj >= 0) {
+                    f2 uv;
+                    uv.y = asinf(-view.y) / TR_PI + 0.5f;
+                    uv.x = atan2f(view.z, view.x) / (2 * TR_PI) + 0.5f;
+                    f4 t = sample_envmap(sv, uv);
+                    c.x *= t.x; c.y *= t.y; c.z *= t.z;
+                }
+                for (uint i = 0; i < sv.directional_light_count; ++i) {
+                    const DirectionalLight dl = sv.directional_lights[i];
+                    if (dl.dir_cutoff >= 1.0f) continue;
+                    float visible = stepf(dl.dir_cutoff, dot(view, -dl.dir));
+                    f3 dc = visible * dl.color / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
+                    if (P.nee_dir) { light += dc; dl_pdf += visible * sample_directional_light_pdf(dl); }
+                    else mat.emission += dc;
+                }
+                v.pos = pos;
+                v.mapped_normal = -view;
+                mat.albedo = F4(0);
+                if (P.nee_env) {
+                    light += F3(c);
+                    env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
+                } else mat.emission += F3(c);
+            }
+            const bool terminal = !surface || bounce == P.opt.max_bounces - 1;
+
+            // ---- emission with MIS (path_tracer.glsl:413-435)
+            float mis_pdf = bsdf_mis_pdf(sv, P, pl_pdf, dl_pdf, tri_pdf, env_pdf, bsdf_pdf);
+            float mis_weight = 1.0f;
+            if (bsdf_pdf != 0) { attenuation = attenuation / bsdf_pdf; mis_weight = bsdf_pdf / mis_pdf; }
+            light = attenuation * mis_weight * (mat.emission + light);
+            if (bounce != 0) light *= clamp_contribution_mul(P, light);
+
+            // folded demodulation (material.glsl:57-73): colour = E0 + Wd * sum(c*pd) + Wr * sum(c*pr)
+            f3 Wd = F3(0), Wr = F3(0);
+            if (bounce == 0) {
+                f3 alb = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(mat.albedo);
+                Wd = alb * (1 - mat.metallic);
+                Wr = mix3(F3(0.02f), alb, mat.metallic) / mixf(0.02f, 1.0f, mat.metallic);
+                first_alpha = mat.albedo.w;
+                // primary_lobes = (0,0,0,1): the first-hit light is counted as emission and as reflection
+                color.x += light.x + light.x * Wr.x; color.y += light.y + light.y * Wr.y; color.z += light.z + light.z * Wr.z;
+            } else {
+                color.x += light.x * wp.x; color.y += light.y * wp.y; color.z += light.z * wp.z;
+            }
+
+            if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
+                if (bsdf_pdf != 0.0f) regularization *= fmax2(1 - P.opt.regularization_gamma / powf(bsdf_pdf, 0.25f), 0.0f);
+                mat.roughness = 1.0f - ((1.0f - mat.roughness) * regularization);
+            }
+
+            if (!terminal) {
+                const m3 tbn = create_tangent_space(v.mapped_normal);
+                const f3 shading_view = view_to_tangent_space(view, tbn);
+                u4 coord;   // only the Sobol-Owen sampler needs the launch coordinate again
+                {
+                    uint i = misc.z;
+                    uint lx = i % P.L.launch_w, ly = (i / P.L.launch_w) % P.L.launch_h, lz = i / (P.L.launch_w * P.L.launch_h);
+                    int px = 0, py = 0;
+                    if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
+                    coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_in_pass + P.sample_counter};
+                }
+                // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
+                const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
+                                     (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
+                u4 rnd = ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u, P.opt.sampler, P.max_sobol_bounces);
+                Lobes lobes = {0, 0, 0, 0};
+                if (any_nee) {
+                    f3 out_dir;
+                    float out_length = 0.0f, light_pdf;
+                    f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
+                    f3 shading_light = mulT(out_dir, tbn);
+                    float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
+                    correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
+                    bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
+                    contrib = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
+                    f3 radiance = attenuation * contrib;
+                    f3 w;
+                    float clamp_lum = 0.0f;   // > 0: indirect clamping applies to (radiance * visibility)
+                    if (bounce != 0) {
+                        radiance *= modulate_bsdf(mat, lobes);
+                        if (P.opt.indirect_clamping > 0.0f) clamp_lum = rgb_to_luminance(radiance);
+                        w = wp;
+                    } else {
+                        w = Wd * (lobes.diffuse + lobes.transmission) + Wr * (lobes.dielectric_reflection + lobes.metallic_reflection);
+                    }
+                    f3 c = radiance * w;
+                    if (cast) {
+                        // contrib *= shadow_ray(...) happens in k_trace_shadow, including the clamp on the occluded value
+                        want_shadow = true;
+                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = c; sh_lum = clamp_lum;
+                    } else {
+                        float mul = (clamp_lum > P.opt.indirect_clamping && clamp_lum > 0.0f) ? P.opt.indirect_clamping / clamp_lum : 1.0f;
+                        color.x += c.x * mul; color.y += c.y * mul; color.z += c.z * mul;
+                    }
+                }
+                // ---- BSDF sampling (path_tracer.glsl:475-497)
+                Lobes bl = {0, 0, 0, 0};
+                f4 ray_sample = u4_to_unit(ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u + 1u, P.opt.sampler, P.max_sobol_bounces));
+                f3 new_dir;
+                material_bsdf_sample(P.opt.bounce_mode, ray_sample, shading_view, mat, new_dir, bl, bsdf_pdf);
+                view = mul(tbn, new_dir);
+                correct_lobes_for_normal_map(v.hard_normal, view, bl);
+                if (bounce != 0) attenuation *= modulate_bsdf(mat, bl);
+                else wp = Wd * (bl.diffuse + bl.transmission) + Wr * (bl.dielectric_reflection + bl.metallic_reflection);
+                pos = v.pos;
+                alive = true;
+                if (P.opt.russian_roulette_delta > 0) {   // USE_RUSSIAN_ROULETTE: the survivor weight is never applied
+                    float qi_ = fmin2(1.0f, 1.0f / P.opt.russian_roulette_delta);
+                    if (ray_sample.w > qi_) alive = false;
+                }
+                if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
+            }
+            // ---- write back
+            pb.color[id] = color;
+            if (bounce == 0) pb.atten_alpha[id] = F4(attenuation, first_alpha);
+            if (alive) {
+                pb.org_pdf[id] = F4(pos, bsdf_pdf);
+                pb.dir_reg[id] = F4(view, regularization);
+                pb.atten_alpha[id] = F4(attenuation, first_alpha);
+                if (bounce == 0) pb.wp[id] = F4(wp, 0);
+                pb.rng[id] = rs;
+                pb.misc[id] = misc;
+            }
+        }
+        // ---- queue compaction (wave ballots)
+        uint sslot = wave_append(&pb.counters[CNT_SHADOW], want_shadow);
+        if (want_shadow) {
+            pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
+            pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
+            pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
+        }
+        uint nslot = wave_append(&pb.counters[CNT_NEXT], alive);
+        if (alive) next_queue[nslot] = id;
+    }
+    if (COUNT && P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) surf += __shfl_xor(surf, off);
+        if ((threadIdx.x & 63) == 0) add64(pb.counters, CNT_SURF, surf);
+    }
+}
+
+// rotate queue counters between bounces: cur <- next, next <- 0, shadow <- 0
+__global__ void k_advance(uint* counters) {
+    counters[CNT_CUR] = counters[CNT_NEXT];
+    counters[CNT_NEXT] = 0;
+    counters[CNT_SHADOW] = 0;
+}
+__global__ void k_clear_shadow(uint* counters) { counters[CNT_SHADOW] = 0; counters[CNT_NEXT] = 0; }
+
+// end of one sample: sum_color += colour (path_tracer.rgen:112)
+__global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= P.n_launch) return;
+    u4 misc = pb.misc[i];
+    if (misc.w & 1u) return;
+    f4 s = pb.sum_color[i], c = pb.color[i];
+    float alpha = pb.atten_alpha[i].w;
+    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, alpha);
+}
+
+// write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
+__global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb, f4* target) {
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= P.n_launch) return;
+    uint lx = i % P.L.launch_w, ly = (i / P.L.launch_w) % P.L.launch_h, lz = i / (P.L.launch_w * P.L.launch_h);
+    int wx, wy;
+    if (!get_write_pixel_pos(P.L, lx, ly, wx, wy)) return;
+    if ((uint)wx >= P.target_w || (uint)wy >= P.target_h) return;
+    f4 s = pb.sum_color[i];
+    const float spp = (float)P.opt.samples_per_pass;
+    f4 out = F4(s.x / spp, s.y / spp, s.z / spp, P.opt.transparent_background ? s.w : 1.0f);
+    size_t idx = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
+    uint prev_samples = P.samples_accumulated + P.previous_samples;
+    if (prev_samples != 0) {
+        f4 prev = target[idx];
+        uint total = (uint)P.opt.samples_per_pass + prev_samples;
+        out = mix4(out, prev, (float)prev_samples / (float)total);
+    }
+    target[idx] = out;
+}
+
+uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strategy.cc:62-69
+    uint n = sx * sy, b = 31;
+    while ((n >> b) < 128 && b > 0) b--;
+    return b;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+}  // namespace
+
+void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/distribution_strategy.cc:33-61
+    if (d.strategy == 0) { w = d.size_x; h = d.size_y; }
+    else if (d.strategy == 1) { w = d.size_x; h = (d.size_y - d.index + d.count - 1) / d.count; }
+    else { w = d.count; h = 1; }
+}
+
+struct PtStage::Impl {
+    PathBuffers pb{};
+    size_t capacity = 0;
+    hipEvent_t ev[16]{};
+    bool ev_init = false;
+};
+
+PtStage::PtStage(DeviceScene* scene, const trhip_pt_options& o) : scene(scene), opt(o), impl(new Impl()) {
+    dist = trhip_distribution{0, 0, 0, 0, 1, 1};
+}
+
+PtStage::~PtStage() {
+    free_buffers();
+    if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
+    delete impl;
+}
+
+void PtStage::free_buffers() {
+    PathBuffers& pb = impl->pb;
+    void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.color, pb.wp, pb.rng, pb.misc, pb.hit, pb.sum_color,
+                    pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.queue[0], pb.queue[1]};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    uint* counters = pb.counters;
+    pb = PathBuffers{};
+    pb.counters = counters;
+    impl->capacity = 0;
+}
+
+int PtStage::ensure_buffers(size_t n) {
+    PathBuffers& pb = impl->pb;
+    if (!pb.counters) {
+        HIPCHK(hipMalloc(&pb.counters, CNT_WORDS * sizeof(uint)));
+        HIPCHK(hipMemset(pb.counters, 0, CNT_WORDS * sizeof(uint)));
+    }
+    if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreate(&e)); impl->ev_init = true; }
+    if (n <= impl->capacity) return 0;
+    free_buffers();
+    HIPCHK(hipMalloc(&pb.org_pdf, n * 16)); HIPCHK(hipMalloc(&pb.dir_reg, n * 16)); HIPCHK(hipMalloc(&pb.atten_alpha, n * 16));
+    HIPCHK(hipMalloc(&pb.color, n * 16)); HIPCHK(hipMalloc(&pb.wp, n * 16)); HIPCHK(hipMalloc(&pb.rng, n * 16));
+    HIPCHK(hipMalloc(&pb.misc, n * 16)); HIPCHK(hipMalloc(&pb.hit, n * 16)); HIPCHK(hipMalloc(&pb.sum_color, n * 16));
+    HIPCHK(hipMalloc(&pb.sh_org_tmax, n * 16)); HIPCHK(hipMalloc(&pb.sh_dir_id, n * 16)); HIPCHK(hipMalloc(&pb.sh_contrib, n * 16));
+    HIPCHK(hipMalloc(&pb.queue[0], n * 4)); HIPCHK(hipMalloc(&pb.queue[1], n * 4));
+    impl->capacity = n;
+    return 0;
+}
+
+int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
+    if (!scene->accel_built) return set_error("trhip_pt_render: call trhip_scene_build_accel first");
+    if (viewports == 0 || viewports > scene->camera_count) return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
+    if (opt.samples_per_pass <= 0 || opt.samples_per_pixel % opt.samples_per_pass != 0)
+        return set_error("trhip_pt_render: samples_per_pixel must be a multiple of samples_per_pass");
+    if (opt.pre_transformed_vertices) return set_error("trhip_pt_render: pre_transformed_vertices is not supported");
+    if (dist.size_x == 0 || dist.size_y == 0) return set_error("trhip_pt_render: distribution not set");
+    PtParams P{};
+    P.opt = opt;
+    uint lw, lh;
+    get_ray_count(dist, lw, lh);
+    P.L.size_x = dist.size_x; P.L.size_y = dist.size_y; P.L.strategy = dist.strategy; P.L.index = dist.index;
+    P.L.count = dist.strategy == 2 ? calculate_shuffled_strips_b(dist.size_x, dist.size_y) : dist.count;
+    P.L.primary = dist.primary; P.L.launch_w = lw; P.L.launch_h = lh;
+    P.viewports = viewports;
+    const size_t n = (size_t)lw * lh * viewports;
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFF0ull) return set_error("trhip_pt_render: launch too large");
+    P.n_launch = (uint)n;
+    P.max_sobol_bounces = (uint)(opt.max_bounces > 8 ? 8 : opt.max_bounces);   // shader/sobol_lookup_table.glsl:4-14
+    P.sample_counter = frame_counter * (uint)opt.samples_per_pixel;               // src/rt_stage.cc:81
+    { uint s = opt.rng_seed; P.rng_seed = s != 0 ? pcg(s) : 0; }                  // src/rt_stage.cc:82
+    P.samples_accumulated = accumulated_samples;
+    P.target_w = target_w; P.target_h = target_h;
+    P.nee_point = opt.nee_point > 0; P.nee_dir = opt.nee_directional > 0; P.nee_env = opt.nee_envmap > 0; P.nee_tri = opt.nee_triangles > 0;
+    {   // get_nee_sampling_probabilities (shader/rt.glsl:302-335): scene constants, evaluated once in fp32
+        float point = (P.nee_point && scene->point_light_count > 0) ? opt.nee_point : 0.0f;
+        float tri = (P.nee_tri && scene->tri_light_count > 0) ? opt.nee_triangles : 0.0f;
+        float dir = (P.nee_dir && scene->directional_light_count > 0) ? opt.nee_directional : 0.0f;
+        float env = (P.nee_env && scene->environment_proj >= 0) ? opt.nee_envmap : 0.0f;
+        float sum = point + tri + dir + env;
+        float inv_sum = sum <= 0.0f ? 0.0f : (1.0f / sum + 1e-5f);
+        P.prob_point = point * inv_sum; P.prob_tri = tri * inv_sum; P.prob_dir = dir * inv_sum; P.prob_env = env * inv_sum;
+    }
+    P.count_work = 1;
+    if (int rc = ensure_buffers(n)) return rc;
+    PathBuffers& pb = impl->pb;
+    SceneView sv = scene->view();
+    const uint blocks_all = (uint)((n + KB - 1) / KB);
+    // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
+    const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
+    const bool count = count_work != 0;
+    const bool timing = detailed_timing != 0;
+    float t_closest = 0, t_shadow = 0, t_shade = 0, t_raygen = 0, t_resolve = 0;
+    auto& ev = impl->ev;
+    HIPCHK(hipEventRecord(ev[0], stream));
+    const int passes = opt.samples_per_pixel / opt.samples_per_pass;
+    for (int pass = 0; pass < passes; ++pass) {
+        P.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
+        for (int s = 0; s < opt.samples_per_pass; ++s) {
+            P.sample_in_pass = (uint)s;
+            if (timing) HIPCHK(hipEventRecord(ev[2], stream));
+            hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, P, pb);
+            hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, stream, pb.counters);
+            if (timing) { HIPCHK(hipEventRecord(ev[3], stream)); }
+            for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
+                const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+                uint* qn = pb.queue[(bounce + 1) & 1];
+                if (timing) HIPCHK(hipEventRecord(ev[4], stream));
+                if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+                if (timing) HIPCHK(hipEventRecord(ev[5], stream));
+                if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
+                else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
+                if (timing) HIPCHK(hipEventRecord(ev[6], stream));
+                if (bounce < opt.max_bounces - 1) {
+                    if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                }
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters);
+                if (timing) {
+                    HIPCHK(hipEventRecord(ev[7], stream));
+                    HIPCHK(hipEventSynchronize(ev[7]));
+                    float a, b, c;
+                    HIPCHK(hipEventElapsedTime(&a, ev[4], ev[5])); HIPCHK(hipEventElapsedTime(&b, ev[5], ev[6])); HIPCHK(hipEventElapsedTime(&c, ev[6], ev[7]));
+                    t_closest += a; t_shade += b; t_shadow += c;
+                }
+            }
+            hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, P, pb);
+            if (timing) { float a; HIPCHK(hipEventSynchronize(ev[3])); HIPCHK(hipEventElapsedTime(&a, ev[2], ev[3])); t_raygen += a; }
+        }
+        if (timing) HIPCHK(hipEventRecord(ev[8], stream));
+        hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev);
+        if (timing) { HIPCHK(hipEventRecord(ev[9], stream)); HIPCHK(hipEventSynchronize(ev[9])); float a; HIPCHK(hipEventElapsedTime(&a, ev[8], ev[9])); t_resolve += a; }
+    }
+    HIPCHK(hipEventRecord(ev[1], stream));
+    HIPCHK(hipGetLastError());
+    timing_pending = true;
+    last.trace_closest_ms = t_closest; last.trace_shadow_ms = t_shadow; last.shade_ms = t_shade; last.raygen_ms = t_raygen; last.resolve_ms = t_resolve;
+    // rt_stage::update: frame_counter++ ; rt_camera_stage::update: accumulated_samples += samples_per_pixel
+    frame_counter++;
+    accumulated_samples += (uint)opt.samples_per_pixel;
+    return 0;
+}
+
+int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
+    memset(out, 0, sizeof(*out));
+    if (!impl->pb.counters) return 0;
+    HIPCHK(hipStreamSynchronize(stream));
+    uint h[CNT_WORDS];
+    HIPCHK(hipMemcpy(h, impl->pb.counters, sizeof(h), hipMemcpyDeviceToHost));
+    auto rd = [&](int i) { return (uint64_t)h[i] | ((uint64_t)h[i + 1] << 32); };
+    out->closest_rays = rd(CNT_CLOSEST); out->shadow_rays = rd(CNT_SHADOWRAYS); out->node_visits = rd(CNT_NODES);
+    out->tri_tests = rd(CNT_TRIS); out->alpha_tests = rd(CNT_ALPHA); out->surface_hits = rd(CNT_SURF);
+    out->stack_overflows = h[CNT_OVERFLOW];
+    return 0;
+}
+
+int PtStage::reset_counters() {
+    if (impl->pb.counters) HIPCHK(hipMemset(impl->pb.counters, 0, CNT_WORDS * sizeof(uint)));
+    return 0;
+}
+
+int PtStage::get_timings(trhip_timings* out) {
+    *out = last;
+    out->path_tracing_ms = 0;
+    if (timing_pending) {
+        HIPCHK(hipEventSynchronize(impl->ev[1]));
+        HIPCHK(hipEventElapsedTime(&out->path_tracing_ms, impl->ev[0], impl->ev[1]));
+        last.path_tracing_ms = out->path_tracing_ms;
+    }
+    return 0;
+}
+
+}  // namespace tr

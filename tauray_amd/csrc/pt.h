@@ -1,0 +1,36 @@
+// Host-side path_tracer_stage object behind trhip_pt (mirrors the state kept by rt_stage /
+// rt_camera_stage / path_tracer_stage: options, distribution params, frame and sample counters).
+#pragma once
+#include "build.h"
+
+namespace tr {
+
+void get_ray_count(const trhip_distribution& d, uint& w, uint& h);
+
+class PtStage {
+public:
+    PtStage(DeviceScene* scene, const trhip_pt_options& opt);
+    ~PtStage();
+    int render(void* color_dev, uint target_w, uint target_h, uint viewports, hipStream_t stream);
+    int get_counters(trhip_counters* out, hipStream_t stream);
+    int reset_counters();
+    int get_timings(trhip_timings* out);
+
+    DeviceScene* scene;
+    trhip_pt_options opt;
+    trhip_distribution dist;
+    uint frame_counter = 0;          // rt_stage::frame_counter (src/rt_stage.cc:81-86)
+    uint accumulated_samples = 0;    // rt_camera_stage::accumulated_samples (src/rt_camera_stage.cc:100)
+    int count_work = 0, detailed_timing = 0;
+    hipStream_t last_stream = nullptr;
+
+private:
+    struct Impl;
+    Impl* impl;
+    trhip_timings last{};
+    bool timing_pending = false;
+    int ensure_buffers(size_t n);
+    void free_buffers();
+};
+
+}  // namespace tr

@@ -1,0 +1,258 @@
+// BVH traversal + watertight ray/triangle test for gfx950 (wave64).
+//
+// Replaces the Vulkan driver's traceRayEXT (shader/path_tracer.glsl:38-50,387-403)
+// and the hit/miss shader table (shader/rt_common*.r*).  One ray per lane; each
+// lane keeps its short traversal stack in LDS (column layout stack[entry][lane]
+// -> conflict free for ds_read/write_b32 regardless of per-lane depth) and
+// spills to a private array only past LDS_STACK entries.
+#pragma once
+#include "common.h"
+#include "rng.h"
+#include "texture.h"
+
+namespace tr {
+
+#define TR_BLOCK 256
+#define TR_LDS_STACK 24
+#define TR_SPILL_STACK 40
+
+struct RayPre {
+    f3 org, dir, inv_dir;
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+
+TR_DEV RayPre make_ray(f3 org, f3 dir) {
+    RayPre r;
+    r.org = org; r.dir = dir;
+    float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+    int kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    if (comp(dir, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = comp(dir, kx) / comp(dir, kz);
+    r.Sy = comp(dir, ky) / comp(dir, kz);
+    r.Sz = 1.0f / comp(dir, kz);
+    r.inv_dir = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    return r;
+}
+
+// Watertight test (Woop, Benthin, Wald 2013), no culling.  Plain IEEE fp32 without
+// contraction: the shared-edge guarantee needs both products of each edge function
+// rounded, and the CPU oracle evaluates exactly the same expression tree.
+TR_DEV bool tri_intersect(const RayPre& r, f3 v0, f3 v1, f3 v2, float tmin, float tmax, float& t, float& bu, float& bv) {
+#pragma clang fp contract(off)
+    const f3 A = v0 - r.org, B = v1 - r.org, C = v2 - r.org;
+    const float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
+    const float Ax = comp(A, r.kx) - r.Sx * Akz, Ay = comp(A, r.ky) - r.Sy * Akz;
+    const float Bx = comp(B, r.kx) - r.Sx * Bkz, By = comp(B, r.ky) - r.Sy * Bkz;
+    const float Cx = comp(C, r.kx) - r.Sx * Ckz, Cy = comp(C, r.ky) - r.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float rcp = 1.0f / det;
+    const float tt = T * rcp;
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt; bu = V * rcp; bv = W * rcp;
+    return true;
+}
+
+// Conservative slab test; returns entry distance in tnear.
+TR_DEV bool box_intersect(const RayPre& r, const float* lo, const float* hi, float tmin, float tmax, float& tnear) {
+    float tx0 = (lo[0] - r.org.x) * r.inv_dir.x, tx1 = (hi[0] - r.org.x) * r.inv_dir.x;
+    float ty0 = (lo[1] - r.org.y) * r.inv_dir.y, ty1 = (hi[1] - r.org.y) * r.inv_dir.y;
+    float tz0 = (lo[2] - r.org.z) * r.inv_dir.z, tz1 = (hi[2] - r.org.z) * r.inv_dir.z;
+    float nx = fminf(tx0, tx1), fx = fmaxf(tx0, tx1);
+    float ny = fminf(ty0, ty1), fy = fmaxf(ty0, ty1);
+    float nz = fminf(tz0, tz1), fz = fmaxf(tz0, tz1);
+    // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a zero-direction axis)
+    float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+    // far planes widened by 1 + 2*gamma(3) so rounding can never cull a true hit
+    float t1 = fminf(fminf(fminf(fx, fy), fz) * 1.0000003576278687f, tmax);
+    tnear = t0;
+    return t0 <= t1;
+}
+
+// Per-lane traversal stack: first TR_LDS_STACK entries in LDS, the rest in scratch.
+struct LaneStack {
+    int* lds;           // &stack[0][lane_in_block]; stride TR_BLOCK
+    int spill[TR_SPILL_STACK];
+    int sp;
+    bool overflow;
+    TR_DEV void init(int* base) { lds = base; sp = 0; overflow = false; }
+    TR_DEV void push(int v) {
+        if (sp < TR_LDS_STACK) lds[sp * TR_BLOCK] = v;
+        else if (sp < TR_LDS_STACK + TR_SPILL_STACK) spill[sp - TR_LDS_STACK] = v;
+        else { overflow = true; return; }
+        sp++;
+    }
+    TR_DEV int pop() {
+        sp--;
+        return sp < TR_LDS_STACK ? lds[sp * TR_BLOCK] : spill[sp - TR_LDS_STACK];
+    }
+};
+
+struct TraceStats { uint nodes, tris, alpha; };
+
+// get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit
+TR_DEV f2 candidate_uv(const SceneView& sv, int inst, int prim, float bu, float bv) {
+    const MeshSpan sp = sv.spans[inst];
+    const uint* ix = sv.indices + sp.index_offset + 3u * (uint)prim;
+    const Vertex* vb = sv.vertices + sp.vertex_offset;
+    f2 uv0 = vb[ix[0]].uv, uv1 = vb[ix[1]].uv, uv2 = vb[ix[2]].uv;
+    float b0 = 1.0f - bu - bv;
+    return uv0 * b0 + uv1 * bu + uv2 * bv;
+}
+
+// Candidate alpha of a non-opaque triangle (albedo_factor.a * texture alpha).
+TR_DEV float candidate_alpha(const SceneView& sv, int inst, int prim, float bu, float bv) {
+    const Material& mat = sv.instances[inst].mat;
+    float alpha = mat.albedo_factor.w;
+    int tex = mat.albedo_tex_id;
+    if (tex >= 0) alpha *= sample_texture(sv, tex, candidate_uv(sv, inst, prim, bu, bv)).w;
+    return alpha;
+}
+
+// Traversal-order independent stand-in for generate_single_uniform_random(payload.random_seed)
+// (shader/rt_common.rahit:21); see DESIGN.md "any-hit order".
+TR_DEV float alpha_cutoff_hash(uint seed, int instance_id, int primitive_id) {
+    uint k = (uint)instance_id * 0x9E3779B9u + (uint)primitive_id;
+    uint h = seed ^ pcg(k);
+    return (float)pcg(h) * 2.3283064365386963e-10f;
+}
+
+// Closest hit over triangles (+ sphere lights).  ALPHA_MODE 0: stochastic alpha keyed by `seed`
+// (shader/rt_common.rahit:15-24); 1: fixed cutoff 1e-4 (shader/rt_feature.rahit:17).
+template <int ALPHA_MODE, bool COUNT>
+TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
+                          int* lds_stack, HitRecord& hit, TraceStats& st, bool& overflow) {
+    hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
+    float best_t = tmax;
+    bool found = false;
+    uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
+    RayPre r = make_ray(org, dir);
+    if (sv.tri_count > 0) {
+        LaneStack stk;
+        stk.init(lds_stack);
+        int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
+        while (true) {
+            if (node >= 0) {
+                const BvhNode n = sv.nodes[node];
+                if (COUNT) st.nodes++;
+                float t0, t1;
+                bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, best_t, t0);
+                bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, best_t, t1);
+                if (h0 && h1) {
+                    bool first0 = t0 <= t1;
+                    stk.push(first0 ? n.child1 : n.child0);
+                    node = first0 ? n.child0 : n.child1;
+                    continue;
+                } else if (h0) { node = n.child0; continue; }
+                else if (h1) { node = n.child1; continue; }
+            } else {
+                const TriRecord tr = sv.tris[~node];
+                if (COUNT) st.tris++;
+                float t, bu, bv;
+                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) {
+                    const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+                    const bool closer = t < best_t ||
+                        (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
+                    if (closer && t < tmax) {
+                        bool accept = true;
+                        if (tr.inst_flags & 0x80000000u) {
+                            if (COUNT) st.alpha++;
+                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
+                            accept = !(a <= cutoff);   // is_material_skippable (shader/rt.glsl:136-144)
+                        }
+                        if (accept) {
+                            best_t = t; found = true; best_inst = inst; best_prim = tr.prim;
+                            hit.instance_id = (int)inst; hit.primitive_id = (int)tr.prim; hit.u = bu; hit.v = bv;
+                        }
+                    }
+                }
+            }
+            if (stk.sp == 0) break;
+            node = stk.pop();
+        }
+        overflow = overflow || stk.overflow;
+    }
+    if (include_lights) {
+        // rt_common_point_light.rint:11-17 / .rchit:10-15, shader/rt_common.glsl:36-51
+        for (uint i = 0; i < sv.point_light_count; ++i) {
+            const PointLight& pl = sv.point_lights[i];
+            float radius = pl.radius;
+            if (radius == 0.0f) continue;
+            f3 oc = org - pl.pos;
+            float a = dot(dir, dir);
+            float b = 2.0f * dot(oc, dir);
+            float c = dot(oc, oc) - radius * radius;
+            float disc = b * b - 4.0f * a * c;
+            if (disc < 0) continue;
+            float h = (-b - sqrtf(disc)) / (2.0f * a);
+            if (h > 0 && h > tmin && h < best_t) {
+                best_t = h; found = true;
+                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
+            }
+        }
+    }
+    hit.t = found ? best_t : -1.0f;
+}
+
+// shadow_ray (shader/path_tracer.glsl:35-52) + rt_common_shadow.rahit/.rchit: product of (1 - alpha)
+// over non-opaque hits, 0 on the first opaque hit; lights are excluded (mask 0xFD).
+template <bool COUNT>
+TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st,
+                          bool& overflow) {
+    float visibility = 1.0f;
+    if (sv.tri_count == 0) return visibility;
+    RayPre r = make_ray(org, dir);
+    LaneStack stk;
+    stk.init(lds_stack);
+    int node = sv.node_count > 0 ? 0 : -1;
+    while (true) {
+        if (node >= 0) {
+            const BvhNode n = sv.nodes[node];
+            if (COUNT) st.nodes++;
+            float t0, t1;
+            bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, tmax, t0);
+            bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, tmax, t1);
+            if (h0 && h1) { stk.push(n.child1); node = n.child0; continue; }
+            else if (h0) { node = n.child0; continue; }
+            else if (h1) { node = n.child1; continue; }
+        } else {
+            const TriRecord tr = sv.tris[~node];
+            if (COUNT) st.tris++;
+            float t, bu, bv;
+            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
+                if (COUNT) st.alpha++;
+                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                visibility *= 1.0f - alpha;
+                if (visibility == 0.0f) break;
+            }
+        }
+        if (stk.sp == 0) break;
+        node = stk.pop();
+    }
+    overflow = overflow || stk.overflow;
+    return visibility;
+}
+
+}  // namespace tr

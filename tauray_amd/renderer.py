@@ -1,0 +1,459 @@
+"""Host-side mirror of the reference's renderer/stage surface for the path-tracer hot path,
+driving the HIP kernels through the C ABI (include/trhip.h).
+
+Reference classes mirrored (same names, argument meaning and error behaviour; errors surface as
+TrhipError where the reference throws std::runtime_error):
+
+* ``Context``            - tr::context / tr::device pair for ONE device (src/context.hh, src/device.hh)
+* ``SceneStage``         - scene_stage uploads + acceleration structure (src/scene_stage.cc)
+* ``PathTracerStage``    - path_tracer_stage / rt_camera_stage / rt_stage (src/path_tracer_stage.{hh,cc})
+* ``FeatureStage``       - feature_stage (src/feature_stage.{hh,cc})
+* ``StitchStage``        - stitch_stage (src/stitch_stage.{hh,cc})
+* ``TonemapStage``       - tonemap_stage (src/tonemap_stage.{hh,cc})
+* ``RtRenderer``         - rt_renderer<path_tracer_stage> (src/rt_renderer.{hh,cc}); one process per GPU,
+                           partial frames gathered with torch.distributed (RCCL) instead of host-bounce copies
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AccelInfoC, CountersC, DistributionC, PtOptionsC, SceneDescC, TimingsC, TonemapInfoC, TrhipError, check)
+from .distribution import (DISTRIBUTION_DUPLICATE, DISTRIBUTION_SCANLINE, DISTRIBUTION_SHUFFLED_STRIPS, DistributionParams,
+                           get_device_distribution_params, get_distribution_target_size)
+from .scene import SceneDesc, build_alias_table
+
+# film_filter, multiple_importance_sampling_mode, bounce_sampling_mode, tri_light_sampling_mode (src/rt_common.hh)
+FILM_POINT, FILM_BOX, FILM_BLACKMAN_HARRIS = 0, 1, 2
+MIS_DISABLED, MIS_BALANCE_HEURISTIC, MIS_POWER_HEURISTIC = 0, 1, 2
+BOUNCE_HEMISPHERE, BOUNCE_COSINE_HEMISPHERE, BOUNCE_MATERIAL = 0, 1, 2
+TRI_LIGHT_AREA, TRI_LIGHT_SOLID_ANGLE, TRI_LIGHT_HYBRID = 0, 1, 2
+SAMPLER_UNIFORM_RANDOM, SAMPLER_SOBOL_OWEN, SAMPLER_SOBOL_Z_ORDER_2D, SAMPLER_SOBOL_Z_ORDER_3D = 0, 1, 2, 3
+TONEMAP_LINEAR, TONEMAP_GAMMA_CORRECTION, TONEMAP_FILMIC, TONEMAP_REINHARD, TONEMAP_REINHARD_LUMINANCE = 0, 1, 2, 3, 4
+FEATURE_ALBEDO, FEATURE_WORLD_NORMAL, FEATURE_VIEW_NORMAL, FEATURE_WORLD_POS, FEATURE_VIEW_POS, FEATURE_DISTANCE = 0, 1, 2, 3, 4, 5
+FEATURE_INSTANCE_ID = 9
+
+
+def make_options(**kw) -> PtOptionsC:
+    """path_tracer_stage::options at the reference's CLI defaults (src/options.hh)."""
+    o = PtOptionsC(max_bounces=8, min_ray_dist=1e-4, rng_seed=0, sampler=SAMPLER_UNIFORM_RANDOM, samples_per_pixel=1,
+                   samples_per_pass=1, projection=0, film=FILM_POINT, film_radius=0.5, mis_mode=MIS_POWER_HEURISTIC,
+                   russian_roulette_delta=0.0, indirect_clamping=0.0, regularization_gamma=0.0, depth_of_field=0,
+                   nee_point=1.0, nee_directional=1.0, nee_envmap=1.0, nee_triangles=1.0, bounce_mode=BOUNCE_MATERIAL,
+                   tri_light_mode=TRI_LIGHT_SOLID_ANGLE, hide_lights=0, use_white_albedo_on_first_bounce=0,
+                   transparent_background=0, pre_transformed_vertices=0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(f"unknown path tracer option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def options_for_scene(scene: SceneDesc, **kw) -> PtOptionsC:
+    """create_renderer's per-scene set-up (src/tauray.cc:355-421): NEE weights are zeroed for light
+    classes the scene does not have, projection follows the scene camera."""
+    o = make_options(**kw)
+    if len(scene.point_lights) == 0:
+        o.nee_point = 0.0
+    if len(scene.directional_lights) == 0:
+        o.nee_directional = 0.0
+    if scene.envmap is None:
+        o.nee_envmap = 0.0
+    if not scene.has_tri_lights():
+        o.nee_triangles = 0.0
+    if scene.cameras and "projection" not in kw:
+        o.projection = scene.cameras[0].projection
+    return o
+
+
+class DeviceBuffer:
+    """gpu_buffer-like owner of one device allocation."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(_lib.lib().trhip_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def data_ptr(self):
+        return self.ptr
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(_lib.lib().trhip_upload(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes, None))
+        return self
+
+    def download(self, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(_lib.lib().trhip_download(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes, None))
+        return out
+
+    def zero(self):
+        check(_lib.lib().trhip_memset(self.ctx.h, self.ptr, 0, self.nbytes, None))
+        return self
+
+    def free(self):
+        if self.ptr:
+            _lib.lib().trhip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+
+
+class Context:
+    """One HIP device (the reference's context enumerates all Vulkan devices in one process; here each
+    process owns one GPU and peers are reached through torch.distributed)."""
+
+    def __init__(self, hip_device: int = 0):
+        h = C.c_void_p()
+        check(_lib.lib().trhip_device_create(hip_device, C.byref(h)))
+        self.h = h.value
+        self.hip_device = hip_device
+
+    def alloc(self, nbytes) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def sync(self, stream=None):
+        check(_lib.lib().trhip_sync(self.h, stream))
+
+    def close(self):
+        if self.h:
+            _lib.lib().trhip_device_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SceneStage:
+    """scene_stage: uploads the flattened scene and builds the acceleration structure on the device."""
+
+    def __init__(self, ctx: Context, scene: Optional[SceneDesc] = None):
+        self.ctx = ctx
+        self.scene = None
+        self.accel = None
+        if scene is not None:
+            self.set_scene(scene)
+
+    def set_scene(self, scene: SceneDesc):
+        L = _lib.lib()
+        keep = []
+
+        def k(a):
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+            return a
+
+        def p(a):
+            return a.ctypes.data if a.size else None
+
+        infos, texels = scene.texture_table()
+        inst, spans, verts, idx = k(scene.instances), k(scene.spans), k(scene.vertices), k(scene.indices)
+        pls, dls, infos, texels = k(scene.point_lights), k(scene.directional_lights), k(infos), k(texels)
+        cams, non_opaque = k(scene.camera_data()), k(scene.potentially_transparent().astype(np.uint8))
+        d = SceneDescC()
+        d.instances, d.spans, d.instance_count = p(inst), p(spans), len(inst)
+        d.vertices, d.vertex_count = p(verts), len(verts)
+        d.indices, d.index_count = p(idx), len(idx)
+        d.point_lights, d.point_light_count = p(pls), len(pls)
+        d.directional_lights, d.directional_light_count = p(dls), len(dls)
+        d.texture_infos, d.texture_count, d.texels = p(infos), len(infos), p(texels)
+        if scene.envmap is not None:
+            env = k(np.asarray(scene.envmap, dtype=np.float32))
+            at = k(build_alias_table(env))
+            d.envmap, d.envmap_width, d.envmap_height, d.alias_table = p(env), env.shape[1], env.shape[0], p(at)
+        d.environment_factor = (C.c_float * 4)(*[float(x) for x in scene.environment_factor])
+        d.cameras, d.camera_count = p(cams), len(cams)
+        d.non_opaque = p(non_opaque)
+        d.gather_emissive_triangles = 1 if getattr(scene, "tri_light_count", 0) > 0 else 0
+        check(L.trhip_scene_upload(self.ctx.h, C.byref(d)))
+        info = AccelInfoC()
+        check(L.trhip_scene_build_accel(self.ctx.h, C.byref(info)))
+        self.scene = scene
+        self.accel = dict(triangle_count=info.triangle_count, node_count=info.node_count,
+                          tri_light_count=info.tri_light_count, build_ms=info.build_ms,
+                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
+        return self.accel
+
+    def update_cameras(self, cameras):
+        data = np.concatenate([c.pack() for c in cameras])
+        check(_lib.lib().trhip_scene_update_cameras(self.ctx.h, data.ctypes.data, len(data)))
+
+    def tri_lights(self) -> np.ndarray:
+        from .scene import TRI_LIGHT
+        n = self.accel["tri_light_count"]
+        out = np.zeros(n, dtype=TRI_LIGHT)
+        if n:
+            check(_lib.lib().trhip_scene_get_tri_lights(self.ctx.h, out.ctypes.data, n))
+        return out
+
+    def trace_closest(self, rays: np.ndarray, seeds: Optional[np.ndarray] = None, include_lights=False) -> np.ndarray:
+        """traceRayEXT closest-hit query on explicit rays (parity hook)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        hit_dtype = np.dtype([("instance_id", "<i4"), ("primitive_id", "<i4"), ("bary_u", "<f4"), ("bary_v", "<f4"), ("t", "<f4")])
+        if n == 0:
+            return np.zeros(0, dtype=hit_dtype)
+        d_rays = self.ctx.alloc(rays.nbytes).upload(rays)
+        d_seeds = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+            d_seeds = self.ctx.alloc(seeds.nbytes).upload(seeds)
+        d_hits = self.ctx.alloc(n * 20)
+        check(_lib.lib().trhip_trace_closest(self.ctx.h, n, d_rays.ptr, d_seeds.ptr if d_seeds else None,
+                                             1 if include_lights else 0, d_hits.ptr, None))
+        return d_hits.download((n,), hit_dtype)
+
+    def trace_shadow(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        if n == 0:
+            return np.zeros(0, dtype=np.float32)
+        d_rays = self.ctx.alloc(rays.nbytes).upload(rays)
+        d_vis = self.ctx.alloc(n * 4)
+        check(_lib.lib().trhip_trace_shadow(self.ctx.h, n, d_rays.ptr, d_vis.ptr, None))
+        return d_vis.download((n,), np.float32)
+
+
+def _dist_c(p: DistributionParams) -> DistributionC:
+    return DistributionC(int(p.size[0]), int(p.size[1]), int(p.strategy), int(p.index), int(p.count), 1 if p.primary else 0)
+
+
+class PathTracerStage:
+    """path_tracer_stage(device&, scene_stage&, const gbuffer_target&, const options&)."""
+
+    def __init__(self, ctx: Context, scene_stage: SceneStage, options: PtOptionsC, distribution: Optional[DistributionParams] = None):
+        self.ctx, self.ss, self.opt = ctx, scene_stage, options
+        h = C.c_void_p()
+        check(_lib.lib().trhip_pt_create(ctx.h, C.byref(options), C.byref(h)))
+        self.h = h.value
+        self.distribution = None
+        if distribution is not None:
+            self.reset_distribution_params(distribution)
+
+    def reset_distribution_params(self, distribution: DistributionParams):
+        d = _dist_c(distribution)
+        check(_lib.lib().trhip_pt_set_distribution(self.h, C.byref(d)))
+        self.distribution = distribution
+
+    def reset_accumulated_samples(self):
+        check(_lib.lib().trhip_pt_reset_accumulation(self.h, 0))
+
+    def reset_sample_counter(self):
+        check(_lib.lib().trhip_pt_reset_accumulation(self.h, 1))
+
+    def run(self, color_target, viewports=1, stream=None):
+        """stage::run: enqueue one frame (all passes) into `color_target` (device RGBA32F)."""
+        tw, th = get_distribution_target_size(self.distribution)
+        check(_lib.lib().trhip_pt_render(self.h, _ptr(color_target), tw, th, viewports, stream))
+
+    def set_profiling(self, count_work=False, detailed_timing=False):
+        check(_lib.lib().trhip_pt_set_profiling(self.h, int(count_work), int(detailed_timing)))
+
+    def counters(self) -> dict:
+        c = CountersC()
+        check(_lib.lib().trhip_pt_get_counters(self.h, C.byref(c)))
+        return {n: int(getattr(c, n)) for n, _ in CountersC._fields_}
+
+    def reset_counters(self):
+        check(_lib.lib().trhip_pt_reset_counters(self.h))
+
+    def timings(self) -> dict:
+        t = TimingsC()
+        check(_lib.lib().trhip_pt_get_timings(self.h, C.byref(t)))
+        return {n: float(getattr(t, n)) for n, _ in TimingsC._fields_}
+
+    def close(self):
+        if self.h:
+            _lib.lib().trhip_pt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FeatureStage:
+    """feature_stage: primary-hit AOVs from the same traversal."""
+
+    def __init__(self, ctx: Context, scene_stage: SceneStage, feature: int, distribution: DistributionParams, projection=0,
+                 min_ray_dist=1e-4, default_value=(np.nan,) * 4):
+        self.ctx, self.ss, self.feature, self.distribution = ctx, scene_stage, feature, distribution
+        self.projection, self.min_ray_dist, self.default_value = projection, min_ray_dist, default_value
+
+    def run(self, color_target, viewport=0, stream=None):
+        tw, th = get_distribution_target_size(self.distribution)
+        d = _dist_c(self.distribution)
+        dv = (C.c_float * 4)(*self.default_value)
+        check(_lib.lib().trhip_feature_render(self.ctx.h, self.feature, C.byref(d), self.projection, viewport, self.min_ray_dist, dv,
+                                              _ptr(color_target), tw, th, stream))
+
+
+class StitchStage:
+    """stitch_stage: scatter non-primary partial images into the primary image."""
+
+    def __init__(self, ctx: Context, size, blend_ratio=1.0):
+        self.ctx, self.size, self.blend_ratio = ctx, tuple(size), blend_ratio
+
+    def set_blend_ratio(self, r):
+        self.blend_ratio = r
+
+    def run_one(self, partial_dist: DistributionParams, partial, primary, viewports=1, stream=None):
+        pw, ph = get_distribution_target_size(partial_dist)
+        d = _dist_c(partial_dist)
+        check(_lib.lib().trhip_stitch(self.ctx.h, C.byref(d), _ptr(partial), pw, ph, _ptr(primary), viewports, self.blend_ratio, stream))
+
+
+class TonemapStage:
+    """tonemap_stage (filmic default, exposure 1, gamma 2.2; alpha grid only when not headless)."""
+
+    def __init__(self, ctx: Context, op=TONEMAP_FILMIC, exposure=1.0, gamma=2.2, alpha_grid_background=False):
+        self.ctx = ctx
+        self.info = TonemapInfoC(op, exposure, gamma, 16 if alpha_grid_background else 0)
+
+    def run(self, src, dst, width, height, layers=1, stream=None):
+        check(_lib.lib().trhip_tonemap(self.ctx.h, _ptr(src), _ptr(dst), width, height, layers, C.byref(self.info), stream))
+
+
+class RtRenderer:
+    """rt_renderer<path_tracer_stage> for one rank of an N-GPU job.
+
+    Each rank renders its share (`get_device_distribution_params`) into its own target; the display
+    rank (0) owns the full-size image.  `render()` = scene update -> ray tracer -> transfer -> stitch ->
+    tonemap (src/rt_renderer.cc:84-133).  Transfers use torch.distributed (backend "nccl" = RCCL over
+    xGMI): non-display ranks `send` their partial, the display rank `recv`s it straight into device
+    memory and runs the stitch kernel - replacing the GPU->pinned host->GPU copies of
+    src/device_transfer.cc:21-347.
+    """
+
+    def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
+                 rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None):
+        self.ctx, self.opt, self.size = ctx, options, (int(size[0]), int(size[1]))
+        self.rank, self.world_size, self.viewports = rank, world_size, viewports
+        self.strategy = DISTRIBUTION_DUPLICATE if world_size == 1 else strategy   # src/tauray.cc:519-521
+        self.accumulate = accumulate
+        self.scene_update = SceneStage(ctx, scene)
+        workloads = [1.0 / world_size] * world_size
+        self.dists = self._device_dists(workloads)
+        self.dist = self.dists[rank]
+        self.ray_tracer = PathTracerStage(ctx, self.scene_update, options, self.dist)
+        tw, th = get_distribution_target_size(self.dist)
+        self.target_size = (tw, th)
+        self.use_torch = (world_size > 1) if use_torch is None else use_torch
+        self._torch = None
+        if self.use_torch:
+            import torch
+            self._torch = torch
+            self.color = torch.zeros((viewports, th, tw, 4), dtype=torch.float32, device=f"cuda:{ctx.hip_device}")
+        else:
+            self.color = ctx.alloc(viewports * tw * th * 16).zero()
+        self.stitch = StitchStage(ctx, self.size) if world_size > 1 else None
+        self.tonemap = TonemapStage(ctx, **(tonemap or {}))
+        self.display = None
+        self.recv_buffers = {}
+        self.accumulated_frames = 0
+
+    def _device_dists(self, ratios) -> List[DistributionParams]:
+        out, cumulative = [], 0.0
+        for i in range(self.world_size):
+            ratio = min(max(ratios[i], 0.0), 1.0 - cumulative)
+            out.append(get_device_distribution_params(self.size, self.strategy, cumulative, ratio, i, self.world_size, i == 0))
+            cumulative += ratio
+        return out
+
+    def set_scene(self, scene: SceneDesc):
+        self.scene_update.set_scene(scene)
+
+    def reset_accumulation(self, reset_sample_counter=False):
+        self.ray_tracer.reset_accumulated_samples()
+        if reset_sample_counter:
+            self.ray_tracer.reset_sample_counter()
+        self.accumulated_frames = 0
+
+    def set_device_workloads(self, ratios):
+        """rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183): only for shuffled strips."""
+        if self.strategy in (DISTRIBUTION_SCANLINE, DISTRIBUTION_DUPLICATE):
+            return
+        self.dists = self._device_dists(ratios)
+        self.dist = self.dists[self.rank]
+        self.ray_tracer.reset_distribution_params(self.dist)
+        if self.rank != 0:
+            self.ray_tracer.reset_accumulated_samples()
+
+    def render_partial(self, stream=None):
+        if not self.accumulate:
+            self.ray_tracer.reset_accumulated_samples()
+        self.ray_tracer.run(self.color, self.viewports, stream)
+
+    def transfer_and_stitch(self):
+        """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0."""
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+        torch = self._torch
+        if self.rank == 0:
+            reqs = []
+            for r in range(1, self.world_size):
+                pw, ph = get_distribution_target_size(self.dists[r])
+                buf = self.recv_buffers.get(r)
+                if buf is None or tuple(buf.shape) != (self.viewports, ph, pw, 4):
+                    buf = torch.empty((self.viewports, ph, pw, 4), dtype=torch.float32, device=self.color.device)
+                    self.recv_buffers[r] = buf
+                reqs.append(dist.irecv(buf, src=r))
+            for q in reqs:
+                q.wait()
+            torch.cuda.current_stream().synchronize()
+            for r in range(1, self.world_size):
+                self.stitch.run_one(self.dists[r], self.recv_buffers[r], self.color, self.viewports)
+            self.stitch.set_blend_ratio(1.0)
+        else:
+            dist.send(self.color, dst=0)
+
+    def render(self, tonemap=True):
+        self.render_partial()
+        if self.use_torch:
+            self.ctx.sync()
+        self.transfer_and_stitch()
+        if tonemap and self.rank == 0:
+            self.post_process()
+        self.accumulated_frames += 1
+
+    def post_process(self):
+        w, h = self.size
+        if self.display is None:
+            if self.use_torch:
+                self.display = self._torch.empty((self.viewports, h, w, 4), dtype=self._torch.float32, device=self.color.device)
+            else:
+                self.display = self.ctx.alloc(self.viewports * w * h * 16)
+        self.tonemap.run(self.color, self.display, w, h, self.viewports)
+
+    def download(self, which="color") -> np.ndarray:
+        self.ctx.sync()
+        buf = self.color if which == "color" else self.display
+        if which == "color":
+            tw, th = self.target_size
+        else:
+            tw, th = self.size
+        if self.use_torch:
+            self._torch.cuda.synchronize()
+            return buf.cpu().numpy()
+        return buf.download((self.viewports, th, tw, 4), np.float32)
