@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the path_tracer_stage hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload test_glb|sponza_class|sponza_teapots]
+
+A "step" is one frame: every pass of path_tracer_stage over one 1920x1080 image (1 spp, 4 bounces, all other
+options at the reference's CLI defaults), followed by the multi-GPU gather/stitch and the tonemap - the
+`render()` sequence of rt_renderer (reference src/rt_renderer.cc:84-133).  Scene upload, BVH build and image
+save are outside the timed region (reference README "Benchmarking", docs/MANUAL.md:405-408).
+
+Prints ONE JSON line (rank 0).  `value` = rays actually traced (closest-hit + shadow, device counters) per second
+over all GPUs.  With N > 1 the frame is sharded by interleaved scanlines (DISTRIBUTION_SCANLINE) and the partial
+frames are gathered on rank 0 over RCCL: total work is fixed, so scaling is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="test_glb", choices=["test_glb", "sponza_class", "sponza_teapots"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--sampler", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from tauray_amd import renderer as R
+    from tauray_amd import scenes
+    from tauray_amd.distribution import DISTRIBUTION_SCANLINE
+
+    world = args.gpus
+    rank = 0
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        world = int(os.environ.get("WORLD_SIZE", str(world)))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        local_rank = 0
+
+    W, H = args.width, args.height
+    scene = scenes.WORKLOADS[args.workload](W, H)
+    ctx = R.Context(local_rank)
+    opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, rank=rank, world_size=world, viewports=1)
+    pt = rr.ray_tracer
+
+    def sync_all():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_frames(n):
+        for _ in range(n):
+            rr.reset_accumulation()     # offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
+            rr.render()
+
+    # ---- timed region: W warm-up frames, then exactly K frames between barriers
+    pt.set_profiling(False, not args.no_roofline)
+    rr.reset_accumulation(reset_sample_counter=True)
+    run_frames(args.warmup)
+    sync_all()
+    pt.reset_counters()
+    t0 = time.perf_counter()
+    run_frames(args.steps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    counters = pt.counters()
+    timings = pt.timings()
+    rays_local = counters["closest_rays"] + counters["shadow_rays"]
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_local], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = int(r.item())
+    else:
+        rays_total = rays_local
+
+    if counters["stack_overflows"]:
+        raise RuntimeError("BVH traversal stack overflow: results invalid")
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_total / elapsed / 1e6
+    result = {
+        "metric": "Mray/s (closest-hit + shadow rays traced) @1920x1080, 4 bounces, 1 spp",
+        "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic" if args.workload != "test_glb" else "reference fixture test/test.glb (81 364 triangles)",
+        "config": {"workload": args.workload, "triangles": scene.triangle_count, "width": W, "height": H, "bounces": args.bounces,
+                   "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
+                   "parallelism": "scanline-sharded x%d + RCCL gather" % world if world > 1 else "single GPU",
+                   "scene_hash": scenes.scene_hash(scene)},
+        "rays_per_frame": rays_total // args.steps,
+        "msample_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
+    }
+
+    # ---- roofline of the dominant kernel (k_trace_closest), rank 0
+    if rank == 0 and not args.no_roofline:
+        launches = max(timings["trace_closest_launches"], 1)
+        avg_ms = timings["trace_closest_ms"] / launches
+        # counted re-run of the identical frames (same frame indices) for the algorithmic byte model
+        pt.set_profiling(True, False)
+        rr.reset_accumulation(reset_sample_counter=True)
+        run_frames(args.warmup)
+        ctx.sync()
+        pt.reset_counters()
+        run_frames(args.steps)
+        ctx.sync()
+        c = pt.counters()
+        # bytes per SURVEY.md section 8(d), restricted to what trace kernels touch; the closest-hit kernel's share of
+        # node/triangle work is apportioned by ray count (both trace kernels walk the same structure)
+        closest_share = c["closest_rays"] / max(c["closest_rays"] + c["shadow_rays"], 1)
+        trace_bytes = (c["node_visits"] * 64 + c["tri_tests"] * 48 + c["alpha_tests"] * 52) * closest_share \
+            + c["closest_rays"] * (16 + 16 + 16 + 16)   # ray origin + direction + misc read, hit record write
+        bytes_per_launch = trace_bytes / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        frame_bytes = (c["node_visits"] * 64 + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
+                       + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.spp * 16 * args.steps) / args.steps
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "kernel_ms_per_frame": {k: round(timings[k + "_ms"] / args.steps, 4) for k in ("trace_closest", "trace_shadow", "shade", "raygen", "resolve")},
+            "node_visits_per_ray": round(c["node_visits"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
+            "tri_tests_per_ray": round(c["tri_tests"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
+        }
+
+    # ---- CPU baseline: the oracle (a port; the reference has no CPU path) on the host cores, rank 0, N = 1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as B
+        osc = B.OracleScene(scene)
+        oopt = B.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, sampler=args.sampler)
+        cores = os.cpu_count() or 1
+        frames = 0
+        t0 = time.perf_counter()
+        while True:
+            osc.render_pt(oopt, W, H, frame_counter=frames, threads=cores)
+            frames += 1
+            if time.perf_counter() - t0 >= args.cpu_seconds:
+                break
+        dt = time.perf_counter() - t0
+        oc = osc.counters()
+        result["cpu_baseline"] = {
+            "value": round((oc["closest_rays"] + oc["shadow_rays"]) / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} full {W}x{H} frame(s) of the same workload, {dt:.1f} s of wall time, OpenMP over rows",
+            "ms_per_frame": round(dt / frames * 1e3, 1),
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

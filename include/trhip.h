@@ -119,7 +119,10 @@ typedef struct trhip_counters {       /* per trhip_pt, cumulative since the last
 
 typedef struct trhip_timings {        /* hipEvent timers with the reference's stage names (src/timer.cc) */
     float path_tracing_ms;            /* "path tracing (N viewports)" of the last trhip_pt_render */
-    float trace_closest_ms, trace_shadow_ms, shade_ms, raygen_ms, resolve_ms;   /* valid when detailed timing is on */
+    /* Per-kernel device time, cumulative since the last trhip_pt_reset_counters; only collected while
+     * detailed timing is on (event pairs around every launch, no host synchronisation). */
+    float trace_closest_ms, trace_shadow_ms, shade_ms, raygen_ms, resolve_ms;
+    uint32_t trace_closest_launches, trace_shadow_launches, shade_launches, frames;
 } trhip_timings;
 
 int trhip_pt_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out);   /* path_tracer_stage ctor */

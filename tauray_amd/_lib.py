@@ -56,7 +56,8 @@ class CountersC(C.Structure):
 
 
 class TimingsC(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("path_tracing_ms", "trace_closest_ms", "trace_shadow_ms", "shade_ms", "raygen_ms", "resolve_ms")]
+    _fields_ = ([(n, C.c_float) for n in ("path_tracing_ms", "trace_closest_ms", "trace_shadow_ms", "shade_ms", "raygen_ms", "resolve_ms")]
+                + [(n, C.c_uint32) for n in ("trace_closest_launches", "trace_shadow_launches", "shade_launches", "frames")])
 
 
 class TonemapInfoC(C.Structure):

@@ -7,6 +7,8 @@
 // are compacted with wave ballots into id queues between bounces so later bounces launch dense waves.
 // Kernel launches are sized for the worst case and read the live count from device memory: there is no
 // host round trip inside a frame.
+#include <vector>
+
 #include "pt.h"
 #include "trace.h"
 
@@ -548,11 +550,23 @@ void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/dis
     else { w = d.count; h = 1; }
 }
 
+struct TimedSpan { int kind; hipEvent_t a, b; };
+enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_KINDS = 5 };
+
 struct PtStage::Impl {
     PathBuffers pb{};
     size_t capacity = 0;
-    hipEvent_t ev[16]{};
+    hipEvent_t ev[2]{};
     bool ev_init = false;
+    std::vector<hipEvent_t> pool;      // recycled events for per-launch timing
+    std::vector<TimedSpan> pending;    // recorded, not yet resolved
+    float acc_ms[T_KINDS] = {0, 0, 0, 0, 0};
+    uint acc_launches[T_KINDS] = {0, 0, 0, 0, 0};
+    uint frames = 0;
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
 };
 
 PtStage::PtStage(DeviceScene* scene, const trhip_pt_options& o) : scene(scene), opt(o), impl(new Impl()) {
@@ -562,6 +576,8 @@ PtStage::PtStage(DeviceScene* scene, const trhip_pt_options& o) : scene(scene), 
 PtStage::~PtStage() {
     free_buffers();
     if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
+    for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto& e : impl->pool) (void)hipEventDestroy(e);
     delete impl;
 }
 
@@ -637,52 +653,53 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
     const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
     const bool count = count_work != 0;
     const bool timing = detailed_timing != 0;
-    float t_closest = 0, t_shadow = 0, t_shade = 0, t_raygen = 0, t_resolve = 0;
     auto& ev = impl->ev;
+    // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
+    auto timed = [&](int kind, auto&& launch) {
+        if (!timing) { launch(); return; }
+        TimedSpan sp{kind, impl->get_event(), impl->get_event()};
+        (void)hipEventRecord(sp.a, stream);
+        launch();
+        (void)hipEventRecord(sp.b, stream);
+        impl->pending.push_back(sp);
+    };
     HIPCHK(hipEventRecord(ev[0], stream));
     const int passes = opt.samples_per_pixel / opt.samples_per_pass;
     for (int pass = 0; pass < passes; ++pass) {
         P.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
         for (int s = 0; s < opt.samples_per_pass; ++s) {
             P.sample_in_pass = (uint)s;
-            if (timing) HIPCHK(hipEventRecord(ev[2], stream));
-            hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, P, pb);
-            hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, stream, pb.counters);
-            if (timing) { HIPCHK(hipEventRecord(ev[3], stream)); }
+            timed(T_RAYGEN, [&] {
+                hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, P, pb);
+                hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, stream, pb.counters);
+            });
             for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                 const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
                 uint* qn = pb.queue[(bounce + 1) & 1];
-                if (timing) HIPCHK(hipEventRecord(ev[4], stream));
-                if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
-                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
-                if (timing) HIPCHK(hipEventRecord(ev[5], stream));
-                if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
-                else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
-                if (timing) HIPCHK(hipEventRecord(ev[6], stream));
+                timed(T_CLOSEST, [&] {
+                    if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+                    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+                });
+                timed(T_SHADE, [&] {
+                    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
+                    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
+                });
                 if (bounce < opt.max_bounces - 1) {
-                    if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
-                    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                    timed(T_SHADOW, [&] {
+                        if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                        else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                    });
                 }
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters);
-                if (timing) {
-                    HIPCHK(hipEventRecord(ev[7], stream));
-                    HIPCHK(hipEventSynchronize(ev[7]));
-                    float a, b, c;
-                    HIPCHK(hipEventElapsedTime(&a, ev[4], ev[5])); HIPCHK(hipEventElapsedTime(&b, ev[5], ev[6])); HIPCHK(hipEventElapsedTime(&c, ev[6], ev[7]));
-                    t_closest += a; t_shade += b; t_shadow += c;
-                }
             }
             hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, P, pb);
-            if (timing) { float a; HIPCHK(hipEventSynchronize(ev[3])); HIPCHK(hipEventElapsedTime(&a, ev[2], ev[3])); t_raygen += a; }
         }
-        if (timing) HIPCHK(hipEventRecord(ev[8], stream));
-        hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev);
-        if (timing) { HIPCHK(hipEventRecord(ev[9], stream)); HIPCHK(hipEventSynchronize(ev[9])); float a; HIPCHK(hipEventElapsedTime(&a, ev[8], ev[9])); t_resolve += a; }
+        timed(T_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev); });
     }
     HIPCHK(hipEventRecord(ev[1], stream));
     HIPCHK(hipGetLastError());
     timing_pending = true;
-    last.trace_closest_ms = t_closest; last.trace_shadow_ms = t_shadow; last.shade_ms = t_shade; last.raygen_ms = t_raygen; last.resolve_ms = t_resolve;
+    impl->frames++;
     // rt_stage::update: frame_counter++ ; rt_camera_stage::update: accumulated_samples += samples_per_pixel
     frame_counter++;
     accumulated_samples += (uint)opt.samples_per_pixel;
@@ -704,17 +721,36 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
 
 int PtStage::reset_counters() {
     if (impl->pb.counters) HIPCHK(hipMemset(impl->pb.counters, 0, CNT_WORDS * sizeof(uint)));
+    if (int rc = resolve_pending()) return rc;
+    for (int k = 0; k < T_KINDS; ++k) { impl->acc_ms[k] = 0; impl->acc_launches[k] = 0; }
+    impl->frames = 0;
+    return 0;
+}
+
+int PtStage::resolve_pending() {
+    for (auto& sp : impl->pending) {
+        HIPCHK(hipEventSynchronize(sp.b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+        impl->acc_ms[sp.kind] += ms;
+        impl->acc_launches[sp.kind]++;
+        impl->pool.push_back(sp.a); impl->pool.push_back(sp.b);
+    }
+    impl->pending.clear();
     return 0;
 }
 
 int PtStage::get_timings(trhip_timings* out) {
-    *out = last;
-    out->path_tracing_ms = 0;
+    memset(out, 0, sizeof(*out));
     if (timing_pending) {
         HIPCHK(hipEventSynchronize(impl->ev[1]));
         HIPCHK(hipEventElapsedTime(&out->path_tracing_ms, impl->ev[0], impl->ev[1]));
-        last.path_tracing_ms = out->path_tracing_ms;
     }
+    if (int rc = resolve_pending()) return rc;
+    out->trace_closest_ms = impl->acc_ms[T_CLOSEST]; out->trace_shadow_ms = impl->acc_ms[T_SHADOW]; out->shade_ms = impl->acc_ms[T_SHADE];
+    out->raygen_ms = impl->acc_ms[T_RAYGEN]; out->resolve_ms = impl->acc_ms[T_RESOLVE];
+    out->trace_closest_launches = impl->acc_launches[T_CLOSEST]; out->trace_shadow_launches = impl->acc_launches[T_SHADOW];
+    out->shade_launches = impl->acc_launches[T_SHADE]; out->frames = impl->frames;
     return 0;
 }
 

@@ -27,9 +27,9 @@ public:
 private:
     struct Impl;
     Impl* impl;
-    trhip_timings last{};
     bool timing_pending = false;
     int ensure_buffers(size_t n);
+    int resolve_pending();
     void free_buffers();
 };
 

@@ -411,27 +411,27 @@ class RtRenderer:
         import torch.distributed as dist
         torch = self._torch
         if self.rank == 0:
-            reqs = []
+            ops = []
             for r in range(1, self.world_size):
                 pw, ph = get_distribution_target_size(self.dists[r])
                 buf = self.recv_buffers.get(r)
                 if buf is None or tuple(buf.shape) != (self.viewports, ph, pw, 4):
                     buf = torch.empty((self.viewports, ph, pw, 4), dtype=torch.float32, device=self.color.device)
                     self.recv_buffers[r] = buf
-                reqs.append(dist.irecv(buf, src=r))
-            for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+            # one ncclGroupStart/End: every peer's slab arrives over its own xGMI link
+            for q in dist.batch_isend_irecv(ops):
                 q.wait()
-            torch.cuda.current_stream().synchronize()
             for r in range(1, self.world_size):
                 self.stitch.run_one(self.dists[r], self.recv_buffers[r], self.color, self.viewports)
             self.stitch.set_blend_ratio(1.0)
         else:
-            dist.send(self.color, dst=0)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.color, 0)]):
+                q.wait()
 
     def render(self, tonemap=True):
         self.render_partial()
-        if self.use_torch:
-            self.ctx.sync()
+        # kernels run on the null stream, which is also torch's current stream: RCCL orders after them
         self.transfer_and_stitch()
         if tonemap and self.rank == 0:
             self.post_process()
