@@ -753,7 +753,12 @@ void trace_closest(const oracle_scene& s, vec3 org, vec3 dir, float tmin, float 
     float best_t = tmax;
     uint best_gid = 0xFFFFFFFFu;
     bool found = false;
-    if (!s.nodes.empty()) {
+    // non-finite or zero-direction rays are outside traceRayEXT's contract (ggx.glsl:343-348 can emit out_dir = 0 at
+    // bounce 0): defined as a miss
+    const bool finite_ray = std::isfinite(org.x) && std::isfinite(org.y) && std::isfinite(org.z) &&
+                            std::isfinite(dir.x) && std::isfinite(dir.y) && std::isfinite(dir.z) &&
+                            (dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f);
+    if (!s.nodes.empty() && finite_ray) {
         ray_pre r = make_ray(org, dir);
         int stack[128];
         int sp = 0;
@@ -799,7 +804,7 @@ void trace_closest(const oracle_scene& s, vec3 org, vec3 dir, float tmin, float 
             }
         }
     }
-    if (include_lights) {
+    if (include_lights && finite_ray) {
         for (size_t i = 0; i < s.point_lights.size(); ++i) {
             const point_light& pl = s.point_lights[i];
             if (pl.radius == 0.0f) continue;   // degenerate AABB at the origin (src/scene_stage.cc:1366-1368)
@@ -821,6 +826,8 @@ float trace_shadow(const oracle_scene& s, vec3 org, vec3 dir, float tmin, float 
     tc.shadow++;
     float visibility = 1.0f;
     if (s.nodes.empty()) return visibility;
+    if (!(std::isfinite(org.x) && std::isfinite(org.y) && std::isfinite(org.z) && std::isfinite(dir.x) && std::isfinite(dir.y) &&
+          std::isfinite(dir.z) && (dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f))) return visibility;
     ray_pre r = make_ray(org, dir);
     int stack[128];
     int sp = 0;

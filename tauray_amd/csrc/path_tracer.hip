@@ -7,6 +7,8 @@
 // are compacted with wave ballots into id queues between bounces so later bounces launch dense waves.
 // Kernel launches are sized for the worst case and read the live count from device memory: there is no
 // host round trip inside a frame.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "pt.h"
@@ -37,7 +39,7 @@ struct PathBuffers {
 };
 
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
-       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_WORDS = 16 };
+       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_WORDS = 32 };
 
 struct PtParams {
     trhip_pt_options opt;
@@ -125,8 +127,18 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
         f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
         HitRecord hit;
         bool include_lights = !(P.opt.hide_lights && bounce == 0);
+        uint before = st.nodes;
         trace_closest<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
                                 misc.x, s_stack + threadIdx.x, hit, st, overflow);
+        if (COUNT) {
+            uint vis = st.nodes - before;
+            uint old = atomicMax(&pb.counters[CNT_MAXVIS], vis);
+            if (vis > old && vis > 100000u) {
+                float* dbg = reinterpret_cast<float*>(pb.counters + CNT_DBG);
+                dbg[0] = o.x; dbg[1] = o.y; dbg[2] = o.z; dbg[3] = d.x; dbg[4] = d.y; dbg[5] = d.z; dbg[6] = (float)bounce; dbg[7] = (float)id;
+                dbg[8] = o.w; dbg[9] = d.w;
+            }
+        }
         pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
         rays++;
     }
@@ -565,7 +577,7 @@ struct PtStage::Impl {
     uint frames = 0;
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e; (void)hipEventCreate(&e); return e;
+        hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
     }
 };
 
@@ -598,7 +610,7 @@ int PtStage::ensure_buffers(size_t n) {
         HIPCHK(hipMalloc(&pb.counters, CNT_WORDS * sizeof(uint)));
         HIPCHK(hipMemset(pb.counters, 0, CNT_WORDS * sizeof(uint)));
     }
-    if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreate(&e)); impl->ev_init = true; }
+    if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity) return 0;
     free_buffers();
     HIPCHK(hipMalloc(&pb.org_pdf, n * 16)); HIPCHK(hipMalloc(&pb.dir_reg, n * 16)); HIPCHK(hipMalloc(&pb.atten_alpha, n * 16));
@@ -716,6 +728,7 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
     out->closest_rays = rd(CNT_CLOSEST); out->shadow_rays = rd(CNT_SHADOWRAYS); out->node_visits = rd(CNT_NODES);
     out->tri_tests = rd(CNT_TRIS); out->alpha_tests = rd(CNT_ALPHA); out->surface_hits = rd(CNT_SURF);
     out->stack_overflows = h[CNT_OVERFLOW];
+    if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
     return 0;
 }
 

@@ -38,6 +38,11 @@ TR_DEV RayPre make_ray(f3 org, f3 dir) {
     return r;
 }
 
+TR_DEV bool ray_is_finite(f3 o, f3 d) {
+    return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(d.x) && isfinite(d.y) && isfinite(d.z) &&
+           (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f);
+}
+
 // Watertight test (Woop, Benthin, Wald 2013), no culling.  Plain IEEE fp32 without
 // contraction: the shared-edge guarantee needs both products of each edge function
 // rounded, and the CPU oracle evaluates exactly the same expression tree.
@@ -145,7 +150,11 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
     bool found = false;
     uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
     RayPre r = make_ray(org, dir);
-    if (sv.tri_count > 0) {
+    // A ray with a non-finite origin/direction or a zero direction is outside traceRayEXT's contract; the reference
+    // produces one when a refraction sample fails at bounce 0 (ggx.glsl:343-348 sets out_dir = vec3(0)).  It is defined
+    // here as a miss; without this guard a zero direction passes the slab test of every box on its positive side.
+    const bool finite_ray = ray_is_finite(org, dir);
+    if (sv.tri_count > 0 && finite_ray) {
         LaneStack stk;
         stk.init(lds_stack);
         int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
@@ -192,7 +201,7 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
         }
         overflow = overflow || stk.overflow;
     }
-    if (include_lights) {
+    if (include_lights && finite_ray) {
         // rt_common_point_light.rint:11-17 / .rchit:10-15, shader/rt_common.glsl:36-51
         for (uint i = 0; i < sv.point_light_count; ++i) {
             const PointLight& pl = sv.point_lights[i];
@@ -220,7 +229,7 @@ template <bool COUNT>
 TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st,
                           bool& overflow) {
     float visibility = 1.0f;
-    if (sv.tri_count == 0) return visibility;
+    if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
     RayPre r = make_ray(org, dir);
     LaneStack stk;
     stk.init(lds_stack);
