@@ -408,26 +408,12 @@ class RtRenderer:
         """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0."""
         if self.world_size == 1:
             return
-        import torch.distributed as dist
-        torch = self._torch
+        from .transfer import gather_to_display
+        partials = gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers)
+        for r, buf in partials.items():
+            self.stitch.run_one(self.dists[r], buf, self.color, self.viewports)
         if self.rank == 0:
-            ops = []
-            for r in range(1, self.world_size):
-                pw, ph = get_distribution_target_size(self.dists[r])
-                buf = self.recv_buffers.get(r)
-                if buf is None or tuple(buf.shape) != (self.viewports, ph, pw, 4):
-                    buf = torch.empty((self.viewports, ph, pw, 4), dtype=torch.float32, device=self.color.device)
-                    self.recv_buffers[r] = buf
-                ops.append(dist.P2POp(dist.irecv, buf, r))
-            # one ncclGroupStart/End: every peer's slab arrives over its own xGMI link
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
-            for r in range(1, self.world_size):
-                self.stitch.run_one(self.dists[r], self.recv_buffers[r], self.color, self.viewports)
             self.stitch.set_blend_ratio(1.0)
-        else:
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.color, 0)]):
-                q.wait()
 
     def render(self, tonemap=True):
         self.render_partial()

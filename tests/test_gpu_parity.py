@@ -1,0 +1,388 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs,
+against the reference's golden images, and - at the benchmark's full size - through size-independent
+properties (sharded == unsharded, determinism, accumulation linearity)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FEATURES = {"distance": 5, "world-pos": 3, "view-pos": 4, "world-normal": 1, "view-normal": 2, "albedo": 0}
+# fp32 tolerance for radiance: HIP and oracle evaluate the same expression trees, so differences come only from
+# libm (sin/cos/pow/atan2 differ by ulps) and are amplified by path divergence in a few pixels.
+REL_TOL = 1e-2          # per-pixel relative tolerance (with +1e-2 absolute floor)
+MAX_BAD_FRACTION = 2e-3  # pixels allowed outside REL_TOL (paths that flipped a discrete decision)
+
+
+@pytest.fixture(scope="module")
+def R():
+    from tauray_amd import renderer
+    return renderer
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    c = R.Context(0)
+    yield c
+
+
+def _dup(size):
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    return DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True)
+
+
+def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, **kw):
+    from tauray_amd.distribution import get_distribution_target_size
+    d = dist or _dup(size)
+    opt = R.options_for_scene(scene, **kw)
+    pt = R.PathTracerStage(ctx, ss, opt, d)
+    tw, th = get_distribution_target_size(d)
+    color = ctx.alloc(viewports * tw * th * 16).zero()
+    for _ in range(frames):
+        pt.run(color, viewports)
+    img = color.download((viewports, th, tw, 4))
+    c = pt.counters()
+    assert c["stack_overflows"] == 0
+    pt.close()
+    return img
+
+
+def _compare(img, ref, what):
+    assert np.isfinite(img).all(), f"{what}: non-finite output"
+    rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
+    bad = float((rel.max(-1) > REL_TOL).mean())
+    mean_err = abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / max(float(ref[..., :3].mean()), 1e-6)
+    assert bad <= MAX_BAD_FRACTION, f"{what}: {bad:.4%} pixels differ by more than {REL_TOL}"
+    assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
+    assert np.array_equal(img[..., 3], ref[..., 3]), f"{what}: alpha differs"
+
+
+@pytest.fixture(scope="module")
+def glb128(R, ctx, test_glb_128):
+    return R.SceneStage(ctx, test_glb_128)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def test_extension_is_loaded_in_tree():
+    from tauray_amd import _lib
+    assert os.path.dirname(_lib.LIB_PATH) == os.path.dirname(_lib.__file__)
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libtrhip.so" in maps
+
+
+def test_tri_lights_bit_exact(glb128, oracle_scene_128):
+    g, o = glb128.tri_lights(), oracle_scene_128.tri_lights()
+    assert len(g) == 4096 and np.array_equal(g.view(np.uint8), o.view(np.uint8))
+
+
+@pytest.mark.parametrize("name", list(FEATURES))
+def test_feature_images(R, ctx, test_glb_512, oracle_scene_512, name):
+    ss = R.SceneStage(ctx, test_glb_512)
+    fs = R.FeatureStage(ctx, ss, FEATURES[name], _dup((512, 512)))
+    buf = ctx.alloc(512 * 512 * 16).zero()
+    fs.run(buf)
+    img = buf.download((512, 512, 4))
+    ref = oracle_scene_512.render_feature(FEATURES[name], 512, 512)
+    gold = load_golden(name)
+    tol = np.abs(gold) * 2.0 ** -10 + 2e-3
+    assert (np.abs(img[..., :3] - gold) > tol).any(-1).sum() == 0, "outside the reference golden's half-float quantisation"
+    if name == "albedo":   # sRGB decode uses powf: ulp-level differences
+        assert np.abs(img - ref).max() < 1e-6
+    else:                   # geometry is bit-exact against the oracle
+        assert np.array_equal(img, ref)
+
+
+def test_closest_hit_queries_bit_exact(R, ctx, glb128, oracle_scene_128):
+    rng = np.random.default_rng(7)
+    n = 200_000
+    org = rng.uniform(-1.9, 1.9, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], axis=1)
+    rays[:100, 7] = rng.uniform(0.1, 2.0, size=100)          # finite tmax
+    seeds = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    for sd, lights in ((seeds, True), (None, False)):
+        g = glb128.trace_closest(rays, sd, include_lights=lights)
+        o = oracle_scene_128.trace_closest(rays, sd, include_lights=lights)
+        assert np.array_equal(g["instance_id"], o["instance_id"]) and np.array_equal(g["primitive_id"], o["primitive_id"])
+        assert np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32))
+        hit = g["instance_id"] >= 0
+        assert np.array_equal(g["bary_u"][hit].view(np.uint32), o["bary_u"][hit].view(np.uint32))
+        assert np.array_equal(g["bary_v"][hit].view(np.uint32), o["bary_v"][hit].view(np.uint32))
+        assert 0.5 < hit.mean() <= 1.0   # the room is open towards the camera
+
+
+def test_shadow_queries(R, ctx, glb128, oracle_scene_128):
+    rng = np.random.default_rng(8)
+    n = 100_000
+    org = rng.uniform(-1.9, 1.9, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, rng.uniform(0.05, 3.0, size=(n, 1)).astype(np.float32)], axis=1)
+    g, o = glb128.trace_shadow(rays), oracle_scene_128.trace_shadow(rays)
+    assert np.array_equal(g == 0, o == 0)
+    assert np.allclose(g, o, atol=1e-6)           # partial coverage: product order may differ
+    assert ((g > 0) & (g < 1)).sum() > 10          # the alpha-blended plane produces fractional visibility
+
+
+def test_degenerate_rays_are_cheap_misses(R, ctx, glb128):
+    rays = np.zeros((6, 8), dtype=np.float32)
+    rays[:, 7] = np.inf
+    rays[0, 4:7] = 0                                # zero direction (failed refraction sample, ggx.glsl:343-348)
+    rays[1, 4:7] = np.nan
+    rays[2, 4:7] = (np.inf, 0, 0)
+    rays[3, 0:3] = np.nan; rays[3, 4:7] = (0, 0, -1)
+    rays[4, 4:7] = (0, 0, -1)                       # a valid ray for contrast
+    rays[5, 4:7] = (0, -0.0, 0)
+    hits = glb128.trace_closest(rays, np.arange(6, dtype=np.uint32), include_lights=True)
+    assert list(hits["instance_id"] >= 0) == [False, False, False, False, True, False]
+    assert np.array_equal(glb128.trace_shadow(rays), np.array([1, 1, 1, 1, 0, 1], dtype=np.float32))
+
+
+OPTION_SETS = {
+    "cli-defaults-8-bounces": dict(),
+    "4-bounces": dict(max_bounces=4),
+    "1-bounce": dict(max_bounces=1),
+    "sobol-owen": dict(max_bounces=4, sampler=1),
+    "sobol-z2": dict(max_bounces=4, sampler=2),
+    "sobol-z3": dict(max_bounces=4, sampler=3, samples_per_pixel=2),
+    "box-film": dict(max_bounces=3, film=1),
+    "blackman-harris": dict(max_bounces=3, film=2, film_radius=1.0),
+    "mis-balance": dict(max_bounces=3, mis_mode=1),
+    "mis-off": dict(max_bounces=3, mis_mode=0),
+    "bounce-hemisphere": dict(max_bounces=3, bounce_mode=0),
+    "bounce-cosine": dict(max_bounces=3, bounce_mode=1),
+    "tri-area": dict(max_bounces=3, tri_light_mode=0),
+    "tri-hybrid": dict(max_bounces=3, tri_light_mode=2),
+    "regularization+clamp": dict(max_bounces=5, regularization_gamma=0.2, indirect_clamping=4.0),
+    "russian-roulette": dict(max_bounces=6, russian_roulette_delta=2.0),
+    "hide-lights-seed": dict(max_bounces=3, hide_lights=1, rng_seed=1234),
+    "no-nee": dict(max_bounces=3, nee_point=0.0, nee_directional=0.0, nee_triangles=0.0),
+    "nee-weights": dict(max_bounces=3, nee_point=3.0, nee_directional=0.5, nee_triangles=2.0),
+    "white-albedo-transparent": dict(max_bounces=3, use_white_albedo_on_first_bounce=1, transparent_background=1),
+    "4spp-2-per-pass": dict(max_bounces=3, samples_per_pixel=4, samples_per_pass=2),
+    "dof": dict(max_bounces=2, depth_of_field=1),
+}
+
+
+@pytest.mark.parametrize("name", list(OPTION_SETS))
+def test_path_tracer_matches_oracle(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128, name):
+    kw = OPTION_SETS[name]
+    scene = test_glb_128
+    if name == "dof":
+        scene.cameras[0].set_focus(0.2, 6.0, 6, 15.0, 0.036)
+        glb128.update_cameras(scene.cameras)
+        osc = oracle.OracleScene(scene)
+    else:
+        osc = oracle_scene_128
+    try:
+        img = _render_hip(R, ctx, glb128, scene, (128, 128), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(scene, **kw), 128, 128)
+        _compare(img, ref, name)
+    finally:
+        if name == "dof":
+            scene.cameras[0].focus = (1.0, 0.0, 0.0, 0.0)
+            glb128.update_cameras(scene.cameras)
+
+
+def test_progressive_accumulation_over_frames(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128):
+    """--accumulation: frame k mixes into the running mean with samples_accumulated (gbuffer.glsl:18-28)."""
+    opt = R.options_for_scene(test_glb_128, max_bounces=3, samples_per_pixel=2)
+    pt = R.PathTracerStage(ctx, glb128, opt, _dup((128, 128)))
+    color = ctx.alloc(128 * 128 * 16).zero()
+    ref = np.zeros((1, 128, 128, 4), dtype=np.float32)
+    oopt = oracle.options_for_scene(test_glb_128, max_bounces=3, samples_per_pixel=2)
+    for f in range(3):
+        pt.run(color)
+        ref = oracle_scene_128.render_pt(oopt, 128, 128, frame_counter=f, samples_accumulated=2 * f, color=ref)
+    _compare(color.download((1, 128, 128, 4)), ref, "accumulated frames")
+    # reset_accumulated_samples keeps the sample counter (offline frames, src/tauray.cc:1101)
+    pt.reset_accumulated_samples()
+    pt.run(color)
+    ref2 = oracle_scene_128.render_pt(oopt, 128, 128, frame_counter=3, samples_accumulated=0)
+    _compare(color.download((1, 128, 128, 4)), ref2, "frame after reset")
+
+
+@pytest.mark.parametrize("world,strategy", [(2, 1), (3, 1), (8, 1), (3, 2)])
+def test_fake_device_sharding_is_bitwise_identical(R, ctx, glb128, test_glb_128, world, strategy):
+    """The reference tests multi-GPU with --fake-devices (src/context.cc:415-416): render every device's share on
+    one GPU, stitch, compare with the unsharded frame.  Pixel -> RNG mapping is by absolute pixel."""
+    from tauray_amd import distribution as D
+    W, H = 128, 128
+    full = _render_hip(R, ctx, glb128, test_glb_128, (W, H), max_bounces=3)
+    dists, cum = [], 0.0
+    for i in range(world):
+        dists.append(D.get_device_distribution_params((W, H), strategy, cum, 1.0 / world, i, world, i == 0))
+        cum += 1.0 / world
+    opt = R.options_for_scene(test_glb_128, max_bounces=3)
+    primary = ctx.alloc(W * H * 16).zero()
+    stitch = R.StitchStage(ctx, (W, H))
+    for i, d in enumerate(dists):
+        pt = R.PathTracerStage(ctx, glb128, opt, d)
+        if i == 0:
+            pt.run(primary)
+        else:
+            tw, th = D.get_distribution_target_size(d)
+            part = ctx.alloc(tw * th * 16).zero()
+            pt.run(part)
+            stitch.run_one(d, part, primary)
+        pt.close()
+    got = primary.download((1, H, W, 4))
+    assert np.array_equal(got, full), f"{(got != full).any(-1).sum()} pixels differ"
+
+
+def test_viewports_and_camera_grid(R, ctx, test_glb_128, oracle):
+    """Viewport (array layer) batching, config 5's light-field grid: layer v == single render with camera v."""
+    import copy
+    from tauray_amd import scene as S
+    scene = copy.copy(test_glb_128)
+    scene.cameras = S.generate_camera_grid(test_glb_128.cameras[0], 3, 2, 0.3, 0.3, 5.0)
+    ss = R.SceneStage(ctx, scene)
+    img = _render_hip(R, ctx, ss, scene, (128, 128), viewports=6, max_bounces=2)
+    osc = oracle.OracleScene(scene)
+    ref = osc.render_pt(oracle.options_for_scene(scene, max_bounces=2), 128, 128, viewports=6)
+    assert img.shape == (6, 128, 128, 4)
+    _compare(img, ref, "camera grid")
+    assert not np.array_equal(img[0], img[5])
+
+
+def test_envmap_scene_matches_oracle(R, ctx, oracle):
+    """Sponza-class scene: environment-map NEE (alias table), directional sun, emissive quads, alpha-tested curtains."""
+    from tauray_amd import scenes
+    scene = scenes.sponza_class(seed=3, target_tris=40000, width=160, height=90)
+    rng = np.random.default_rng(0)
+    scene.envmap = (rng.uniform(0.2, 1.0, size=(8, 16, 4)) ** 2).astype(np.float32)      # non-uniform sky
+    scene.envmap[1, 3, :3] = 20.0
+    ss = R.SceneStage(ctx, scene)
+    osc = oracle.OracleScene(scene)
+    for kw in (dict(max_bounces=4), dict(max_bounces=3, sampler=1)):
+        img = _render_hip(R, ctx, ss, scene, (160, 90), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(scene, **kw), 160, 90)
+        _compare(img, ref, f"sponza_class {kw}")
+        assert img[..., :3].mean() > 0.01
+
+
+def test_other_projections(R, ctx, test_glb_128, oracle):
+    import copy
+    from tauray_amd import scene as S
+    for proj in (S.PROJ_ORTHOGRAPHIC, S.PROJ_EQUIRECTANGULAR):
+        scene = copy.copy(test_glb_128)
+        cam = copy.deepcopy(test_glb_128.cameras[0])
+        cam.projection = proj
+        if proj == S.PROJ_ORTHOGRAPHIC:
+            cam.ortho = (-2.0, 2.0, -2.0, 2.0, 0.0, 100.0)
+        else:
+            cam.transform = np.eye(4)
+        scene.cameras = [cam]
+        ss = R.SceneStage(ctx, scene)
+        img = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=2, projection=proj)
+        ref = oracle.OracleScene(scene).render_pt(oracle.options_for_scene(scene, max_bounces=2, projection=proj), 128, 128)
+        _compare(img, ref, f"projection {proj}")
+
+
+def test_edge_scenes(R, ctx, oracle):
+    """Empty scene, single triangle, degenerate triangles."""
+    from tauray_amd import scene as S
+    cam = S.Camera(fov=60, aspect=1.0)
+    cam.transform = S.trs_matrix((0, 0, 3))
+    tri = np.zeros(3, dtype=S.VERTEX)
+    tri["pos"] = [(-1, -1, 0), (1, -1, 0), (0, 1, 0)]
+    tri["normal"] = (0, 0, 1)
+    tri["tangent"] = (1, 0, 0, 1)
+    mat = S.make_material(albedo=(0.8, 0.8, 0.8, 1), metallic=0.0, roughness=0.5, emission=(0.5, 0.2, 0.1))
+    light = S.make_point_light((5, 5, 5), (0, 0, 2), 0.2)
+
+    def scene_with(verts, idx):
+        n = len(idx) // 3
+        inst = S.make_instance(np.eye(4), mat) if n else np.zeros(0, dtype=S.INSTANCE)
+        return S.SceneDesc(instances=inst, spans=np.array([(0, len(verts), 0, n)] if n else [], dtype=S.MESH_SPAN), vertices=verts,
+                           indices=np.asarray(idx, dtype=np.uint32), point_lights=light, cameras=[cam]).finalize(True)
+
+    deg = np.zeros(6, dtype=S.VERTEX)
+    deg[:3] = tri
+    deg["pos"][3:] = (0.25, 0.25, 0.5)       # zero-area triangle in front of the real one
+    deg["normal"][3:] = (0, 0, 1)
+    for what, sc in (("empty", scene_with(np.zeros(0, dtype=S.VERTEX), [])), ("single triangle", scene_with(tri, [0, 1, 2])),
+                     ("degenerate", scene_with(deg, [0, 1, 2, 3, 4, 5]))):
+        ss = R.SceneStage(ctx, sc)
+        img = _render_hip(R, ctx, ss, sc, (64, 64), max_bounces=3)
+        ref = oracle.OracleScene(sc).render_pt(oracle.options_for_scene(sc, max_bounces=3), 64, 64)
+        _compare(img, ref, what)
+    assert ss.accel["triangle_count"] == 2
+
+
+def test_tonemap_operators(R, ctx, oracle):
+    rng = np.random.default_rng(4)
+    x = (rng.uniform(0, 1, size=(2, 33, 47, 4)) ** 3 * 20).astype(np.float32)
+    x[..., 3] = rng.uniform(0, 1, size=x.shape[:-1])
+    src = ctx.alloc(x.nbytes).upload(x)
+    dst = ctx.alloc(x.nbytes)
+    for op in range(5):
+        R.TonemapStage(ctx, op=op, exposure=1.3, gamma=2.2).run(src, dst, 47, 33, 2)
+        got = dst.download(x.shape)
+        ref = oracle.tonemap(x, op=op, exposure=1.3, gamma=2.2)
+        assert np.allclose(got, ref, rtol=2e-6, atol=1e-6), f"operator {op}"
+    R.TonemapStage(ctx, op=2, alpha_grid_background=True).run(src, dst, 47, 33, 2)
+    assert np.isfinite(dst.download(x.shape)).all()
+
+
+def test_api_errors(R, ctx, test_glb_128):
+    """Errors surface as exceptions with the library's message (the reference throws std::runtime_error)."""
+    c2 = R.Context(0)
+    ss = R.SceneStage(c2)            # nothing uploaded
+    pt = R.PathTracerStage(c2, ss, R.make_options(), _dup((8, 8)))
+    with pytest.raises(R.TrhipError, match="build_accel"):
+        pt.run(c2.alloc(8 * 8 * 16))
+    with pytest.raises(R.TrhipError, match="max_bounces"):
+        R.PathTracerStage(c2, ss, R.make_options(max_bounces=0))
+    with pytest.raises(R.TrhipError):
+        R.Context(4096)
+    import copy
+    bad = copy.copy(test_glb_128)
+    bad.indices = test_glb_128.indices.copy()
+    bad.indices[5] = 10**6
+    with pytest.raises(R.TrhipError, match="out of range"):
+        R.SceneStage(c2, bad)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs 2 and 4)
+def test_full_size_properties(R, ctx):
+    from tauray_amd import scenes
+    from tauray_amd import distribution as D
+    W, H = 1920, 1080
+    scene = scenes.test_glb(W, H)
+    ss = R.SceneStage(ctx, scene)
+    a = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
+    b = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
+    assert np.isfinite(a).all() and np.array_equal(a, b), "a frame is a pure function of (scene, options, frame index)"
+    assert (a[..., 3] == 1).all() and a[..., :3].min() >= 0
+    # 8-way scanline sharding + stitch == unsharded (config 4's partitioning)
+    opt = R.options_for_scene(scene, max_bounces=4)
+    primary = ctx.alloc(W * H * 16).zero()
+    stitch = R.StitchStage(ctx, (W, H))
+    for i in range(8):
+        d = D.get_device_distribution_params((W, H), D.DISTRIBUTION_SCANLINE, i / 8, 1 / 8, i, 8, i == 0)
+        pt = R.PathTracerStage(ctx, ss, opt, d)
+        if i == 0:
+            pt.run(primary)
+        else:
+            tw, th = D.get_distribution_target_size(d)
+            assert (tw, th) == (1920, 135)
+            part = ctx.alloc(tw * th * 16)
+            pt.run(part)
+            stitch.run_one(d, part, primary)
+        pt.close()
+    assert np.array_equal(primary.download((1, H, W, 4)), a)
+    # accumulation linearity: two accumulated 1-spp frames == mean of the two independent frames (up to 1 ulp of mix())
+    pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+    acc = ctx.alloc(W * H * 16).zero()
+    pt.run(acc); f0 = acc.download((1, H, W, 4)).copy()
+    pt.run(acc); both = acc.download((1, H, W, 4))
+    pt.reset_accumulated_samples(); pt.reset_sample_counter()
+    pt.run(acc); pt.reset_accumulated_samples(); pt.run(acc); f1 = acc.download((1, H, W, 4))
+    assert np.array_equal(f0, a)
+    assert np.allclose(both[..., :3], 0.5 * (f0[..., :3] + f1[..., :3]), rtol=1e-6, atol=1e-7)
