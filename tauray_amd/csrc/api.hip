@@ -34,8 +34,8 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     get_screen_camera_ray(L, px, py, cam, projection, false, F2(0), F2(0.5f), origin, dir);
     f3 ray_origin = projection == 2 ? origin : F3(cam.origin);   // rt_feature.rgen:35 traces from cam.origin
     HitRecord hit;
-    TraceStats st = {0, 0, 0};
-    bool overflow = false;
+    TraceStats st = {0, 0, 0, 0};
+    int overflow = 0;
     trace_closest<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
     if (overflow) *overflow_flag = 1;
     f4 data = default_value;
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
 __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
                                                       HitRecord* out, uint* overflow_flag) {
     __shared__ int s_stack[TR_LDS_STACK * KB];
-    bool overflow = false;
-    TraceStats st = {0, 0, 0};
+    int overflow = 0;
+    TraceStats st = {0, 0, 0, 0};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
         HitRecord hit;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, cons
 }
 __global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
     __shared__ int s_stack[TR_LDS_STACK * KB];
-    bool overflow = false;
-    TraceStats st = {0, 0, 0};
+    int overflow = 0;
+    TraceStats st = {0, 0, 0, 0};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
         out[i] = trace_shadow<false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow);

@@ -39,7 +39,7 @@ struct PathBuffers {
 };
 
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
-       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_WORDS = 32 };
+       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORDS = 32 };
 
 struct PtParams {
     trhip_pt_options opt;
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
                                                       const uint* count_ptr) {
     __shared__ int s_stack[TR_LDS_STACK * KB];
     const uint n = queue ? *count_ptr : P.n_launch;
-    TraceStats st = {0, 0, 0};
+    TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
-    bool overflow = false;
+    int overflow = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
         uint id = queue ? queue[qi] : qi;
         u4 misc = pb.misc[id];
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
         trace_closest<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
                                 misc.x, s_stack + threadIdx.x, hit, st, overflow);
         if (COUNT) {
+            atomicMax(&pb.counters[CNT_MAXSP], st.maxsp);
             uint vis = st.nodes - before;
             uint old = atomicMax(&pb.counters[CNT_MAXVIS], vis);
             if (vis > old && vis > 100000u) {
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
         pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
         rays++;
     }
-    if (overflow) pb.counters[CNT_OVERFLOW] = 1;
+    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 1000 + bounce; }
     if (P.count_work) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_xor(rays, off);
@@ -159,9 +160,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
     __shared__ int s_stack[TR_LDS_STACK * KB];
     const uint n = pb.counters[CNT_SHADOW];
-    TraceStats st = {0, 0, 0};
+    TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
-    bool overflow = false;
+    int overflow = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
         f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
         float vis = trace_shadow<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
         }
         rays++;
     }
-    if (overflow) pb.counters[CNT_OVERFLOW] = 1;
+    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 2000; }
     if (P.count_work) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_xor(rays, off);
@@ -728,7 +729,7 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
     out->closest_rays = rd(CNT_CLOSEST); out->shadow_rays = rd(CNT_SHADOWRAYS); out->node_visits = rd(CNT_NODES);
     out->tri_tests = rd(CNT_TRIS); out->alpha_tests = rd(CNT_ALPHA); out->surface_hits = rd(CNT_SURF);
     out->stack_overflows = h[CNT_OVERFLOW];
-    if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
+    if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] overflow %u src %u; max stack depth %u; max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_OVERFLOW], h[CNT_DBG + 12], h[CNT_MAXSP], h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
     return 0;
 }
 

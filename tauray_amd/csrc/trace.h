@@ -13,8 +13,8 @@
 namespace tr {
 
 #define TR_BLOCK 256
-#define TR_LDS_STACK 24
-#define TR_SPILL_STACK 40
+#define TR_LDS_STACK 16
+#define TR_SPILL_STACK 112
 
 struct RayPre {
     f3 org, dir, inv_dir;
@@ -92,26 +92,32 @@ TR_DEV bool box_intersect(const RayPre& r, const float* lo, const float* hi, flo
     return t0 <= t1;
 }
 
-// Per-lane traversal stack: first TR_LDS_STACK entries in LDS, the rest in scratch.
+// Per-lane traversal stack: first TR_LDS_STACK entries in LDS, the rest in a private spill array.
+// `sp` must stay in a VGPR and the LDS access must stay a ds_read/ds_write: the spill array is therefore a separate
+// local (a struct member array drags the whole struct, sp included, into scratch) and pop() reads LDS
+// unconditionally (an if/else over the two memories is if-converted into a generic pointer + flat_load).
 struct LaneStack {
     int* lds;           // &stack[0][lane_in_block]; stride TR_BLOCK
-    int spill[TR_SPILL_STACK];
     int sp;
-    bool overflow;
-    TR_DEV void init(int* base) { lds = base; sp = 0; overflow = false; }
-    TR_DEV void push(int v) {
+    int overflow;       // count of dropped pushes (an int in a VGPR, not a wave-level predicate)
+    TR_DEV void init(int* base) { lds = base; sp = 0; overflow = 0; }
+    TR_DEV void push(int* spill, int v) {
+        const bool ok = sp < TR_LDS_STACK + TR_SPILL_STACK;
         if (sp < TR_LDS_STACK) lds[sp * TR_BLOCK] = v;
-        else if (sp < TR_LDS_STACK + TR_SPILL_STACK) spill[sp - TR_LDS_STACK] = v;
-        else { overflow = true; return; }
-        sp++;
+        else if (ok) spill[sp - TR_LDS_STACK] = v;
+        overflow += ok ? 0 : 1;
+        sp += ok ? 1 : 0;
     }
-    TR_DEV int pop() {
+    TR_DEV int pop(const int* spill) {
         sp--;
-        return sp < TR_LDS_STACK ? lds[sp * TR_BLOCK] : spill[sp - TR_LDS_STACK];
+        int v = lds[(sp < TR_LDS_STACK ? sp : 0) * TR_BLOCK];
+        asm volatile("" : "+v"(v));   // pin the ds_read: no select-of-pointers + flat_load
+        if (sp >= TR_LDS_STACK) v = spill[sp - TR_LDS_STACK];
+        return v;
     }
 };
 
-struct TraceStats { uint nodes, tris, alpha; };
+struct TraceStats { uint nodes, tris, alpha, maxsp; };
 
 // get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit
 TR_DEV f2 candidate_uv(const SceneView& sv, int inst, int prim, float bu, float bv) {
@@ -144,7 +150,7 @@ TR_DEV float alpha_cutoff_hash(uint seed, int instance_id, int primitive_id) {
 // (shader/rt_common.rahit:15-24); 1: fixed cutoff 1e-4 (shader/rt_feature.rahit:17).
 template <int ALPHA_MODE, bool COUNT>
 TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                          int* lds_stack, HitRecord& hit, TraceStats& st, bool& overflow) {
+                          int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
     hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
     float best_t = tmax;
     bool found = false;
@@ -156,6 +162,7 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
     const bool finite_ray = ray_is_finite(org, dir);
     if (sv.tri_count > 0 && finite_ray) {
         LaneStack stk;
+        int spill[TR_SPILL_STACK];
         stk.init(lds_stack);
         int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
         while (true) {
@@ -167,7 +174,8 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
                 bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, best_t, t1);
                 if (h0 && h1) {
                     bool first0 = t0 <= t1;
-                    stk.push(first0 ? n.child1 : n.child0);
+                    stk.push(spill, first0 ? n.child1 : n.child0);
+                    if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                     node = first0 ? n.child0 : n.child1;
                     continue;
                 } else if (h0) { node = n.child0; continue; }
@@ -197,9 +205,9 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
                 }
             }
             if (stk.sp == 0) break;
-            node = stk.pop();
+            node = stk.pop(spill);
         }
-        overflow = overflow || stk.overflow;
+        overflow += stk.overflow;
     }
     if (include_lights && finite_ray) {
         // rt_common_point_light.rint:11-17 / .rchit:10-15, shader/rt_common.glsl:36-51
@@ -227,11 +235,12 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
 // over non-opaque hits, 0 on the first opaque hit; lights are excluded (mask 0xFD).
 template <bool COUNT>
 TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st,
-                          bool& overflow) {
+                          int& overflow) {
     float visibility = 1.0f;
     if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
     RayPre r = make_ray(org, dir);
     LaneStack stk;
+    int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
     int node = sv.node_count > 0 ? 0 : -1;
     while (true) {
@@ -241,7 +250,7 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
             float t0, t1;
             bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, tmax, t0);
             bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, tmax, t1);
-            if (h0 && h1) { stk.push(n.child1); node = n.child0; continue; }
+            if (h0 && h1) { stk.push(spill, n.child1); node = n.child0; continue; }
             else if (h0) { node = n.child0; continue; }
             else if (h1) { node = n.child1; continue; }
         } else {
@@ -258,9 +267,9 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
             }
         }
         if (stk.sp == 0) break;
-        node = stk.pop();
+        node = stk.pop(spill);
     }
-    overflow = overflow || stk.overflow;
+    overflow += stk.overflow;
     return visibility;
 }
 
