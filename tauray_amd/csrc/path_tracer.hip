@@ -39,7 +39,7 @@ struct PathBuffers {
 };
 
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
-       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORDS = 32 };
+       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORK_CLOSEST = 31, CNT_WORK_SHADOW = 32, CNT_WORDS = 34 };
 
 struct PtParams {
     trhip_pt_options opt;
@@ -120,7 +120,22 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
-    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
+    // persistent waves: each wave pulls the next 64 rays from a device-side cursor until the queue is drained
+    // first chunk by wave id (no atomic: avoids a burst of ~7000 dequeues on one word at kernel start), later
+    // chunks from the shared cursor, which starts past the statically assigned range
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    bool first = true;
+    while (true) {
+        uint base = 0;
+        if (first) base = wave_id * 64u;
+        else {
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_CLOSEST], 64u);
+            base = __shfl(base, 0);
+        }
+        first = false;
+        if (base >= n) break;
+        uint qi = base + (threadIdx.x & 63);
+        if (qi >= n) continue;
         uint id = queue ? queue[qi] : qi;
         u4 misc = pb.misc[id];
         if (misc.w & 1u) continue;
@@ -163,7 +178,21 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
-    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
+    // first chunk by wave id (no atomic: avoids a burst of ~7000 dequeues on one word at kernel start), later
+    // chunks from the shared cursor, which starts past the statically assigned range
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    bool first = true;
+    while (true) {
+        uint base = 0;
+        if (first) base = wave_id * 64u;
+        else {
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_SHADOW], 64u);
+            base = __shfl(base, 0);
+        }
+        first = false;
+        if (base >= n) break;
+        uint qi = base + (threadIdx.x & 63);
+        if (qi >= n) continue;
         f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
         float vis = trace_shadow<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
         uint id = __float_as_uint(d.w);
@@ -512,8 +541,12 @@ __global__ void k_advance(uint* counters) {
     counters[CNT_CUR] = counters[CNT_NEXT];
     counters[CNT_NEXT] = 0;
     counters[CNT_SHADOW] = 0;
+    counters[CNT_WORK_CLOSEST] = 0;
+    counters[CNT_WORK_SHADOW] = 0;
 }
-__global__ void k_clear_shadow(uint* counters) { counters[CNT_SHADOW] = 0; counters[CNT_NEXT] = 0; }
+__global__ void k_clear_shadow(uint* counters) {
+    counters[CNT_SHADOW] = 0; counters[CNT_NEXT] = 0; counters[CNT_WORK_CLOSEST] = 0; counters[CNT_WORK_SHADOW] = 0;
+}
 
 // end of one sample: sum_color += colour (path_tracer.rgen:112)
 __global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
