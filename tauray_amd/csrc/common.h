@@ -141,6 +141,23 @@ struct alignas(16) TriRecord {
 };
 static_assert(sizeof(TriRecord) == 48, "tri layout");
 
+// 80-byte compressed 8-wide node (layout after Ylitie, Karras, Laine 2017): child boxes are 8-bit offsets on a
+// per-node power-of-two grid anchored at `p`; five 16-byte loads fetch eight children.
+//   meta[i]: 0 empty | internal: 0b001_xxxxx with xxxxx = 24 + slot | leaf: unary triangle count (0b001/011/111) << 5 | offset
+//   imask  : bit i set = slot i holds an internal child; child node index = child_base + popcount(imask below slot)
+//   leaf triangles live at tris8[tri_base + offset .. + count)
+struct alignas(16) Bvh8Node {
+    float p[3];
+    uint8_t e[3];          // biased exponents: scale = 2^(e - 127)
+    uint8_t imask;
+    uint child_base, tri_base;
+    uint8_t meta[8];
+    uint8_t qlo_x[8], qlo_y[8];
+    uint8_t qlo_z[8], qhi_x[8];
+    uint8_t qhi_y[8], qhi_z[8];
+};
+static_assert(sizeof(Bvh8Node) == 80, "wide node layout");
+
 struct HitRecord { int instance_id, primitive_id; float u, v, t; };
 
 // Everything a kernel needs to see the scene (passed by value).
@@ -159,6 +176,7 @@ struct SceneView {
     const CameraData* cameras;
     const BvhNode* nodes;
     const TriRecord* tris;
+    const Bvh8Node* nodes8;      // non-null selects the 8-wide traversal; tris is then in wide-node order
     f4 environment_factor;
     int environment_proj;
     uint instance_count, point_light_count, directional_light_count, tri_light_count;

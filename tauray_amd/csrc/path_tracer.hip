@@ -112,10 +112,10 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       const uint* count_ptr) {
-    __shared__ int s_stack[TR_LDS_STACK * KB];
+    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
     const uint n = queue ? *count_ptr : P.n_launch;
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
         HitRecord hit;
         bool include_lights = !(P.opt.hide_lights && bounce == 0);
         uint before = st.nodes;
-        trace_closest<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                misc.x, s_stack + threadIdx.x, hit, st, overflow);
+        trace_closest_any<0, COUNT, WIDE>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                misc.x, s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), hit, st, overflow);
         if (COUNT) {
             atomicMax(&pb.counters[CNT_MAXSP], st.maxsp);
             uint vis = st.nodes - before;
@@ -171,9 +171,9 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
-    __shared__ int s_stack[TR_LDS_STACK * KB];
+    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
     const uint n = pb.counters[CNT_SHADOW];
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
         uint qi = base + (threadIdx.x & 63);
         if (qi >= n) continue;
         f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
-        float vis = trace_shadow<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
+        float vis = trace_shadow_any<COUNT, WIDE>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), st, overflow);
         uint id = __float_as_uint(d.w);
         if (vis != 0.0f) {
             // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
@@ -698,6 +698,7 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
     // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
     const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
     const bool count = count_work != 0;
+    const bool wide = sv.nodes8 != nullptr;
     const bool timing = detailed_timing != 0;
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
@@ -723,8 +724,9 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
                 const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
                 uint* qn = pb.queue[(bounce + 1) & 1];
                 timed(T_CLOSEST, [&] {
-                    if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
-                    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+                    auto kc = wide ? (count ? k_trace_closest<true, true> : k_trace_closest<false, true>)
+                                   : (count ? k_trace_closest<true, false> : k_trace_closest<false, false>);
+                    hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
                 });
                 timed(T_SHADE, [&] {
                     if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
@@ -732,8 +734,9 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
                 });
                 if (bounce < opt.max_bounces - 1) {
                     timed(T_SHADOW, [&] {
-                        if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
-                        else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                        auto ks = wide ? (count ? k_trace_shadow<true, true> : k_trace_shadow<false, true>)
+                                       : (count ? k_trace_shadow<true, false> : k_trace_shadow<false, false>);
+                        hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
                     });
                 }
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters);

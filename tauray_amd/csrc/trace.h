@@ -273,4 +273,244 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
     return visibility;
 }
 
+// =====================================================================================================================
+// 8-wide compressed BVH traversal.  Stack entries are node groups (child_base, hit bits << 24 | imask); one entry
+// per level at most, so twelve LDS entries cover trees over 10^9 triangles before spilling.
+#define TR_LDS_STACK8 12
+#define TR_SPILL_STACK8 20
+
+struct LaneStack8 {
+    uint2* lds;          // &stack[0][lane_in_block]; stride TR_BLOCK
+    int sp;
+    int overflow;
+    TR_DEV void init(int* base) { lds = reinterpret_cast<uint2*>(base); sp = 0; overflow = 0; }
+    TR_DEV void push(uint2* spill, uint2 v) {
+        const bool ok = sp < TR_LDS_STACK8 + TR_SPILL_STACK8;
+        if (sp < TR_LDS_STACK8) lds[sp * TR_BLOCK] = v;
+        else if (ok) spill[sp - TR_LDS_STACK8] = v;
+        overflow += ok ? 0 : 1;
+        sp += ok ? 1 : 0;
+    }
+    TR_DEV uint2 pop(const uint2* spill) {
+        sp--;
+        uint2 v = lds[(sp < TR_LDS_STACK8 ? sp : 0) * TR_BLOCK];
+        asm volatile("" : "+v"(v.x), "+v"(v.y));   // keep the LDS read a ds_read_b64
+        if (sp >= TR_LDS_STACK8) v = spill[sp - TR_LDS_STACK8];
+        return v;
+    }
+};
+
+struct Ray8 {
+    f3 org, inv_dir;     // inv_dir with zero components replaced by +-huge so slabs outside the origin reject
+    uint octinv;         // 7 - octant
+};
+
+TR_DEV Ray8 make_ray8(f3 org, f3 dir) {
+    Ray8 r;
+    r.org = org;
+    const float eps = 1e-30f;
+    r.inv_dir.x = 1.0f / (fabsf(dir.x) > eps ? dir.x : copysignf(eps, dir.x));
+    r.inv_dir.y = 1.0f / (fabsf(dir.y) > eps ? dir.y : copysignf(eps, dir.y));
+    r.inv_dir.z = 1.0f / (fabsf(dir.z) > eps ? dir.z : copysignf(eps, dir.z));
+    uint oct = (dir.x < 0.0f ? 4u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 1u : 0u);
+    r.octinv = 7u - oct;
+    return r;
+}
+
+// Tests the eight quantised child boxes of one node.  Returns hit bits: bits 24..31 internal children in traversal
+// priority order (slot ^ octinv), bits 0..23 leaf triangles.
+TR_DEV uint intersect_node8(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4, float tmin, float tmax) {
+    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+    const float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
+                sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+    uint hitmask = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint meta4 = half ? n1.w : n1.z;
+        const uint qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z;
+        const uint qlz = half ? n3.y : n3.x, qhx = half ? n3.w : n3.z;
+        const uint qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int sh = 8 * k;
+            // plane positions decoded exactly as the builder verified them: q * scale + p.  The product is exact
+            // (q <= 255, scale a power of two), so one fma gives the same bits as mul + add.
+            const float x0 = __fmaf_rn((float)((qlx >> sh) & 0xFFu), sx, px), x1 = __fmaf_rn((float)((qhx >> sh) & 0xFFu), sx, px);
+            const float y0 = __fmaf_rn((float)((qly >> sh) & 0xFFu), sy, py), y1 = __fmaf_rn((float)((qhy >> sh) & 0xFFu), sy, py);
+            const float z0 = __fmaf_rn((float)((qlz >> sh) & 0xFFu), sz, pz), z1 = __fmaf_rn((float)((qhz >> sh) & 0xFFu), sz, pz);
+            const float tx0 = (x0 - r.org.x) * r.inv_dir.x, tx1 = (x1 - r.org.x) * r.inv_dir.x;
+            const float ty0 = (y0 - r.org.y) * r.inv_dir.y, ty1 = (y1 - r.org.y) * r.inv_dir.y;
+            const float tz0 = (z0 - r.org.z) * r.inv_dir.z, tz1 = (z1 - r.org.z) * r.inv_dir.z;
+            const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+            const float tf = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000003576278687f, tmax);
+            const uint m = (meta4 >> sh) & 0xFFu;
+            // an empty slot has meta 0 (no bits); branch-free insertion of the child's bits at its priority position
+            const uint inner = ((m & 0x18u) == 0x18u) ? r.octinv : 0u;
+            const uint bits = (m >> 5) << ((m ^ inner) & 0x1Fu);
+            hitmask |= (tn <= tf) ? bits : 0u;
+        }
+    }
+    return hitmask;
+}
+
+TR_DEV void load_node8(const Bvh8Node* nodes, uint index, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4) {
+    const uint4* p = reinterpret_cast<const uint4*>(nodes + index);
+    n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4];
+}
+
+template <int ALPHA_MODE, bool COUNT>
+TR_DEV void trace_closest8(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
+                           int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
+    hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
+    float best_t = tmax;
+    bool found = false;
+    uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
+    const bool finite_ray = ray_is_finite(org, dir);
+    if (sv.tri_count > 0 && finite_ray) {
+        const RayPre r = make_ray(org, dir);
+        const Ray8 r8 = make_ray8(org, dir);
+        LaneStack8 stk;
+        uint2 spill[TR_SPILL_STACK8];
+        stk.init(lds_stack);
+        uint2 G = make_uint2(0u, 0x80000000u);     // the root as a one-child node group
+        while (true) {
+            uint2 T;
+            if (G.y > 0x00FFFFFFu) {
+                const uint hits = G.y;
+                const int bit = 31 - __clz((int)hits);
+                G.y &= ~(1u << bit);
+                if (G.y > 0x00FFFFFFu) { stk.push(spill, G); if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); }
+                const uint slot = ((uint)bit - 24u) ^ r8.octinv;
+                const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
+                uint4 n0, n1, n2, n3, n4;
+                load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
+                if (COUNT) st.nodes++;
+                const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, best_t);
+                G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
+                T = make_uint2(n1.y, hm & 0x00FFFFFFu);
+            } else {
+                T = make_uint2(0u, 0u);
+            }
+            while (T.y) {
+                const int b = __ffs((int)T.y) - 1;
+                T.y &= T.y - 1u;
+                const TriRecord tr = sv.tris[T.x + (uint)b];
+                if (COUNT) st.tris++;
+                float t, bu, bv;
+                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) {
+                    const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+                    const bool closer = t < best_t ||
+                        (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
+                    if (closer && t < tmax) {
+                        bool accept = true;
+                        if (tr.inst_flags & 0x80000000u) {
+                            if (COUNT) st.alpha++;
+                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
+                            accept = !(a <= cutoff);
+                        }
+                        if (accept) {
+                            best_t = t; found = true; best_inst = inst; best_prim = tr.prim;
+                            hit.instance_id = (int)inst; hit.primitive_id = (int)tr.prim; hit.u = bu; hit.v = bv;
+                        }
+                    }
+                }
+            }
+            if (G.y <= 0x00FFFFFFu) {
+                if (stk.sp == 0) break;
+                G = stk.pop(spill);
+            }
+        }
+        overflow += stk.overflow;
+    }
+    if (include_lights && finite_ray) {
+        for (uint i = 0; i < sv.point_light_count; ++i) {
+            const PointLight& pl = sv.point_lights[i];
+            float radius = pl.radius;
+            if (radius == 0.0f) continue;
+            f3 oc = org - pl.pos;
+            float a = dot(dir, dir);
+            float b = 2.0f * dot(oc, dir);
+            float c = dot(oc, oc) - radius * radius;
+            float disc = b * b - 4.0f * a * c;
+            if (disc < 0) continue;
+            float h = (-b - sqrtf(disc)) / (2.0f * a);
+            if (h > 0 && h > tmin && h < best_t) {
+                best_t = h; found = true;
+                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
+            }
+        }
+    }
+    hit.t = found ? best_t : -1.0f;
+}
+
+template <bool COUNT>
+TR_DEV float trace_shadow8(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
+    float visibility = 1.0f;
+    if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
+    const RayPre r = make_ray(org, dir);
+    const Ray8 r8 = make_ray8(org, dir);
+    LaneStack8 stk;
+    uint2 spill[TR_SPILL_STACK8];
+    stk.init(lds_stack);
+    uint2 G = make_uint2(0u, 0x80000000u);
+    bool done = false;
+    while (!done) {
+        uint2 T;
+        if (G.y > 0x00FFFFFFu) {
+            const uint hits = G.y;
+            const int bit = 31 - __clz((int)hits);
+            G.y &= ~(1u << bit);
+            if (G.y > 0x00FFFFFFu) stk.push(spill, G);
+            const uint slot = ((uint)bit - 24u) ^ r8.octinv;
+            const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
+            uint4 n0, n1, n2, n3, n4;
+            load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
+            if (COUNT) st.nodes++;
+            const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, tmax);
+            G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
+            T = make_uint2(n1.y, hm & 0x00FFFFFFu);
+        } else {
+            T = make_uint2(0u, 0u);
+        }
+        while (T.y) {
+            const int b = __ffs((int)T.y) - 1;
+            T.y &= T.y - 1u;
+            const TriRecord tr = sv.tris[T.x + (uint)b];
+            if (COUNT) st.tris++;
+            float t, bu, bv;
+            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; done = true; break; }
+                if (COUNT) st.alpha++;
+                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                visibility *= 1.0f - alpha;
+                if (visibility == 0.0f) { done = true; break; }
+            }
+        }
+        if (!done && G.y <= 0x00FFFFFFu) {
+            if (stk.sp == 0) break;
+            G = stk.pop(spill);
+        }
+    }
+    overflow += stk.overflow;
+    return visibility;
+}
+
+// LDS words per block for the per-lane stacks of either traversal
+#define TR_STACK_WORDS(WIDE) ((WIDE) ? 2 * TR_LDS_STACK8 * TR_BLOCK : TR_LDS_STACK * TR_BLOCK)
+
+template <int ALPHA_MODE, bool COUNT, bool WIDE>
+TR_DEV void trace_closest_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
+                              int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
+    if (WIDE) trace_closest8<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
+    else trace_closest<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
+}
+template <bool COUNT, bool WIDE>
+TR_DEV float trace_shadow_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
+    if (WIDE) return trace_shadow8<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
+    return trace_shadow<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
+}
+
 }  // namespace tr
