@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrhip.so")
+LIB_PATH = os.environ.get("TRHIP_LIB", os.path.join(_HERE, "libtrhip.so"))   # TRHIP_LIB: A/B builds while tuning
 
 
 class TrhipError(RuntimeError):

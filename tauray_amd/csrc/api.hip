@@ -284,7 +284,7 @@ int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint3
 
 int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
-    if (const char* w = getenv("TRHIP_BVH_WIDTH")) dev->scene.bvh_width = atoi(w) == 2 ? 2 : 8;   // A/B switch for profiling
+    if (const char* w = getenv("TRHIP_BVH_WIDTH")) dev->scene.bvh_width = atoi(w) == 8 ? 8 : 2;   // A/B switch for profiling
     return build_accel(dev->scene, nullptr, out);
 }
 

@@ -35,7 +35,7 @@ struct DeviceScene {
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
     uint node_count = 0, tri_light_count = 0, node_count8 = 0, bvh8_levels = 0;
-    int bvh_width = 8;                   // 2 = binary LBVH nodes, 8 = compressed wide nodes (TRHIP_BVH_WIDTH)
+    int bvh_width = 2;                   // 2 = binary LBVH nodes (default, fastest measured), 8 = compressed wide nodes (TRHIP_BVH_WIDTH=8)
     bool accel_built = false;
 
     SceneView view() const {

@@ -9,6 +9,7 @@
 // host round trip inside a frame.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "pt.h"
@@ -213,6 +214,175 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
             if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
         }
         if ((threadIdx.x & 63) == 0) {
+            add64(pb.counters, CNT_SHADOWRAYS, rays);
+            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent 8-wide trace kernels with lane-level dynamic fetch: a wave keeps stepping its live rays and, whenever
+// at least TR_REFILL lanes are idle, hands them the next rays of the queue (one atomic per refill).
+#ifndef TR_REFILL
+#define TR_REFILL 32
+#endif
+
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(KB) void k_trace_closest_dyn(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+                                                          const uint* count_ptr) {
+    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
+    const uint n = queue ? *count_ptr : P.n_launch;
+    const bool usable = sv.tri_count > 0;
+    TraceStats st = {0, 0, 0, 0};
+    uint rays = 0;
+    const uint lane = threadIdx.x & 63u;
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    const bool include_lights = !(P.opt.hide_lights && bounce == 0);
+    const float tmin = bounce == 0 ? 0.0f : P.opt.min_ray_dist;
+    typename std::conditional<WIDE, Trav8<false, 0, COUNT>, Trav2<false, 0, COUNT>>::type tv;
+    typename std::conditional<WIDE, uint2, int>::type spill[WIDE ? TR_SPILL_STACK8 : TR_SPILL_STACK];
+    tv.stk.overflow = 0;
+    bool active = false, first = true, exhausted = false, pending = false;
+    uint id = 0;
+    f3 org = F3(0), dir = F3(0);
+    int overflow = 0;
+    while (true) {
+        const unsigned long long idle = __ballot(!active);
+        const uint n_idle = (uint)__popcll(idle);
+        if (!exhausted && (n_idle >= TR_REFILL)) {
+            uint base = 0;
+            if (first) base = wave_id * 64u;
+            else {
+                if (lane == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_CLOSEST], n_idle);
+                base = __shfl(base, 0);
+            }
+            first = false;
+            if (base + n_idle >= n) exhausted = true;
+            if (!active) {
+                if (pending) {   // results of finished rays are written in batches, at refill time
+                    HitRecord hit;
+                    finish_closest_hit(sv, tv, org, dir, include_lights, hit);
+                    pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+                    pending = false;
+                }
+                const uint qi = base + (uint)__popcll(idle & ((1ull << lane) - 1ull));
+                if (qi < n) {
+                    id = queue ? queue[qi] : qi;
+                    const u4 misc = pb.misc[id];
+                    if (!(misc.w & 1u)) {
+                        const f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
+                        org = F3(o); dir = F3(d);
+                        rays++;
+                        if (usable && ray_is_finite(org, dir)) {
+                            overflow += tv.stk.overflow;
+                            if constexpr (WIDE) tv.begin(org, dir, tmin, __builtin_huge_valf(), misc.x, s_stack + 2 * threadIdx.x);
+                            else tv.begin(sv, org, dir, tmin, __builtin_huge_valf(), misc.x, s_stack + threadIdx.x);
+                            active = true;
+                        } else {
+                            // invalid ray (zero / non-finite direction) or empty scene: a miss (sphere lights need a valid ray)
+                            tv.found = false; tv.best_t = __builtin_huge_valf(); tv.tmin = tmin; tv.hu = tv.hv = 0;
+                            HitRecord hit;
+                            finish_closest_hit(sv, tv, org, dir, include_lights && ray_is_finite(org, dir), hit);
+                            pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(active)) { if (exhausted) break; else continue; }
+        if (active) {
+            if (tv.step(sv, spill, st)) { active = false; pending = true; }
+        }
+    }
+    if (pending) {
+        HitRecord hit;
+        finish_closest_hit(sv, tv, org, dir, include_lights, hit);
+        pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+    }
+    overflow += tv.stk.overflow;
+    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 3000 + bounce; }
+    if (P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_xor(rays, off);
+            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+        }
+        if (lane == 0) {
+            add64(pb.counters, CNT_CLOSEST, rays);
+            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
+        }
+    }
+}
+
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(KB) void k_trace_shadow_dyn(SceneView sv, PtParams P, PathBuffers pb) {
+    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
+    const uint n = pb.counters[CNT_SHADOW];
+    const bool usable = sv.tri_count > 0;
+    TraceStats st = {0, 0, 0, 0};
+    uint rays = 0;
+    const uint lane = threadIdx.x & 63u;
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    typename std::conditional<WIDE, Trav8<true, 0, COUNT>, Trav2<true, 0, COUNT>>::type tv;
+    typename std::conditional<WIDE, uint2, int>::type spill[WIDE ? TR_SPILL_STACK8 : TR_SPILL_STACK];
+    tv.stk.overflow = 0;
+    bool active = false, first = true, exhausted = false, pending = false;
+    uint id = 0;
+    f4 contrib = F4(0);
+    int overflow = 0;
+    auto deposit = [&](float vis) {
+        if (vis != 0.0f) {
+            // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): contrib.w = luminance before visibility
+            float m = contrib.w * vis;
+            if (contrib.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
+            f4 col = pb.color[id];
+            col.x += contrib.x * vis; col.y += contrib.y * vis; col.z += contrib.z * vis;
+            pb.color[id] = col;
+        }
+    };
+    while (true) {
+        const unsigned long long idle = __ballot(!active);
+        const uint n_idle = (uint)__popcll(idle);
+        if (!exhausted && (n_idle >= TR_REFILL)) {
+            uint base = 0;
+            if (first) base = wave_id * 64u;
+            else {
+                if (lane == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_SHADOW], n_idle);
+                base = __shfl(base, 0);
+            }
+            first = false;
+            if (base + n_idle >= n) exhausted = true;
+            if (!active) {
+                if (pending) { deposit(tv.best_t); pending = false; }
+                const uint qi = base + (uint)__popcll(idle & ((1ull << lane) - 1ull));
+                if (qi < n) {
+                    const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi];
+                    contrib = pb.sh_contrib[qi];
+                    id = __float_as_uint(d.w);
+                    rays++;
+                    if (usable && ray_is_finite(F3(o), F3(d))) {
+                        overflow += tv.stk.overflow;
+                        if constexpr (WIDE) tv.begin(F3(o), F3(d), P.opt.min_ray_dist, o.w, 0u, s_stack + 2 * threadIdx.x);
+                        else tv.begin(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, 0u, s_stack + threadIdx.x);
+                        active = true;
+                    } else deposit(1.0f);
+                }
+            }
+        }
+        if (!__any(active)) { if (exhausted) break; else continue; }
+        if (active) {
+            if (tv.step(sv, spill, st)) { active = false; pending = true; }
+        }
+    }
+    if (pending) deposit(tv.best_t);
+    overflow += tv.stk.overflow;
+    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 4000; }
+    if (P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_xor(rays, off);
+            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+        }
+        if (lane == 0) {
             add64(pb.counters, CNT_SHADOWRAYS, rays);
             if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
         }
@@ -699,6 +869,7 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
     const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
     const bool count = count_work != 0;
     const bool wide = sv.nodes8 != nullptr;
+    static const bool dyn = getenv("TRHIP_DYN") && atoi(getenv("TRHIP_DYN"));   // A/B switch: lane-level refill kernels (slower so far)
     const bool timing = detailed_timing != 0;
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
@@ -724,8 +895,10 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
                 const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
                 uint* qn = pb.queue[(bounce + 1) & 1];
                 timed(T_CLOSEST, [&] {
-                    auto kc = wide ? (count ? k_trace_closest<true, true> : k_trace_closest<false, true>)
-                                   : (count ? k_trace_closest<true, false> : k_trace_closest<false, false>);
+                    auto kc = dyn ? (wide ? (count ? k_trace_closest_dyn<true, true> : k_trace_closest_dyn<false, true>)
+                                          : (count ? k_trace_closest_dyn<true, false> : k_trace_closest_dyn<false, false>))
+                                  : (wide ? (count ? k_trace_closest<true, true> : k_trace_closest<false, true>)
+                                          : (count ? k_trace_closest<true, false> : k_trace_closest<false, false>));
                     hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
                 });
                 timed(T_SHADE, [&] {
@@ -734,8 +907,10 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
                 });
                 if (bounce < opt.max_bounces - 1) {
                     timed(T_SHADOW, [&] {
-                        auto ks = wide ? (count ? k_trace_shadow<true, true> : k_trace_shadow<false, true>)
-                                       : (count ? k_trace_shadow<true, false> : k_trace_shadow<false, false>);
+                        auto ks = dyn ? (wide ? (count ? k_trace_shadow_dyn<true, true> : k_trace_shadow_dyn<false, true>)
+                                              : (count ? k_trace_shadow_dyn<true, false> : k_trace_shadow_dyn<false, false>))
+                                      : (wide ? (count ? k_trace_shadow<true, true> : k_trace_shadow<false, true>)
+                                              : (count ? k_trace_shadow<true, false> : k_trace_shadow<false, false>));
                         hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
                     });
                 }

@@ -13,6 +13,9 @@
 namespace tr {
 
 #define TR_BLOCK 256
+#ifndef TR_VOTE
+#define TR_VOTE 8          // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote)
+#endif
 #define TR_LDS_STACK 16
 #define TR_SPILL_STACK 112
 
@@ -166,6 +169,13 @@ TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float
         stk.init(lds_stack);
         int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
         while (true) {
+#if TR_VOTE > 0
+            // wave vote: run the (expensive) triangle branch only when enough lanes hold a leaf; leaf lanes wait otherwise
+            const bool at_leaf = node < 0;
+            const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
+            const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
+            if (at_leaf != leaf_phase) continue;
+#endif
             if (node >= 0) {
                 const BvhNode n = sv.nodes[node];
                 if (COUNT) st.nodes++;
@@ -244,6 +254,12 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
     stk.init(lds_stack);
     int node = sv.node_count > 0 ? 0 : -1;
     while (true) {
+#ifdef TR_VOTE_SHADOW
+        const bool at_leaf = node < 0;
+        const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
+        const bool leaf_phase = n_leaf >= TR_VOTE_SHADOW || n_leaf == n_all;
+        if (at_leaf != leaf_phase) continue;
+#endif
         if (node >= 0) {
             const BvhNode n = sv.nodes[node];
             if (COUNT) st.nodes++;
@@ -496,6 +512,181 @@ TR_DEV float trace_shadow8(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     }
     overflow += stk.overflow;
     return visibility;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stepwise 8-wide traversal for the persistent kernels: `step()` performs one node visit plus the triangles of that
+// node and reports completion, so a wave can hand finished lanes a new ray instead of idling until its slowest
+// ray is done (lane-level dynamic fetch, Aila & Laine 2009).
+template <bool SHADOW, int ALPHA_MODE, bool COUNT>
+struct Trav8 {
+    RayPre r;
+    Ray8 r8;
+    uint2 G;
+    LaneStack8 stk;
+    float tmin, tmax, best_t;      // best_t: closest distance (closest-hit) or accumulated visibility (shadow)
+    uint best_inst, best_prim, seed;
+    float hu, hv;
+    bool found;
+
+    TR_DEV void begin(f3 org, f3 dir, float tmin_, float tmax_, uint seed_, int* lds_stack) {
+        r = make_ray(org, dir);
+        r8 = make_ray8(org, dir);
+        G = make_uint2(0u, 0x80000000u);
+        stk.init(lds_stack);
+        tmin = tmin_; tmax = tmax_; seed = seed_;
+        best_t = SHADOW ? 1.0f : tmax_;
+        best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu; hu = 0; hv = 0; found = false;
+    }
+
+    // returns true when the ray is finished
+    TR_DEV bool step(const SceneView& sv, uint2* spill, TraceStats& st) {
+        uint2 T = make_uint2(0u, 0u);
+        if (G.y > 0x00FFFFFFu) {
+            const uint hits = G.y;
+            const int bit = 31 - __clz((int)hits);
+            G.y &= ~(1u << bit);
+            if (G.y > 0x00FFFFFFu) { stk.push(spill, G); if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); }
+            const uint slot = ((uint)bit - 24u) ^ r8.octinv;
+            const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
+            uint4 n0, n1, n2, n3, n4;
+            load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
+            if (COUNT) st.nodes++;
+            const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, SHADOW ? tmax : best_t);
+            G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
+            T = make_uint2(n1.y, hm & 0x00FFFFFFu);
+        }
+        while (T.y) {
+            const int b = __ffs((int)T.y) - 1;
+            T.y &= T.y - 1u;
+            const TriRecord tr = sv.tris[T.x + (uint)b];
+            if (COUNT) st.tris++;
+            float t, bu, bv;
+            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+            if (!tri_intersect(r, v0, v1, v2, tmin, SHADOW ? tmax : __builtin_huge_valf(), t, bu, bv)) continue;
+            const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+            if (SHADOW) {
+                if (!(tr.inst_flags & 0x80000000u)) { best_t = 0.0f; return true; }
+                if (COUNT) st.alpha++;
+                best_t *= 1.0f - candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                if (best_t == 0.0f) return true;
+            } else {
+                const bool closer = t < best_t || (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
+                if (closer && t < tmax) {
+                    bool accept = true;
+                    if (tr.inst_flags & 0x80000000u) {
+                        if (COUNT) st.alpha++;
+                        float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                        float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
+                        accept = !(a <= cutoff);
+                    }
+                    if (accept) { best_t = t; found = true; best_inst = inst; best_prim = tr.prim; hu = bu; hv = bv; }
+                }
+            }
+        }
+        if (G.y <= 0x00FFFFFFu) {
+            if (stk.sp == 0) return true;
+            G = stk.pop(spill);
+        }
+        return false;
+    }
+
+};
+
+
+// Stepwise BVH2 traversal (one node OR one triangle per step) for the lane-refill kernels.
+template <bool SHADOW, int ALPHA_MODE, bool COUNT>
+struct Trav2 {
+    RayPre r;
+    LaneStack stk;
+    int node;
+    float tmin, tmax, best_t;
+    uint best_inst, best_prim, seed;
+    float hu, hv;
+    bool found;
+
+    TR_DEV void begin(const SceneView& sv, f3 org, f3 dir, float tmin_, float tmax_, uint seed_, int* lds_stack) {
+        r = make_ray(org, dir);
+        stk.init(lds_stack);
+        node = sv.node_count > 0 ? 0 : -1;
+        tmin = tmin_; tmax = tmax_; seed = seed_;
+        best_t = SHADOW ? 1.0f : tmax_;
+        best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu; hu = 0; hv = 0; found = false;
+    }
+
+    TR_DEV bool step(const SceneView& sv, int* spill, TraceStats& st) {
+        if (node >= 0) {
+            const BvhNode n = sv.nodes[node];
+            if (COUNT) st.nodes++;
+            float t0, t1;
+            const float far = SHADOW ? tmax : best_t;
+            bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, far, t0);
+            bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, far, t1);
+            if (h0 && h1) {
+                bool first0 = SHADOW ? true : (t0 <= t1);
+                stk.push(spill, first0 ? n.child1 : n.child0);
+                if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
+                node = first0 ? n.child0 : n.child1;
+                return false;
+            } else if (h0) { node = n.child0; return false; }
+            else if (h1) { node = n.child1; return false; }
+        } else {
+            const TriRecord tr = sv.tris[~node];
+            if (COUNT) st.tris++;
+            float t, bu, bv;
+            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+            if (tri_intersect(r, v0, v1, v2, tmin, SHADOW ? tmax : __builtin_huge_valf(), t, bu, bv)) {
+                const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+                if (SHADOW) {
+                    if (!(tr.inst_flags & 0x80000000u)) { best_t = 0.0f; return true; }
+                    if (COUNT) st.alpha++;
+                    best_t *= 1.0f - candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                    if (best_t == 0.0f) return true;
+                } else {
+                    const bool closer = t < best_t || (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
+                    if (closer && t < tmax) {
+                        bool accept = true;
+                        if (tr.inst_flags & 0x80000000u) {
+                            if (COUNT) st.alpha++;
+                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
+                            accept = !(a <= cutoff);
+                        }
+                        if (accept) { best_t = t; found = true; best_inst = inst; best_prim = tr.prim; hu = bu; hv = bv; }
+                    }
+                }
+            }
+        }
+        if (stk.sp == 0) return true;
+        node = stk.pop(spill);
+        return false;
+    }
+};
+
+// sphere lights + hit record (rt_common_point_light.rint/.rchit), shared by the stepwise traversals
+template <class TRAV>
+TR_DEV void finish_closest_hit(const SceneView& sv, TRAV& tv, f3 org, f3 dir, bool include_lights, HitRecord& hit) {
+    hit.instance_id = tv.found ? (int)tv.best_inst : -1; hit.primitive_id = tv.found ? (int)tv.best_prim : -1; hit.u = tv.hu; hit.v = tv.hv;
+    if (include_lights) {
+        for (uint i = 0; i < sv.point_light_count; ++i) {
+            const PointLight& pl = sv.point_lights[i];
+            float radius = pl.radius;
+            if (radius == 0.0f) continue;
+            f3 oc = org - pl.pos;
+            float a = dot(dir, dir);
+            float b = 2.0f * dot(oc, dir);
+            float c = dot(oc, oc) - radius * radius;
+            float disc = b * b - 4.0f * a * c;
+            if (disc < 0) continue;
+            float h = (-b - sqrtf(disc)) / (2.0f * a);
+            if (h > 0 && h > tv.tmin && h < tv.best_t) {
+                tv.best_t = h; tv.found = true;
+                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
+            }
+        }
+    }
+    hit.t = tv.found ? tv.best_t : -1.0f;
 }
 
 // LDS words per block for the per-lane stacks of either traversal
