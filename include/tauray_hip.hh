@@ -1,0 +1,646 @@
+// tauray_hip.hh - C++17 host layer over the trhip C ABI, keeping Tauray's renderer/stage surface for the
+// path-tracer hot path (header-only; link with -ltrhip).
+//
+// Class and function names, option fields and the render() sequence follow the reference:
+//   distribution_strategy / distribution_params ... src/distribution_strategy.{hh,cc}
+//   scene_stage .................................... src/scene_stage.{hh,cc} (uploads + acceleration structure)
+//   path_tracer_stage (+ options) .................. src/path_tracer_stage.{hh,cc}, rt_camera_stage, rt_stage
+//   stitch_stage, tonemap_stage .................... src/stitch_stage.{hh,cc}, src/tonemap_stage.{hh,cc}
+//   rt_renderer .................................... src/rt_renderer.{hh,cc}: per-device stages, transfer, stitch, tonemap
+//   headless ....................................... src/headless.{hh,cc}: readback, NaN report, file naming, EXR/RAW writers
+//   load_balancer .................................. src/load_balancer.{hh,cc}
+// Errors are thrown as std::runtime_error carrying trhip_last_error(), like the reference.
+#ifndef TAURAY_HIP_HH
+#define TAURAY_HIP_HH
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "trhip.h"
+
+namespace tr
+{
+
+inline void check(int rc)
+{
+    if(rc != 0) throw std::runtime_error(trhip_last_error());
+}
+
+struct uvec2 { uint32_t x = 0, y = 0; };
+
+//==============================================================================
+// distribution_strategy.hh
+//==============================================================================
+enum distribution_strategy
+{
+    DISTRIBUTION_DUPLICATE = 0,
+    DISTRIBUTION_SCANLINE = 1,
+    DISTRIBUTION_SHUFFLED_STRIPS = 2
+};
+
+struct distribution_params
+{
+    uvec2 size;
+    distribution_strategy strategy = DISTRIBUTION_SCANLINE;
+    unsigned index = 0;
+    unsigned count = 1;
+    bool primary = true;
+};
+
+inline uvec2 get_distribution_render_size(const distribution_params& p)
+{
+    switch(p.strategy)
+    {
+    case DISTRIBUTION_DUPLICATE: return p.size;
+    case DISTRIBUTION_SCANLINE: return uvec2{p.size.x, (p.size.y - p.index + p.count - 1) / p.count};
+    default: return uvec2{p.count, 1};
+    }
+}
+
+inline uvec2 get_distribution_target_size(const distribution_params& p)
+{
+    if(p.primary) return p.size;
+    if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS) return uvec2{p.size.x, (p.count + p.size.x - 1) / p.size.x};
+    return get_distribution_render_size(p);
+}
+
+inline uvec2 get_ray_count(const distribution_params& p)
+{
+    if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS) return uvec2{p.count, 1};
+    return get_distribution_render_size(p);
+}
+
+inline unsigned calculate_shuffled_strips_b(uvec2 size)
+{
+    unsigned n = size.x * size.y;
+    unsigned b = 31;
+    while((n >> b) < 128 && b > 0) b--;
+    return b;
+}
+
+inline unsigned calculate_shuffled_strips_pixels_per_device(uvec2 size, float max_ratio)
+{
+    unsigned b = calculate_shuffled_strips_b(size);
+    size_t n_regions = size_t(1) << b;
+    size_t region = (size_t(size.x) * size.y + n_regions - 1) / n_regions;
+    return (unsigned)std::ceil(max_ratio * region * (1 << b));
+}
+
+inline distribution_params get_device_distribution_params(
+    uvec2 full_image_size, distribution_strategy strategy, double workload_offset, double workload_size,
+    unsigned device_index, unsigned device_count, bool primary
+){
+    distribution_params d;
+    d.strategy = strategy;
+    d.size = full_image_size;
+    d.primary = primary;
+    if(strategy == DISTRIBUTION_SHUFFLED_STRIPS)
+    {
+        unsigned before = calculate_shuffled_strips_pixels_per_device(full_image_size, workload_offset);
+        unsigned after = calculate_shuffled_strips_pixels_per_device(full_image_size, workload_offset + workload_size);
+        d.index = before;
+        d.count = after - before;
+    }
+    else
+    {
+        d.index = device_index;
+        d.count = device_count;
+    }
+    return d;
+}
+
+inline trhip_distribution to_abi(const distribution_params& p)
+{
+    return trhip_distribution{p.size.x, p.size.y, (int32_t)p.strategy, p.index, p.count, p.primary ? 1u : 0u};
+}
+
+//==============================================================================
+// device (context holds one per HIP device; --fake-devices repeats a device, src/context.cc:415-416)
+//==============================================================================
+class device
+{
+public:
+    explicit device(int hip_device): hip_device(hip_device) { check(trhip_device_create(hip_device, &h)); }
+    device(const device&) = delete;
+    ~device() { trhip_device_destroy(h); }
+
+    void* alloc(size_t bytes) { void* p = nullptr; check(trhip_malloc(h, bytes, &p)); return p; }
+    void free(void* p) { trhip_free(h, p); }
+    void sync() { check(trhip_sync(h, nullptr)); }
+
+    trhip_device* h = nullptr;
+    int hip_device;
+};
+
+//==============================================================================
+// scene: the flattened scene_stage inputs (SURVEY.md Appendix A arrays)
+//==============================================================================
+struct scene_data
+{
+    std::vector<uint8_t> instances, spans, vertices, indices, point_lights, directional_lights, texture_infos, texels,
+        envmap, alias_table, cameras, non_opaque;
+    uint32_t envmap_width = 0, envmap_height = 0;
+    float environment_factor[4] = {0, 0, 0, 0};
+    uint32_t gather_emissive_triangles = 0;
+    uint32_t projection = 0;
+
+    uint32_t instance_count() const { return (uint32_t)(instances.size() / 288); }
+    uint32_t camera_count() const { return (uint32_t)(cameras.size() / 320); }
+    uint32_t point_light_count() const { return (uint32_t)(point_lights.size() / 64); }
+    uint32_t directional_light_count() const { return (uint32_t)(directional_lights.size() / 32); }
+    bool has_tri_lights() const
+    {
+        for(uint32_t i = 0; i < instance_count(); ++i)
+        {
+            const float* e = reinterpret_cast<const float*>(instances.data() + 288 * i + 208 + 32);   // mat.emission_factor
+            if(e[0] != 0 || e[1] != 0 || e[2] != 0) return true;
+        }
+        return false;
+    }
+};
+
+// .trsc reader (written by tauray_amd/scene_io.py)
+inline scene_data load_scene_dump(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if(!f) throw std::runtime_error("Failed to open " + path);
+    char magic[4]; uint32_t version = 0;
+    f.read(magic, 4); f.read(reinterpret_cast<char*>(&version), 4);
+    if(std::memcmp(magic, "TRSC", 4) != 0 || version != 1) throw std::runtime_error(path + " is not a version-1 scene dump");
+    scene_data s;
+    std::vector<uint8_t>* sections[] = {&s.instances, &s.spans, &s.vertices, &s.indices, &s.point_lights, &s.directional_lights,
+        &s.texture_infos, &s.texels, &s.envmap, &s.alias_table, &s.cameras, &s.non_opaque};
+    for(auto* sec: sections)
+    {
+        uint64_t n = 0;
+        f.read(reinterpret_cast<char*>(&n), 8);
+        sec->resize(n);
+        f.read(reinterpret_cast<char*>(sec->data()), (std::streamsize)n);
+    }
+    f.read(reinterpret_cast<char*>(&s.envmap_width), 4);
+    f.read(reinterpret_cast<char*>(&s.envmap_height), 4);
+    f.read(reinterpret_cast<char*>(s.environment_factor), 16);
+    f.read(reinterpret_cast<char*>(&s.gather_emissive_triangles), 4);
+    f.read(reinterpret_cast<char*>(&s.projection), 4);
+    if(!f) throw std::runtime_error(path + " is truncated");
+    return s;
+}
+
+class scene_stage
+{
+public:
+    explicit scene_stage(device& dev): dev(&dev) {}
+
+    void set_scene(const scene_data& s)
+    {
+        trhip_scene_desc d = {};
+        d.instances = s.instances.data(); d.spans = s.spans.data(); d.instance_count = s.instance_count();
+        d.vertices = s.vertices.data(); d.vertex_count = (uint32_t)(s.vertices.size() / 48);
+        d.indices = reinterpret_cast<const uint32_t*>(s.indices.data()); d.index_count = (uint32_t)(s.indices.size() / 4);
+        d.point_lights = s.point_lights.data(); d.point_light_count = s.point_light_count();
+        d.directional_lights = s.directional_lights.data(); d.directional_light_count = s.directional_light_count();
+        d.texture_infos = s.texture_infos.data(); d.texture_count = (uint32_t)(s.texture_infos.size() / 16);
+        d.texels = s.texels.data();
+        if(!s.envmap.empty())
+        {
+            d.envmap = reinterpret_cast<const float*>(s.envmap.data());
+            d.envmap_width = s.envmap_width; d.envmap_height = s.envmap_height;
+            d.alias_table = s.alias_table.data();
+        }
+        std::memcpy(d.environment_factor, s.environment_factor, 16);
+        d.cameras = s.cameras.data(); d.camera_count = s.camera_count();
+        d.non_opaque = s.non_opaque.data();
+        d.gather_emissive_triangles = s.gather_emissive_triangles;
+        check(trhip_scene_upload(dev->h, &d));
+        check(trhip_scene_build_accel(dev->h, &accel));
+    }
+
+    device* dev;
+    trhip_accel_info accel = {};
+};
+
+//==============================================================================
+// rt_common.hh enums + path_tracer_stage
+//==============================================================================
+enum class film_filter { POINT = 0, BOX, BLACKMAN_HARRIS };
+enum class multiple_importance_sampling_mode { MIS_DISABLED, MIS_BALANCE_HEURISTIC, MIS_POWER_HEURISTIC };
+enum class bounce_sampling_mode { HEMISPHERE, COSINE_HEMISPHERE, MATERIAL };
+enum class tri_light_sampling_mode { AREA, SOLID_ANGLE, HYBRID };
+enum class sampler_type { UNIFORM_RANDOM = 0, SOBOL_OWEN, SOBOL_Z_ORDER_2D, SOBOL_Z_ORDER_3D };
+
+struct light_sampling_weights
+{
+    float point_lights = 1.0f;
+    float directional_lights = 1.0f;
+    float envmap = 1.0f;
+    float emissive_triangles = 1.0f;
+};
+
+class path_tracer_stage
+{
+public:
+    // rt_stage::options + rt_camera_stage::options + path_tracer_stage::options; defaults are the reference's
+    // CLI defaults (src/options.hh), not the struct defaults, because that is what `tauray scene.glb` renders with.
+    struct options
+    {
+        int max_ray_depth = 8;
+        float min_ray_dist = 1e-4f;
+        int rng_seed = 0;
+        sampler_type local_sampler = sampler_type::UNIFORM_RANDOM;
+        distribution_params distribution;
+        size_t active_viewport_count = 1;
+        int samples_per_pixel = 1;
+        int samples_per_pass = 1;
+        int projection = 0;                 // camera::projection_type
+        bool transparent_background = false;
+        bool use_white_albedo_on_first_bounce = false;
+        bool hide_lights = false;
+        film_filter film = film_filter::POINT;
+        multiple_importance_sampling_mode mis_mode = multiple_importance_sampling_mode::MIS_POWER_HEURISTIC;
+        float film_radius = 0.5f;
+        float russian_roulette_delta = 0;
+        float indirect_clamping = 0;
+        float regularization_gamma = 0.0f;
+        bool depth_of_field = false;
+        light_sampling_weights sampling_weights;
+        bounce_sampling_mode bounce_mode = bounce_sampling_mode::MATERIAL;
+        tri_light_sampling_mode tri_light_mode = tri_light_sampling_mode::SOLID_ANGLE;
+    };
+
+    path_tracer_stage(device& dev, scene_stage& ss, void* color_target, const options& opt)
+    : dev(&dev), ss(&ss), color(color_target), opt(opt)
+    {
+        trhip_pt_options o = {};
+        o.max_bounces = opt.max_ray_depth; o.min_ray_dist = opt.min_ray_dist; o.rng_seed = (uint32_t)opt.rng_seed;
+        o.sampler = (int)opt.local_sampler; o.samples_per_pixel = opt.samples_per_pixel; o.samples_per_pass = opt.samples_per_pass;
+        o.projection = opt.projection; o.film = (int)opt.film; o.film_radius = opt.film_radius; o.mis_mode = (int)opt.mis_mode;
+        o.russian_roulette_delta = opt.russian_roulette_delta; o.indirect_clamping = opt.indirect_clamping;
+        o.regularization_gamma = opt.regularization_gamma; o.depth_of_field = opt.depth_of_field;
+        o.nee_point = opt.sampling_weights.point_lights; o.nee_directional = opt.sampling_weights.directional_lights;
+        o.nee_envmap = opt.sampling_weights.envmap; o.nee_triangles = opt.sampling_weights.emissive_triangles;
+        o.bounce_mode = (int)opt.bounce_mode; o.tri_light_mode = (int)opt.tri_light_mode; o.hide_lights = opt.hide_lights;
+        o.use_white_albedo_on_first_bounce = opt.use_white_albedo_on_first_bounce;
+        o.transparent_background = opt.transparent_background;
+        check(trhip_pt_create(dev.h, &o, &pt));
+        reset_distribution_params(opt.distribution);
+    }
+    path_tracer_stage(const path_tracer_stage&) = delete;
+    ~path_tracer_stage() { trhip_pt_destroy(pt); }
+
+    void reset_accumulated_samples() { check(trhip_pt_reset_accumulation(pt, 0)); }
+    void reset_sample_counter() { check(trhip_pt_reset_accumulation(pt, 1)); }
+    void reset_distribution_params(distribution_params distribution)
+    {
+        opt.distribution = distribution;
+        trhip_distribution d = to_abi(distribution);
+        check(trhip_pt_set_distribution(pt, &d));
+    }
+    // stage::run: enqueue the frame (all passes) on the device's stream
+    void run()
+    {
+        uvec2 ts = get_distribution_target_size(opt.distribution);
+        check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count, nullptr));
+    }
+    float get_duration_ms() { trhip_timings t; check(trhip_pt_get_timings(pt, &t)); return t.path_tracing_ms; }
+    trhip_counters get_counters() { trhip_counters c; check(trhip_pt_get_counters(pt, &c)); return c; }
+
+    device* dev;
+    scene_stage* ss;
+    void* color;
+    options opt;
+    trhip_pt* pt = nullptr;
+};
+
+//==============================================================================
+// tonemap_stage / load_balancer
+//==============================================================================
+class tonemap_stage
+{
+public:
+    enum operator_type { LINEAR = 0, GAMMA_CORRECTION, FILMIC, REINHARD, REINHARD_LUMINANCE };
+    struct options
+    {
+        operator_type tonemap_operator = FILMIC;
+        float exposure = 1.0f;
+        float gamma = 2.2f;
+        bool alpha_grid_background = false;
+    };
+    tonemap_stage(device& dev, const options& opt): dev(&dev), opt(opt) {}
+    void run(const void* in, void* out, uvec2 size, uint32_t layers)
+    {
+        trhip_tonemap_info info = {(int32_t)opt.tonemap_operator, opt.exposure, opt.gamma, opt.alpha_grid_background ? 16 : 0};
+        check(trhip_tonemap(dev->h, in, out, size.x, size.y, layers, &info, nullptr));
+    }
+    device* dev;
+    options opt;
+};
+
+class load_balancer
+{
+public:
+    explicit load_balancer(size_t device_count, std::vector<double> initial = {}): workloads(std::move(initial))
+    {
+        workloads.resize(device_count);
+        double sum = 0, add = 0;
+        for(double w: workloads) sum += w;
+        if(sum == 0) { add = 1.0; sum = (double)workloads.size(); }
+        for(double& w: workloads) w = (std::max(w, 0.0) + add) / sum;
+    }
+    // times[i] = "path tracing" timer of device i
+    const std::vector<double>& update(const std::vector<double>& times)
+    {
+        double sum_speed = 0;
+        for(size_t i = 0; i < workloads.size(); ++i) sum_speed += std::max(workloads[i] / times[i], 0.0);
+        if(sum_speed > 0 && std::isfinite(sum_speed))
+            for(size_t i = 0; i < workloads.size(); ++i)
+                workloads[i] = workloads[i] * 0.9 + (workloads[i] / times[i]) / sum_speed * 0.1;
+        return workloads;
+    }
+    std::vector<double> workloads;
+};
+
+//==============================================================================
+// rt_renderer<path_tracer_stage>: all devices in one process, like the reference
+//==============================================================================
+class rt_renderer
+{
+public:
+    struct options: path_tracer_stage::options
+    {
+        tonemap_stage::options tonemap;
+        bool accumulate = false;
+    };
+
+    // `devices`: HIP device index per logical device (repeat an index for --fake-devices); device 0 displays.
+    rt_renderer(const std::vector<int>& devices, const scene_data& scene, uvec2 size, options opt)
+    : size(size), opt(opt)
+    {
+        if(devices.empty()) throw std::runtime_error("rt_renderer needs at least one device");
+        if(devices.size() == 1) this->opt.distribution.strategy = DISTRIBUTION_DUPLICATE;   // src/tauray.cc:519-521
+        per_device.resize(devices.size());
+        std::vector<double> ratios(devices.size(), 1.0 / devices.size());
+        double cumulative = 0;
+        for(size_t i = 0; i < devices.size(); ++i)
+        {
+            per_device_data& d = per_device[i];
+            d.dev = std::make_unique<device>(devices[i]);
+            d.scene_update = std::make_unique<scene_stage>(*d.dev);
+            d.scene_update->set_scene(scene);               // scene replicated on every device (src/gpu_buffer.hh:63-116)
+            d.dist = get_device_distribution_params(size, this->opt.distribution.strategy, cumulative, ratios[i], (unsigned)i,
+                                                    (unsigned)devices.size(), i == 0);
+            cumulative += ratios[i];
+            uvec2 ts = get_distribution_target_size(d.dist);
+            d.target_bytes = size_t(ts.x) * ts.y * 16 * this->opt.active_viewport_count;
+            d.color = d.dev->alloc(d.target_bytes);
+            check(trhip_memset(d.dev->h, d.color, 0, d.target_bytes, nullptr));
+            path_tracer_stage::options po = this->opt;
+            po.distribution = d.dist;
+            d.ray_tracer = std::make_unique<path_tracer_stage>(*d.dev, *d.scene_update, d.color, po);
+            if(i != 0) d.gbuffer_copy = per_device[0].dev->alloc(d.target_bytes);   // receive buffer on the display device
+        }
+        display_bytes = size_t(size.x) * size.y * 16 * this->opt.active_viewport_count;
+        display = per_device[0].dev->alloc(display_bytes);
+        tonemap = std::make_unique<tonemap_stage>(*per_device[0].dev, this->opt.tonemap);
+    }
+
+    ~rt_renderer()
+    {
+        for(auto& d: per_device) d.dev->sync();
+        for(size_t i = 0; i < per_device.size(); ++i)
+        {
+            per_device[i].ray_tracer.reset();
+            if(per_device[i].gbuffer_copy) per_device[0].dev->free(per_device[i].gbuffer_copy);
+            per_device[i].dev->free(per_device[i].color);
+        }
+        per_device[0].dev->free(display);
+    }
+
+    void reset_accumulation(bool reset_sample_counter = false)
+    {
+        for(auto& d: per_device)
+        {
+            d.ray_tracer->reset_accumulated_samples();
+            if(reset_sample_counter) d.ray_tracer->reset_sample_counter();
+        }
+        accumulated_frames = 0;
+    }
+
+    // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap
+    void render()
+    {
+        if(!opt.accumulate) for(auto& d: per_device) d.ray_tracer->reset_accumulated_samples();
+        for(auto& d: per_device) d.ray_tracer->run();
+        device& display_device = *per_device[0].dev;
+        for(size_t i = 1; i < per_device.size(); ++i)
+        {
+            per_device_data& d = per_device[i];
+            d.dev->sync();
+            check(trhip_copy_peer(display_device.h, d.gbuffer_copy, d.dev->h, d.color, d.target_bytes, nullptr));
+            d.dev->sync();
+        }
+        for(size_t i = 1; i < per_device.size(); ++i)
+        {
+            per_device_data& d = per_device[i];
+            uvec2 ts = get_distribution_target_size(d.dist);
+            trhip_distribution pd = to_abi(d.dist);
+            check(trhip_stitch(display_device.h, &pd, d.gbuffer_copy, ts.x, ts.y, per_device[0].color,
+                               (uint32_t)opt.active_viewport_count, 1.0f, nullptr));
+        }
+        tonemap->run(per_device[0].color, display, size, (uint32_t)opt.active_viewport_count);
+        accumulated_frames++;
+    }
+
+    void set_device_workloads(const std::vector<double>& ratios)
+    {
+        if(opt.distribution.strategy != DISTRIBUTION_SHUFFLED_STRIPS) return;
+        double cumulative = 0;
+        for(size_t i = 0; i < per_device.size(); ++i)
+        {
+            double ratio = std::min(std::max(ratios[i], 0.0), 1.0 - cumulative);
+            per_device[i].dist = get_device_distribution_params(size, opt.distribution.strategy, cumulative, ratio, (unsigned)i,
+                                                                (unsigned)per_device.size(), i == 0);
+            cumulative += ratio;
+            per_device[i].ray_tracer->reset_distribution_params(per_device[i].dist);
+            if(i != 0) per_device[i].ray_tracer->reset_accumulated_samples();
+        }
+    }
+
+    std::vector<double> get_path_tracing_times()
+    {
+        std::vector<double> t;
+        for(auto& d: per_device) t.push_back(d.ray_tracer->get_duration_ms());
+        return t;
+    }
+
+    struct per_device_data
+    {
+        std::unique_ptr<device> dev;
+        std::unique_ptr<scene_stage> scene_update;
+        std::unique_ptr<path_tracer_stage> ray_tracer;
+        distribution_params dist;
+        void* color = nullptr;
+        void* gbuffer_copy = nullptr;
+        size_t target_bytes = 0;
+    };
+    std::vector<per_device_data> per_device;
+    uvec2 size;
+    options opt;
+    void* display = nullptr;          // tonemapped RGBA32F on the display device
+    size_t display_bytes = 0;
+    std::unique_ptr<tonemap_stage> tonemap;
+    unsigned accumulated_frames = 0;
+};
+
+//==============================================================================
+// headless (src/headless.{hh,cc}): readback + writers.  EXR: scanline, uncompressed, channels B,G,R[,A] like the
+// reference (which defaults to PIZ; compression "none" is one of its options), half or float.
+//==============================================================================
+class headless
+{
+public:
+    enum image_file_type { EXR = 0, RAW, EMPTY };
+    enum pixel_format { RGB16, RGB32, RGBA16, RGBA32 };
+    struct options
+    {
+        uvec2 size;
+        std::string output_prefix = "capture";
+        image_file_type output_file_type = EXR;
+        pixel_format output_format = RGB16;
+        bool single_frame = false;
+        bool skip_nan_check = false;
+        unsigned first_frame_index = 0;
+        unsigned display_count = 1;
+    };
+
+    explicit headless(const options& opt): opt(opt) {}
+
+    static uint16_t float_to_half(float f)
+    {
+        uint32_t x; std::memcpy(&x, &f, 4);
+        uint32_t sign = (x >> 16) & 0x8000u, man = x & 0x7FFFFFu;
+        int32_t exp = (int32_t)((x >> 23) & 0xFF);
+        if(exp == 255) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+        exp = exp - 127 + 15;
+        if(exp >= 31) return (uint16_t)(sign | 0x7C00u);
+        if(exp <= 0)
+        {
+            if(exp < -10) return (uint16_t)sign;
+            man |= 0x800000u;
+            int shift = 14 - exp;
+            uint32_t h = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+            if(rem > half || (rem == half && (h & 1))) h++;
+            return (uint16_t)(sign | h);
+        }
+        uint32_t h = ((uint32_t)exp << 10) | (man >> 13), rem = man & 0x1FFFu;
+        if(rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+
+    std::string get_filename(unsigned display_index, unsigned frame_number) const
+    {
+        std::string filename = opt.output_prefix;                                       // src/headless.cc:305-309
+        if(opt.display_count > 1) filename += std::to_string(display_index) + "_";
+        if(!opt.single_frame) filename += std::to_string(frame_number);
+        return filename + (opt.output_file_type == EXR ? ".exr" : ".raw");
+    }
+
+    // finish_image + save_image for every display layer; returns the number of NaN pixels reported
+    size_t save(device& dev, const void* display_image, unsigned frame_number)
+    {
+        const size_t pixels = size_t(opt.size.x) * opt.size.y;
+        std::vector<float> mem(pixels * 4 * opt.display_count);
+        check(trhip_download(dev.h, mem.data(), display_image, mem.size() * 4, nullptr));
+        size_t nan_pixels = 0;
+        for(unsigned d = 0; d < opt.display_count; ++d)
+        {
+            const float* img = mem.data() + pixels * 4 * d;
+            if(!opt.skip_nan_check)
+                for(size_t j = 0; j < pixels; ++j)
+                    if(std::isnan(img[4 * j]) || std::isnan(img[4 * j + 1]) || std::isnan(img[4 * j + 2]) || std::isnan(img[4 * j + 3]))
+                    {
+                        std::fprintf(stderr, "NaN pixel at: %zu, %zu\n", j % opt.size.x, j / opt.size.x);
+                        nan_pixels++;
+                    }
+            if(opt.output_file_type == EMPTY) continue;
+            const std::string filename = get_filename(d, frame_number);
+            if(opt.output_file_type == RAW) write_raw(filename, img, pixels);
+            else write_exr(filename, img);
+        }
+        return nan_pixels;
+    }
+
+    options opt;
+
+private:
+    void write_raw(const std::string& filename, const float* img, size_t pixels) const
+    {
+        std::ofstream f(filename, std::ios::binary);
+        if(!f) throw std::runtime_error("Failed to write " + filename);
+        f.write(reinterpret_cast<const char*>(img), (std::streamsize)(pixels * 16));
+    }
+
+    void write_exr(const std::string& filename, const float* img) const
+    {
+        const bool alpha = opt.output_format == RGBA16 || opt.output_format == RGBA32;
+        const bool half = opt.output_format == RGB16 || opt.output_format == RGBA16;
+        const int nch = alpha ? 4 : 3;
+        const char* names[4] = {"A", "B", "G", "R"};          // alphabetical = file order
+        const int src[4] = {3, 2, 1, 0};
+        const int first = alpha ? 0 : 1;
+        std::vector<uint8_t> out;
+        auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; out.insert(out.end(), b, b + n); };
+        auto put_i32 = [&](int32_t v) { put(&v, 4); };
+        auto put_str = [&](const char* s) { put(s, std::strlen(s) + 1); };
+        auto attr = [&](const char* name, const char* type, int32_t size) { put_str(name); put_str(type); put_i32(size); };
+        put_i32(20000630); put_i32(2);
+        attr("channels", "chlist", nch * (2 + 16) + 1);
+        for(int c = first; c < 4; ++c)
+        {
+            put_str(names[c]);
+            put_i32(half ? 1 : 2); uint8_t plinear[4] = {0, 0, 0, 0}; put(plinear, 4); put_i32(1); put_i32(1);
+        }
+        uint8_t zero = 0; put(&zero, 1);
+        attr("compression", "compression", 1); put(&zero, 1);
+        int32_t box[4] = {0, 0, (int32_t)opt.size.x - 1, (int32_t)opt.size.y - 1};
+        attr("dataWindow", "box2i", 16); put(box, 16);
+        attr("displayWindow", "box2i", 16); put(box, 16);
+        attr("lineOrder", "lineOrder", 1); put(&zero, 1);
+        float one = 1.0f, origin[2] = {0, 0};
+        attr("pixelAspectRatio", "float", 4); put(&one, 4);
+        attr("screenWindowCenter", "v2f", 8); put(origin, 8);
+        attr("screenWindowWidth", "float", 4); put(&one, 4);
+        put(&zero, 1);
+        const size_t bpp = half ? 2 : 4;
+        const size_t line_bytes = size_t(opt.size.x) * nch * bpp;
+        const size_t table_pos = out.size();
+        out.resize(out.size() + 8 * size_t(opt.size.y));
+        for(uint32_t y = 0; y < opt.size.y; ++y)
+        {
+            uint64_t off = out.size();
+            std::memcpy(out.data() + table_pos + 8 * size_t(y), &off, 8);
+            put_i32((int32_t)y); put_i32((int32_t)line_bytes);
+            for(int c = first; c < 4; ++c)
+                for(uint32_t x = 0; x < opt.size.x; ++x)
+                {
+                    float v = img[(size_t(y) * opt.size.x + x) * 4 + src[c]];
+                    if(half) { uint16_t h = float_to_half(v); put(&h, 2); }
+                    else put(&v, 4);
+                }
+        }
+        std::ofstream f(filename, std::ios::binary);
+        if(!f) throw std::runtime_error("Failed to write " + filename);
+        f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());
+    }
+};
+
+}
+
+#endif

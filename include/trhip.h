@@ -35,6 +35,9 @@ int trhip_upload(trhip_device* dev, void* dst_dev, const void* src_host, size_t 
 int trhip_download(trhip_device* dev, void* dst_host, const void* src_dev, size_t bytes, void* stream); /* headless readback, src/headless.cc:292-303 */
 int trhip_memset(trhip_device* dev, void* dst_dev, int value, size_t bytes, void* stream);
 int trhip_sync(trhip_device* dev, void* stream);
+/* device -> device copy over xGMI (replaces the pinned-host bounce of src/device_transfer.cc:140-290 when all
+ * devices live in one process; with one process per GPU the same transfer is an RCCL send/recv) */
+int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream);
 
 /* ---- scene (replaces scene_stage::update's uploads, src/scene_stage.cc:1026-1496) */
 typedef struct trhip_scene_desc {

@@ -76,6 +76,7 @@ SYMBOLS = {
     "trhip_download": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "trhip_memset": (_i, [_vp, _vp, _i, C.c_size_t, _vp]),
     "trhip_sync": (_i, [_vp, _vp]),
+    "trhip_copy_peer": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "trhip_scene_upload": (_i, [_vp, C.POINTER(SceneDescC)]),
     "trhip_scene_update_cameras": (_i, [_vp, _vp, _u32]),
     "trhip_scene_build_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),

@@ -207,6 +207,12 @@ int trhip_download(trhip_device* dev, void* dst, const void* src, size_t bytes, 
 }
 int trhip_memset(trhip_device* dev, void* dst, int value, size_t bytes, void* stream) { DEVCHK(dev); HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream)); return 0; }
 int trhip_sync(trhip_device* dev, void* stream) { DEVCHK(dev); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream) {
+    if (!dst_dev || !src_dev) return set_error("null trhip_device");
+    DEVCHK(src_dev);
+    HIPCHK(hipMemcpyPeerAsync(dst, dst_dev->hip_device, src, src_dev->hip_device, bytes, (hipStream_t)stream));
+    return 0;
+}
 
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     DEVCHK(dev);

@@ -1,0 +1,132 @@
+// tauray_hip - headless command line front-end of the MI355X path-tracing core, shaped after `tauray --headless`
+// (reference src/main.cc, src/tauray.cc:1017-1132 replay_viewer): load a scene, create an rt_renderer over the
+// selected devices, render N frames, tonemap, save.  Scene input is a .trsc dump (tauray_amd/scene_io.py).
+//
+//   tauray_hip scene.trsc --width=512 --height=512 --headless=out/frame [--max-ray-depth=8] [--samples-per-pixel=1]
+//              [--frames=1] [--fake-devices=N | --devices=0,1,...] [--distribution-strategy=scanline|shuffled-strips]
+//              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
+//              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
+//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0]
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+#include "tauray_hip.hh"
+
+using namespace tr;
+
+static bool starts(const std::string& s, const std::string& p) { return s.compare(0, p.size(), p) == 0; }
+
+int main(int argc, char** argv)
+{
+    try
+    {
+        std::string scene_path, prefix = "capture";
+        uvec2 size{1280, 720};
+        int frames = 1, warmup = 0, fake_devices = 1;
+        std::vector<int> devices;
+        bool timing = false;
+        rt_renderer::options opt;
+        opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
+        headless::options hopt;
+        hopt.single_frame = true;
+        for(int i = 1; i < argc; ++i)
+        {
+            std::string a = argv[i];
+            auto val = [&](const char* key) { return a.substr(std::strlen(key)); };
+            if(a == "-t") timing = true;
+            else if(a == "--accumulation") opt.accumulate = true;
+            else if(starts(a, "--width=")) size.x = (uint32_t)std::stoul(val("--width="));
+            else if(starts(a, "--height=")) size.y = (uint32_t)std::stoul(val("--height="));
+            else if(starts(a, "--headless=")) prefix = val("--headless=");
+            else if(starts(a, "--max-ray-depth=")) opt.max_ray_depth = std::stoi(val("--max-ray-depth="));
+            else if(starts(a, "--min-ray-dist=")) opt.min_ray_dist = std::stof(val("--min-ray-dist="));
+            else if(starts(a, "--samples-per-pixel=")) opt.samples_per_pixel = std::stoi(val("--samples-per-pixel="));
+            else if(starts(a, "--samples-per-pass=")) opt.samples_per_pass = std::stoi(val("--samples-per-pass="));
+            else if(starts(a, "--frames=")) { frames = std::stoi(val("--frames=")); hopt.single_frame = frames == 1; }
+            else if(starts(a, "--warmup-frames=")) warmup = std::stoi(val("--warmup-frames="));
+            else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
+            else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
+            else if(starts(a, "--exposure=")) opt.tonemap.exposure = std::stof(val("--exposure="));
+            else if(starts(a, "--gamma=")) opt.tonemap.gamma = std::stof(val("--gamma="));
+            else if(starts(a, "--devices="))
+            {
+                std::stringstream ss(val("--devices=")); std::string tok;
+                while(std::getline(ss, tok, ',')) devices.push_back(std::stoi(tok));
+            }
+            else if(starts(a, "--distribution-strategy="))
+            {
+                std::string v = val("--distribution-strategy=");
+                opt.distribution.strategy = v == "scanline" ? DISTRIBUTION_SCANLINE : v == "duplicate" ? DISTRIBUTION_DUPLICATE : DISTRIBUTION_SHUFFLED_STRIPS;
+            }
+            else if(starts(a, "--filetype="))
+            {
+                std::string v = val("--filetype=");
+                hopt.output_file_type = v == "raw" ? headless::RAW : (v == "none" ? headless::EMPTY : headless::EXR);
+            }
+            else if(starts(a, "--format="))
+            {
+                std::string v = val("--format=");
+                hopt.output_format = v == "rgb32" ? headless::RGB32 : v == "rgba16" ? headless::RGBA16 : v == "rgba32" ? headless::RGBA32 : headless::RGB16;
+            }
+            else if(starts(a, "--tonemap="))
+            {
+                static const std::map<std::string, tonemap_stage::operator_type> ops = {
+                    {"linear", tonemap_stage::LINEAR}, {"gamma-correction", tonemap_stage::GAMMA_CORRECTION}, {"filmic", tonemap_stage::FILMIC},
+                    {"reinhard", tonemap_stage::REINHARD}, {"reinhard-luminance", tonemap_stage::REINHARD_LUMINANCE}};
+                auto it = ops.find(val("--tonemap="));
+                if(it == ops.end()) throw std::runtime_error("unknown tonemap operator");
+                opt.tonemap.tonemap_operator = it->second;
+            }
+            else if(starts(a, "--sampler="))
+            {
+                std::string v = val("--sampler=");
+                opt.local_sampler = v == "sobol-owen" ? sampler_type::SOBOL_OWEN : v == "sobol-z2" ? sampler_type::SOBOL_Z_ORDER_2D :
+                    v == "sobol-z3" ? sampler_type::SOBOL_Z_ORDER_3D : sampler_type::UNIFORM_RANDOM;
+            }
+            else if(starts(a, "--")) throw std::runtime_error("unknown option " + a);
+            else scene_path = a;
+        }
+        if(scene_path.empty()) throw std::runtime_error("usage: tauray_hip scene.trsc [options]");
+        if(devices.empty()) devices.assign((size_t)std::max(fake_devices, 1), 0);
+
+        scene_data scene = load_scene_dump(scene_path);
+        // create_renderer (src/tauray.cc:355-421): classes without lights get weight 0, projection follows the camera
+        if(scene.point_light_count() == 0) opt.sampling_weights.point_lights = 0;
+        if(scene.directional_light_count() == 0) opt.sampling_weights.directional_lights = 0;
+        if(scene.envmap.empty()) opt.sampling_weights.envmap = 0;
+        if(!scene.has_tri_lights()) opt.sampling_weights.emissive_triangles = 0;
+        opt.projection = (int)scene.projection;
+        opt.samples_per_pass = std::min(opt.samples_per_pass, opt.samples_per_pixel);
+        opt.active_viewport_count = 1;
+
+        rt_renderer rr(devices, scene, size, opt);
+        hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = 1;
+        headless out(hopt);
+        for(int f = -warmup; f < frames; ++f)
+        {
+            auto t0 = std::chrono::high_resolution_clock::now();
+            rr.reset_accumulation();                   // offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
+            rr.render();
+            for(auto& d: rr.per_device) d.dev->sync();
+            auto t1 = std::chrono::high_resolution_clock::now();
+            if(f < 0) continue;
+            if(timing)
+            {   // print_simple_trace (src/tracing.cc:247-279)
+                std::cout << "FRAME " << f << ":\n";
+                std::vector<double> pt = rr.get_path_tracing_times();
+                for(size_t i = 0; i < pt.size(); ++i)
+                    std::cout << "\tDEVICE " << i << ":\n\t\t[path tracing (" << opt.active_viewport_count << " viewports)] " << pt[i] << " ms\n";
+                std::cout << "\tHOST: " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms\n";
+            }
+            out.save(*rr.per_device[0].dev, rr.display, (unsigned)f);
+        }
+        return 0;
+    }
+    catch(std::exception& e)
+    {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}
