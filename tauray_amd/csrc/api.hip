@@ -290,6 +290,8 @@ int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint3
 
 int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
+    if (const char* b = getenv("TRHIP_BUILDER")) dev->scene.builder = std::string(b) == "lbvh" ? 0 : 1;
+    if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     if (const char* w = getenv("TRHIP_BVH_WIDTH")) dev->scene.bvh_width = atoi(w) == 8 ? 8 : 2;   // A/B switch for profiling
     return build_accel(dev->scene, nullptr, out);
 }

@@ -35,6 +35,9 @@ struct DeviceScene {
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
     uint node_count = 0, tri_light_count = 0, node_count8 = 0, bvh8_levels = 0;
+    int builder = 1;                     // 0 = Karras LBVH, 1 = PLOC over the Morton order (TRHIP_BUILDER=lbvh|ploc)
+    uint build_rounds = 0;
+    int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
     int bvh_width = 2;                   // 2 = binary LBVH nodes (default, fastest measured), 8 = compressed wide nodes (TRHIP_BVH_WIDTH=8)
     bool accel_built = false;
 

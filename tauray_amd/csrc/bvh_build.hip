@@ -126,7 +126,7 @@ TR_DEV int delta(const unsigned long long* keys, int n, int i, int j) {
 
 // one thread per internal node i in [0, n-1): children + parent links.
 // refs: >= 0 internal node, < 0 leaf ~leaf_index (leaf_index = position in sorted order)
-__global__ __launch_bounds__(BT) void k_hierarchy(int n, const unsigned long long* keys, int2* children, int2* ranges, int* parent_internal, int* parent_leaf) {
+__global__ __launch_bounds__(BT) void k_hierarchy(int n, const unsigned long long* keys, int2* children, uint* subtree_size, int* parent_internal, int* parent_leaf) {
     int i = blockIdx.x * BT + threadIdx.x;
     if (i >= n - 1) return;
     int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BT) void k_hierarchy(int n, const unsigned long lon
     int left = (min(i, j) == gamma) ? ~gamma : gamma;
     int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     children[i] = make_int2(left, right);
-    ranges[i] = make_int2(min(i, j), max(i, j));   // leaves (sorted order) covered by this node
+    subtree_size[i] = (uint)(max(i, j) - min(i, j) + 1);   // leaves covered by this node
     if (left >= 0) parent_internal[left] = i; else parent_leaf[~left] = i;
     if (right >= 0) parent_internal[right] = i; else parent_leaf[~right] = i;
     if (i == 0) parent_internal[0] = -1;
@@ -205,6 +205,113 @@ __global__ __launch_bounds__(BT) void k_refit(int n, const int2* children, const
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) on the Morton-sorted leaves: every cluster
+// looks for the neighbour within +-PLOC_RADIUS positions whose merged box has the smallest area; mutual nearest
+// neighbours merge; the cluster array is compacted and the round repeats until one cluster is left.  Gives
+// near-SAH trees while staying a radix-sort-based on-device build.  Internal node ids are handed out from the top
+// so that the last merge (the root) is node 0.
+#define PLOC_RADIUS 16
+
+TR_DEV float merged_area(const float* a, const float* b) {
+    float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]);
+    float dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]);
+    float dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(BT) void k_ploc_nn(uint c, const float* cbox, uint* nn) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= c) return;
+    float mine[6];
+    for (int k = 0; k < 6; ++k) mine[k] = cbox[6 * (size_t)i + k];
+    uint lo = i > PLOC_RADIUS ? i - PLOC_RADIUS : 0, hi = min(c - 1, i + PLOC_RADIUS);
+    float best = __builtin_huge_valf(); uint bj = i;
+    for (uint j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        float a = merged_area(mine, cbox + 6 * (size_t)j);
+        if (a < best) { best = a; bj = j; }
+    }
+    nn[i] = bj;
+}
+
+__global__ __launch_bounds__(BT) void k_ploc_merge(uint c, uint n_leaves, const int* cref, const float* cbox, const uint* nn, uint* valid, int* out_ref,
+                                                   float* out_box, uint* alloc, int2* children, float* node_box, uint* subtree_size, int* parent_internal) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= c) return;
+    uint j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    if (mutual && i > j) { valid[i] = 0; return; }
+    int ref = cref[i];
+    float box[6];
+    for (int k = 0; k < 6; ++k) box[k] = cbox[6 * (size_t)i + k];
+    if (mutual) {
+        const int other = cref[j];
+        const float* ob = cbox + 6 * (size_t)j;
+        for (int k = 0; k < 3; ++k) { box[k] = fminf(box[k], ob[k]); box[3 + k] = fmaxf(box[3 + k], ob[3 + k]); }
+        const uint id = (n_leaves - 2u) - atomicAdd(alloc, 1u);
+        children[id] = make_int2(ref, other);
+        if (ref >= 0) parent_internal[ref] = (int)id;
+        if (other >= 0) parent_internal[other] = (int)id;
+        for (int k = 0; k < 6; ++k) node_box[6 * (size_t)id + k] = box[k];
+        subtree_size[id] = (ref < 0 ? 1u : subtree_size[ref]) + (other < 0 ? 1u : subtree_size[other]);
+        ref = (int)id;
+    }
+    valid[i] = 1;
+    out_ref[i] = ref;
+    for (int k = 0; k < 6; ++k) out_box[6 * (size_t)i + k] = box[k];
+}
+
+__global__ __launch_bounds__(BT) void k_ploc_compact(uint c, const uint* valid, const uint* pos, const int* in_ref, const float* in_box, int* cref, float* cbox) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= c || !valid[i]) return;
+    uint p = pos[i];
+    cref[p] = in_ref[i];
+    for (int k = 0; k < 6; ++k) cbox[6 * (size_t)p + k] = in_box[6 * (size_t)i + k];
+}
+
+__global__ __launch_bounds__(BT) void k_ploc_init(uint n, int* cref) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i < n) cref[i] = ~(int)i;
+}
+
+__global__ __launch_bounds__(BT) void k_identity(uint n, int* v) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i < n) v[i] = (int)i;
+}
+
+// Depth-first relabelling: a node's slot is its pre-order index among the internal nodes, so a left child sits right
+// after its parent and every subtree is one contiguous run of 64-byte nodes (keeps the lower levels of one ray's walk
+// within a few cache lines / one TLB page instead of scattered by merge order).
+__global__ __launch_bounds__(BT) void k_dfs_order(uint n_internal, const int2* children, const uint* subtree_size, const int* parent_internal, int* new_id) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_internal) return;
+    uint pos = 0;
+    int cur = (int)i;
+    for (int p = parent_internal[cur]; p >= 0; cur = p, p = parent_internal[cur]) {
+        const int2 ch = children[p];
+        pos += 1u;
+        if (ch.y == cur && ch.x >= 0) pos += subtree_size[ch.x] - 1u;   // skip the left subtree's internal nodes
+    }
+    new_id[i] = (int)pos;
+}
+
+// 64-byte traversal nodes from (children, boxes)
+__global__ __launch_bounds__(BT) void k_emit_nodes(uint n_internal, const int2* children, const float* node_box, const float* leaf_box, const int* new_id,
+                                                   BvhNode* nodes) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_internal) return;
+    const int2 ch = children[i];
+    const float* b0 = ch.x >= 0 ? node_box + 6 * (size_t)ch.x : leaf_box + 6 * (size_t)(~ch.x);
+    const float* b1 = ch.y >= 0 ? node_box + 6 * (size_t)ch.y : leaf_box + 6 * (size_t)(~ch.y);
+    BvhNode out;
+    for (int k = 0; k < 3; ++k) { out.lo0[k] = b0[k]; out.hi0[k] = b0[3 + k]; out.lo1[k] = b1[k]; out.hi1[k] = b1[3 + k]; }
+    out.child0 = ch.x >= 0 ? new_id[ch.x] : ch.x;
+    out.child1 = ch.y >= 0 ? new_id[ch.y] : ch.y;
+    out.pad0 = 0; out.pad1 = 0;
+    nodes[new_id[i]] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // BVH2 -> compressed 8-wide BVH.  One thread per wide node of the current level: open the child with the largest
 // surface area until eight children (subtrees of <= 3 triangles become leaf children), assign children to slots
 // by octant (so traversal can order them with one XOR), quantise the boxes conservatively and copy the leaf
@@ -215,11 +322,22 @@ TR_DEV void ref_box(int ref, const float* node_box, const float* leaf_box, float
     const float* b = ref >= 0 ? node_box + 6 * (size_t)ref : leaf_box + 6 * (size_t)(~ref);
     for (int k = 0; k < 3; ++k) { lo[k] = b[k]; hi[k] = b[3 + k]; }
 }
-TR_DEV int ref_count(int ref, const int2* ranges) { return ref < 0 ? 1 : ranges[ref].y - ranges[ref].x + 1; }
-TR_DEV int ref_first(int ref, const int2* ranges) { return ref < 0 ? ~ref : ranges[ref].x; }
+TR_DEV int ref_count(int ref, const uint* subtree_size) { return ref < 0 ? 1 : (int)subtree_size[ref]; }
+// leaves of a subtree with at most 3 triangles (depth <= 2), in left-to-right order
+TR_DEV int ref_leaves(int ref, const int2* children, int* out) {
+    if (ref < 0) { out[0] = ~ref; return 1; }
+    int n = 0;
+    const int2 c = children[ref];
+    const int sub[2] = {c.x, c.y};
+    for (int k = 0; k < 2; ++k) {
+        if (sub[k] < 0) out[n++] = ~sub[k];
+        else { const int2 g = children[sub[k]]; out[n++] = ~g.x; out[n++] = ~g.y; }   // a 2-leaf child of a 3-leaf subtree
+    }
+    return n;
+}
 
 __global__ __launch_bounds__(BT) void k_collapse(uint n_items, const CollapseItem* in, CollapseItem* out, uint* counters /* 0 out, 1 nodes, 2 tris */,
-                                                 const int2* children, const int2* ranges, const float* node_box, const float* leaf_box,
+                                                 const int2* children, const uint* ranges, const float* node_box, const float* leaf_box,
                                                  const TriRecord* tris_sorted, Bvh8Node* nodes8, TriRecord* tris8) {
     uint t = blockIdx.x * BT + threadIdx.x;
     if (t >= n_items) return;
@@ -326,8 +444,9 @@ __global__ __launch_bounds__(BT) void k_collapse(uint n_items, const CollapseIte
         } else {
             const uint unary = cnt == 1 ? 1u : (cnt == 2 ? 3u : 7u);
             nd.meta[sl] = (uint8_t)((unary << 5) | tri_off);
-            int first = ref_first(cand[c], ranges);
-            for (int q = 0; q < cnt; ++q) tris8[tri_base + tri_off + (uint)q] = tris_sorted[first + q];
+            int leaves[4];
+            ref_leaves(cand[c], children, leaves);
+            for (int q = 0; q < cnt; ++q) tris8[tri_base + tri_off + (uint)q] = tris_sorted[leaves[q]];
             tri_off += (uint)cnt;
         }
     }
@@ -381,7 +500,8 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         TriRecord* unsorted = nullptr;
         unsigned long long *keys = nullptr, *keys_sorted = nullptr;
         uint *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
-        int2 *children = nullptr, *ranges = nullptr;
+        int2* children = nullptr;
+        uint* ranges = nullptr;   // subtree sizes (leaves per internal node)
         int *parent_internal = nullptr, *parent_leaf = nullptr;
         float *leaf_box = nullptr, *node_box = nullptr;
         HIPCHK(hipMalloc(&unsorted, (size_t)n * sizeof(TriRecord)));
@@ -402,16 +522,62 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         if (n > 1) {
             HIPCHK(hipMalloc(&ds.nodes, (size_t)(n - 1) * sizeof(BvhNode)));
             HIPCHK(hipMalloc(&children, (size_t)(n - 1) * sizeof(int2)));
-            HIPCHK(hipMalloc(&ranges, (size_t)(n - 1) * sizeof(int2)));
+            HIPCHK(hipMalloc(&ranges, (size_t)(n - 1) * sizeof(uint)));
             HIPCHK(hipMalloc(&parent_internal, (size_t)(n - 1) * 4));
             HIPCHK(hipMalloc(&parent_leaf, (size_t)n * 4));
             HIPCHK(hipMalloc(&node_box, (size_t)(n - 1) * 24));
             HIPCHK(hipMalloc(&arrive, (size_t)(n - 1) * 4));
             HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
             const uint iblocks = (n - 1 + BT - 1) / BT;
-            hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(BT), 0, stream, (int)n, keys_sorted, children, ranges, parent_internal, parent_leaf);
-            hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BT), 0, stream, (int)n, children, parent_internal, parent_leaf, leaf_box,
-                               node_box, arrive, ds.nodes);
+            if (ds.builder == 0) {
+                // Karras 2012 LBVH + atomic bottom-up refit
+                hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(BT), 0, stream, (int)n, keys_sorted, children, ranges, parent_internal, parent_leaf);
+                hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BT), 0, stream, (int)n, children, parent_internal, parent_leaf, leaf_box,
+                                   node_box, arrive, ds.nodes);
+            } else {
+                // PLOC over the Morton order
+                int* cref[2]; float* cbox[2]; uint *nn, *valid, *pos, *alloc;
+                HIPCHK(hipMalloc(&cref[0], (size_t)n * 4)); HIPCHK(hipMalloc(&cref[1], (size_t)n * 4));
+                HIPCHK(hipMalloc(&cbox[0], (size_t)n * 24)); HIPCHK(hipMalloc(&cbox[1], (size_t)n * 24));
+                HIPCHK(hipMalloc(&nn, (size_t)n * 4)); HIPCHK(hipMalloc(&valid, (size_t)n * 4)); HIPCHK(hipMalloc(&pos, (size_t)n * 4));
+                HIPCHK(hipMalloc(&alloc, 4)); HIPCHK(hipMemsetAsync(alloc, 0, 4, stream));
+                HIPCHK(hipMemsetAsync(parent_internal, 0xFF, (size_t)(n - 1) * 4, stream));   // root keeps -1
+                hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(BT), 0, stream, n, cref[0]);
+                HIPCHK(hipMemcpyAsync(cbox[0], leaf_box, (size_t)n * 24, hipMemcpyDeviceToDevice, stream));
+                size_t scan_bytes = 0;
+                HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, n, rocprim::plus<uint>(), stream));
+                void* scan_temp = nullptr;
+                HIPCHK(hipMalloc(&scan_temp, scan_bytes ? scan_bytes : 16));
+                uint c = n;
+                int rounds = 0;
+                while (c > 1) {
+                    const uint cb = (c + BT - 1) / BT;
+                    hipLaunchKernelGGL(k_ploc_nn, dim3(cb), dim3(BT), 0, stream, c, cbox[0], nn);
+                    hipLaunchKernelGGL(k_ploc_merge, dim3(cb), dim3(BT), 0, stream, c, n, cref[0], cbox[0], nn, valid, cref[1], cbox[1], alloc, children,
+                                       node_box, ranges, parent_internal);
+                    HIPCHK(rocprim::exclusive_scan(scan_temp, scan_bytes, valid, pos, 0u, c, rocprim::plus<uint>(), stream));
+                    hipLaunchKernelGGL(k_ploc_compact, dim3(cb), dim3(BT), 0, stream, c, valid, pos, cref[1], cbox[1], cref[0], cbox[0]);
+                    uint last[2];
+                    HIPCHK(hipMemcpyAsync(&last[0], pos + (c - 1), 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipMemcpyAsync(&last[1], valid + (c - 1), 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    const uint c_new = last[0] + last[1];
+                    if (c_new >= c || ++rounds > 4096) return set_error("PLOC: clustering did not converge");
+                    c = c_new;
+                }
+                ds.build_rounds = (uint)rounds;
+                (void)hipFree(cref[0]); (void)hipFree(cref[1]); (void)hipFree(cbox[0]); (void)hipFree(cbox[1]);
+                (void)hipFree(nn); (void)hipFree(valid); (void)hipFree(pos); (void)hipFree(alloc); (void)hipFree(scan_temp);
+            }
+            if (ds.builder != 0 || ds.dfs_layout) {
+                int* new_id = nullptr;
+                HIPCHK(hipMalloc(&new_id, (size_t)(n - 1) * 4));
+                if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
+                else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
+                hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
+                HIPCHK(hipStreamSynchronize(stream));
+                (void)hipFree(new_id);
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
