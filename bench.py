@@ -84,7 +84,7 @@ def main():
             rr.render()
 
     # ---- timed region: W warm-up frames, then exactly K frames between barriers
-    pt.set_profiling(False, not args.no_roofline)
+    pt.set_profiling(False, False)
     rr.reset_accumulation(reset_sample_counter=True)
     run_frames(args.warmup)
     sync_all()
@@ -128,9 +128,19 @@ def main():
 
     # ---- roofline of the dominant kernel (k_trace_closest), rank 0
     if rank == 0 and not args.no_roofline:
+        # re-run of the identical frames (same frame indices) with per-kernel HIP events; detailed timing serialises the
+        # frame (no shadow/closest overlap), so every kernel is measured owning the chip (instance k_trace_closest<false, true>)
+        pt.set_profiling(False, True)
+        rr.reset_accumulation(reset_sample_counter=True)
+        run_frames(args.warmup)
+        ctx.sync()
+        pt.reset_counters()
+        run_frames(args.steps)
+        ctx.sync()
+        timings = pt.timings()
         launches = max(timings["trace_closest_launches"], 1)
         avg_ms = timings["trace_closest_ms"] / launches
-        # counted re-run of the identical frames (same frame indices) for the algorithmic byte model
+        # counted re-run for the algorithmic byte model
         pt.set_profiling(True, False)
         rr.reset_accumulation(reset_sample_counter=True)
         run_frames(args.warmup)
@@ -142,11 +152,12 @@ def main():
         # bytes per SURVEY.md section 8(d), restricted to what trace kernels touch; the closest-hit kernel's share of
         # node/triangle work is apportioned by ray count (both trace kernels walk the same structure)
         closest_share = c["closest_rays"] / max(c["closest_rays"] + c["shadow_rays"], 1)
-        trace_bytes = (c["node_visits"] * 64 + c["tri_tests"] * 48 + c["alpha_tests"] * 52) * closest_share \
+        node_bytes = rr.scene_update.accel["node_bytes"]   # what one node visit reads (trhip_accel_info)
+        trace_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52) * closest_share \
             + c["closest_rays"] * (16 + 16 + 16 + 16)   # ray origin + direction + misc read, hit record write
         bytes_per_launch = trace_bytes / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        frame_bytes = (c["node_visits"] * 64 + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
+        frame_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
                        + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.spp * 16 * args.steps) / args.steps
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -71,12 +71,13 @@ typedef struct trhip_accel_info {
     uint32_t tri_light_count;
     float build_ms;                   /* device time of the whole build */
     float bounds_min[3], bounds_max[3];
+    uint32_t node_bytes;              /* bytes one node visit reads (112: six box planes + child refs of a 4-wide node) */
 } trhip_accel_info;
 
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
 /* Replaces vkCmdBuildAccelerationStructuresKHR (src/acceleration_structure.cc:198,266,421) with an
- * on-device LBVH (pre-transform -> bounds -> Morton -> radix sort -> Karras hierarchy -> refit) and
+ * on-device build (pre-transform -> bounds -> Morton -> radix sort -> PLOC clustering -> 4-wide collapse) and
  * runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).  Synchronous. */
 int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out);
 /* copies the 64-byte tri_light records back to the host (test hook) */

@@ -29,7 +29,8 @@ class SceneDescC(C.Structure):
 
 class AccelInfoC(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_light_count", C.c_uint32),
-                ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
+                ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("node_bytes", C.c_uint32)]
 
 
 class PtOptionsC(C.Structure):

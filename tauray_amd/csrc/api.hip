@@ -22,10 +22,9 @@ constexpr int KB = TR_BLOCK;
 
 // ---------------------------------------------------------------------------------------------------
 // feature_stage: shader/rt_feature.rgen:21-45 + rt_feature.rchit:16-27 with FEATURE of src/feature_stage.cc:33-65
-template <bool WIDE>
 __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int feature, int projection, uint viewport, float min_ray_dist,
                                                 f4 default_value, f4* target, uint target_w, uint target_h, uint* overflow_flag) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
+    __shared__ int s_stack[TR_STACK_WORDS];
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= L.launch_w * L.launch_h) return;
     uint lx = i % L.launch_w, ly = i / L.launch_w;
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     HitRecord hit;
     TraceStats st = {0, 0, 0, 0};
     int overflow = 0;
-    trace_closest_any<1, false, WIDE>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), hit, st, overflow);
+    trace_closest_any<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
     if (overflow) *overflow_flag = 1;
     f4 data = default_value;
     if (hit.instance_id >= 0) {
@@ -61,30 +60,28 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
 }
 
 // ray-level hooks
-template <bool WIDE>
 __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
                                                       HitRecord* out, uint* overflow_flag) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
-    int* my_stack = s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x);
+    __shared__ int s_stack[TR_STACK_WORDS];
+    int* my_stack = s_stack + threadIdx.x;
     int overflow = 0;
     TraceStats st = {0, 0, 0, 0};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
         HitRecord hit;
-        if (seeds) trace_closest_any<0, false, WIDE>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seeds[i], my_stack, hit, st, overflow);
-        else trace_closest_any<1, false, WIDE>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow);
+        if (seeds) trace_closest_any<0, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seeds[i], my_stack, hit, st, overflow);
+        else trace_closest_any<1, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow);
         out[i] = hit;
     }
     if (overflow) *overflow_flag = 1;
 }
-template <bool WIDE>
 __global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
+    __shared__ int s_stack[TR_STACK_WORDS];
     int overflow = 0;
     TraceStats st = {0, 0, 0, 0};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
-        out[i] = trace_shadow_any<false, WIDE>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), st, overflow);
+        out[i] = trace_shadow_any<false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow);
     }
     if (overflow) *overflow_flag = 1;
 }
@@ -292,7 +289,6 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
     if (const char* b = getenv("TRHIP_BUILDER")) dev->scene.builder = std::string(b) == "lbvh" ? 0 : 1;
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
-    if (const char* w = getenv("TRHIP_BVH_WIDTH")) dev->scene.bvh_width = atoi(w) == 8 ? 8 : 2;   // A/B switch for profiling
     return build_accel(dev->scene, nullptr, out);
 }
 
@@ -370,7 +366,7 @@ int trhip_feature_render(trhip_device* dev, int feature, const trhip_distributio
     size_t n = (size_t)L.launch_w * L.launch_h;
     if (n == 0) return 0;
     f4 dv = F4(default_value[0], default_value[1], default_value[2], default_value[3]);
-    hipLaunchKernelGGL(dev->scene.bvh_width == 8 ? k_feature<true> : k_feature<false>, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), L, feature, projection,
+    hipLaunchKernelGGL(k_feature, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), L, feature, projection,
                        viewport, min_ray_dist, dv, (f4*)color_dev, target_w, target_h, dev->overflow_flag);
     HIPCHK(hipGetLastError());
     return 0;
@@ -381,7 +377,7 @@ int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, con
     if (!dev->scene.accel_built) return set_error("trhip_trace_closest: call trhip_scene_build_accel first");
     if (n == 0) return 0;
     uint blocks = std::min((n + KB - 1) / KB, 2048u);
-    hipLaunchKernelGGL(dev->scene.bvh_width == 8 ? k_query_closest<true> : k_query_closest<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+    hipLaunchKernelGGL(k_query_closest, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
                        (const uint*)seeds_dev, include_lights, (HitRecord*)hits_dev, dev->overflow_flag);
     HIPCHK(hipGetLastError());
     return 0;
@@ -391,7 +387,7 @@ int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void
     if (!dev->scene.accel_built) return set_error("trhip_trace_shadow: call trhip_scene_build_accel first");
     if (n == 0) return 0;
     uint blocks = std::min((n + KB - 1) / KB, 2048u);
-    hipLaunchKernelGGL(dev->scene.bvh_width == 8 ? k_query_shadow<true> : k_query_shadow<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+    hipLaunchKernelGGL(k_query_shadow, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
                        (float*)visibility_dev, dev->overflow_flag);
     HIPCHK(hipGetLastError());
     return 0;

@@ -31,14 +31,13 @@ struct DeviceScene {
     uint gather_emissive_triangles = 0, host_tri_light_count = 0;
     // built by trhip_scene_build_accel
     BvhNode* nodes = nullptr;
-    Bvh8Node* nodes8 = nullptr;
+    Bvh4Node* nodes4 = nullptr;
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
-    uint node_count = 0, tri_light_count = 0, node_count8 = 0, bvh8_levels = 0;
+    uint node_count = 0, tri_light_count = 0;
     int builder = 1;                     // 0 = Karras LBVH, 1 = PLOC over the Morton order (TRHIP_BUILDER=lbvh|ploc)
     uint build_rounds = 0;
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
-    int bvh_width = 2;                   // 2 = binary LBVH nodes (default, fastest measured), 8 = compressed wide nodes (TRHIP_BVH_WIDTH=8)
     bool accel_built = false;
 
     SceneView view() const {
@@ -46,20 +45,19 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.nodes = nodes; v.tris = tris; v.nodes8 = nodes8;
+        v.cameras = cameras; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
         v.env_w = env_w; v.env_h = env_h; v.tri_count = accel_built ? tri_count : 0; v.node_count = node_count;
-        if (bvh_width != 8) v.nodes8 = nullptr;
         return v;
     }
     void free_accel() {
         if (nodes) (void)hipFree(nodes);
-        if (nodes8) (void)hipFree(nodes8);
+        if (nodes4) (void)hipFree(nodes4);
         if (tris) (void)hipFree(tris);
         if (tri_lights) (void)hipFree(tri_lights);
-        nodes = nullptr; nodes8 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;
+        nodes = nullptr; nodes4 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;
     }
     void free_all() {
         free_accel();

@@ -311,147 +311,45 @@ __global__ __launch_bounds__(BT) void k_emit_nodes(uint n_internal, const int2* 
     nodes[new_id[i]] = out;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// BVH2 -> compressed 8-wide BVH.  One thread per wide node of the current level: open the child with the largest
-// surface area until eight children (subtrees of <= 3 triangles become leaf children), assign children to slots
-// by octant (so traversal can order them with one XOR), quantise the boxes conservatively and copy the leaf
-// triangles into wide-node order.  Levels are processed breadth-first from the root.
-struct CollapseItem { int bvh2; uint wide; };
-
-TR_DEV void ref_box(int ref, const float* node_box, const float* leaf_box, float* lo, float* hi) {
-    const float* b = ref >= 0 ? node_box + 6 * (size_t)ref : leaf_box + 6 * (size_t)(~ref);
-    for (int k = 0; k < 3; ++k) { lo[k] = b[k]; hi[k] = b[3 + k]; }
-}
-TR_DEV int ref_count(int ref, const uint* subtree_size) { return ref < 0 ? 1 : (int)subtree_size[ref]; }
-// leaves of a subtree with at most 3 triangles (depth <= 2), in left-to-right order
-TR_DEV int ref_leaves(int ref, const int2* children, int* out) {
-    if (ref < 0) { out[0] = ~ref; return 1; }
-    int n = 0;
-    const int2 c = children[ref];
-    const int sub[2] = {c.x, c.y};
-    for (int k = 0; k < 2; ++k) {
-        if (sub[k] < 0) out[n++] = ~sub[k];
-        else { const int2 g = children[sub[k]]; out[n++] = ~g.x; out[n++] = ~g.y; }   // a 2-leaf child of a 3-leaf subtree
-    }
-    return n;
-}
-
-__global__ __launch_bounds__(BT) void k_collapse(uint n_items, const CollapseItem* in, CollapseItem* out, uint* counters /* 0 out, 1 nodes, 2 tris */,
-                                                 const int2* children, const uint* ranges, const float* node_box, const float* leaf_box,
-                                                 const TriRecord* tris_sorted, Bvh8Node* nodes8, TriRecord* tris8) {
-    uint t = blockIdx.x * BT + threadIdx.x;
-    if (t >= n_items) return;
-    const CollapseItem item = in[t];
-    int cand[8];
-    int ncand;
-    if (item.bvh2 < 0 || ref_count(item.bvh2, ranges) <= 3) {   // tiny scene: the root itself is a leaf child
-        cand[0] = item.bvh2; ncand = 1;
-    } else {
-        cand[0] = children[item.bvh2].x; cand[1] = children[item.bvh2].y; ncand = 2;
-        while (ncand < 8) {
-            int best = -1; float best_area = -1.0f;
-            for (int i = 0; i < ncand; ++i) {
-                if (cand[i] < 0 || ref_count(cand[i], ranges) <= 3) continue;
-                float lo[3], hi[3];
-                ref_box(cand[i], node_box, leaf_box, lo, hi);
-                float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-                float area = dx * dy + dy * dz + dz * dx;
-                if (area > best_area) { best_area = area; best = i; }
-            }
-            if (best < 0) break;
-            int2 ch = children[cand[best]];
-            cand[best] = ch.x; cand[ncand++] = ch.y;
-        }
-    }
-    // node box = union of the children
-    float plo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
-    float phi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
-    float clo[8][3], chi[8][3];
-    for (int i = 0; i < ncand; ++i) {
-        ref_box(cand[i], node_box, leaf_box, clo[i], chi[i]);
-        for (int k = 0; k < 3; ++k) { plo[k] = fminf(plo[k], clo[i][k]); phi[k] = fmaxf(phi[k], chi[i][k]); }
-    }
-    // greedy octant assignment: slot s lies towards (+/-x, +/-y, +/-z) for bits (4, 2, 1)
-    int slot_child[8];
-    for (int s = 0; s < 8; ++s) slot_child[s] = -1;
-    bool assigned[8] = {false, false, false, false, false, false, false, false};
-    float pc[3] = {(plo[0] + phi[0]) * 0.5f, (plo[1] + phi[1]) * 0.5f, (plo[2] + phi[2]) * 0.5f};
-    for (int round = 0; round < ncand; ++round) {
-        float best = -__builtin_huge_valf(); int bc = -1, bs = -1;
+// BVH2 -> BVH4, in place: every binary node keeps its (depth-first) index and adopts up to four descendants, found by
+// repeatedly opening the adopted inner node with the largest box.  Nodes that were adopted away are never referenced
+// again; they stay as dead 128-byte lines, which costs memory but neither bandwidth nor cache (a node is one line).
+__global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* children, const float* node_box, const float* leaf_box, const int* new_id,
+                                                  Bvh4Node* nodes4) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_internal) return;
+    int cand[4];
+    cand[0] = children[i].x; cand[1] = children[i].y;
+    int ncand = 2;
+    while (ncand < 4) {
+        int best = -1; float best_area = -1.0f;
         for (int c = 0; c < ncand; ++c) {
-            if (assigned[c]) continue;
-            float d[3];
-            for (int k = 0; k < 3; ++k) d[k] = (clo[c][k] + chi[c][k]) * 0.5f - pc[k];
-            for (int sl = 0; sl < 8; ++sl) {
-                if (slot_child[sl] >= 0) continue;
-                float cost = ((sl & 4) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 1) ? d[2] : -d[2]);
-                if (cost > best) { best = cost; bc = c; bs = sl; }
-            }
+            if (cand[c] < 0) continue;
+            const float* b = node_box + 6 * (size_t)cand[c];
+            float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            float area = dx * dy + dy * dz + dz * dx;
+            if (area > best_area) { best_area = area; best = c; }
         }
-        assigned[bc] = true; slot_child[bs] = bc;
+        if (best < 0) break;
+        const int2 ch = children[cand[best]];
+        cand[best] = ch.x; cand[ncand++] = ch.y;
     }
-    // counts and allocation
-    uint n_inner = 0, n_tris = 0;
-    for (int sl = 0; sl < 8; ++sl) {
-        int c = slot_child[sl];
-        if (c < 0) continue;
-        int cnt = ref_count(cand[c], ranges);
-        if (cand[c] >= 0 && cnt > 3) n_inner++; else n_tris += (uint)cnt;
-    }
-    const uint child_base = n_inner ? atomicAdd(&counters[1], n_inner) : 0u;
-    const uint tri_base = n_tris ? atomicAdd(&counters[2], n_tris) : 0u;
-    const uint out_base = n_inner ? atomicAdd(&counters[0], n_inner) : 0u;
-    Bvh8Node nd;
-    // power-of-two grid: 2^e * 254 > extent
-    float scale[3];
-    for (int k = 0; k < 3; ++k) {
-        nd.p[k] = plo[k];
-        float sgrid = (phi[k] - plo[k]) / 254.0f;
-        int ex = 0;
-        if (sgrid > 0.0f) frexpf(sgrid, &ex);       // sgrid = m * 2^ex with m in [0.5, 1) => 2^ex > sgrid
-        else ex = -126;
-        ex = max(-126, min(127, ex));
-        nd.e[k] = (uint8_t)(ex + 127);
-        scale[k] = __uint_as_float((uint)(ex + 127) << 23);
-    }
-    nd.imask = 0; nd.child_base = child_base; nd.tri_base = tri_base;
-    uint inner_rank = 0, tri_off = 0;
-    uint8_t* qlo[3] = {nd.qlo_x, nd.qlo_y, nd.qlo_z};
-    uint8_t* qhi[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
-    for (int sl = 0; sl < 8; ++sl) {
-        int c = slot_child[sl];
-        if (c < 0) {
-            nd.meta[sl] = 0;
-            for (int k = 0; k < 3; ++k) { qlo[k][sl] = 255; qhi[k][sl] = 0; }   // inverted box: never hit
-            continue;
-        }
-        for (int k = 0; k < 3; ++k) {
-            // conservative: the box decoded with the traversal's own arithmetic (q * scale + p) must contain the child
-            int ql = (int)floorf((clo[c][k] - nd.p[k]) / scale[k]);
-            ql = max(0, min(255, ql));
-            while (ql > 0 && __fmaf_rn((float)ql, scale[k], nd.p[k]) > clo[c][k]) ql--;
-            int qh = (int)ceilf((chi[c][k] - nd.p[k]) / scale[k]);
-            qh = max(0, min(255, qh));
-            while (qh < 255 && __fmaf_rn((float)qh, scale[k], nd.p[k]) < chi[c][k]) qh++;
-            qlo[k][sl] = (uint8_t)ql; qhi[k][sl] = (uint8_t)qh;
-        }
-        int cnt = ref_count(cand[c], ranges);
-        if (cand[c] >= 0 && cnt > 3) {
-            nd.imask |= (uint8_t)(1u << sl);
-            nd.meta[sl] = (uint8_t)((1u << 5) | (24u + (uint)sl));
-            out[out_base + inner_rank] = CollapseItem{cand[c], child_base + inner_rank};
-            inner_rank++;
+    Bvh4Node out;
+    for (int c = 0; c < 4; ++c) {
+        if (c < ncand) {
+            const float* b = cand[c] >= 0 ? node_box + 6 * (size_t)cand[c] : leaf_box + 6 * (size_t)(~cand[c]);
+            out.lox[c] = b[0]; out.loy[c] = b[1]; out.loz[c] = b[2]; out.hix[c] = b[3]; out.hiy[c] = b[4]; out.hiz[c] = b[5];
+            out.child[c] = cand[c] >= 0 ? new_id[cand[c]] : cand[c];
         } else {
-            const uint unary = cnt == 1 ? 1u : (cnt == 2 ? 3u : 7u);
-            nd.meta[sl] = (uint8_t)((unary << 5) | tri_off);
-            int leaves[4];
-            ref_leaves(cand[c], children, leaves);
-            for (int q = 0; q < cnt; ++q) tris8[tri_base + tri_off + (uint)q] = tris_sorted[leaves[q]];
-            tri_off += (uint)cnt;
+            out.lox[c] = out.loy[c] = out.loz[c] = __builtin_huge_valf();
+            out.hix[c] = out.hiy[c] = out.hiz[c] = -__builtin_huge_valf();
+            out.child[c] = 0x7FFFFFFF;
         }
+        out.pad[c] = 0;
     }
-    nodes8[item.wide] = nd;
+    nodes4[new_id[i]] = out;
 }
+
 
 // shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
 __global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const uint* tri_prefix, TriLight* out) {
@@ -569,55 +467,25 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 (void)hipFree(cref[0]); (void)hipFree(cref[1]); (void)hipFree(cbox[0]); (void)hipFree(cbox[1]);
                 (void)hipFree(nn); (void)hipFree(valid); (void)hipFree(pos); (void)hipFree(alloc); (void)hipFree(scan_temp);
             }
-            if (ds.builder != 0 || ds.dfs_layout) {
+            if (ds.builder != 0 || ds.dfs_layout || TR_BVH4) {
                 int* new_id = nullptr;
                 HIPCHK(hipMalloc(&new_id, (size_t)(n - 1) * 4));
                 if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
                 hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
+#if TR_BVH4
+                HIPCHK(hipMalloc(&ds.nodes4, (size_t)(n - 1) * sizeof(Bvh4Node)));
+                hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes4);
+#endif
                 HIPCHK(hipStreamSynchronize(stream));
                 (void)hipFree(new_id);
+#if TR_BVH4
+                (void)hipFree(ds.nodes); ds.nodes = nullptr;   // the binary nodes were only the collapse input
+#endif
             }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        if (ds.bvh_width == 8) {
-            // collapse the binary LBVH into the compressed 8-wide layout, level by level from the root
-            CollapseItem *items[2] = {nullptr, nullptr};
-            uint* ccount = nullptr;
-            TriRecord* tris8 = nullptr;
-            const size_t max_nodes = n > 1 ? n - 1 : 1;
-            HIPCHK(hipMalloc(&ds.nodes8, max_nodes * sizeof(Bvh8Node)));
-            HIPCHK(hipMalloc(&tris8, (size_t)n * sizeof(TriRecord)));
-            HIPCHK(hipMalloc(&items[0], max_nodes * sizeof(CollapseItem)));
-            HIPCHK(hipMalloc(&items[1], max_nodes * sizeof(CollapseItem)));
-            HIPCHK(hipMalloc(&ccount, 3 * sizeof(uint)));
-            uint hc[3] = {0, 1, 0};
-            HIPCHK(hipMemcpy(ccount, hc, sizeof(hc), hipMemcpyHostToDevice));
-            CollapseItem root{n > 1 ? 0 : -1, 0u};
-            HIPCHK(hipMemcpy(items[0], &root, sizeof(root), hipMemcpyHostToDevice));
-            uint n_items = 1;
-            int cur = 0, levels = 0;
-            while (n_items > 0) {
-                hipLaunchKernelGGL(k_collapse, dim3((n_items + BT - 1) / BT), dim3(BT), 0, stream, n_items, items[cur], items[cur ^ 1], ccount,
-                                   children, ranges, node_box, leaf_box, ds.tris, ds.nodes8, tris8);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(stream));
-                HIPCHK(hipMemcpy(hc, ccount, sizeof(hc), hipMemcpyDeviceToHost));
-                n_items = hc[0];
-                if (hc[1] > max_nodes) return set_error("BVH8 collapse: node budget exceeded");
-                uint zero = 0;
-                HIPCHK(hipMemcpy(ccount, &zero, sizeof(zero), hipMemcpyHostToDevice));
-                cur ^= 1;
-                if (++levels > 256) return set_error("BVH8 collapse: hierarchy too deep");
-            }
-            if (hc[2] != n) return set_error("BVH8 collapse: triangle count mismatch");
-            ds.node_count8 = hc[1];
-            ds.bvh8_levels = (uint)levels;
-            (void)hipFree(ds.tris); ds.tris = tris8;
-            if (ds.nodes) { (void)hipFree(ds.nodes); ds.nodes = nullptr; }
-            (void)hipFree(items[0]); (void)hipFree(items[1]); (void)hipFree(ccount);
-        }
         (void)hipFree(ranges);
         (void)hipFree(unsorted); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted); (void)hipFree(leaf_box);
         (void)hipFree(temp); (void)hipFree(children); (void)hipFree(parent_internal); (void)hipFree(parent_leaf); (void)hipFree(node_box); (void)hipFree(arrive);
@@ -643,7 +511,8 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     (void)hipFree(cbounds);
     if (info) {
         info->triangle_count = n;
-        info->node_count = ds.bvh_width == 8 ? ds.node_count8 : ds.node_count;
+        info->node_count = ds.node_count;
+        info->node_bytes = TR_BVH4 ? 112u : 64u;
         info->tri_light_count = ds.tri_light_count;
         info->build_ms = ms;
         for (int k = 0; k < 3; ++k) { info->bounds_min[k] = float_unflip(hb[k]); info->bounds_max[k] = float_unflip(hb[3 + k]); }

@@ -133,6 +133,18 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node layout");
 
+#ifndef TR_BVH4
+#define TR_BVH4 1         // 1: traverse the 4-wide fp32 nodes (SceneView::nodes4); 0: the binary nodes they are collapsed from
+#endif
+// 4-wide node, one 128-byte line: child boxes in SoA (one dwordx4 per plane), child references as in BvhNode
+// (>= 0 inner node, < 0 ~triangle).  Empty slots hold an inverted box (lo = +inf, hi = -inf) and are never hit.
+struct alignas(128) Bvh4Node {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int child[4];
+    int pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
+
 // 48-byte world-space triangle record, stored in Morton (leaf) order.
 //   inst_flags: bits 0..30 instance id, bit 31 = non-opaque (runs the any-hit path)
 struct alignas(16) TriRecord {
@@ -140,23 +152,6 @@ struct alignas(16) TriRecord {
     uint inst_flags, prim, pad;
 };
 static_assert(sizeof(TriRecord) == 48, "tri layout");
-
-// 80-byte compressed 8-wide node (layout after Ylitie, Karras, Laine 2017): child boxes are 8-bit offsets on a
-// per-node power-of-two grid anchored at `p`; five 16-byte loads fetch eight children.
-//   meta[i]: 0 empty | internal: 0b001_xxxxx with xxxxx = 24 + slot | leaf: unary triangle count (0b001/011/111) << 5 | offset
-//   imask  : bit i set = slot i holds an internal child; child node index = child_base + popcount(imask below slot)
-//   leaf triangles live at tris8[tri_base + offset .. + count)
-struct alignas(16) Bvh8Node {
-    float p[3];
-    uint8_t e[3];          // biased exponents: scale = 2^(e - 127)
-    uint8_t imask;
-    uint child_base, tri_base;
-    uint8_t meta[8];
-    uint8_t qlo_x[8], qlo_y[8];
-    uint8_t qlo_z[8], qhi_x[8];
-    uint8_t qhi_y[8], qhi_z[8];
-};
-static_assert(sizeof(Bvh8Node) == 80, "wide node layout");
 
 struct HitRecord { int instance_id, primitive_id; float u, v, t; };
 
@@ -176,7 +171,7 @@ struct SceneView {
     const CameraData* cameras;
     const BvhNode* nodes;
     const TriRecord* tris;
-    const Bvh8Node* nodes8;      // non-null selects the 8-wide traversal; tris is then in wide-node order
+    const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)
     f4 environment_factor;
     int environment_proj;
     uint instance_count, point_light_count, directional_light_count, tri_light_count;

@@ -20,6 +20,14 @@ namespace tr {
 namespace {
 
 constexpr int KB = TR_BLOCK;
+// Register budgets of the traversal kernels (waves per SIMD): the loops are latency-bound, so the shadow kernel runs at
+// the full 8 waves (<= 64 VGPRs); the closest-hit kernel sorts four children and spills below 80 VGPRs, 6 waves win.
+#ifndef TR_CLOSEST_WAVES
+#define TR_CLOSEST_WAVES (TR_BVH4 ? 6 : 8)
+#endif
+#ifndef TR_SHADOW_WAVES
+#define TR_SHADOW_WAVES 8
+#endif
 
 struct PathBuffers {
     f4* org_pdf;      // origin.xyz, bsdf_pdf
@@ -40,7 +48,10 @@ struct PathBuffers {
 };
 
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
-       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORK_CLOSEST = 31, CNT_WORK_SHADOW = 32, CNT_WORDS = 34 };
+       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORK_CLOSEST = 31, CNT_WORK_SHADOW = 32, CNT_SHADOW_ODD = 33, CNT_WORDS = 34 };
+// the shadow queue length is double-buffered by bounce parity: shadow(b) may still run (side stream) while the main
+// stream has already rotated the other counters for closest(b+1)
+TR_HD int shadow_counter(int bounce) { return (bounce & 1) ? CNT_SHADOW_ODD : CNT_SHADOW; }
 
 struct PtParams {
     trhip_pt_options opt;
@@ -56,6 +67,7 @@ struct PtParams {
     float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
     int nee_point, nee_tri, nee_dir, nee_env;
     int count_work;
+    int shadow_cnt;               // counter word holding this bounce's shadow queue length
 };
 
 TR_DEV void add64(uint* counters, int idx, uint v) {
@@ -113,10 +125,12 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+// SOLO only names the instance launched while detailed timing serialises the frame, so that a profiler lists the
+// kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
+template <bool COUNT, bool SOLO>
+__global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       const uint* count_ptr) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
+    __shared__ int s_stack[TR_STACK_WORDS];
     const uint n = queue ? *count_ptr : P.n_launch;
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
@@ -144,8 +158,8 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
         HitRecord hit;
         bool include_lights = !(P.opt.hide_lights && bounce == 0);
         uint before = st.nodes;
-        trace_closest_any<0, COUNT, WIDE>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                misc.x, s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), hit, st, overflow);
+        trace_closest_any<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                misc.x, s_stack + threadIdx.x, hit, st, overflow);
         if (COUNT) {
             atomicMax(&pb.counters[CNT_MAXSP], st.maxsp);
             uint vis = st.nodes - before;
@@ -172,10 +186,10 @@ __global__ __launch_bounds__(KB) void k_trace_closest(SceneView sv, PtParams P, 
     }
 }
 
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
-    const uint n = pb.counters[CNT_SHADOW];
+template <bool COUNT>
+__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
+    __shared__ int s_stack[TR_STACK_WORDS];
+    const uint n = pb.counters[P.shadow_cnt];
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
         uint qi = base + (threadIdx.x & 63);
         if (qi >= n) continue;
         f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
-        float vis = trace_shadow_any<COUNT, WIDE>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + (WIDE ? 2 * threadIdx.x : threadIdx.x), st, overflow);
+        float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
         uint id = __float_as_uint(d.w);
         if (vis != 0.0f) {
             // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
@@ -220,174 +234,6 @@ __global__ __launch_bounds__(KB) void k_trace_shadow(SceneView sv, PtParams P, P
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent 8-wide trace kernels with lane-level dynamic fetch: a wave keeps stepping its live rays and, whenever
-// at least TR_REFILL lanes are idle, hands them the next rays of the queue (one atomic per refill).
-#ifndef TR_REFILL
-#define TR_REFILL 32
-#endif
-
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(KB) void k_trace_closest_dyn(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
-                                                          const uint* count_ptr) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
-    const uint n = queue ? *count_ptr : P.n_launch;
-    const bool usable = sv.tri_count > 0;
-    TraceStats st = {0, 0, 0, 0};
-    uint rays = 0;
-    const uint lane = threadIdx.x & 63u;
-    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
-    const bool include_lights = !(P.opt.hide_lights && bounce == 0);
-    const float tmin = bounce == 0 ? 0.0f : P.opt.min_ray_dist;
-    typename std::conditional<WIDE, Trav8<false, 0, COUNT>, Trav2<false, 0, COUNT>>::type tv;
-    typename std::conditional<WIDE, uint2, int>::type spill[WIDE ? TR_SPILL_STACK8 : TR_SPILL_STACK];
-    tv.stk.overflow = 0;
-    bool active = false, first = true, exhausted = false, pending = false;
-    uint id = 0;
-    f3 org = F3(0), dir = F3(0);
-    int overflow = 0;
-    while (true) {
-        const unsigned long long idle = __ballot(!active);
-        const uint n_idle = (uint)__popcll(idle);
-        if (!exhausted && (n_idle >= TR_REFILL)) {
-            uint base = 0;
-            if (first) base = wave_id * 64u;
-            else {
-                if (lane == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_CLOSEST], n_idle);
-                base = __shfl(base, 0);
-            }
-            first = false;
-            if (base + n_idle >= n) exhausted = true;
-            if (!active) {
-                if (pending) {   // results of finished rays are written in batches, at refill time
-                    HitRecord hit;
-                    finish_closest_hit(sv, tv, org, dir, include_lights, hit);
-                    pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-                    pending = false;
-                }
-                const uint qi = base + (uint)__popcll(idle & ((1ull << lane) - 1ull));
-                if (qi < n) {
-                    id = queue ? queue[qi] : qi;
-                    const u4 misc = pb.misc[id];
-                    if (!(misc.w & 1u)) {
-                        const f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
-                        org = F3(o); dir = F3(d);
-                        rays++;
-                        if (usable && ray_is_finite(org, dir)) {
-                            overflow += tv.stk.overflow;
-                            if constexpr (WIDE) tv.begin(org, dir, tmin, __builtin_huge_valf(), misc.x, s_stack + 2 * threadIdx.x);
-                            else tv.begin(sv, org, dir, tmin, __builtin_huge_valf(), misc.x, s_stack + threadIdx.x);
-                            active = true;
-                        } else {
-                            // invalid ray (zero / non-finite direction) or empty scene: a miss (sphere lights need a valid ray)
-                            tv.found = false; tv.best_t = __builtin_huge_valf(); tv.tmin = tmin; tv.hu = tv.hv = 0;
-                            HitRecord hit;
-                            finish_closest_hit(sv, tv, org, dir, include_lights && ray_is_finite(org, dir), hit);
-                            pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-                        }
-                    }
-                }
-            }
-        }
-        if (!__any(active)) { if (exhausted) break; else continue; }
-        if (active) {
-            if (tv.step(sv, spill, st)) { active = false; pending = true; }
-        }
-    }
-    if (pending) {
-        HitRecord hit;
-        finish_closest_hit(sv, tv, org, dir, include_lights, hit);
-        pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-    }
-    overflow += tv.stk.overflow;
-    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 3000 + bounce; }
-    if (P.count_work) {
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_xor(rays, off);
-            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
-        }
-        if (lane == 0) {
-            add64(pb.counters, CNT_CLOSEST, rays);
-            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
-        }
-    }
-}
-
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(KB) void k_trace_shadow_dyn(SceneView sv, PtParams P, PathBuffers pb) {
-    __shared__ int s_stack[TR_STACK_WORDS(WIDE)];
-    const uint n = pb.counters[CNT_SHADOW];
-    const bool usable = sv.tri_count > 0;
-    TraceStats st = {0, 0, 0, 0};
-    uint rays = 0;
-    const uint lane = threadIdx.x & 63u;
-    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
-    typename std::conditional<WIDE, Trav8<true, 0, COUNT>, Trav2<true, 0, COUNT>>::type tv;
-    typename std::conditional<WIDE, uint2, int>::type spill[WIDE ? TR_SPILL_STACK8 : TR_SPILL_STACK];
-    tv.stk.overflow = 0;
-    bool active = false, first = true, exhausted = false, pending = false;
-    uint id = 0;
-    f4 contrib = F4(0);
-    int overflow = 0;
-    auto deposit = [&](float vis) {
-        if (vis != 0.0f) {
-            // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): contrib.w = luminance before visibility
-            float m = contrib.w * vis;
-            if (contrib.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
-            f4 col = pb.color[id];
-            col.x += contrib.x * vis; col.y += contrib.y * vis; col.z += contrib.z * vis;
-            pb.color[id] = col;
-        }
-    };
-    while (true) {
-        const unsigned long long idle = __ballot(!active);
-        const uint n_idle = (uint)__popcll(idle);
-        if (!exhausted && (n_idle >= TR_REFILL)) {
-            uint base = 0;
-            if (first) base = wave_id * 64u;
-            else {
-                if (lane == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_SHADOW], n_idle);
-                base = __shfl(base, 0);
-            }
-            first = false;
-            if (base + n_idle >= n) exhausted = true;
-            if (!active) {
-                if (pending) { deposit(tv.best_t); pending = false; }
-                const uint qi = base + (uint)__popcll(idle & ((1ull << lane) - 1ull));
-                if (qi < n) {
-                    const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi];
-                    contrib = pb.sh_contrib[qi];
-                    id = __float_as_uint(d.w);
-                    rays++;
-                    if (usable && ray_is_finite(F3(o), F3(d))) {
-                        overflow += tv.stk.overflow;
-                        if constexpr (WIDE) tv.begin(F3(o), F3(d), P.opt.min_ray_dist, o.w, 0u, s_stack + 2 * threadIdx.x);
-                        else tv.begin(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, 0u, s_stack + threadIdx.x);
-                        active = true;
-                    } else deposit(1.0f);
-                }
-            }
-        }
-        if (!__any(active)) { if (exhausted) break; else continue; }
-        if (active) {
-            if (tv.step(sv, spill, st)) { active = false; pending = true; }
-        }
-    }
-    if (pending) deposit(tv.best_t);
-    overflow += tv.stk.overflow;
-    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 4000; }
-    if (P.count_work) {
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_xor(rays, off);
-            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
-        }
-        if (lane == 0) {
-            add64(pb.counters, CNT_SHADOWRAYS, rays);
-            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // MIS (path_tracer.glsl:54-89)
@@ -510,8 +356,11 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
 }
 
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
+#ifndef TR_SHADE_WAVES
+#define TR_SHADE_WAVES 3
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(KB) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+__global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                               const uint* count_ptr, uint* next_queue) {
     const uint n = queue ? *count_ptr : P.n_launch;
     const uint n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
@@ -691,7 +540,7 @@ __global__ __launch_bounds__(KB) void k_shade(SceneView sv, PtParams P, PathBuff
             }
         }
         // ---- queue compaction (wave ballots)
-        uint sslot = wave_append(&pb.counters[CNT_SHADOW], want_shadow);
+        uint sslot = wave_append(&pb.counters[P.shadow_cnt], want_shadow);
         if (want_shadow) {
             pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
             pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
@@ -707,15 +556,15 @@ __global__ __launch_bounds__(KB) void k_shade(SceneView sv, PtParams P, PathBuff
 }
 
 // rotate queue counters between bounces: cur <- next, next <- 0, shadow <- 0
-__global__ void k_advance(uint* counters) {
+__global__ void k_advance(uint* counters, int next_shadow_cnt) {
     counters[CNT_CUR] = counters[CNT_NEXT];
     counters[CNT_NEXT] = 0;
-    counters[CNT_SHADOW] = 0;
+    counters[next_shadow_cnt] = 0;   // the queue the NEXT bounce's shade fills; this bounce's stays for k_trace_shadow
     counters[CNT_WORK_CLOSEST] = 0;
     counters[CNT_WORK_SHADOW] = 0;
 }
 __global__ void k_clear_shadow(uint* counters) {
-    counters[CNT_SHADOW] = 0; counters[CNT_NEXT] = 0; counters[CNT_WORK_CLOSEST] = 0; counters[CNT_WORK_SHADOW] = 0;
+    counters[CNT_SHADOW] = 0; counters[CNT_SHADOW_ODD] = 0; counters[CNT_NEXT] = 0; counters[CNT_WORK_CLOSEST] = 0; counters[CNT_WORK_SHADOW] = 0;
 }
 
 // end of one sample: sum_color += colour (path_tracer.rgen:112)
@@ -779,6 +628,8 @@ struct PtStage::Impl {
     float acc_ms[T_KINDS] = {0, 0, 0, 0, 0};
     uint acc_launches[T_KINDS] = {0, 0, 0, 0, 0};
     uint frames = 0;
+    hipStream_t side = nullptr;        // shadow rays of bounce b trace here while closest(b+1) runs on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
@@ -794,6 +645,7 @@ PtStage::~PtStage() {
     if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
     for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
+    if (impl->side) { (void)hipStreamDestroy(impl->side); (void)hipEventDestroy(impl->ev_fork); (void)hipEventDestroy(impl->ev_join); }
     delete impl;
 }
 
@@ -868,17 +720,25 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
     // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
     const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
     const bool count = count_work != 0;
-    const bool wide = sv.nodes8 != nullptr;
-    static const bool dyn = getenv("TRHIP_DYN") && atoi(getenv("TRHIP_DYN"));   // A/B switch: lane-level refill kernels (slower so far)
     const bool timing = detailed_timing != 0;
+    // A/B switch TRHIP_OVERLAP=0: everything on the caller's stream
+    static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);
+    // per-kernel timing wants kernels that do not share the chip: detailed timing serialises the frame
+    const bool overlap = overlap_enabled && !timing;
+    if (overlap && !impl->side) {
+        HIPCHK(hipStreamCreateWithFlags(&impl->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
+    }
+    bool shadow_in_flight = false;
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
-    auto timed = [&](int kind, auto&& launch) {
+    auto timed = [&](int kind, hipStream_t on, auto&& launch) {
         if (!timing) { launch(); return; }
         TimedSpan sp{kind, impl->get_event(), impl->get_event()};
-        (void)hipEventRecord(sp.a, stream);
+        (void)hipEventRecord(sp.a, on);
         launch();
-        (void)hipEventRecord(sp.b, stream);
+        (void)hipEventRecord(sp.b, on);
         impl->pending.push_back(sp);
     };
     HIPCHK(hipEventRecord(ev[0], stream));
@@ -887,38 +747,42 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
         P.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
         for (int s = 0; s < opt.samples_per_pass; ++s) {
             P.sample_in_pass = (uint)s;
-            timed(T_RAYGEN, [&] {
+            timed(T_RAYGEN, stream, [&] {
                 hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, P, pb);
                 hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, stream, pb.counters);
             });
             for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                 const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
                 uint* qn = pb.queue[(bounce + 1) & 1];
-                timed(T_CLOSEST, [&] {
-                    auto kc = dyn ? (wide ? (count ? k_trace_closest_dyn<true, true> : k_trace_closest_dyn<false, true>)
-                                          : (count ? k_trace_closest_dyn<true, false> : k_trace_closest_dyn<false, false>))
-                                  : (wide ? (count ? k_trace_closest<true, true> : k_trace_closest<false, true>)
-                                          : (count ? k_trace_closest<true, false> : k_trace_closest<false, false>));
+                timed(T_CLOSEST, stream, [&] {
+                    auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
                     hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
                 });
-                timed(T_SHADE, [&] {
+                if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0)); shadow_in_flight = false; }
+                P.shadow_cnt = shadow_counter(bounce);
+                timed(T_SHADE, stream, [&] {
                     if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
                     else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
                 });
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters, shadow_counter(bounce + 1));
                 if (bounce < opt.max_bounces - 1) {
-                    timed(T_SHADOW, [&] {
-                        auto ks = dyn ? (wide ? (count ? k_trace_shadow_dyn<true, true> : k_trace_shadow_dyn<false, true>)
-                                              : (count ? k_trace_shadow_dyn<true, false> : k_trace_shadow_dyn<false, false>))
-                                      : (wide ? (count ? k_trace_shadow<true, true> : k_trace_shadow<false, true>)
-                                              : (count ? k_trace_shadow<true, false> : k_trace_shadow<false, false>));
-                        hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb);
+                    hipStream_t ss = stream;
+                    if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
+                        HIPCHK(hipEventRecord(impl->ev_fork, stream));
+                        HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
+                        ss = impl->side;
+                    }
+                    timed(T_SHADOW, ss, [&] {
+                        auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
+                        hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, P, pb);
                     });
+                    if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                 }
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters);
             }
+            if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0)); shadow_in_flight = false; }
             hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, P, pb);
         }
-        timed(T_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev); });
+        timed(T_RESOLVE, stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev); });
     }
     HIPCHK(hipEventRecord(ev[1], stream));
     HIPCHK(hipGetLastError());

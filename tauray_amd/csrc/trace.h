@@ -290,127 +290,67 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
 }
 
 // =====================================================================================================================
-// 8-wide compressed BVH traversal.  Stack entries are node groups (child_base, hit bits << 24 | imask); one entry
-// per level at most, so twelve LDS entries cover trees over 10^9 triangles before spilling.
-#define TR_LDS_STACK8 12
-#define TR_SPILL_STACK8 20
+// 4-wide fp32 BVH: half the dependent node fetches of the binary tree for about the same box-test arithmetic.
+struct Hit4 { float t[4]; int c[4]; };
 
-struct LaneStack8 {
-    uint2* lds;          // &stack[0][lane_in_block]; stride TR_BLOCK
-    int sp;
-    int overflow;
-    TR_DEV void init(int* base) { lds = reinterpret_cast<uint2*>(base); sp = 0; overflow = 0; }
-    TR_DEV void push(uint2* spill, uint2 v) {
-        const bool ok = sp < TR_LDS_STACK8 + TR_SPILL_STACK8;
-        if (sp < TR_LDS_STACK8) lds[sp * TR_BLOCK] = v;
-        else if (ok) spill[sp - TR_LDS_STACK8] = v;
-        overflow += ok ? 0 : 1;
-        sp += ok ? 1 : 0;
-    }
-    TR_DEV uint2 pop(const uint2* spill) {
-        sp--;
-        uint2 v = lds[(sp < TR_LDS_STACK8 ? sp : 0) * TR_BLOCK];
-        asm volatile("" : "+v"(v.x), "+v"(v.y));   // keep the LDS read a ds_read_b64
-        if (sp >= TR_LDS_STACK8) v = spill[sp - TR_LDS_STACK8];
-        return v;
-    }
-};
-
-struct Ray8 {
-    f3 org, inv_dir;     // inv_dir with zero components replaced by +-huge so slabs outside the origin reject
-    uint octinv;         // 7 - octant
-};
-
-TR_DEV Ray8 make_ray8(f3 org, f3 dir) {
-    Ray8 r;
-    r.org = org;
-    const float eps = 1e-30f;
-    r.inv_dir.x = 1.0f / (fabsf(dir.x) > eps ? dir.x : copysignf(eps, dir.x));
-    r.inv_dir.y = 1.0f / (fabsf(dir.y) > eps ? dir.y : copysignf(eps, dir.y));
-    r.inv_dir.z = 1.0f / (fabsf(dir.z) > eps ? dir.z : copysignf(eps, dir.z));
-    uint oct = (dir.x < 0.0f ? 4u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 1u : 0u);
-    r.octinv = 7u - oct;
-    return r;
-}
-
-// Tests the eight quantised child boxes of one node.  Returns hit bits: bits 24..31 internal children in traversal
-// priority order (slot ^ octinv), bits 0..23 leaf triangles.
-TR_DEV uint intersect_node8(const Ray8& r, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4, float tmin, float tmax) {
-    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
-    const float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
-                sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
-    uint hitmask = 0;
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* np, float tmin, float tmax, Hit4& h) {
+    const f4 lox = *reinterpret_cast<const f4*>(np->lox), loy = *reinterpret_cast<const f4*>(np->loy), loz = *reinterpret_cast<const f4*>(np->loz);
+    const f4 hix = *reinterpret_cast<const f4*>(np->hix), hiy = *reinterpret_cast<const f4*>(np->hiy), hiz = *reinterpret_cast<const f4*>(np->hiz);
+    const int4 ch = *reinterpret_cast<const int4*>(np->child);
+    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    h.c[0] = ch.x; h.c[1] = ch.y; h.c[2] = ch.z; h.c[3] = ch.w;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const uint meta4 = half ? n1.w : n1.z;
-        const uint qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z;
-        const uint qlz = half ? n3.y : n3.x, qhx = half ? n3.w : n3.z;
-        const uint qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int sh = 8 * k;
-            // plane positions decoded exactly as the builder verified them: q * scale + p.  The product is exact
-            // (q <= 255, scale a power of two), so one fma gives the same bits as mul + add.
-            const float x0 = __fmaf_rn((float)((qlx >> sh) & 0xFFu), sx, px), x1 = __fmaf_rn((float)((qhx >> sh) & 0xFFu), sx, px);
-            const float y0 = __fmaf_rn((float)((qly >> sh) & 0xFFu), sy, py), y1 = __fmaf_rn((float)((qhy >> sh) & 0xFFu), sy, py);
-            const float z0 = __fmaf_rn((float)((qlz >> sh) & 0xFFu), sz, pz), z1 = __fmaf_rn((float)((qhz >> sh) & 0xFFu), sz, pz);
-            const float tx0 = (x0 - r.org.x) * r.inv_dir.x, tx1 = (x1 - r.org.x) * r.inv_dir.x;
-            const float ty0 = (y0 - r.org.y) * r.inv_dir.y, ty1 = (y1 - r.org.y) * r.inv_dir.y;
-            const float tz0 = (z0 - r.org.z) * r.inv_dir.z, tz1 = (z1 - r.org.z) * r.inv_dir.z;
-            const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-            const float tf = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000003576278687f, tmax);
-            const uint m = (meta4 >> sh) & 0xFFu;
-            // an empty slot has meta 0 (no bits); branch-free insertion of the child's bits at its priority position
-            const uint inner = ((m & 0x18u) == 0x18u) ? r.octinv : 0u;
-            const uint bits = (m >> 5) << ((m ^ inner) & 0x1Fu);
-            hitmask |= (tn <= tf) ? bits : 0u;
-        }
+    for (int k = 0; k < 4; ++k) {
+        float tx0 = (lx[k] - r.org.x) * r.inv_dir.x, tx1 = (hx[k] - r.org.x) * r.inv_dir.x;
+        float ty0 = (ly[k] - r.org.y) * r.inv_dir.y, ty1 = (hy[k] - r.org.y) * r.inv_dir.y;
+        float tz0 = (lz[k] - r.org.z) * r.inv_dir.z, tz1 = (hz[k] - r.org.z) * r.inv_dir.z;
+        float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+        float t1 = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000003576278687f, tmax);
+        // empty slots carry the sentinel child (their inverted box would pass the min/max slab test)
+        h.t[k] = (t0 <= t1 && h.c[k] != 0x7FFFFFFF) ? t0 : __builtin_huge_valf();
     }
-    return hitmask;
 }
 
-TR_DEV void load_node8(const Bvh8Node* nodes, uint index, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4) {
-    const uint4* p = reinterpret_cast<const uint4*>(nodes + index);
-    n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4];
-}
+#define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
+                       h.t[a] = sw ? tb : ta; h.t[b] = sw ? ta : tb; h.c[a] = sw ? cb : ca; h.c[b] = sw ? ca : cb; }
 
 template <int ALPHA_MODE, bool COUNT>
-TR_DEV void trace_closest8(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
+TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
                            int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
     hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
     float best_t = tmax;
     bool found = false;
     uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
+    RayPre r = make_ray(org, dir);
     const bool finite_ray = ray_is_finite(org, dir);
     if (sv.tri_count > 0 && finite_ray) {
-        const RayPre r = make_ray(org, dir);
-        const Ray8 r8 = make_ray8(org, dir);
-        LaneStack8 stk;
-        uint2 spill[TR_SPILL_STACK8];
+        LaneStack stk;
+        int spill[TR_SPILL_STACK];
         stk.init(lds_stack);
-        uint2 G = make_uint2(0u, 0x80000000u);     // the root as a one-child node group
+        int node = sv.node_count > 0 ? 0 : -1;
         while (true) {
-            uint2 T;
-            if (G.y > 0x00FFFFFFu) {
-                const uint hits = G.y;
-                const int bit = 31 - __clz((int)hits);
-                G.y &= ~(1u << bit);
-                if (G.y > 0x00FFFFFFu) { stk.push(spill, G); if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); }
-                const uint slot = ((uint)bit - 24u) ^ r8.octinv;
-                const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
-                uint4 n0, n1, n2, n3, n4;
-                load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
+#if TR_VOTE > 0
+            const bool at_leaf = node < 0;
+            const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
+            const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
+            if (at_leaf != leaf_phase) continue;
+#endif
+            if (node >= 0) {
+                Hit4 h;
+                box4_intersect(r, sv.nodes4 + node, tmin, best_t, h);
                 if (COUNT) st.nodes++;
-                const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, best_t);
-                G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
-                T = make_uint2(n1.y, hm & 0x00FFFFFFu);
+                TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
+                if (h.t[0] < __builtin_huge_valf()) {
+                    if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
+                    if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
+                    if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
+                    if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
+                    node = h.c[0];
+                    continue;
+                }
             } else {
-                T = make_uint2(0u, 0u);
-            }
-            while (T.y) {
-                const int b = __ffs((int)T.y) - 1;
-                T.y &= T.y - 1u;
-                const TriRecord tr = sv.tris[T.x + (uint)b];
+                const TriRecord tr = sv.tris[~node];
                 if (COUNT) st.tris++;
                 float t, bu, bv;
                 f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
@@ -433,10 +373,8 @@ TR_DEV void trace_closest8(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     }
                 }
             }
-            if (G.y <= 0x00FFFFFFu) {
-                if (stk.sp == 0) break;
-                G = stk.pop(spill);
-            }
+            if (stk.sp == 0) break;
+            node = stk.pop(spill);
         }
         overflow += stk.overflow;
     }
@@ -451,10 +389,10 @@ TR_DEV void trace_closest8(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             float c = dot(oc, oc) - radius * radius;
             float disc = b * b - 4.0f * a * c;
             if (disc < 0) continue;
-            float h = (-b - sqrtf(disc)) / (2.0f * a);
-            if (h > 0 && h > tmin && h < best_t) {
-                best_t = h; found = true;
-                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
+            float hh = (-b - sqrtf(disc)) / (2.0f * a);
+            if (hh > 0 && hh > tmin && hh < best_t) {
+                best_t = hh; found = true;
+                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = hh; hit.v = 0;
             }
         }
     }
@@ -462,245 +400,60 @@ TR_DEV void trace_closest8(const SceneView& sv, f3 org, f3 dir, float tmin, floa
 }
 
 template <bool COUNT>
-TR_DEV float trace_shadow8(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
+TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
     float visibility = 1.0f;
     if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
-    const RayPre r = make_ray(org, dir);
-    const Ray8 r8 = make_ray8(org, dir);
-    LaneStack8 stk;
-    uint2 spill[TR_SPILL_STACK8];
+    RayPre r = make_ray(org, dir);
+    LaneStack stk;
+    int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
-    uint2 G = make_uint2(0u, 0x80000000u);
-    bool done = false;
-    while (!done) {
-        uint2 T;
-        if (G.y > 0x00FFFFFFu) {
-            const uint hits = G.y;
-            const int bit = 31 - __clz((int)hits);
-            G.y &= ~(1u << bit);
-            if (G.y > 0x00FFFFFFu) stk.push(spill, G);
-            const uint slot = ((uint)bit - 24u) ^ r8.octinv;
-            const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
-            uint4 n0, n1, n2, n3, n4;
-            load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
+    int node = sv.node_count > 0 ? 0 : -1;
+    while (true) {
+        if (node >= 0) {
+            Hit4 h;
+            box4_intersect(r, sv.nodes4 + node, tmin, tmax, h);
             if (COUNT) st.nodes++;
-            const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, tmax);
-            G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
-            T = make_uint2(n1.y, hm & 0x00FFFFFFu);
-        } else {
-            T = make_uint2(0u, 0u);
-        }
-        while (T.y) {
-            const int b = __ffs((int)T.y) - 1;
-            T.y &= T.y - 1u;
-            const TriRecord tr = sv.tris[T.x + (uint)b];
-            if (COUNT) st.tris++;
-            float t, bu, bv;
-            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
-                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; done = true; break; }
-                if (COUNT) st.alpha++;
-                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
-                visibility *= 1.0f - alpha;
-                if (visibility == 0.0f) { done = true; break; }
-            }
-        }
-        if (!done && G.y <= 0x00FFFFFFu) {
-            if (stk.sp == 0) break;
-            G = stk.pop(spill);
-        }
-    }
-    overflow += stk.overflow;
-    return visibility;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Stepwise 8-wide traversal for the persistent kernels: `step()` performs one node visit plus the triangles of that
-// node and reports completion, so a wave can hand finished lanes a new ray instead of idling until its slowest
-// ray is done (lane-level dynamic fetch, Aila & Laine 2009).
-template <bool SHADOW, int ALPHA_MODE, bool COUNT>
-struct Trav8 {
-    RayPre r;
-    Ray8 r8;
-    uint2 G;
-    LaneStack8 stk;
-    float tmin, tmax, best_t;      // best_t: closest distance (closest-hit) or accumulated visibility (shadow)
-    uint best_inst, best_prim, seed;
-    float hu, hv;
-    bool found;
-
-    TR_DEV void begin(f3 org, f3 dir, float tmin_, float tmax_, uint seed_, int* lds_stack) {
-        r = make_ray(org, dir);
-        r8 = make_ray8(org, dir);
-        G = make_uint2(0u, 0x80000000u);
-        stk.init(lds_stack);
-        tmin = tmin_; tmax = tmax_; seed = seed_;
-        best_t = SHADOW ? 1.0f : tmax_;
-        best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu; hu = 0; hv = 0; found = false;
-    }
-
-    // returns true when the ray is finished
-    TR_DEV bool step(const SceneView& sv, uint2* spill, TraceStats& st) {
-        uint2 T = make_uint2(0u, 0u);
-        if (G.y > 0x00FFFFFFu) {
-            const uint hits = G.y;
-            const int bit = 31 - __clz((int)hits);
-            G.y &= ~(1u << bit);
-            if (G.y > 0x00FFFFFFu) { stk.push(spill, G); if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); }
-            const uint slot = ((uint)bit - 24u) ^ r8.octinv;
-            const uint rel = __popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu);
-            uint4 n0, n1, n2, n3, n4;
-            load_node8(sv.nodes8, G.x + rel, n0, n1, n2, n3, n4);
-            if (COUNT) st.nodes++;
-            const uint hm = intersect_node8(r8, n0, n1, n2, n3, n4, tmin, SHADOW ? tmax : best_t);
-            G = make_uint2(n1.x, (hm & 0xFF000000u) | (n0.w >> 24));
-            T = make_uint2(n1.y, hm & 0x00FFFFFFu);
-        }
-        while (T.y) {
-            const int b = __ffs((int)T.y) - 1;
-            T.y &= T.y - 1u;
-            const TriRecord tr = sv.tris[T.x + (uint)b];
-            if (COUNT) st.tris++;
-            float t, bu, bv;
-            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            if (!tri_intersect(r, v0, v1, v2, tmin, SHADOW ? tmax : __builtin_huge_valf(), t, bu, bv)) continue;
-            const uint inst = tr.inst_flags & 0x7FFFFFFFu;
-            if (SHADOW) {
-                if (!(tr.inst_flags & 0x80000000u)) { best_t = 0.0f; return true; }
-                if (COUNT) st.alpha++;
-                best_t *= 1.0f - candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                if (best_t == 0.0f) return true;
-            } else {
-                const bool closer = t < best_t || (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
-                if (closer && t < tmax) {
-                    bool accept = true;
-                    if (tr.inst_flags & 0x80000000u) {
-                        if (COUNT) st.alpha++;
-                        float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                        float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
-                        accept = !(a <= cutoff);
-                    }
-                    if (accept) { best_t = t; found = true; best_inst = inst; best_prim = tr.prim; hu = bu; hv = bv; }
+            int next = 0x7FFFFFFF;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (h.t[k] < __builtin_huge_valf()) {
+                    if (next == 0x7FFFFFFF) next = h.c[k];
+                    else stk.push(spill, h.c[k]);
                 }
             }
-        }
-        if (G.y <= 0x00FFFFFFu) {
-            if (stk.sp == 0) return true;
-            G = stk.pop(spill);
-        }
-        return false;
-    }
-
-};
-
-
-// Stepwise BVH2 traversal (one node OR one triangle per step) for the lane-refill kernels.
-template <bool SHADOW, int ALPHA_MODE, bool COUNT>
-struct Trav2 {
-    RayPre r;
-    LaneStack stk;
-    int node;
-    float tmin, tmax, best_t;
-    uint best_inst, best_prim, seed;
-    float hu, hv;
-    bool found;
-
-    TR_DEV void begin(const SceneView& sv, f3 org, f3 dir, float tmin_, float tmax_, uint seed_, int* lds_stack) {
-        r = make_ray(org, dir);
-        stk.init(lds_stack);
-        node = sv.node_count > 0 ? 0 : -1;
-        tmin = tmin_; tmax = tmax_; seed = seed_;
-        best_t = SHADOW ? 1.0f : tmax_;
-        best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu; hu = 0; hv = 0; found = false;
-    }
-
-    TR_DEV bool step(const SceneView& sv, int* spill, TraceStats& st) {
-        if (node >= 0) {
-            const BvhNode n = sv.nodes[node];
-            if (COUNT) st.nodes++;
-            float t0, t1;
-            const float far = SHADOW ? tmax : best_t;
-            bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, far, t0);
-            bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, far, t1);
-            if (h0 && h1) {
-                bool first0 = SHADOW ? true : (t0 <= t1);
-                stk.push(spill, first0 ? n.child1 : n.child0);
-                if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
-                node = first0 ? n.child0 : n.child1;
-                return false;
-            } else if (h0) { node = n.child0; return false; }
-            else if (h1) { node = n.child1; return false; }
+            if (next != 0x7FFFFFFF) { node = next; continue; }
         } else {
             const TriRecord tr = sv.tris[~node];
             if (COUNT) st.tris++;
             float t, bu, bv;
             f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            if (tri_intersect(r, v0, v1, v2, tmin, SHADOW ? tmax : __builtin_huge_valf(), t, bu, bv)) {
-                const uint inst = tr.inst_flags & 0x7FFFFFFFu;
-                if (SHADOW) {
-                    if (!(tr.inst_flags & 0x80000000u)) { best_t = 0.0f; return true; }
-                    if (COUNT) st.alpha++;
-                    best_t *= 1.0f - candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                    if (best_t == 0.0f) return true;
-                } else {
-                    const bool closer = t < best_t || (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
-                    if (closer && t < tmax) {
-                        bool accept = true;
-                        if (tr.inst_flags & 0x80000000u) {
-                            if (COUNT) st.alpha++;
-                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                            float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
-                            accept = !(a <= cutoff);
-                        }
-                        if (accept) { best_t = t; found = true; best_inst = inst; best_prim = tr.prim; hu = bu; hv = bv; }
-                    }
-                }
+            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
+                if (COUNT) st.alpha++;
+                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                visibility *= 1.0f - alpha;
+                if (visibility == 0.0f) break;
             }
         }
-        if (stk.sp == 0) return true;
+        if (stk.sp == 0) break;
         node = stk.pop(spill);
-        return false;
     }
-};
-
-// sphere lights + hit record (rt_common_point_light.rint/.rchit), shared by the stepwise traversals
-template <class TRAV>
-TR_DEV void finish_closest_hit(const SceneView& sv, TRAV& tv, f3 org, f3 dir, bool include_lights, HitRecord& hit) {
-    hit.instance_id = tv.found ? (int)tv.best_inst : -1; hit.primitive_id = tv.found ? (int)tv.best_prim : -1; hit.u = tv.hu; hit.v = tv.hv;
-    if (include_lights) {
-        for (uint i = 0; i < sv.point_light_count; ++i) {
-            const PointLight& pl = sv.point_lights[i];
-            float radius = pl.radius;
-            if (radius == 0.0f) continue;
-            f3 oc = org - pl.pos;
-            float a = dot(dir, dir);
-            float b = 2.0f * dot(oc, dir);
-            float c = dot(oc, oc) - radius * radius;
-            float disc = b * b - 4.0f * a * c;
-            if (disc < 0) continue;
-            float h = (-b - sqrtf(disc)) / (2.0f * a);
-            if (h > 0 && h > tv.tmin && h < tv.best_t) {
-                tv.best_t = h; tv.found = true;
-                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
-            }
-        }
-    }
-    hit.t = tv.found ? tv.best_t : -1.0f;
+    overflow += stk.overflow;
+    return visibility;
 }
 
-// LDS words per block for the per-lane stacks of either traversal
-#define TR_STACK_WORDS(WIDE) ((WIDE) ? 2 * TR_LDS_STACK8 * TR_BLOCK : TR_LDS_STACK * TR_BLOCK)
+// LDS words per block for the per-lane stacks
+#define TR_STACK_WORDS (TR_LDS_STACK * TR_BLOCK)
 
-template <int ALPHA_MODE, bool COUNT, bool WIDE>
+template <int ALPHA_MODE, bool COUNT>
 TR_DEV void trace_closest_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
                               int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
-    if (WIDE) trace_closest8<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
+    if (TR_BVH4) trace_closest4<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
     else trace_closest<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
 }
-template <bool COUNT, bool WIDE>
+template <bool COUNT>
 TR_DEV float trace_shadow_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
-    if (WIDE) return trace_shadow8<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
+    if (TR_BVH4) return trace_shadow4<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
     return trace_shadow<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
 }
 

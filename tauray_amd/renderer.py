@@ -189,7 +189,8 @@ class SceneStage:
         self.scene = scene
         self.accel = dict(triangle_count=info.triangle_count, node_count=info.node_count,
                           tri_light_count=info.tri_light_count, build_ms=info.build_ms,
-                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
+                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max),
+                          node_bytes=info.node_bytes)
         return self.accel
 
     def update_cameras(self, cameras):

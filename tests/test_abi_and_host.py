@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.CountersC) == 7 * 8
     assert C.sizeof(_lib.TimingsC) == 10 * 4
     assert C.sizeof(_lib.TonemapInfoC) == 16
-    assert C.sizeof(_lib.AccelInfoC) == 40
+    assert C.sizeof(_lib.AccelInfoC) == 44
     from oracle import binding as B
     assert C.sizeof(B.PtOptionsC) == C.sizeof(_lib.PtOptionsC)
     assert [f[0] for f in B.PtOptionsC._fields_] == [f[0] for f in _lib.PtOptionsC._fields_]
