@@ -122,6 +122,7 @@ def main():
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
                    "parallelism": "scanline-sharded x%d + RCCL gather" % world if world > 1 else "single GPU",
                    "scene_hash": scenes.scene_hash(scene)},
+        "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         "rays_per_frame": rays_total // args.steps,
         "msample_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
     }
@@ -159,9 +160,22 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
                        + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.spp * 16 * args.steps) / args.steps
+        # HBM traffic of the same kernel from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE + WRITE_SIZE in
+        # separate runs).  Lower bound as reported; FETCH_SIZE may under-report by up to 2x on gfx950 (upper bound given too).
+        traffic, traffic_range, traffic_src = None, None, None
+        try:
+            import glob, json as _json
+            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_summary.json")), reverse=True):
+                k = _json.load(open(f)).get(args.workload, {}).get("k_trace_closest", {})
+                if "hbm_traffic_bytes_per_launch_range" in k:
+                    traffic_range = k["hbm_traffic_bytes_per_launch_range"]
+                    traffic, traffic_src = traffic_range[0], os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))
+                    break
+        except Exception:
+            pass
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_range": traffic_range, "traffic_source": traffic_src,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "kernel_ms_per_frame": {k: round(timings[k + "_ms"] / args.steps, 4) for k in ("trace_closest", "trace_shadow", "shade", "raygen", "resolve")},

@@ -288,6 +288,7 @@ int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint3
 int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
     if (const char* b = getenv("TRHIP_BUILDER")) dev->scene.builder = std::string(b) == "lbvh" ? 0 : 1;
+    if (const char* r = getenv("TRHIP_PLOC_RADIUS")) dev->scene.ploc_radius = std::max(1, atoi(r));
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
 }

@@ -37,6 +37,7 @@ struct DeviceScene {
     uint node_count = 0, tri_light_count = 0;
     int builder = 1;                     // 0 = Karras LBVH, 1 = PLOC over the Morton order (TRHIP_BUILDER=lbvh|ploc)
     uint build_rounds = 0;
+    int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
     bool accel_built = false;
 

@@ -219,12 +219,12 @@ TR_DEV float merged_area(const float* a, const float* b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(BT) void k_ploc_nn(uint c, const float* cbox, uint* nn) {
+__global__ __launch_bounds__(BT) void k_ploc_nn(uint c, uint radius, const float* cbox, uint* nn) {
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= c) return;
     float mine[6];
     for (int k = 0; k < 6; ++k) mine[k] = cbox[6 * (size_t)i + k];
-    uint lo = i > PLOC_RADIUS ? i - PLOC_RADIUS : 0, hi = min(c - 1, i + PLOC_RADIUS);
+    uint lo = i > radius ? i - radius : 0, hi = min(c - 1, i + radius);
     float best = __builtin_huge_valf(); uint bj = i;
     for (uint j = lo; j <= hi; ++j) {
         if (j == i) continue;
@@ -450,7 +450,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 int rounds = 0;
                 while (c > 1) {
                     const uint cb = (c + BT - 1) / BT;
-                    hipLaunchKernelGGL(k_ploc_nn, dim3(cb), dim3(BT), 0, stream, c, cbox[0], nn);
+                    hipLaunchKernelGGL(k_ploc_nn, dim3(cb), dim3(BT), 0, stream, c, (uint)ds.ploc_radius, cbox[0], nn);
                     hipLaunchKernelGGL(k_ploc_merge, dim3(cb), dim3(BT), 0, stream, c, n, cref[0], cbox[0], nn, valid, cref[1], cbox[1], alloc, children,
                                        node_box, ranges, parent_internal);
                     HIPCHK(rocprim::exclusive_scan(scan_temp, scan_bytes, valid, pos, 0u, c, rocprim::plus<uint>(), stream));

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     __shared__ int s_stack[TR_STACK_WORDS];
     const uint n = queue ? *count_ptr : P.n_launch;
     TraceStats st = {0, 0, 0, 0};
-    uint rays = 0;
+    uint rays = 0, max_vis = 0;
     int overflow = 0;
     // persistent waves: each wave pulls the next 64 rays from a device-side cursor until the queue is drained
     // first chunk by wave id (no atomic: avoids a burst of ~7000 dequeues on one word at kernel start), later
@@ -161,10 +161,9 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         trace_closest_any<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
                                 misc.x, s_stack + threadIdx.x, hit, st, overflow);
         if (COUNT) {
-            atomicMax(&pb.counters[CNT_MAXSP], st.maxsp);
             uint vis = st.nodes - before;
-            uint old = atomicMax(&pb.counters[CNT_MAXVIS], vis);
-            if (vis > old && vis > 100000u) {
+            max_vis = max(max_vis, vis);
+            if (vis > 100000u && vis > atomicMax(&pb.counters[CNT_MAXVIS], vis)) {   // debugging aid: remember a pathological ray
                 float* dbg = reinterpret_cast<float*>(pb.counters + CNT_DBG);
                 dbg[0] = o.x; dbg[1] = o.y; dbg[2] = o.z; dbg[3] = d.x; dbg[4] = d.y; dbg[5] = d.z; dbg[6] = (float)bounce; dbg[7] = (float)id;
                 dbg[8] = o.w; dbg[9] = d.w;
@@ -178,6 +177,10 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_xor(rays, off);
             if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+        }
+        if (COUNT) {
+            for (int off = 32; off > 0; off >>= 1) { st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off)); }
+            if ((threadIdx.x & 63) == 0) { atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis); }
         }
         if ((threadIdx.x & 63) == 0) {
             add64(pb.counters, CNT_CLOSEST, rays);
