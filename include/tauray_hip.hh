@@ -309,6 +309,13 @@ public:
         uvec2 ts = get_distribution_target_size(opt.distribution);
         check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count, nullptr));
     }
+    // the same frame into a gbuffer (src/gbuffer.hh: the entries path_tracer.rgen writes); null members are skipped
+    using gbuffer_target = trhip_pt_targets;
+    void run(const gbuffer_target& targets)
+    {
+        uvec2 ts = get_distribution_target_size(opt.distribution);
+        check(trhip_pt_render_targets(pt, &targets, ts.x, ts.y, (uint32_t)opt.active_viewport_count, nullptr));
+    }
     float get_duration_ms() { trhip_timings t; check(trhip_pt_get_timings(pt, &t)); return t.path_tracing_ms; }
     trhip_counters get_counters() { trhip_counters c; check(trhip_pt_get_counters(pt, &c)); return c; }
 

@@ -137,6 +137,24 @@ int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /*
  * `color` is the device RGBA32F image2DArray [viewports][target_h][target_w] where target size is
  * get_distribution_target_size(dist) (src/distribution_strategy.cc:6-19). */
 int trhip_pt_render(trhip_pt* pt, void* color_dev, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
+/* The same frame into any subset of the gbuffer targets path_tracer.rgen writes (write_all_outputs,
+ * shader/path_tracer.glsl:535-576; gbuffer_target of src/gbuffer.hh): device images [viewports][target_h][target_w],
+ * null = not requested.  color / diffuse / reflection are running means over the accumulated samples
+ * (shader/gbuffer.glsl:18-28,68-78,118-128); diffuse and reflection are the demodulated light of material.glsl:66-73
+ * with a = 1/length of the second path segment.  albedo, material (metallic, roughness, ior/4, transmittance:
+ * gbuffer.glsl:256-260), normal (octahedral, math.glsl:480-485), pos and instance_id describe the first hit and are
+ * written by the first sample only. */
+typedef struct trhip_pt_targets {
+    void* color;        /* RGBA32F */
+    void* diffuse;      /* RGBA32F */
+    void* reflection;   /* RGBA32F */
+    void* albedo;       /* RGBA32F */
+    void* material;     /* RGBA32F */
+    void* normal;       /* RG32F   */
+    void* pos;          /* RGBA32F, world space, w = 0 */
+    void* instance_id;  /* R32I, -1 = no surface */
+} trhip_pt_targets;
+int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */
 int trhip_pt_reset_counters(trhip_pt* pt);

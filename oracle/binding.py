@@ -49,6 +49,10 @@ class PtOptionsC(C.Structure):
         ("transparent_background", C.c_int32), ("pre_transformed_vertices", C.c_int32)]
 
 
+class PtTargetsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id")]
+
+
 class DistributionC(C.Structure):
     _fields_ = [("size_x", C.c_uint32), ("size_y", C.c_uint32), ("strategy", C.c_int32),
                 ("index", C.c_uint32), ("count", C.c_uint32), ("primary", C.c_uint32)]
@@ -72,6 +76,9 @@ def lib():
         L.oracle_scene_tri_light_count.restype = C.c_uint32
         L.oracle_scene_tri_light_count.argtypes = [C.c_void_p]
         L.oracle_scene_get_tri_lights.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_pt_render_targets.restype = C.c_int
+        L.oracle_pt_render_targets.argtypes = [C.c_void_p, C.POINTER(PtOptionsC), C.POINTER(DistributionC), C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.POINTER(PtTargetsC), C.c_uint32, C.c_uint32, C.c_int]
         L.oracle_pt_render.restype = C.c_int
         L.oracle_pt_render.argtypes = [C.c_void_p, C.POINTER(PtOptionsC), C.POINTER(DistributionC), C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
@@ -205,6 +212,28 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("oracle_pt_render failed")
         return color
+
+    TARGETS = {"color": (4, np.float32), "diffuse": (4, np.float32), "reflection": (4, np.float32), "albedo": (4, np.float32),
+               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32)}
+
+    def render_pt_targets(self, opt: PtOptionsC, width, height, names, dist: DistributionC = None, viewports=1, frame_counter=0,
+                          samples_accumulated=0, targets=None, target_size=None, threads=0):
+        """oracle_pt_render_targets: returns {name: array[viewports, th, tw, channels]} for the requested gbuffer targets."""
+        if dist is None:
+            dist = DistributionC(width, height, 0, 0, 1, 1)
+        tw, th = target_size if target_size else (width, height)
+        out = dict(targets) if targets else {}
+        t = PtTargetsC()
+        for n in names:
+            ch, dt = self.TARGETS[n]
+            if n not in out:
+                out[n] = np.zeros((viewports, th, tw, ch), dtype=dt)
+            setattr(t, n, out[n].ctypes.data)
+        rc = lib().oracle_pt_render_targets(self.h, C.byref(opt), C.byref(dist), viewports, frame_counter, samples_accumulated,
+                                            C.byref(t), tw, th, threads)
+        if rc != 0:
+            raise RuntimeError("oracle_pt_render_targets failed")
+        return out
 
     def render_feature(self, feature, width, height, dist: DistributionC = None, projection=0, viewport=0,
                        min_ray_dist=1e-4, default_value=(np.nan,) * 4, threads=0, target_size=None):

@@ -1631,7 +1631,7 @@ void get_world_camera_ray(const pt_ctx& c, const launch_ctx& L, ivec2 pixel, con
 }
 
 // path_tracer.rgen:77-127 + write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
-void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, float* color,
+void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
                    uint target_w, uint target_h) {
     const oracle_scene& s = *c.s;
     ivec2 pixel;
@@ -1641,6 +1641,7 @@ void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, 
     pt_vertex_data first_hit_vertex{};
     sampled_material first_hit_material{};
     vec3 sum_color = V3(0);
+    vec4 sum_diffuse = V4(0), sum_reflection = V4(0);
     const int spp = c.opt.samples_per_pass;
     for (int i = 0; i < spp; ++i) {
         local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples + (uint)i},
@@ -1652,20 +1653,45 @@ void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, 
         vec4 old_albedo = first_hit_material.albedo;
         if (c.opt.use_white_albedo_on_first_bounce) { first_hit_material.albedo.x = first_hit_material.albedo.y = first_hit_material.albedo.z = 1; }
         sum_color += first_hit_material.emission + modulate_color(first_hit_material, V3(diffuse), V3(reflection));
+        sum_diffuse = sum_diffuse + diffuse;
+        sum_reflection = sum_reflection + reflection;
         first_hit_material.albedo = old_albedo;
     }
     vec3 col = sum_color / (float)spp;
     const float alpha = c.opt.transparent_background ? first_hit_material.albedo.w : 1.0f;
-    vec4 out = V4(col, alpha);
     if ((uint)wp.x >= target_w || (uint)wp.y >= target_h) return;
-    float* px = color + (((size_t)wp.z * target_h + wp.y) * target_w + wp.x) * 4;
-    uint prev_samples = samples_accumulated + previous_samples;
-    if (prev_samples != 0) {
-        vec4 prev_color = V4(px[0], px[1], px[2], px[3]);
-        uint total = (uint)spp + prev_samples;
-        out = mix(out, prev_color, (float)prev_samples / (float)total);
+    const size_t pix = ((size_t)wp.z * target_h + wp.y) * target_w + wp.x;
+    const uint prev_samples = samples_accumulated + previous_samples;
+    if (prev_samples == 0) {   // only the first sample writes the gbuffer (path_tracer.glsl:549-563)
+        if (T.albedo) { float* a = T.albedo + pix * 4; a[0] = first_hit_material.albedo.x; a[1] = first_hit_material.albedo.y; a[2] = first_hit_material.albedo.z; a[3] = first_hit_material.albedo.w; }
+        if (T.material) {   // pack_gbuffer_material (gbuffer.glsl:256-260)
+            float* m = T.material + pix * 4;
+            float ior = first_hit_material.ior_out / first_hit_material.ior_in;
+            m[0] = first_hit_material.metallic; m[1] = first_hit_material.roughness; m[2] = ior * 0.25f; m[3] = first_hit_material.transmittance;
+        }
+        if (T.normal) {     // octahedral_pack (math.glsl:480-485)
+            vec3 n = first_hit_vertex.mapped_normal;
+            n = n / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+            vec2 o = n.z >= 0.0f ? V2(n.x, n.y)
+                                 : V2((1 - fabsf(n.y)) * ((n.x >= 0.0f ? 1.0f : 0.0f) * 2 - 1), (1 - fabsf(n.x)) * ((n.y >= 0.0f ? 1.0f : 0.0f) * 2 - 1));
+            T.normal[pix * 2] = o.x; T.normal[pix * 2 + 1] = o.y;
+        }
+        if (T.pos) { float* q = T.pos + pix * 4; q[0] = first_hit_vertex.pos.x; q[1] = first_hit_vertex.pos.y; q[2] = first_hit_vertex.pos.z; q[3] = 0; }
+        if (T.instance_id) T.instance_id[pix] = first_hit_vertex.instance_id;
     }
-    px[0] = out.x; px[1] = out.y; px[2] = out.z; px[3] = out.w;
+    auto accumulate = [&](float* target, vec4 value) {   // accumulate_gbuffer_{color,diffuse,reflection} (gbuffer.glsl:18-28,68-78,118-128)
+        if (!target) return;
+        float* px = target + pix * 4;
+        if (prev_samples != 0) {
+            vec4 prev = V4(px[0], px[1], px[2], px[3]);
+            uint total = (uint)spp + prev_samples;
+            value = mix(value, prev, (float)prev_samples / (float)total);
+        }
+        px[0] = value.x; px[1] = value.y; px[2] = value.z; px[3] = value.w;
+    };
+    accumulate(T.color, V4(col, alpha));
+    accumulate(T.diffuse, sum_diffuse / (float)spp);
+    accumulate(T.reflection, sum_reflection / (float)spp);
 }
 
 uvec2 get_ray_count(const oracle_distribution& d) {   // src/distribution_strategy.cc:33-61
@@ -1729,6 +1755,14 @@ void oracle_scene_get_tri_lights(const oracle_scene* s, void* out) { memcpy(out,
 int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
                      uint32_t frame_counter, uint32_t samples_accumulated, float* color, uint32_t target_w, uint32_t target_h,
                      int threads) {
+    oracle_pt_targets T{};
+    T.color = color;
+    return oracle_pt_render_targets(s, opt, dist_in, viewport_count, frame_counter, samples_accumulated, &T, target_w, target_h, threads);
+}
+
+int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
+                             uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
+                             uint32_t target_h, int threads) {
     if (viewport_count > s->cameras.size()) return 1;
     pt_ctx c;
     c.s = s; c.opt = *opt;
@@ -1762,7 +1796,7 @@ int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle
                     for (uint x = 0; x < rays.x; ++x) {
                         launch_ctx L = base;
                         L.launch_id = {x, (uint)y, z};
-                        pt_invocation(lc, L, previous_samples, samples_accumulated, color, target_w, target_h);
+                        pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
                     }
                 }
 #pragma omp critical

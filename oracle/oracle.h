@@ -99,6 +99,18 @@ int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle
                      uint32_t viewport_count, uint32_t frame_counter, uint32_t samples_accumulated,
                      float* color, uint32_t target_w, uint32_t target_h, int threads);
 
+/* The same frame with the other gbuffer targets path_tracer.rgen can write (write_all_outputs,
+ * shader/path_tracer.glsl:535-576; formats of shader/gbuffer.glsl): any pointer may be null.
+ * color/diffuse/reflection/albedo/material/pos: 4 floats per pixel; normal: 2 floats (octahedral);
+ * instance_id: 1 int32.  Same target size as `color`. */
+typedef struct oracle_pt_targets {
+    float* color; float* diffuse; float* reflection; float* albedo; float* material; float* normal; float* pos;
+    int32_t* instance_id;
+} oracle_pt_targets;
+int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist,
+                             uint32_t viewport_count, uint32_t frame_counter, uint32_t samples_accumulated,
+                             const oracle_pt_targets* targets, uint32_t target_w, uint32_t target_h, int threads);
+
 /* feature_stage (src/feature_stage.cc:33-65): 0 albedo, 1 world normal, 2 view normal,
  * 3 world pos, 4 view pos, 5 distance, 9 instance id */
 int oracle_feature_render(oracle_scene* s, int feature, const oracle_distribution* dist, int projection,

@@ -61,6 +61,11 @@ class TimingsC(C.Structure):
                 + [(n, C.c_uint32) for n in ("trace_closest_launches", "trace_shadow_launches", "shade_launches", "frames")])
 
 
+class PtTargetsC(C.Structure):
+    """trhip_pt_targets: device images, None = not requested."""
+    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id")]
+
+
 class TonemapInfoC(C.Structure):
     _fields_ = [("op", C.c_int32), ("exposure", C.c_float), ("gamma", C.c_float), ("alpha_grid_background", C.c_int32)]
 
@@ -87,6 +92,7 @@ SYMBOLS = {
     "trhip_pt_set_distribution": (_i, [_vp, C.POINTER(DistributionC)]),
     "trhip_pt_reset_accumulation": (_i, [_vp, _i]),
     "trhip_pt_render": (_i, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    "trhip_pt_render_targets": (_i, [_vp, C.POINTER(PtTargetsC), _u32, _u32, _u32, _vp]),
     "trhip_pt_set_profiling": (_i, [_vp, _i, _i]),
     "trhip_pt_get_counters": (_i, [_vp, C.POINTER(CountersC)]),
     "trhip_pt_reset_counters": (_i, [_vp]),

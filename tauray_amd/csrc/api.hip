@@ -335,8 +335,16 @@ int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter) {
 int trhip_pt_render(trhip_pt* pt, void* color_dev, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream) {
     if (!pt) return set_error("null trhip_pt");
     DEVCHK(pt->dev);
+    trhip_pt_targets t = {};
+    t.color = color_dev;
+    return trhip_pt_render_targets(pt, &t, target_w, target_h, viewports, stream);
+}
+int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream) {
+    if (!pt) return set_error("null trhip_pt");
+    if (!targets) return set_error("trhip_pt_render_targets: null targets");
+    DEVCHK(pt->dev);
     pt->stage->last_stream = (hipStream_t)stream;
-    return pt->stage->render(color_dev, target_w, target_h, viewports, (hipStream_t)stream);
+    return pt->stage->render(*targets, target_w, target_h, viewports, (hipStream_t)stream);
 }
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
     if (!pt) return set_error("null trhip_pt");

@@ -33,16 +33,22 @@ struct PathBuffers {
     f4* org_pdf;      // origin.xyz, bsdf_pdf
     f4* dir_reg;      // direction.xyz, regularization
     f4* atten_alpha;  // attenuation.rgb, first-hit albedo.a
-    f4* color;        // accumulated colour of the current sample (folded demodulated colour), w unused
-    f4* wp;           // per-path colour weight after bounce 0: Wd*pd + Wr*pr
+    f4* diffuse;      // demodulated diffuse light of the current sample (path_tracer.glsl:376), a = 1/length at bounce 1
+    f4* reflection;   // demodulated reflected light, same layout
+    f2* plobes;       // primary_lobes as add_demodulated_color uses them: (diffuse + transmission, dielectric + metallic reflection)
+    f4* first_mat;    // first_hit_material: albedo.rgb, metallic
+    f4* first_emis;   // first_hit_material.emission (= bounce-0 light), albedo.a
     u4* rng;          // random_sampler.seed
     u4* misc;         // payload.random_seed, sobol_index, launch linear id, flags (bit0 = dead)
     int4* hit;        // instance, primitive, bary.u bits, bary.v bits (u carries t for sphere lights)
     f4* sum_color;    // sum over the samples of one pass (+ alpha of the last sample)
+    f4* sum_diffuse;  // only allocated when the diffuse / reflection targets are requested
+    f4* sum_reflection;
     // shadow rays of the current bounce (compact)
     f4* sh_org_tmax;  // origin.xyz, tmax
     f4* sh_dir_id;    // direction.xyz, path id bits
-    f4* sh_contrib;   // rgb contribution if visible
+    f4* sh_contrib;   // rgb radiance if visible, luminance for the indirect clamp
+    f2* sh_lobes;     // lobe weights the contribution is demodulated with
     uint* queue[2];
     uint* counters;   // [0] next-queue count, [1] shadow count, [2] overflow flag, [4..] work counters
 };
@@ -68,6 +74,7 @@ struct PtParams {
     int nee_point, nee_tri, nee_dir, nee_env;
     int count_work;
     int shadow_cnt;               // counter word holding this bounce's shadow queue length
+    trhip_pt_targets T;           // device images; null = target not requested
 };
 
 TR_DEV void add64(uint* counters, int idx, uint v) {
@@ -92,13 +99,15 @@ TR_DEV uint wave_append(uint* counter, bool pred) {
 __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= P.n_launch) return;
-    uint lx = i % P.L.launch_w;
-    uint ly = (i / P.L.launch_w) % P.L.launch_h;
-    uint lz = i / (P.L.launch_w * P.L.launch_h);
+    uint lx, ly, lz;
+    launch_coord(P.L, i, lx, ly, lz);
     int px, py;
     bool valid = get_pixel_pos(P.L, lx, ly, px, py);
     u4 misc = {0, 0, i, valid ? 0u : 1u};
-    if (P.sample_in_pass == 0) pb.sum_color[i] = F4(0, 0, 0, 1);
+    if (P.sample_in_pass == 0) {
+        pb.sum_color[i] = F4(0, 0, 0, 1);
+        if (pb.sum_diffuse) { pb.sum_diffuse[i] = F4(0); pb.sum_reflection[i] = F4(0); }
+    }
     if (!valid) { pb.misc[i] = misc; return; }
     LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, lz, P.previous_samples + P.sample_in_pass}, P.sample_counter,
                                          P.rng_seed, P.opt.sampler);
@@ -118,8 +127,6 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
     pb.org_pdf[i] = F4(origin, 0.0f);            // bsdf_pdf = 0
     pb.dir_reg[i] = F4(dir, 1.0f);               // regularization = 1
     pb.atten_alpha[i] = F4(1, 1, 1, 1);          // attenuation = 1
-    pb.color[i] = F4(0);
-    pb.wp[i] = F4(0);
     pb.rng[i] = ls.rs;
     pb.misc[i] = misc;
 }
@@ -218,9 +225,11 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
             // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
             float m = c.w * vis;
             if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
-            f4 col = pb.color[id];
-            col.x += c.x * vis; col.y += c.y * vis; col.z += c.z * vis;
-            pb.color[id] = col;
+            const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
+            const f2 w = pb.sh_lobes[qi];
+            // add_demodulated_color; a zero weight adds exactly nothing, so that target is left alone
+            if (w.x != 0.0f) { f4 d4 = pb.diffuse[id]; d4.x += radiance.x * w.x; d4.y += radiance.y * w.x; d4.z += radiance.z * w.x; pb.diffuse[id] = d4; }
+            if (w.y != 0.0f) { f4 r4 = pb.reflection[id]; r4.x += radiance.x * w.y; r4.y += radiance.y * w.y; r4.z += radiance.z * w.y; pb.reflection[id] = r4; }
         }
         rays++;
     }
@@ -376,6 +385,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
         bool alive = false;        // continues to the next bounce
         bool want_shadow = false;
         f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
+        f2 sh_w = F2(0.0f);
         float sh_tmax = 0, sh_lum = 0;
         if (active) {
             const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id], a4 = pb.atten_alpha[id];
@@ -383,9 +393,11 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             f3 pos = F3(o4), view = F3(d4);
             float bsdf_pdf = o4.w, regularization = d4.w;
             f3 attenuation = F3(a4);
-            float first_alpha = a4.w;
-            f4 color = pb.color[id];
-            f3 wp = F3(pb.wp[id]);
+            // demodulated light of this sample: known to be zero before bounce 0, otherwise fetched only by the paths that add to
+            // it in this kernel (emitters, envmap/light hits, NEE samples too dim for a shadow ray)
+            f4 dif = F4(0), ref = F4(0);
+            bool have = bounce == 0;
+            f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
             u4 rs = pb.rng[id];
             pcg(misc.x);   // the any-hit seed advances once per closest-hit trace
 
@@ -450,17 +462,37 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             light = attenuation * mis_weight * (mat.emission + light);
             if (bounce != 0) light *= clamp_contribution_mul(P, light);
 
-            // folded demodulation (material.glsl:57-73): colour = E0 + Wd * sum(c*pd) + Wr * sum(c*pr)
-            f3 Wd = F3(0), Wr = F3(0);
-            if (bounce == 0) {
-                f3 alb = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(mat.albedo);
-                Wd = alb * (1 - mat.metallic);
-                Wr = mix3(F3(0.02f), alb, mat.metallic) / mixf(0.02f, 1.0f, mat.metallic);
-                first_alpha = mat.albedo.w;
-                // primary_lobes = (0,0,0,1): the first-hit light is counted as emission and as reflection
-                color.x += light.x + light.x * Wr.x; color.y += light.y + light.y * Wr.y; color.z += light.z + light.z * Wr.z;
-            } else {
-                color.x += light.x * wp.x; color.y += light.y * wp.y; color.z += light.z * wp.z;
+            // add_demodulated_color(primary_lobes, light, diffuse, reflection) (path_tracer.glsl:435, material.glsl:66-73)
+            if (bounce == 0 || light.x != 0.0f || light.y != 0.0f || light.z != 0.0f) {
+                if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
+                dif.x += light.x * pl.x; dif.y += light.y * pl.x; dif.z += light.z * pl.x;
+                ref.x += light.x * pl.y; ref.y += light.y * pl.y; ref.z += light.z * pl.y;
+            }
+            if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
+                pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
+                pb.first_emis[id] = F4(light, mat.albedo.w);
+                const uint prev_samples = P.samples_accumulated + P.previous_samples;
+                if (prev_samples == 0 && P.sample_in_pass == (uint)P.opt.samples_per_pass - 1u &&
+                    (P.T.albedo || P.T.material || P.T.normal || P.T.pos || P.T.instance_id)) {
+                    // write_all_outputs: only the first sample writes the gbuffer (path_tracer.glsl:549-563)
+                    uint lx, ly, lz;
+                    launch_coord(P.L, misc.z, lx, ly, lz);
+                    int wx, wy;
+                    if (get_write_pixel_pos(P.L, lx, ly, wx, wy) && (uint)wx < P.target_w && (uint)wy < P.target_h) {
+                        const size_t pix = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
+                        if (P.T.albedo) reinterpret_cast<f4*>(P.T.albedo)[pix] = mat.albedo;
+                        if (P.T.material)   // pack_gbuffer_material (gbuffer.glsl:256-260)
+                            reinterpret_cast<f4*>(P.T.material)[pix] = F4(mat.metallic, mat.roughness, (mat.ior_out / mat.ior_in) * 0.25f, mat.transmittance);
+                        if (P.T.normal) {   // octahedral_pack (math.glsl:480-485)
+                            f3 nn = v.mapped_normal / (fabsf(v.mapped_normal.x) + fabsf(v.mapped_normal.y) + fabsf(v.mapped_normal.z));
+                            f2 o = nn.z >= 0.0f ? F2(nn.x, nn.y)
+                                                : F2((1 - fabsf(nn.y)) * ((nn.x >= 0.0f ? 1.0f : 0.0f) * 2 - 1), (1 - fabsf(nn.x)) * ((nn.y >= 0.0f ? 1.0f : 0.0f) * 2 - 1));
+                            reinterpret_cast<f2*>(P.T.normal)[pix] = o;
+                        }
+                        if (P.T.pos) reinterpret_cast<f4*>(P.T.pos)[pix] = F4(v.pos, 0);
+                        if (P.T.instance_id) reinterpret_cast<int*>(P.T.instance_id)[pix] = surface ? h.x : -1;
+                    }
+                }
             }
 
             if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
@@ -474,7 +506,8 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                 u4 coord;   // only the Sobol-Owen sampler needs the launch coordinate again
                 {
                     uint i = misc.z;
-                    uint lx = i % P.L.launch_w, ly = (i / P.L.launch_w) % P.L.launch_h, lz = i / (P.L.launch_w * P.L.launch_h);
+                    uint lx, ly, lz;
+                    launch_coord(P.L, i, lx, ly, lz);
                     int px = 0, py = 0;
                     if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
                     coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_in_pass + P.sample_counter};
@@ -494,24 +527,30 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                     bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
                     contrib = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
                     f3 radiance = attenuation * contrib;
-                    f3 w;
                     float clamp_lum = 0.0f;   // > 0: indirect clamping applies to (radiance * visibility)
                     if (bounce != 0) {
                         radiance *= modulate_bsdf(mat, lobes);
                         if (P.opt.indirect_clamping > 0.0f) clamp_lum = rgb_to_luminance(radiance);
-                        w = wp;
                     } else {
-                        w = Wd * (lobes.diffuse + lobes.transmission) + Wr * (lobes.dielectric_reflection + lobes.metallic_reflection);
+                        // primary_lobes = lobes (path_tracer.glsl:466)
+                        pl = F2(lobes.diffuse + lobes.transmission, lobes.dielectric_reflection + lobes.metallic_reflection);
                     }
-                    f3 c = radiance * w;
                     if (cast) {
                         // contrib *= shadow_ray(...) happens in k_trace_shadow, including the clamp on the occluded value
                         want_shadow = true;
-                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = c; sh_lum = clamp_lum;
+                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = radiance; sh_lum = clamp_lum; sh_w = pl;
                     } else {
                         float mul = (clamp_lum > P.opt.indirect_clamping && clamp_lum > 0.0f) ? P.opt.indirect_clamping / clamp_lum : 1.0f;
-                        color.x += c.x * mul; color.y += c.y * mul; color.z += c.z * mul;
+                        if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
+                        const f3 r = radiance * mul;
+                        dif.x += r.x * pl.x; dif.y += r.y * pl.x; dif.z += r.z * pl.x;
+                        ref.x += r.x * pl.y; ref.y += r.y * pl.y; ref.z += r.z * pl.y;
                     }
+                }
+                if (bounce == 1) {   // diffuse.a = reflection.a = 1 / length(v.pos - pos) (path_tracer.glsl:470-471)
+                    const float inv_len = 1.0f / length(v.pos - pos);
+                    if (have) { dif.w = inv_len; ref.w = inv_len; }
+                    else { pb.diffuse[id].w = inv_len; pb.reflection[id].w = inv_len; }
                 }
                 // ---- BSDF sampling (path_tracer.glsl:475-497)
                 Lobes bl = {0, 0, 0, 0};
@@ -521,7 +560,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                 view = mul(tbn, new_dir);
                 correct_lobes_for_normal_map(v.hard_normal, view, bl);
                 if (bounce != 0) attenuation *= modulate_bsdf(mat, bl);
-                else wp = Wd * (bl.diffuse + bl.transmission) + Wr * (bl.dielectric_reflection + bl.metallic_reflection);
+                else pl = F2(bl.diffuse + bl.transmission, bl.dielectric_reflection + bl.metallic_reflection);   // primary_lobes = lobes
                 pos = v.pos;
                 alive = true;
                 if (P.opt.russian_roulette_delta > 0) {   // USE_RUSSIAN_ROULETTE: the survivor weight is never applied
@@ -531,13 +570,12 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                 if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
             }
             // ---- write back
-            pb.color[id] = color;
-            if (bounce == 0) pb.atten_alpha[id] = F4(attenuation, first_alpha);
+            if (have) { pb.diffuse[id] = dif; pb.reflection[id] = ref; }
             if (alive) {
                 pb.org_pdf[id] = F4(pos, bsdf_pdf);
                 pb.dir_reg[id] = F4(view, regularization);
-                pb.atten_alpha[id] = F4(attenuation, first_alpha);
-                if (bounce == 0) pb.wp[id] = F4(wp, 0);
+                pb.atten_alpha[id] = F4(attenuation, 0);
+                if (bounce == 0) pb.plobes[id] = pl;
                 pb.rng[id] = rs;
                 pb.misc[id] = misc;
             }
@@ -548,6 +586,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
             pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
             pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
+            pb.sh_lobes[sslot] = sh_w;
         }
         uint nslot = wave_append(&pb.counters[CNT_NEXT], alive);
         if (alive) next_queue[nslot] = id;
@@ -570,36 +609,52 @@ __global__ void k_clear_shadow(uint* counters) {
     counters[CNT_SHADOW] = 0; counters[CNT_SHADOW_ODD] = 0; counters[CNT_NEXT] = 0; counters[CNT_WORK_CLOSEST] = 0; counters[CNT_WORK_SHADOW] = 0;
 }
 
-// end of one sample: sum_color += colour (path_tracer.rgen:112)
+// end of one sample (path_tracer.rgen:105-118): sum_color += first_hit_material.emission + modulate_color(first_hit_material,
+// diffuse, reflection) with material.glsl:57-65; sum_diffuse / sum_reflection when those targets exist
 __global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= P.n_launch) return;
     u4 misc = pb.misc[i];
     if (misc.w & 1u) return;
-    f4 s = pb.sum_color[i], c = pb.color[i];
-    float alpha = pb.atten_alpha[i].w;
-    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, alpha);
+    const f4 s = pb.sum_color[i], d = pb.diffuse[i], r = pb.reflection[i], fm = pb.first_mat[i], fe = pb.first_emis[i];
+    const f3 albedo = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(fm);
+    const float metallic = fm.w;
+    const float approx_fresnel = 0.02f;
+    const f3 dd = F3(d) * albedo * (1 - metallic);
+    const f3 rr = F3(r) * mix3(F3(approx_fresnel), albedo, metallic) / mixf(approx_fresnel, 1.0f, metallic);
+    const f3 c = F3(fe) + (dd + rr);
+    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, fe.w);
+    if (pb.sum_diffuse) {
+        const f4 sd = pb.sum_diffuse[i], sr = pb.sum_reflection[i];
+        pb.sum_diffuse[i] = F4(sd.x + d.x, sd.y + d.y, sd.z + d.z, sd.w + d.w);
+        pb.sum_reflection[i] = F4(sr.x + r.x, sr.y + r.y, sr.z + r.z, sr.w + r.w);
+    }
 }
 
-// write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
-__global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb, f4* target) {
+// write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_{color,diffuse,reflection} (gbuffer.glsl:18-28,68-78,118-128)
+__global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= P.n_launch) return;
-    uint lx = i % P.L.launch_w, ly = (i / P.L.launch_w) % P.L.launch_h, lz = i / (P.L.launch_w * P.L.launch_h);
+    uint lx, ly, lz;
+    launch_coord(P.L, i, lx, ly, lz);
     int wx, wy;
     if (!get_write_pixel_pos(P.L, lx, ly, wx, wy)) return;
     if ((uint)wx >= P.target_w || (uint)wy >= P.target_h) return;
-    f4 s = pb.sum_color[i];
     const float spp = (float)P.opt.samples_per_pass;
-    f4 out = F4(s.x / spp, s.y / spp, s.z / spp, P.opt.transparent_background ? s.w : 1.0f);
-    size_t idx = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
-    uint prev_samples = P.samples_accumulated + P.previous_samples;
-    if (prev_samples != 0) {
-        f4 prev = target[idx];
-        uint total = (uint)P.opt.samples_per_pass + prev_samples;
-        out = mix4(out, prev, (float)prev_samples / (float)total);
+    const size_t idx = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
+    const uint prev_samples = P.samples_accumulated + P.previous_samples;
+    const float keep = prev_samples != 0 ? (float)prev_samples / (float)((uint)P.opt.samples_per_pass + prev_samples) : 0.0f;
+    auto accumulate = [&](void* image, f4 value) {
+        f4* target = reinterpret_cast<f4*>(image);
+        if (prev_samples != 0) value = mix4(value, target[idx], keep);
+        target[idx] = value;
+    };
+    if (P.T.color) {
+        const f4 s = pb.sum_color[i];
+        accumulate(P.T.color, F4(s.x / spp, s.y / spp, s.z / spp, P.opt.transparent_background ? s.w : 1.0f));
     }
-    target[idx] = out;
+    if (P.T.diffuse) { const f4 s = pb.sum_diffuse[i]; accumulate(P.T.diffuse, F4(s.x / spp, s.y / spp, s.z / spp, s.w / spp)); }
+    if (P.T.reflection) { const f4 s = pb.sum_reflection[i]; accumulate(P.T.reflection, F4(s.x / spp, s.y / spp, s.z / spp, s.w / spp)); }
 }
 
 uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strategy.cc:62-69
@@ -654,8 +709,8 @@ PtStage::~PtStage() {
 
 void PtStage::free_buffers() {
     PathBuffers& pb = impl->pb;
-    void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.color, pb.wp, pb.rng, pb.misc, pb.hit, pb.sum_color,
-                    pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.queue[0], pb.queue[1]};
+    void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
+                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint* counters = pb.counters;
     pb = PathBuffers{};
@@ -663,25 +718,28 @@ void PtStage::free_buffers() {
     impl->capacity = 0;
 }
 
-int PtStage::ensure_buffers(size_t n) {
+int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     PathBuffers& pb = impl->pb;
     if (!pb.counters) {
         HIPCHK(hipMalloc(&pb.counters, CNT_WORDS * sizeof(uint)));
         HIPCHK(hipMemset(pb.counters, 0, CNT_WORDS * sizeof(uint)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
-    if (n <= impl->capacity) return 0;
+    if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
     free_buffers();
     HIPCHK(hipMalloc(&pb.org_pdf, n * 16)); HIPCHK(hipMalloc(&pb.dir_reg, n * 16)); HIPCHK(hipMalloc(&pb.atten_alpha, n * 16));
-    HIPCHK(hipMalloc(&pb.color, n * 16)); HIPCHK(hipMalloc(&pb.wp, n * 16)); HIPCHK(hipMalloc(&pb.rng, n * 16));
+    HIPCHK(hipMalloc(&pb.diffuse, n * 16)); HIPCHK(hipMalloc(&pb.reflection, n * 16)); HIPCHK(hipMalloc(&pb.plobes, n * 8));
+    HIPCHK(hipMalloc(&pb.first_mat, n * 16)); HIPCHK(hipMalloc(&pb.first_emis, n * 16)); HIPCHK(hipMalloc(&pb.rng, n * 16));
     HIPCHK(hipMalloc(&pb.misc, n * 16)); HIPCHK(hipMalloc(&pb.hit, n * 16)); HIPCHK(hipMalloc(&pb.sum_color, n * 16));
     HIPCHK(hipMalloc(&pb.sh_org_tmax, n * 16)); HIPCHK(hipMalloc(&pb.sh_dir_id, n * 16)); HIPCHK(hipMalloc(&pb.sh_contrib, n * 16));
+    HIPCHK(hipMalloc(&pb.sh_lobes, n * 8));
+    if (lobe_sums) { HIPCHK(hipMalloc(&pb.sum_diffuse, n * 16)); HIPCHK(hipMalloc(&pb.sum_reflection, n * 16)); }
     HIPCHK(hipMalloc(&pb.queue[0], n * 4)); HIPCHK(hipMalloc(&pb.queue[1], n * 4));
     impl->capacity = n;
     return 0;
 }
 
-int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
+int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
     if (!scene->accel_built) return set_error("trhip_pt_render: call trhip_scene_build_accel first");
     if (viewports == 0 || viewports > scene->camera_count) return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
     if (opt.samples_per_pass <= 0 || opt.samples_per_pixel % opt.samples_per_pass != 0)
@@ -716,7 +774,8 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
         P.prob_point = point * inv_sum; P.prob_tri = tri * inv_sum; P.prob_dir = dir * inv_sum; P.prob_env = env * inv_sum;
     }
     P.count_work = 1;
-    if (int rc = ensure_buffers(n)) return rc;
+    P.T = targets;
+    if (int rc = ensure_buffers(n, targets.diffuse || targets.reflection)) return rc;
     PathBuffers& pb = impl->pb;
     SceneView sv = scene->view();
     const uint blocks_all = (uint)((n + KB - 1) / KB);
@@ -785,7 +844,7 @@ int PtStage::render(void* color_dev, uint target_w, uint target_h, uint viewport
             if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0)); shadow_in_flight = false; }
             hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, P, pb);
         }
-        timed(T_RESOLVE, stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb, (f4*)color_dev); });
+        timed(T_RESOLVE, stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb); });
     }
     HIPCHK(hipEventRecord(ev[1], stream));
     HIPCHK(hipGetLastError());

@@ -11,7 +11,7 @@ class PtStage {
 public:
     PtStage(DeviceScene* scene, const trhip_pt_options& opt);
     ~PtStage();
-    int render(void* color_dev, uint target_w, uint target_h, uint viewports, hipStream_t stream);
+    int render(const trhip_pt_targets& targets, uint target_w, uint target_h, uint viewports, hipStream_t stream);
     int get_counters(trhip_counters* out, hipStream_t stream);
     int reset_counters();
     int get_timings(trhip_timings* out);
@@ -28,7 +28,7 @@ private:
     struct Impl;
     Impl* impl;
     bool timing_pending = false;
-    int ensure_buffers(size_t n);
+    int ensure_buffers(size_t n, bool lobe_sums);
     int resolve_pending();
     void free_buffers();
 };

@@ -496,6 +496,23 @@ struct LaunchCtx {
     uint index, count, primary;   // count = b (strip bits) for shuffled strips, as uploaded by rt_camera_stage.cc:86-87
     uint launch_w, launch_h;      // gl_LaunchSizeEXT.xy
 };
+// Path id -> launch coordinate.  Path ids walk the launch grid in 8x8 tiles (when the width divides by 8) instead of
+// rows, so the 64 rays of a wave start from an 8x8 pixel block: more coherent traversal and texture access on every
+// bounce.  Results do not depend on this mapping (all random streams are keyed by the absolute pixel).
+TR_DEV void launch_coord(const LaunchCtx& L, uint i, uint& lx, uint& ly, uint& lz) {
+    const uint per_layer = L.launch_w * L.launch_h;
+    lz = i / per_layer;
+    const uint j = i - lz * per_layer;
+    if ((L.launch_w & 7u) == 0u && j < L.launch_w * (L.launch_h & ~7u)) {   // rows past the last full tile row stay row-major
+        const uint tile = j >> 6, k = j & 63u, tiles_x = L.launch_w >> 3;
+        const uint ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        lx = (tx << 3) + (k & 7u);
+        ly = (ty << 3) + (k >> 3);
+    } else {
+        ly = j / L.launch_w;
+        lx = j - ly * L.launch_w;
+    }
+}
 TR_HD uint permute_region_id(uint i, uint size_x, uint size_y, uint b) {
     uint region_size = ((size_x * size_y) + (1u << b) - 1) >> b;
     uint region_id = i / region_size;

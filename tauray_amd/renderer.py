@@ -265,6 +265,22 @@ class PathTracerStage:
         tw, th = get_distribution_target_size(self.distribution)
         check(_lib.lib().trhip_pt_render(self.h, _ptr(color_target), tw, th, viewports, stream))
 
+    # gbuffer_target entries path_tracer.rgen can write (src/gbuffer.hh; shader/path_tracer.glsl:535-576):
+    # name -> (channels, numpy dtype)
+    TARGETS = {"color": (4, np.float32), "diffuse": (4, np.float32), "reflection": (4, np.float32), "albedo": (4, np.float32),
+               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32)}
+
+    def run_targets(self, targets: dict, viewports=1, stream=None):
+        """stage::run with a gbuffer: `targets` maps any subset of TARGETS to device images."""
+        unknown = set(targets) - set(self.TARGETS)
+        if unknown:
+            raise ValueError(f"unknown gbuffer targets: {sorted(unknown)}")
+        t = _lib.PtTargetsC()
+        for name, buf in targets.items():
+            setattr(t, name, _ptr(buf))
+        tw, th = get_distribution_target_size(self.distribution)
+        check(_lib.lib().trhip_pt_render_targets(self.h, C.byref(t), tw, th, viewports, stream))
+
     def set_profiling(self, count_work=False, detailed_timing=False):
         check(_lib.lib().trhip_pt_set_profiling(self.h, int(count_work), int(detailed_timing)))
 

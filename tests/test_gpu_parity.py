@@ -207,6 +207,61 @@ def test_progressive_accumulation_over_frames(R, ctx, glb128, test_glb_128, orac
     _compare(color.download((1, 128, 128, 4)), ref2, "frame after reset")
 
 
+def _render_targets_hip(R, ctx, ss, scene, size, names, frames=1, **kw):
+    opt = R.options_for_scene(scene, **kw)
+    pt = R.PathTracerStage(ctx, ss, opt, _dup(size))
+    w, h = size
+    bufs = {n: ctx.alloc(w * h * R.PathTracerStage.TARGETS[n][0] * 4).zero() for n in names}
+    for _ in range(frames):
+        pt.run_targets(bufs)
+    out = {}
+    for n in names:
+        ch, dt = R.PathTracerStage.TARGETS[n]
+        out[n] = np.frombuffer(bufs[n].download((1, h, w, ch)).tobytes(), dtype=dt).reshape(1, h, w, ch)
+    assert pt.counters()["stack_overflows"] == 0
+    pt.close()
+    return out
+
+
+@pytest.mark.parametrize("name,kw,frames", [
+    ("default", dict(max_bounces=4), 1),
+    ("2-per-pass-accumulated", dict(max_bounces=3, samples_per_pixel=4, samples_per_pass=2), 2),
+    ("white-albedo-clamp", dict(max_bounces=4, use_white_albedo_on_first_bounce=1, indirect_clamping=4.0), 1),
+])
+def test_gbuffer_targets_match_oracle(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128, name, kw, frames):
+    """write_all_outputs (path_tracer.glsl:535-576): every gbuffer target the path tracer can write, against the oracle:
+    demodulated diffuse / reflection (running means, a = 1/length of the second segment) and the first-hit AOVs."""
+    names = list(R.PathTracerStage.TARGETS)
+    got = _render_targets_hip(R, ctx, glb128, test_glb_128, (128, 128), names, frames=frames, **kw)
+    oopt = oracle.options_for_scene(test_glb_128, **kw)
+    ref = None
+    spp = kw.get("samples_per_pixel", 1)
+    for f in range(frames):
+        ref = oracle_scene_128.render_pt_targets(oopt, 128, 128, names, frame_counter=f, samples_accumulated=spp * f, targets=ref)
+    _compare(got["color"], ref["color"], f"{name}: color")
+    # first-hit AOVs: same arithmetic on bit-equal hits; textures / pow differ by ulps at most
+    assert np.array_equal(got["instance_id"], ref["instance_id"]), "instance id target"
+    for n, tol in (("albedo", 1e-6), ("material", 1e-6), ("normal", 1e-5), ("pos", 1e-5)):
+        d = np.abs(got[n] - ref[n])
+        assert float(d.max()) <= tol * max(1.0, float(np.abs(ref[n]).max())), f"{name}: {n} target differs by {float(d.max()):.3e}"
+    # demodulated light: same tolerance model as radiance; alpha (1/length) is exact arithmetic on the same hit points
+    for n in ("diffuse", "reflection"):
+        g, r = got[n], ref[n]
+        assert np.isfinite(g).all()
+        rel = np.abs(g[..., :3] - r[..., :3]) / (np.abs(r[..., :3]) + 1e-2)
+        assert float((rel.max(-1) > REL_TOL).mean()) <= MAX_BAD_FRACTION, f"{name}: {n} rgb"
+        bad_a = np.abs(g[..., 3] - r[..., 3]) > 1e-4 * (np.abs(r[..., 3]) + 1.0)
+        assert float(bad_a.mean()) <= MAX_BAD_FRACTION, f"{name}: {n} alpha"
+    # the colour target is emission + modulate_color(first hit, diffuse, reflection) (path_tracer.rgen:112, material.glsl:57-65)
+    if frames == 1 and spp == 1:
+        alb = np.ones_like(got["albedo"][..., :3]) if kw.get("use_white_albedo_on_first_bounce") else got["albedo"][..., :3]
+        met = got["material"][..., 0:1]
+        mod = got["diffuse"][..., :3] * alb * (1 - met) + got["reflection"][..., :3] * (0.02 * (1 - met) + alb * met) / (0.02 * (1 - met) + met)
+        resid = got["color"][..., :3] - mod      # = first-hit emission: zero wherever the first hit neither emits nor misses
+        lit = (got["instance_id"][..., 0] >= 0) & (np.abs(resid).max(-1) < 1e-3)
+        assert lit.mean() > 0.5
+
+
 @pytest.mark.parametrize("world,strategy", [(2, 1), (3, 1), (8, 1), (3, 2)])
 def test_fake_device_sharding_is_bitwise_identical(R, ctx, glb128, test_glb_128, world, strategy):
     """The reference tests multi-GPU with --fake-devices (src/context.cc:415-416): render every device's share on
