@@ -105,7 +105,7 @@ typedef struct trhip_pt_options {     /* == path_tracer_stage::options flattened
     int32_t hide_lights;
     int32_t use_white_albedo_on_first_bounce;
     int32_t transparent_background;
-    int32_t pre_transformed_vertices; /* must be 0 in this build (the reference default) */
+    int32_t pre_transformed_vertices; /* PRE_TRANSFORMED_VERTICES: shade from the world-space vertex copy of shader/pre_transform.comp (built on first use) */
 } trhip_pt_options;
 
 typedef struct trhip_distribution {   /* == distribution_params (src/distribution_strategy.hh:21-28) */

@@ -457,6 +457,9 @@ struct oracle_scene {
     int environment_proj = -1;
     std::vector<camera_data> cameras;
     std::vector<uint8_t> non_opaque;
+    // pre_transform.comp output (world-space vertex copy, one span per instance); built on first use
+    std::vector<vertex> world_vertices;
+    std::vector<mesh_span> world_spans;
     std::vector<wtri> tris;       // BVH order
     std::vector<bnode> nodes;
     counters_t counters;
@@ -1239,12 +1242,13 @@ vertex_data get_interpolated_vertex(const pt_ctx& c, vec3 view, vec2 barycentric
                                     vec3 pos, float& pdf) {   // rt.glsl:27-101
     const oracle_scene& s = *c.s;
     const instance& o = s.instances[instance_id];
-    const mesh_span& sp = s.spans[instance_id];
+    const bool pre = c.opt.pre_transformed_vertices != 0;   // PRE_TRANSFORMED_VERTICES: the stage binds scene_stage's pre-transformed copy
+    const mesh_span& sp = pre ? s.world_spans[instance_id] : s.spans[instance_id];
+    const std::vector<vertex>& verts = pre ? s.world_vertices : s.vertices;
     const uint* ix = &s.indices[sp.index_offset + 3 * primitive_id];
-    const vertex& v0 = s.vertices[sp.vertex_offset + ix[0]];
-    const vertex& v1 = s.vertices[sp.vertex_offset + ix[1]];
-    const vertex& v2 = s.vertices[sp.vertex_offset + ix[2]];
-    const bool pre = c.opt.pre_transformed_vertices != 0;
+    const vertex& v0 = verts[sp.vertex_offset + ix[0]];
+    const vertex& v1 = verts[sp.vertex_offset + ix[1]];
+    const vertex& v2 = verts[sp.vertex_offset + ix[2]];
     vec3 b = V3(1.0f - barycentrics.x - barycentrics.y, barycentrics.x, barycentrics.y);
     vec4 avg_tangent = v0.tangent * b.x + v1.tangent * b.y + v2.tangent * b.z;
     vertex_data interp;
@@ -1630,6 +1634,37 @@ void get_world_camera_ray(const pt_ctx& c, const launch_ctx& L, ivec2 pixel, con
     get_screen_camera_ray(L, pixel, cam, c.opt.projection, c.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
 }
 
+// shader/pre_transform.comp:26-42 (dispatched per instance by src/scene_stage.cc:1685-1723)
+void ensure_world_vertices(oracle_scene& s) {
+    if (!s.world_spans.empty()) return;
+    s.world_spans.resize(s.instances.size());
+    size_t total = 0;
+    for (size_t i = 0; i < s.instances.size(); ++i) total += s.spans[i].vertex_count;
+    s.world_vertices.resize(total);
+    uint offset = 0;
+    for (size_t i = 0; i < s.instances.size(); ++i) {
+        const instance& o = s.instances[i];
+        const mesh_span& sp = s.spans[i];
+        s.world_spans[i] = sp;
+        s.world_spans[i].vertex_offset = offset;
+        const mat3 mn = M3(o.model_normal);
+        // determinant(mat3(o.model_normal)), cofactor expansion along the first column
+        const float det = mn.c[0].x * (mn.c[1].y * mn.c[2].z - mn.c[2].y * mn.c[1].z)
+                        - mn.c[1].x * (mn.c[0].y * mn.c[2].z - mn.c[2].y * mn.c[0].z)
+                        + mn.c[2].x * (mn.c[0].y * mn.c[1].z - mn.c[1].y * mn.c[0].z);
+        for (uint k = 0; k < sp.vertex_count; ++k) {
+            vertex v = s.vertices[sp.vertex_offset + k];
+            v.pos = V3(o.model * V4(v.pos, 1));
+            v.normal = normalize(mn * v.normal);
+            vec3 t = normalize(mn * V3(v.tangent));
+            v.tangent = V4(t, v.tangent.w);
+            if (det < 0) { v.normal = -v.normal; v.tangent = V4(-t.x, -t.y, -t.z, -v.tangent.w); }
+            s.world_vertices[offset + k] = v;
+        }
+        offset += sp.vertex_count;
+    }
+}
+
 // path_tracer.rgen:77-127 + write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
 void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
                    uint target_w, uint target_h) {
@@ -1764,6 +1799,7 @@ int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, cons
                              uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
                              uint32_t target_h, int threads) {
     if (viewport_count > s->cameras.size()) return 1;
+    if (opt->pre_transformed_vertices) ensure_world_vertices(*s);
     pt_ctx c;
     c.s = s; c.opt = *opt;
     c.max_sobol_bounces = (uint)(opt->max_bounces > 8 ? 8 : opt->max_bounces);   // sobol_lookup_table.glsl:4-14

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     if (hit.instance_id >= 0) {
         SurfacePoint v;
         SampledMaterial mat;
-        shade_surface(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v, dir, ray_origin, false, 0, v, mat);
+        shade_surface(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v, dir, ray_origin, false, 0, false, v, mat);
         switch (feature) {
             default:
             case 0: data = mat.albedo; break;
@@ -237,6 +237,15 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     }
     if (upload_array(s.instances, d->instances, d->instance_count)) return 1;
     if (upload_array(s.spans, d->spans, d->instance_count)) return 1;
+    {   // spans of the pre-transformed copy: every instance gets its own vertex range (instances may share a mesh)
+        s.host_spans.assign(spans, spans + d->instance_count);
+        s.host_world_spans = s.host_spans;
+        uint64_t offset = 0;
+        for (uint32_t i = 0; i < d->instance_count; ++i) { s.host_world_spans[i].vertex_offset = (uint)offset; offset += spans[i].vertex_count; }
+        if (offset > 0xFFFFFFF0ull) return set_error("trhip_scene_upload: too many vertices for the pre-transformed copy");
+        s.world_vertex_count = (uint)offset;
+        if (upload_array(s.world_spans, s.host_world_spans.data(), s.host_world_spans.size())) return 1;
+    }
     if (upload_array(s.vertices, d->vertices, d->vertex_count)) return 1;
     if (upload_array(s.indices, d->indices, d->index_count)) return 1;
     if (upload_array(s.point_lights, d->point_lights, d->point_light_count)) return 1;

@@ -1,6 +1,7 @@
 // Host-side device scene container shared by the API and the BVH builder.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "common.h"
 #include "shading.h"
@@ -24,6 +25,11 @@ struct DeviceScene {
     CameraData* cameras = nullptr;
     uint8_t* non_opaque = nullptr;
     uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
+    // scene_stage's pre-transformed vertex copy (shader/pre_transform.comp): one span per instance; vertices built on first use
+    std::vector<MeshSpan> host_spans, host_world_spans;
+    MeshSpan* world_spans = nullptr;
+    Vertex* world_vertices = nullptr;
+    uint world_vertex_count = 0;
     f4 environment_factor = {0, 0, 0, 0};
     int environment_proj = -1;
     uint instance_count = 0, point_light_count = 0, directional_light_count = 0, camera_count = 0, texture_count = 0;
@@ -63,12 +69,13 @@ struct DeviceScene {
     void free_all() {
         free_accel();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
-                        alias_table, cameras, non_opaque, tri_prefix};
+                        alias_table, cameras, non_opaque, tri_prefix, world_spans, world_vertices};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = DeviceScene();
     }
 };
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);
+int ensure_world_vertices(DeviceScene& ds, hipStream_t stream);   // pre_transform.comp per instance
 
 }  // namespace tr

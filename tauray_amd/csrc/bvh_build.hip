@@ -379,6 +379,38 @@ __global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const u
 
 }  // namespace
 
+// shader/pre_transform.comp:26-42
+__global__ __launch_bounds__(BT) void k_pre_transform_vertices(uint vertex_count, const Instance* instance, const Vertex* in, Vertex* out) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= vertex_count) return;
+    const m4 model = instance->model;
+    const m3 mn = upper3(instance->model_normal);
+    // determinant(mat3(o.model_normal)), cofactor expansion along the first column
+    const float det = mn.c[0].x * (mn.c[1].y * mn.c[2].z - mn.c[2].y * mn.c[1].z)
+                    - mn.c[1].x * (mn.c[0].y * mn.c[2].z - mn.c[2].y * mn.c[0].z)
+                    + mn.c[2].x * (mn.c[0].y * mn.c[1].z - mn.c[1].y * mn.c[0].z);
+    Vertex v = in[i];
+    v.pos = transform_point(model, v.pos);
+    v.normal = normalize(mul(mn, v.normal));
+    f3 t = normalize(mul(mn, F3(v.tangent)));
+    v.tangent = F4(t, v.tangent.w);
+    if (det < 0) { v.normal = -v.normal; v.tangent = F4(-t.x, -t.y, -t.z, -v.tangent.w); }
+    out[i] = v;
+}
+
+int ensure_world_vertices(DeviceScene& ds, hipStream_t stream) {
+    if (ds.world_vertices || ds.world_vertex_count == 0) return 0;
+    HIPCHK(hipMalloc(&ds.world_vertices, (size_t)ds.world_vertex_count * sizeof(Vertex)));
+    for (uint i = 0; i < ds.instance_count; ++i) {   // one dispatch per instance, as src/scene_stage.cc:1685-1723 records them
+        const MeshSpan& sp = ds.host_spans[i];
+        if (sp.vertex_count == 0) continue;
+        hipLaunchKernelGGL(k_pre_transform_vertices, dim3((sp.vertex_count + BT - 1) / BT), dim3(BT), 0, stream, sp.vertex_count, ds.instances + i,
+                           ds.vertices + sp.vertex_offset, ds.world_vertices + ds.host_world_spans[i].vertex_offset);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     const uint n = ds.tri_count;
     hipEvent_t e0, e1;

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             if (h.x >= 0) {
                 surface = true;
                 if (COUNT) surf++;
-                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, v, mat);
+                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat);
                 mat.albedo.w = 1.0f;
                 if (P.nee_tri) {
                     tri_pdf = v.tri_light_pdf;
@@ -744,7 +744,6 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     if (viewports == 0 || viewports > scene->camera_count) return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
     if (opt.samples_per_pass <= 0 || opt.samples_per_pixel % opt.samples_per_pass != 0)
         return set_error("trhip_pt_render: samples_per_pixel must be a multiple of samples_per_pass");
-    if (opt.pre_transformed_vertices) return set_error("trhip_pt_render: pre_transformed_vertices is not supported");
     if (dist.size_x == 0 || dist.size_y == 0) return set_error("trhip_pt_render: distribution not set");
     PtParams P{};
     P.opt = opt;
@@ -778,6 +777,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     if (int rc = ensure_buffers(n, targets.diffuse || targets.reflection)) return rc;
     PathBuffers& pb = impl->pb;
     SceneView sv = scene->view();
+    if (opt.pre_transformed_vertices) {   // PRE_TRANSFORMED_VERTICES: shade from scene_stage's world-space vertex copy
+        if (int rc = ensure_world_vertices(*scene, stream)) return rc;
+        sv.vertices = scene->world_vertices; sv.spans = scene->world_spans;
+    }
     const uint blocks_all = (uint)((n + KB - 1) / KB);
     // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
     const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;

@@ -551,7 +551,7 @@ struct SurfacePoint {
 // get_interpolated_vertex + sample_material fused: fetches 3 indices, 3 x 48-byte vertices and the 288-byte
 // instance once.  `want_tri_pdf` = NEE_SAMPLE_EMISSIVE_TRIANGLES.
 TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id, float bu, float bv, f3 view, f3 ray_origin,
-                          bool want_tri_pdf, int tri_light_mode, SurfacePoint& sp, SampledMaterial& res) {
+                          bool want_tri_pdf, int tri_light_mode, bool pre, SurfacePoint& sp, SampledMaterial& res) {
     const Instance& o = sv.instances[instance_id];
     const MeshSpan span = sv.spans[instance_id];
     const uint* ix = sv.indices + span.index_offset + 3u * (uint)primitive_id;
@@ -562,17 +562,19 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
     const f3 b = F3(1.0f - bu - bv, bu, bv);
     f4 avg_tangent = v0.tangent * b.x + v1.tangent * b.y + v2.tangent * b.z;
     f4 model_pos = F4(v0.pos * b.x + v1.pos * b.y + v2.pos * b.z, 1);
-    sp.pos = F3(mul(model, model_pos));
+    sp.pos = pre ? F3(model_pos) : F3(mul(model, model_pos));   // `pre` = PRE_TRANSFORMED_VERTICES (rt.glsl:18-22): TRANSFORM_MAT is the identity
     sp.tri_light_pdf = 0.0f;
     if (want_tri_pdf && o.light_base_id >= 0) {
-        f3 p0 = transform_point(model, v0.pos), p1 = transform_point(model, v1.pos), p2 = transform_point(model, v2.pos);
+        f3 p0 = pre ? v0.pos : transform_point(model, v0.pos), p1 = pre ? v1.pos : transform_point(model, v1.pos), p2 = pre ? v2.pos : transform_point(model, v2.pos);
         sp.tri_light_pdf = sample_triangle_light_pdf(tri_light_mode, sp.pos - ray_origin, p0 - ray_origin, p1 - ray_origin, p2 - ray_origin);
     }
-    f3 smooth_normal = normalize(mul(mn, v0.normal * b.x + v1.normal * b.y + v2.normal * b.z));
-    f3 tangent = normalize(mul(mn, F3(avg_tangent)));
+    const f3 sn = v0.normal * b.x + v1.normal * b.y + v2.normal * b.z;
+    f3 smooth_normal = normalize(pre ? sn : mul(mn, sn));
+    f3 tangent = normalize(pre ? F3(avg_tangent) : mul(mn, F3(avg_tangent)));
     f3 bitangent = normalize(cross(smooth_normal, tangent) * avg_tangent.w);
     f2 uv = v0.uv * b.x + v1.uv * b.y + v2.uv * b.z;
-    f3 hard_normal = normalize(mul(mn, cross(v1.pos - v0.pos, v2.pos - v0.pos)));
+    const f3 hn = cross(v1.pos - v0.pos, v2.pos - v0.pos);
+    f3 hard_normal = normalize(pre ? hn : mul(mn, hn));
     bool back_facing = dot(hard_normal, view) > 0;
     if (back_facing) { smooth_normal = -smooth_normal; hard_normal = -hard_normal; }
     sp.hard_normal = hard_normal;

@@ -207,6 +207,23 @@ def test_progressive_accumulation_over_frames(R, ctx, glb128, test_glb_128, orac
     _compare(color.download((1, 128, 128, 4)), ref2, "frame after reset")
 
 
+def test_pre_transformed_vertices(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128):
+    """PRE_TRANSFORMED_VERTICES (--pre-transform-vertices): shading reads scene_stage's world-space vertex copy
+    (shader/pre_transform.comp:26-42) and skips the model / normal-matrix transforms (shader/rt.glsl:18-22)."""
+    kw = dict(max_bounces=4, pre_transformed_vertices=1)
+    names = ["color", "normal", "pos", "instance_id"]
+    got = _render_targets_hip(R, ctx, glb128, test_glb_128, (128, 128), names, **kw)
+    ref = oracle_scene_128.render_pt_targets(oracle.options_for_scene(test_glb_128, **kw), 128, 128, names)
+    _compare(got["color"], ref["color"], "pre-transformed vertices")
+    assert np.array_equal(got["instance_id"], ref["instance_id"])
+    assert float(np.abs(got["pos"] - ref["pos"]).max()) <= 1e-5 * float(np.abs(ref["pos"]).max())
+    assert float(np.abs(got["normal"] - ref["normal"]).max()) <= 1e-5
+    # against the default path the image is the same up to the rounding of interpolate-then-transform vs transform-then-interpolate
+    base = _render_targets_hip(R, ctx, glb128, test_glb_128, (128, 128), ["color", "pos"], max_bounces=4)
+    assert float(np.abs(got["pos"] - base["pos"]).max()) < 1e-4
+    assert abs(float(got["color"][..., :3].mean()) - float(base["color"][..., :3].mean())) < 0.02 * float(base["color"][..., :3].mean())
+
+
 def _render_targets_hip(R, ctx, ss, scene, size, names, frames=1, **kw):
     opt = R.options_for_scene(scene, **kw)
     pt = R.PathTracerStage(ctx, ss, opt, _dup(size))
