@@ -76,6 +76,13 @@ typedef struct trhip_accel_info {
 
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
+/* camera_pair.previous of every viewport (shader/scene.glsl:176-185); the current cameras until set.  Feeds the motion
+ * features and the screen-motion target. */
+int trhip_scene_set_previous_cameras(trhip_device* dev, const void* camera_data, uint32_t count);
+/* Dynamic scenes: replaces the 288-byte instance records (model, model_normal, model_prev, material) of the uploaded
+ * scene, same count and meshes (what scene_stage::update rewrites per frame, src/scene_stage.cc:1066-1116).  The
+ * acceleration structure is invalidated: call trhip_scene_build_accel again (full rebuild on the device). */
+int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint32_t count);
 /* Replaces vkCmdBuildAccelerationStructuresKHR (src/acceleration_structure.cc:198,266,421) with an
  * on-device build (pre-transform -> bounds -> Morton -> radix sort -> PLOC clustering -> 4-wide collapse) and
  * runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).  Synchronous. */
@@ -153,6 +160,7 @@ typedef struct trhip_pt_targets {
     void* normal;       /* RG32F   */
     void* pos;          /* RGBA32F, world space, w = 0 */
     void* instance_id;  /* R32I, -1 = no surface */
+    void* screen_motion;/* RG32F: get_camera_projection(previous camera, previous position).xy (shader/camera.glsl:61-67) */
 } trhip_pt_targets;
 int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
@@ -161,7 +169,7 @@ int trhip_pt_reset_counters(trhip_pt* pt);
 int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out);       /* synchronises the stream */
 
 /* ---- feature_stage (src/feature_stage.cc:22-104): 0 albedo, 1 world normal, 2 view normal, 3 world pos,
- *      4 view pos, 5 distance, 9 instance id */
+ *      4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */
 int trhip_feature_render(trhip_device* dev, int feature, const trhip_distribution* dist, int projection,
                          uint32_t viewport, float min_ray_dist, const float default_value[4],
                          void* color_dev, uint32_t target_w, uint32_t target_h, void* stream);

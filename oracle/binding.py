@@ -50,7 +50,7 @@ class PtOptionsC(C.Structure):
 
 
 class PtTargetsC(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id")]
+    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id", "screen_motion")]
 
 
 class DistributionC(C.Structure):
@@ -76,6 +76,8 @@ def lib():
         L.oracle_scene_tri_light_count.restype = C.c_uint32
         L.oracle_scene_tri_light_count.argtypes = [C.c_void_p]
         L.oracle_scene_get_tri_lights.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_scene_set_previous_cameras.restype = C.c_int
+        L.oracle_scene_set_previous_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_pt_render_targets.restype = C.c_int
         L.oracle_pt_render_targets.argtypes = [C.c_void_p, C.POINTER(PtOptionsC), C.POINTER(DistributionC), C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.POINTER(PtTargetsC), C.c_uint32, C.c_uint32, C.c_int]
@@ -214,7 +216,13 @@ class OracleScene:
         return color
 
     TARGETS = {"color": (4, np.float32), "diffuse": (4, np.float32), "reflection": (4, np.float32), "albedo": (4, np.float32),
-               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32)}
+               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32),
+               "screen_motion": (2, np.float32)}
+
+    def set_previous_cameras(self, cameras):
+        data = np.concatenate([c.pack() for c in cameras])
+        if lib().oracle_scene_set_previous_cameras(self.h, data.ctypes.data, len(cameras)) != 0:
+            raise RuntimeError("oracle_scene_set_previous_cameras: camera count mismatch")
 
     def render_pt_targets(self, opt: PtOptionsC, width, height, names, dist: DistributionC = None, viewports=1, frame_counter=0,
                           samples_accumulated=0, targets=None, target_size=None, threads=0):

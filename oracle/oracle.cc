@@ -81,10 +81,10 @@ struct bsdf_lobes { float transmission, diffuse, dielectric_reflection, metallic
 #define MATERIAL_LOBE_ALL 0
 
 struct vertex_data {                                                               // shader/scene.glsl:22-41
-    vec3 pos, hard_normal, smooth_normal, mapped_normal; vec2 uv; vec3 tangent, bitangent;
+    vec3 pos, prev_pos, hard_normal, smooth_normal, mapped_normal; vec2 uv; vec3 tangent, bitangent;
     bool back_facing; int instance_id, primitive_id;
 };
-struct pt_vertex_data { vec3 pos, hard_normal, smooth_normal, mapped_normal; int instance_id; };  // path_tracer.glsl:11-22
+struct pt_vertex_data { vec3 pos, prev_pos, hard_normal, smooth_normal, mapped_normal; int instance_id; };  // path_tracer.glsl:11-22
 struct intersection_pdf { float point_light_pdf, directional_light_pdf, tri_light_pdf, envmap_pdf; };
 struct hit_payload { uint random_seed; int instance_id, primitive_id; vec2 barycentrics; };  // rt_common_payload.glsl:4-21
 
@@ -456,6 +456,7 @@ struct oracle_scene {
     vec4 environment_factor;
     int environment_proj = -1;
     std::vector<camera_data> cameras;
+    std::vector<camera_data> prev_cameras;   // camera_pair.previous (shader/scene.glsl:176-185); = cameras until set
     std::vector<uint8_t> non_opaque;
     // pre_transform.comp output (world-space vertex copy, one span per instance); built on first use
     std::vector<vertex> world_vertices;
@@ -1254,6 +1255,14 @@ vertex_data get_interpolated_vertex(const pt_ctx& c, vec3 view, vec2 barycentric
     vertex_data interp;
     vec4 model_pos = V4(v0.pos * b.x + v1.pos * b.y + v2.pos * b.z, 1);
     interp.pos = pre ? V3(model_pos) : V3(o.model * model_pos);
+    {   // CALC_PREV_VERTEX_POS (rt.glsl:73-79).  With pre-transformed vertices the reference forms model_prev * inverse(model) *
+        // model_pos with the driver's inverse(); here the model-space point comes from the untransformed vertices instead.
+        const mesh_span& osp = s.spans[instance_id];
+        const uint* oix = &s.indices[osp.index_offset + 3 * primitive_id];
+        vec3 object_pos = s.vertices[osp.vertex_offset + oix[0]].pos * b.x + s.vertices[osp.vertex_offset + oix[1]].pos * b.y +
+                          s.vertices[osp.vertex_offset + oix[2]].pos * b.z;
+        interp.prev_pos = V3(o.model_prev * V4(object_pos, 1));
+    }
     pdf = 0.0f;
     if (c.nee_tri) {
         if (o.light_base_id >= 0) {
@@ -1406,7 +1415,7 @@ bool get_intersection_info(const pt_ctx& c, const hit_payload& payload, vec3 ori
             mat.emission = V3(0);
         } else light = V3(0);
         v.pos = vd.pos; v.hard_normal = vd.hard_normal; v.smooth_normal = vd.smooth_normal;
-        v.mapped_normal = vd.mapped_normal; v.instance_id = vd.instance_id;
+        v.mapped_normal = vd.mapped_normal; v.instance_id = vd.instance_id; v.prev_pos = vd.prev_pos;
         return true;
     } else if (payload.primitive_id >= 0) {
         const point_light& pl = s.point_lights[payload.primitive_id];
@@ -1417,6 +1426,7 @@ bool get_intersection_info(const pt_ctx& c, const hit_payload& payload, vec3 ori
             nee_pdf.point_light_pdf = sample_point_light_pdf(pl, origin);
         } else { light = V3(0); mat.emission = color; }
         v.pos = origin + payload.barycentrics.x * view;
+        v.prev_pos = v.pos;   // path_tracer.glsl:151
         v.mapped_normal = normalize(v.pos - pl.pos);
         v.instance_id = -1;
         mat.albedo = V4(0, 0, 0, 1);
@@ -1444,6 +1454,7 @@ bool get_intersection_info(const pt_ctx& c, const hit_payload& payload, vec3 ori
         }
         v.instance_id = -1;
         v.pos = origin;
+        v.prev_pos = v.pos;   // path_tracer.glsl:188
         v.mapped_normal = -view;
         mat.albedo = V4(0);
         if (c.nee_env) {
@@ -1634,6 +1645,21 @@ void get_world_camera_ray(const pt_ctx& c, const launch_ctx& L, ivec2 pixel, con
     get_screen_camera_ray(L, pixel, cam, c.opt.projection, c.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
 }
 
+// get_camera_projection (shader/camera.glsl:61-67 perspective / orthographic, :126-134 equirectangular)
+vec3 get_camera_projection(const camera_data& cam, int projection, vec3 world_pos) {
+    if (projection == 2) {
+        vec3 t = V3(cam.view * V4(world_pos, 1.0f));
+        float t_len = length(t);
+        t = t / t_len;
+        const float* raw = reinterpret_cast<const float*>(&cam);   // equirect layout: view, view_inverse, origin, fov (src/camera.cc:409-415)
+        const float fov[2] = {raw[36], raw[37]};
+        vec2 a = V2(atan2f(t.x, -t.z), asinf(t.y));
+        return V3((a.x / fov[0]) * 0.5f + 0.5f, (a.y / fov[1]) * 0.5f + 0.5f, t_len);
+    }
+    vec4 projected_pos = cam.view_proj * V4(world_pos, 1.0f);
+    return V3((projected_pos.x / projected_pos.w) * 0.5f + 0.5f, (projected_pos.y / projected_pos.w) * 0.5f + 0.5f, projected_pos.w);
+}
+
 // shader/pre_transform.comp:26-42 (dispatched per instance by src/scene_stage.cc:1685-1723)
 void ensure_world_vertices(oracle_scene& s) {
     if (!s.world_spans.empty()) return;
@@ -1713,6 +1739,10 @@ void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, 
         }
         if (T.pos) { float* q = T.pos + pix * 4; q[0] = first_hit_vertex.pos.x; q[1] = first_hit_vertex.pos.y; q[2] = first_hit_vertex.pos.z; q[3] = 0; }
         if (T.instance_id) T.instance_id[pix] = first_hit_vertex.instance_id;
+        if (T.screen_motion) {   // write_gbuffer_screen_motion(get_camera_projection(get_prev_camera(), prev_pos)): rg32f keeps xy
+            vec3 m = get_camera_projection(s.prev_cameras[L.launch_id.z], c.opt.projection, first_hit_vertex.prev_pos);
+            T.screen_motion[pix * 2] = m.x; T.screen_motion[pix * 2 + 1] = m.y;
+        }
     }
     auto accumulate = [&](float* target, vec4 value) {   // accumulate_gbuffer_{color,diffuse,reflection} (gbuffer.glsl:18-28,68-78,118-128)
         if (!target) return;
@@ -1778,12 +1808,18 @@ oracle_scene* oracle_scene_create(const oracle_scene_desc* d) {
         s->environment_proj = -1;
     }
     s->cameras.assign((const camera_data*)d->cameras, (const camera_data*)d->cameras + d->camera_count);
+    s->prev_cameras = s->cameras;
     s->non_opaque.assign(d->non_opaque, d->non_opaque + d->instance_count);
     build_scene_accel(*s);
     if (d->gather_emissive_triangles) extract_tri_lights(*s);
     return s;
 }
 void oracle_scene_destroy(oracle_scene* s) { delete s; }
+int oracle_scene_set_previous_cameras(oracle_scene* s, const void* camera_data_array, uint32_t count) {
+    if (count != s->cameras.size()) return 1;
+    s->prev_cameras.assign((const camera_data*)camera_data_array, (const camera_data*)camera_data_array + count);
+    return 0;
+}
 uint32_t oracle_scene_tri_light_count(const oracle_scene* s) { return (uint32_t)s->tri_lights.size(); }
 void oracle_scene_get_tri_lights(const oracle_scene* s, void* out) { memcpy(out, s->tri_lights.data(), s->tri_lights.size() * sizeof(tri_light)); }
 
@@ -1895,6 +1931,9 @@ int oracle_feature_render(oracle_scene* s, int feature, const oracle_distributio
                         case 3: data = V4(v.pos, 1); break;
                         case 4: data = cam.view * V4(v.pos, 1); break;
                         case 5: data = V4(hit_t, hit_t, hit_t, 1); break;
+                        case 6: data = V4(v.pos - v.prev_pos, 1); break;
+                        case 7: data = V4(V3(cam.view * V4(v.pos, 1) - s->prev_cameras[viewport].view * V4(v.prev_pos, 1)), 1); break;
+                        case 8: data = V4(get_camera_projection(s->prev_cameras[viewport], projection, v.prev_pos), 1); break;
                         case 9: data = V4((float)payload.instance_id, (float)payload.primitive_id, 0, 1); break;
                     }
                 }

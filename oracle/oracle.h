@@ -106,13 +106,16 @@ int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle
 typedef struct oracle_pt_targets {
     float* color; float* diffuse; float* reflection; float* albedo; float* material; float* normal; float* pos;
     int32_t* instance_id;
+    float* screen_motion;   /* 2 floats: get_camera_projection(previous camera, previous position).xy */
 } oracle_pt_targets;
 int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist,
                              uint32_t viewport_count, uint32_t frame_counter, uint32_t samples_accumulated,
                              const oracle_pt_targets* targets, uint32_t target_w, uint32_t target_h, int threads);
 
 /* feature_stage (src/feature_stage.cc:33-65): 0 albedo, 1 world normal, 2 view normal,
- * 3 world pos, 4 view pos, 5 distance, 9 instance id */
+ * 3 world pos, 4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */
+/* camera_pair.previous per viewport (defaults to the current cameras) */
+int oracle_scene_set_previous_cameras(oracle_scene* s, const void* camera_data_array, uint32_t count);
 int oracle_feature_render(oracle_scene* s, int feature, const oracle_distribution* dist, int projection,
                           uint32_t viewport, float min_ray_dist, const float default_value[4],
                           float* color, uint32_t target_w, uint32_t target_h, int threads);

@@ -63,7 +63,7 @@ class TimingsC(C.Structure):
 
 class PtTargetsC(C.Structure):
     """trhip_pt_targets: device images, None = not requested."""
-    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id")]
+    _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id", "screen_motion")]
 
 
 class TonemapInfoC(C.Structure):
@@ -85,6 +85,8 @@ SYMBOLS = {
     "trhip_copy_peer": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "trhip_scene_upload": (_i, [_vp, C.POINTER(SceneDescC)]),
     "trhip_scene_update_cameras": (_i, [_vp, _vp, _u32]),
+    "trhip_scene_set_previous_cameras": (_i, [_vp, _vp, _u32]),
+    "trhip_scene_update_instances": (_i, [_vp, _vp, _u32]),
     "trhip_scene_build_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
     "trhip_scene_get_tri_lights": (_i, [_vp, _vp, _u32]),
     "trhip_pt_create": (_i, [_vp, C.POINTER(PtOptionsC), C.POINTER(_vp)]),

@@ -52,6 +52,13 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
             case 3: data = F4(v.pos, 1); break;
             case 4: data = mul(cam.view, F4(v.pos, 1)); break;
             case 5: data = F4(hit.t, hit.t, hit.t, 1); break;
+            case 6: data = F4(v.pos - surface_prev_pos(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v), 1); break;
+            case 7: {
+                const f3 pp = surface_prev_pos(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v);
+                data = F4(F3(mul(cam.view, F4(v.pos, 1)) - mul(sv.prev_cameras[viewport].view, F4(pp, 1))), 1);
+                break;
+            }
+            case 8: data = F4(get_camera_projection(sv.prev_cameras[viewport], projection, surface_prev_pos(sv, hit.instance_id, hit.primitive_id, hit.u, hit.v)), 1); break;
             case 9: data = F4((float)hit.instance_id, (float)hit.primitive_id, 0, 1); break;
         }
     }
@@ -290,7 +297,29 @@ int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint3
         HIPCHK(hipMalloc(&s.cameras, (size_t)count * sizeof(CameraData)));
     }
     if (count) HIPCHK(hipMemcpy(s.cameras, camera_data, (size_t)count * sizeof(CameraData), hipMemcpyHostToDevice));
+    if (count != s.camera_count && s.prev_cameras) { (void)hipFree(s.prev_cameras); s.prev_cameras = nullptr; }   // falls back to the current cameras
     s.camera_count = count;
+    return 0;
+}
+int trhip_scene_set_previous_cameras(trhip_device* dev, const void* camera_data, uint32_t count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    if (count != s.camera_count) return set_error("trhip_scene_set_previous_cameras: count differs from the uploaded cameras");
+    HIPCHK(hipDeviceSynchronize());
+    if (!s.prev_cameras && count) HIPCHK(hipMalloc(&s.prev_cameras, (size_t)count * sizeof(CameraData)));
+    if (count) HIPCHK(hipMemcpy(s.prev_cameras, camera_data, (size_t)count * sizeof(CameraData), hipMemcpyHostToDevice));
+    return 0;
+}
+int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint32_t count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    if (count != s.instance_count) return set_error("trhip_scene_update_instances: count differs from the uploaded instances");
+    if (count && !instances) return set_error("trhip_scene_update_instances: null instances");
+    HIPCHK(hipDeviceSynchronize());
+    if (count) HIPCHK(hipMemcpy(s.instances, instances, (size_t)count * sizeof(Instance), hipMemcpyHostToDevice));
+    // transforms changed: the acceleration structure, the tri lights and the pre-transformed vertex copy are stale
+    s.free_accel();
+    if (s.world_vertices) { (void)hipFree(s.world_vertices); s.world_vertices = nullptr; }
     return 0;
 }
 

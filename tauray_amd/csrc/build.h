@@ -23,6 +23,7 @@ struct DeviceScene {
     f4* envmap = nullptr;
     AliasEntry* alias_table = nullptr;
     CameraData* cameras = nullptr;
+    CameraData* prev_cameras = nullptr;  // defaults to a copy of `cameras`
     uint8_t* non_opaque = nullptr;
     uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
     // scene_stage's pre-transformed vertex copy (shader/pre_transform.comp): one span per instance; vertices built on first use
@@ -52,7 +53,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
@@ -69,7 +70,7 @@ struct DeviceScene {
     void free_all() {
         free_accel();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
-                        alias_table, cameras, non_opaque, tri_prefix, world_spans, world_vertices};
+                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = DeviceScene();
     }

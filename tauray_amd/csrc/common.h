@@ -169,6 +169,9 @@ struct SceneView {
     const f4* envmap;
     const AliasEntry* alias_table;
     const CameraData* cameras;
+    const CameraData* prev_cameras;   // camera_pair.previous (shader/scene.glsl:176-185)
+    const MeshSpan* obj_spans;        // the uploaded model-space vertices even when `vertices` is the pre-transformed copy
+    const Vertex* obj_vertices;
     const BvhNode* nodes;
     const TriRecord* tris;
     const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)

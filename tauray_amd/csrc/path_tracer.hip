@@ -473,7 +473,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                 pb.first_emis[id] = F4(light, mat.albedo.w);
                 const uint prev_samples = P.samples_accumulated + P.previous_samples;
                 if (prev_samples == 0 && P.sample_in_pass == (uint)P.opt.samples_per_pass - 1u &&
-                    (P.T.albedo || P.T.material || P.T.normal || P.T.pos || P.T.instance_id)) {
+                    (P.T.albedo || P.T.material || P.T.normal || P.T.pos || P.T.instance_id || P.T.screen_motion)) {
                     // write_all_outputs: only the first sample writes the gbuffer (path_tracer.glsl:549-563)
                     uint lx, ly, lz;
                     launch_coord(P.L, misc.z, lx, ly, lz);
@@ -491,6 +491,11 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                         }
                         if (P.T.pos) reinterpret_cast<f4*>(P.T.pos)[pix] = F4(v.pos, 0);
                         if (P.T.instance_id) reinterpret_cast<int*>(P.T.instance_id)[pix] = surface ? h.x : -1;
+                        if (P.T.screen_motion) {   // write_gbuffer_screen_motion (path_tracer.glsl:557-562); lights and misses: prev_pos = pos
+                            const f3 prev_pos = surface ? surface_prev_pos(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w)) : v.pos;
+                            const f3 m = get_camera_projection(sv.prev_cameras[lz], P.opt.projection, prev_pos);
+                            reinterpret_cast<f2*>(P.T.screen_motion)[pix] = F2(m.x, m.y);
+                        }
                     }
                 }
             }

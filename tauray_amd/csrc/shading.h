@@ -548,6 +548,30 @@ struct SurfacePoint {
     float tri_light_pdf;
 };
 
+// CALC_PREV_VERTEX_POS (shader/rt.glsl:73-79): the hit point under the previous frame's model matrix.  Interpolates the
+// uploaded model-space vertices (also under PRE_TRANSFORMED_VERTICES, where the reference goes through inverse(model)).
+TR_DEV f3 surface_prev_pos(const SceneView& sv, int instance_id, int primitive_id, float bu, float bv) {
+    const MeshSpan span = sv.obj_spans[instance_id];
+    const uint* ix = sv.indices + span.index_offset + 3u * (uint)primitive_id;
+    const Vertex* vb = sv.obj_vertices + span.vertex_offset;
+    const f3 b = F3(1.0f - bu - bv, bu, bv);
+    const f3 object_pos = vb[ix[0]].pos * b.x + vb[ix[1]].pos * b.y + vb[ix[2]].pos * b.z;
+    return F3(mul(sv.instances[instance_id].model_prev, F4(object_pos, 1)));
+}
+
+// get_camera_projection (shader/camera.glsl:61-67 perspective / orthographic, :126-134 equirectangular)
+TR_DEV f3 get_camera_projection(const CameraData& cam, int projection, f3 world_pos) {
+    if (projection == 2) {
+        f3 t = F3(mul(cam.view, F4(world_pos, 1.0f)));
+        const float t_len = length(t);
+        t = t / t_len;
+        const float* raw = reinterpret_cast<const float*>(&cam);   // equirect layout: view, view_inverse, origin, fov
+        return F3((atan2f(t.x, -t.z) / raw[36]) * 0.5f + 0.5f, (asinf(t.y) / raw[37]) * 0.5f + 0.5f, t_len);
+    }
+    const f4 p = mul(cam.view_proj, F4(world_pos, 1.0f));
+    return F3((p.x / p.w) * 0.5f + 0.5f, (p.y / p.w) * 0.5f + 0.5f, p.w);
+}
+
 // get_interpolated_vertex + sample_material fused: fetches 3 indices, 3 x 48-byte vertices and the 288-byte
 // instance once.  `want_tri_pdf` = NEE_SAMPLE_EMISSIVE_TRIANGLES.
 TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id, float bu, float bv, f3 view, f3 ray_origin,

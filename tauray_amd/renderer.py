@@ -197,6 +197,22 @@ class SceneStage:
         data = np.concatenate([c.pack() for c in cameras])
         check(_lib.lib().trhip_scene_update_cameras(self.ctx.h, data.ctypes.data, len(data)))
 
+    def set_previous_cameras(self, cameras):
+        """camera_pair.previous per viewport (motion features, screen-motion target)."""
+        data = np.concatenate([c.pack() for c in cameras])
+        check(_lib.lib().trhip_scene_set_previous_cameras(self.ctx.h, data.ctypes.data, len(data)))
+
+    def update_instances(self, instances: np.ndarray):
+        """Dynamic scenes: new instance records (transforms / materials) for the same meshes, then a full rebuild of the
+        acceleration structure on the device (what scene_stage::update + the TLAS rebuild do per frame)."""
+        inst = np.ascontiguousarray(instances)
+        check(_lib.lib().trhip_scene_update_instances(self.ctx.h, inst.ctypes.data, len(inst)))
+        info = AccelInfoC()
+        check(_lib.lib().trhip_scene_build_accel(self.ctx.h, C.byref(info)))
+        self.accel.update(node_count=info.node_count, build_ms=info.build_ms, tri_light_count=info.tri_light_count,
+                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
+        return self.accel
+
     def tri_lights(self) -> np.ndarray:
         from .scene import TRI_LIGHT
         n = self.accel["tri_light_count"]
@@ -268,7 +284,8 @@ class PathTracerStage:
     # gbuffer_target entries path_tracer.rgen can write (src/gbuffer.hh; shader/path_tracer.glsl:535-576):
     # name -> (channels, numpy dtype)
     TARGETS = {"color": (4, np.float32), "diffuse": (4, np.float32), "reflection": (4, np.float32), "albedo": (4, np.float32),
-               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32)}
+               "material": (4, np.float32), "normal": (2, np.float32), "pos": (4, np.float32), "instance_id": (1, np.int32),
+               "screen_motion": (2, np.float32)}
 
     def run_targets(self, targets: dict, viewports=1, stream=None):
         """stage::run with a gbuffer: `targets` maps any subset of TARGETS to device images."""

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TimingsC) == 10 * 4
     assert C.sizeof(_lib.TonemapInfoC) == 16
     assert C.sizeof(_lib.AccelInfoC) == 44
-    assert C.sizeof(_lib.PtTargetsC) == 8 * 8
+    assert C.sizeof(_lib.PtTargetsC) == 9 * 8
     from oracle import binding as B
     assert C.sizeof(B.PtOptionsC) == C.sizeof(_lib.PtOptionsC)
     assert C.sizeof(B.PtTargetsC) == C.sizeof(_lib.PtTargetsC)
