@@ -263,6 +263,7 @@ public:
         bool transparent_background = false;
         bool use_white_albedo_on_first_bounce = false;
         bool hide_lights = false;
+        bool pre_transformed_vertices = false;   // --pre-transform-vertices (src/options.hh)
         film_filter film = film_filter::POINT;
         multiple_importance_sampling_mode mis_mode = multiple_importance_sampling_mode::MIS_POWER_HEURISTIC;
         float film_radius = 0.5f;
@@ -289,6 +290,7 @@ public:
         o.bounce_mode = (int)opt.bounce_mode; o.tri_light_mode = (int)opt.tri_light_mode; o.hide_lights = opt.hide_lights;
         o.use_white_albedo_on_first_bounce = opt.use_white_albedo_on_first_bounce;
         o.transparent_background = opt.transparent_background;
+        o.pre_transformed_vertices = opt.pre_transformed_vertices;
         check(trhip_pt_create(dev.h, &o, &pt));
         reset_distribution_params(opt.distribution);
     }

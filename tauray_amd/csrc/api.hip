@@ -318,7 +318,8 @@ int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint3
     HIPCHK(hipDeviceSynchronize());
     if (count) HIPCHK(hipMemcpy(s.instances, instances, (size_t)count * sizeof(Instance), hipMemcpyHostToDevice));
     // transforms changed: the acceleration structure, the tri lights and the pre-transformed vertex copy are stale
-    s.free_accel();
+    // (their buffers stay: trhip_scene_build_accel refills them without allocating)
+    s.accel_built = false;
     if (s.world_vertices) { (void)hipFree(s.world_vertices); s.world_vertices = nullptr; }
     return 0;
 }

@@ -47,6 +47,9 @@ struct DeviceScene {
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
     bool accel_built = false;
+    uint accel_capacity = 0xFFFFFFFFu;   // triangle count the output buffers were allocated for
+    void* scratch = nullptr;             // build temporaries, kept between builds
+    size_t scratch_bytes = 0;
 
     SceneView view() const {
         SceneView v;
@@ -66,11 +69,12 @@ struct DeviceScene {
         if (tris) (void)hipFree(tris);
         if (tri_lights) (void)hipFree(tri_lights);
         nodes = nullptr; nodes4 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;
+        accel_capacity = 0xFFFFFFFFu;
     }
     void free_all() {
         free_accel();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
-                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices};
+                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = DeviceScene();
     }

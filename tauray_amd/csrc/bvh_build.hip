@@ -219,7 +219,10 @@ TR_DEV float merged_area(const float* a, const float* b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(BT) void k_ploc_nn(uint c, uint radius, const float* cbox, uint* nn) {
+// The live cluster count of a round sits in device memory (c_ptr): the host only learns it every few rounds and sizes
+// the grids by its last known value, so a round costs launches but no host round trip.
+__global__ __launch_bounds__(BT) void k_ploc_nn(const uint* c_ptr, uint radius, const float* cbox, uint* nn) {
+    const uint c = *c_ptr;
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= c) return;
     float mine[6];
@@ -234,10 +237,11 @@ __global__ __launch_bounds__(BT) void k_ploc_nn(uint c, uint radius, const float
     nn[i] = bj;
 }
 
-__global__ __launch_bounds__(BT) void k_ploc_merge(uint c, uint n_leaves, const int* cref, const float* cbox, const uint* nn, uint* valid, int* out_ref,
+__global__ __launch_bounds__(BT) void k_ploc_merge(const uint* c_ptr, uint n_leaves, const int* cref, const float* cbox, const uint* nn, uint* valid, int* out_ref,
                                                    float* out_box, uint* alloc, int2* children, float* node_box, uint* subtree_size, int* parent_internal) {
+    const uint c = *c_ptr;
     uint i = blockIdx.x * BT + threadIdx.x;
-    if (i >= c) return;
+    if (i >= c) { if (i < gridDim.x * BT) valid[i] = 0; return; }   // keeps the scan input defined past the live range
     uint j = nn[i];
     const bool mutual = j != i && nn[j] == i;
     if (mutual && i > j) { valid[i] = 0; return; }
@@ -261,9 +265,13 @@ __global__ __launch_bounds__(BT) void k_ploc_merge(uint c, uint n_leaves, const 
     for (int k = 0; k < 6; ++k) out_box[6 * (size_t)i + k] = box[k];
 }
 
-__global__ __launch_bounds__(BT) void k_ploc_compact(uint c, const uint* valid, const uint* pos, const int* in_ref, const float* in_box, int* cref, float* cbox) {
+__global__ __launch_bounds__(BT) void k_ploc_compact(const uint* c_ptr, uint* c_next, const uint* valid, const uint* pos, const int* in_ref, const float* in_box,
+                                                     int* cref, float* cbox) {
+    const uint c = *c_ptr;
     uint i = blockIdx.x * BT + threadIdx.x;
-    if (i >= c || !valid[i]) return;
+    if (i >= c) return;
+    if (i == c - 1) *c_next = pos[i] + valid[i];   // cluster count of the next round
+    if (!valid[i]) return;
     uint p = pos[i];
     cref[p] = in_ref[i];
     for (int k = 0; k < 6; ++k) cbox[6 * (size_t)p + k] = in_box[6 * (size_t)i + k];
@@ -416,117 +424,129 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));
-    ds.free_accel();
+    ds.accel_built = false;
     SceneView sv = ds.view();
     sv.tri_count = n;
-    uint* cbounds = nullptr;
-    HIPCHK(hipMalloc(&cbounds, 6 * sizeof(uint)));
-    {
-        uint init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
-        HIPCHK(hipMemcpyAsync(cbounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-    }
+    // Temporaries come out of one scratch arena that survives the call, and the outputs keep their allocation while the
+    // triangle count does not change: a rebuild (dynamic scenes) performs no allocation at all.
+    size_t plan_bytes = 0;
+    auto plan = [&](size_t bytes) { size_t o = plan_bytes; plan_bytes += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t n1 = n > 1 ? n - 1 : 0;
+    size_t sort_bytes = 0, scan_bytes = 0;
     if (n > 0) {
-        TriRecord* unsorted = nullptr;
-        unsigned long long *keys = nullptr, *keys_sorted = nullptr;
-        uint *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
-        int2* children = nullptr;
-        uint* ranges = nullptr;   // subtree sizes (leaves per internal node)
-        int *parent_internal = nullptr, *parent_leaf = nullptr;
-        float *leaf_box = nullptr, *node_box = nullptr;
-        HIPCHK(hipMalloc(&unsorted, (size_t)n * sizeof(TriRecord)));
-        HIPCHK(hipMalloc(&ds.tris, (size_t)n * sizeof(TriRecord)));
-        HIPCHK(hipMalloc(&keys, (size_t)n * 8)); HIPCHK(hipMalloc(&keys_sorted, (size_t)n * 8));
-        HIPCHK(hipMalloc(&vals, (size_t)n * 4)); HIPCHK(hipMalloc(&vals_sorted, (size_t)n * 4));
-        HIPCHK(hipMalloc(&leaf_box, (size_t)n * 24));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint*)nullptr, (uint*)nullptr, n, 0, 64, stream));
+        HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, (uint*)nullptr, (uint*)nullptr, 0u, n, rocprim::plus<uint>(), stream));
+    }
+    const size_t o_cbounds = plan(16 * sizeof(uint)), o_unsorted = plan((size_t)n * sizeof(TriRecord)), o_keys = plan((size_t)n * 8),
+                 o_keys_sorted = plan((size_t)n * 8), o_vals = plan((size_t)n * 4), o_vals_sorted = plan((size_t)n * 4),
+                 o_leaf_box = plan((size_t)n * 24), o_sort = plan(sort_bytes + 16), o_children = plan(n1 * sizeof(int2)),
+                 o_sizes = plan(n1 * 4), o_parent = plan(n1 * 4), o_parent_leaf = plan((size_t)n * 4), o_node_box = plan(n1 * 24),
+                 o_arrive = plan(n1 * 4), o_cref0 = plan((size_t)n * 4), o_cref1 = plan((size_t)n * 4), o_cbox0 = plan((size_t)n * 24),
+                 o_cbox1 = plan((size_t)n * 24), o_nn = plan((size_t)n * 4), o_valid = plan(((size_t)n + BT) * 4), o_pos = plan(((size_t)n + BT) * 4),
+                 o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(TR_BVH4 ? n1 * sizeof(BvhNode) : 0);
+    if (plan_bytes > ds.scratch_bytes) {
+        if (ds.scratch) (void)hipFree(ds.scratch);
+        ds.scratch = nullptr; ds.scratch_bytes = 0;
+        HIPCHK(hipMalloc(&ds.scratch, plan_bytes));
+        ds.scratch_bytes = plan_bytes;
+    }
+    char* base = static_cast<char*>(ds.scratch);
+    uint* cbounds = reinterpret_cast<uint*>(base + o_cbounds);   // 6 flipped centroid bounds, [6] PLOC node allocator, [8..9] cluster counts
+    {
+        const uint init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(cbounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    }
+    if (ds.accel_capacity != n) {   // outputs
+        ds.free_accel();
+        if (n > 0) HIPCHK(hipMalloc(&ds.tris, (size_t)n * sizeof(TriRecord)));
+        if (n1 > 0) {
+#if TR_BVH4
+            HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node)));
+#else
+            HIPCHK(hipMalloc(&ds.nodes, n1 * sizeof(BvhNode)));
+#endif
+        }
+        ds.accel_capacity = n;
+    }
+    ds.node_count = (uint)n1;
+    if (n > 0) {
+        TriRecord* unsorted = reinterpret_cast<TriRecord*>(base + o_unsorted);
+        unsigned long long *keys = reinterpret_cast<unsigned long long*>(base + o_keys), *keys_sorted = reinterpret_cast<unsigned long long*>(base + o_keys_sorted);
+        uint *vals = reinterpret_cast<uint*>(base + o_vals), *vals_sorted = reinterpret_cast<uint*>(base + o_vals_sorted);
+        float *leaf_box = reinterpret_cast<float*>(base + o_leaf_box), *node_box = reinterpret_cast<float*>(base + o_node_box);
+        int2* children = reinterpret_cast<int2*>(base + o_children);
+        uint* ranges = reinterpret_cast<uint*>(base + o_sizes);   // subtree sizes (leaves per internal node)
+        int *parent_internal = reinterpret_cast<int*>(base + o_parent), *parent_leaf = reinterpret_cast<int*>(base + o_parent_leaf);
+        uint* arrive = reinterpret_cast<uint*>(base + o_arrive);
+#if TR_BVH4
+        BvhNode* nodes2 = reinterpret_cast<BvhNode*>(base + o_nodes2);   // binary nodes: only the collapse input
+#else
+        BvhNode* nodes2 = ds.nodes;
+#endif
         const uint blocks = (n + BT - 1) / BT;
         hipLaunchKernelGGL(k_pretransform, dim3(blocks), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
         hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
-        size_t temp_bytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
-        void* temp = nullptr;
-        HIPCHK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
-        HIPCHK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+        HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
         hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
-        ds.node_count = n > 1 ? n - 1 : 0;
         if (n > 1) {
-            HIPCHK(hipMalloc(&ds.nodes, (size_t)(n - 1) * sizeof(BvhNode)));
-            HIPCHK(hipMalloc(&children, (size_t)(n - 1) * sizeof(int2)));
-            HIPCHK(hipMalloc(&ranges, (size_t)(n - 1) * sizeof(uint)));
-            HIPCHK(hipMalloc(&parent_internal, (size_t)(n - 1) * 4));
-            HIPCHK(hipMalloc(&parent_leaf, (size_t)n * 4));
-            HIPCHK(hipMalloc(&node_box, (size_t)(n - 1) * 24));
-            HIPCHK(hipMalloc(&arrive, (size_t)(n - 1) * 4));
-            HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
             const uint iblocks = (n - 1 + BT - 1) / BT;
             if (ds.builder == 0) {
                 // Karras 2012 LBVH + atomic bottom-up refit
+                HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
                 hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(BT), 0, stream, (int)n, keys_sorted, children, ranges, parent_internal, parent_leaf);
                 hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BT), 0, stream, (int)n, children, parent_internal, parent_leaf, leaf_box,
-                                   node_box, arrive, ds.nodes);
+                                   node_box, arrive, nodes2);
             } else {
                 // PLOC over the Morton order
-                int* cref[2]; float* cbox[2]; uint *nn, *valid, *pos, *alloc;
-                HIPCHK(hipMalloc(&cref[0], (size_t)n * 4)); HIPCHK(hipMalloc(&cref[1], (size_t)n * 4));
-                HIPCHK(hipMalloc(&cbox[0], (size_t)n * 24)); HIPCHK(hipMalloc(&cbox[1], (size_t)n * 24));
-                HIPCHK(hipMalloc(&nn, (size_t)n * 4)); HIPCHK(hipMalloc(&valid, (size_t)n * 4)); HIPCHK(hipMalloc(&pos, (size_t)n * 4));
-                HIPCHK(hipMalloc(&alloc, 4)); HIPCHK(hipMemsetAsync(alloc, 0, 4, stream));
-                HIPCHK(hipMemsetAsync(parent_internal, 0xFF, (size_t)(n - 1) * 4, stream));   // root keeps -1
+                int* cref[2] = {reinterpret_cast<int*>(base + o_cref0), reinterpret_cast<int*>(base + o_cref1)};
+                float* cbox[2] = {reinterpret_cast<float*>(base + o_cbox0), reinterpret_cast<float*>(base + o_cbox1)};
+                uint *nn = reinterpret_cast<uint*>(base + o_nn), *valid = reinterpret_cast<uint*>(base + o_valid), *pos = reinterpret_cast<uint*>(base + o_pos);
+                uint *alloc = cbounds + 6, *c_dev = cbounds + 8;   // count of round r in c_dev[r & 1]; k_ploc_compact writes the other one
+                HIPCHK(hipMemsetAsync(parent_internal, 0xFF, n1 * 4, stream));   // root keeps -1
                 hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(BT), 0, stream, n, cref[0]);
                 HIPCHK(hipMemcpyAsync(cbox[0], leaf_box, (size_t)n * 24, hipMemcpyDeviceToDevice, stream));
-                size_t scan_bytes = 0;
-                HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, n, rocprim::plus<uint>(), stream));
-                void* scan_temp = nullptr;
-                HIPCHK(hipMalloc(&scan_temp, scan_bytes ? scan_bytes : 16));
-                uint c = n;
+                HIPCHK(hipMemcpyAsync(c_dev, &n, 4, hipMemcpyHostToDevice, stream));
+                uint c = n;   // last cluster count the host has seen (upper bound of the live count)
                 int rounds = 0;
                 while (c > 1) {
+                    // rounds between host checks: few while the grids are large (an over-sized grid costs), many once they are small
+                    const int batch = c > (1u << 16) ? 2 : (c > 4096 ? 4 : 8);
                     const uint cb = (c + BT - 1) / BT;
-                    hipLaunchKernelGGL(k_ploc_nn, dim3(cb), dim3(BT), 0, stream, c, (uint)ds.ploc_radius, cbox[0], nn);
-                    hipLaunchKernelGGL(k_ploc_merge, dim3(cb), dim3(BT), 0, stream, c, n, cref[0], cbox[0], nn, valid, cref[1], cbox[1], alloc, children,
-                                       node_box, ranges, parent_internal);
-                    HIPCHK(rocprim::exclusive_scan(scan_temp, scan_bytes, valid, pos, 0u, c, rocprim::plus<uint>(), stream));
-                    hipLaunchKernelGGL(k_ploc_compact, dim3(cb), dim3(BT), 0, stream, c, valid, pos, cref[1], cbox[1], cref[0], cbox[0]);
-                    uint last[2];
-                    HIPCHK(hipMemcpyAsync(&last[0], pos + (c - 1), 4, hipMemcpyDeviceToHost, stream));
-                    HIPCHK(hipMemcpyAsync(&last[1], valid + (c - 1), 4, hipMemcpyDeviceToHost, stream));
+                    for (int r = 0; r < batch; ++r) {
+                        const uint* c_cur = c_dev + ((rounds + r) & 1);
+                        hipLaunchKernelGGL(k_ploc_nn, dim3(cb), dim3(BT), 0, stream, c_cur, (uint)ds.ploc_radius, cbox[0], nn);
+                        hipLaunchKernelGGL(k_ploc_merge, dim3(cb), dim3(BT), 0, stream, c_cur, n, cref[0], cbox[0], nn, valid, cref[1], cbox[1], alloc, children,
+                                           node_box, ranges, parent_internal);
+                        HIPCHK(rocprim::exclusive_scan(base + o_scan, scan_bytes, valid, pos, 0u, cb * BT, rocprim::plus<uint>(), stream));
+                        hipLaunchKernelGGL(k_ploc_compact, dim3(cb), dim3(BT), 0, stream, c_cur, c_dev + ((rounds + r + 1) & 1), valid, pos, cref[1], cbox[1], cref[0], cbox[0]);
+                    }
+                    rounds += batch;
+                    uint c_new = 0;
+                    HIPCHK(hipMemcpyAsync(&c_new, c_dev + (rounds & 1), 4, hipMemcpyDeviceToHost, stream));
                     HIPCHK(hipStreamSynchronize(stream));
-                    const uint c_new = last[0] + last[1];
-                    if (c_new >= c || ++rounds > 4096) return set_error("PLOC: clustering did not converge");
+                    if (c_new >= c || rounds > 4096) return set_error("PLOC: clustering did not converge");
                     c = c_new;
                 }
                 ds.build_rounds = (uint)rounds;
-                (void)hipFree(cref[0]); (void)hipFree(cref[1]); (void)hipFree(cbox[0]); (void)hipFree(cbox[1]);
-                (void)hipFree(nn); (void)hipFree(valid); (void)hipFree(pos); (void)hipFree(alloc); (void)hipFree(scan_temp);
             }
             if (ds.builder != 0 || ds.dfs_layout || TR_BVH4) {
-                int* new_id = nullptr;
-                HIPCHK(hipMalloc(&new_id, (size_t)(n - 1) * 4));
+                int* new_id = reinterpret_cast<int*>(base + o_new_id);
                 if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
-                hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
 #if TR_BVH4
-                HIPCHK(hipMalloc(&ds.nodes4, (size_t)(n - 1) * sizeof(Bvh4Node)));
                 hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes4);
-#endif
-                HIPCHK(hipStreamSynchronize(stream));
-                (void)hipFree(new_id);
-#if TR_BVH4
-                (void)hipFree(ds.nodes); ds.nodes = nullptr;   // the binary nodes were only the collapse input
+#else
+                hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
 #endif
             }
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
-        (void)hipFree(ranges);
-        (void)hipFree(unsorted); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted); (void)hipFree(leaf_box);
-        (void)hipFree(temp); (void)hipFree(children); (void)hipFree(parent_internal); (void)hipFree(parent_leaf); (void)hipFree(node_box); (void)hipFree(arrive);
     }
     ds.accel_built = true;
     // tri lights
     ds.tri_light_count = 0;
     if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0) {
-        HIPCHK(hipMalloc(&ds.tri_lights, (size_t)ds.host_tri_light_count * sizeof(TriLight)));
+        if (!ds.tri_lights) HIPCHK(hipMalloc(&ds.tri_lights, (size_t)ds.host_tri_light_count * sizeof(TriLight)));
         HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
         ds.tri_light_count = ds.host_tri_light_count;
         SceneView sv2 = ds.view();
@@ -540,7 +560,6 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     uint hb[6];
     HIPCHK(hipMemcpy(hb, cbounds, sizeof(hb), hipMemcpyDeviceToHost));
-    (void)hipFree(cbounds);
     if (info) {
         info->triangle_count = n;
         info->node_count = ds.node_count;

@@ -37,6 +37,7 @@ int main(int argc, char** argv)
             auto val = [&](const char* key) { return a.substr(std::strlen(key)); };
             if(a == "-t") timing = true;
             else if(a == "--accumulation") opt.accumulate = true;
+            else if(a == "--pre-transform-vertices") opt.pre_transformed_vertices = true;
             else if(starts(a, "--width=")) size.x = (uint32_t)std::stoul(val("--width="));
             else if(starts(a, "--height=")) size.y = (uint32_t)std::stoul(val("--height="));
             else if(starts(a, "--headless=")) prefix = val("--headless=");
