@@ -64,6 +64,7 @@ struct PtParams {
     LaunchCtx L;
     uint viewports;
     uint n_launch;                // launch_w * launch_h * viewports
+    uint id_offset, n_ids;        // the slice of path ids this launch group (lane) works on
     uint max_sobol_bounces;
     uint sample_counter, rng_seed;
     uint previous_samples;        // control.previous_samples of the pass
@@ -98,7 +99,8 @@ TR_DEV uint wave_append(uint* counter, bool pred) {
 // path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
 __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_launch) return;
+    if (i >= P.n_ids) return;
+    i += P.id_offset;
     uint lx, ly, lz;
     launch_coord(P.L, i, lx, ly, lz);
     int px, py;
@@ -138,7 +140,7 @@ template <bool COUNT, bool SOLO>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       const uint* count_ptr) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = queue ? *count_ptr : P.n_launch;
+    const uint n = queue ? *count_ptr : P.n_ids;
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0, max_vis = 0;
     int overflow = 0;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         if (base >= n) break;
         uint qi = base + (threadIdx.x & 63);
         if (qi >= n) continue;
-        uint id = queue ? queue[qi] : qi;
+        uint id = queue ? queue[qi] : qi + P.id_offset;
         u4 misc = pb.misc[id];
         if (misc.w & 1u) continue;
         f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
@@ -374,14 +376,14 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                               const uint* count_ptr, uint* next_queue) {
-    const uint n = queue ? *count_ptr : P.n_launch;
+    const uint n = queue ? *count_ptr : P.n_ids;
     const uint n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
     uint surf = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
         bool active = qi < n;
         uint id = 0;
         u4 misc = {0, 0, 0, 1};
-        if (active) { id = queue ? queue[qi] : qi; misc = pb.misc[id]; active = !(misc.w & 1u); }
+        if (active) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; active = !(misc.w & 1u); }
         bool alive = false;        // continues to the next bounce
         bool want_shadow = false;
         f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
@@ -618,7 +620,8 @@ __global__ void k_clear_shadow(uint* counters) {
 // diffuse, reflection) with material.glsl:57-65; sum_diffuse / sum_reflection when those targets exist
 __global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_launch) return;
+    if (i >= P.n_ids) return;
+    i += P.id_offset;
     u4 misc = pb.misc[i];
     if (misc.w & 1u) return;
     const f4 s = pb.sum_color[i], d = pb.diffuse[i], r = pb.reflection[i], fm = pb.first_mat[i], fe = pb.first_emis[i];
@@ -639,7 +642,8 @@ __global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffer
 // write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_{color,diffuse,reflection} (gbuffer.glsl:18-28,68-78,118-128)
 __global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_launch) return;
+    if (i >= P.n_ids) return;
+    i += P.id_offset;
     uint lx, ly, lz;
     launch_coord(P.L, i, lx, ly, lz);
     int wx, wy;
@@ -678,6 +682,7 @@ void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/dis
     else { w = d.count; h = 1; }
 }
 
+constexpr int PT_LANES = 4;   // independent slices of a frame that run concurrently (see PtStage::render)
 struct TimedSpan { int kind; hipEvent_t a, b; };
 enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_KINDS = 5 };
 
@@ -691,8 +696,10 @@ struct PtStage::Impl {
     float acc_ms[T_KINDS] = {0, 0, 0, 0, 0};
     uint acc_launches[T_KINDS] = {0, 0, 0, 0, 0};
     uint frames = 0;
-    hipStream_t side = nullptr;        // shadow rays of bounce b trace here while closest(b+1) runs on the caller's stream
+    hipStream_t side = nullptr;        // lane 1, or (single lane) shadow rays of bounce b while closest(b+1) runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_stream[PT_LANES] = {};   // lanes 2.. (lane 0 = caller's stream, lane 1 = side)
+    hipEvent_t lane_join[PT_LANES] = {};
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
@@ -709,6 +716,7 @@ PtStage::~PtStage() {
     for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
     if (impl->side) { (void)hipStreamDestroy(impl->side); (void)hipEventDestroy(impl->ev_fork); (void)hipEventDestroy(impl->ev_join); }
+    for (int l = 2; l < PT_LANES; ++l) if (impl->lane_stream[l]) { (void)hipStreamDestroy(impl->lane_stream[l]); (void)hipEventDestroy(impl->lane_join[l]); }
     delete impl;
 }
 
@@ -726,8 +734,8 @@ void PtStage::free_buffers() {
 int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     PathBuffers& pb = impl->pb;
     if (!pb.counters) {
-        HIPCHK(hipMalloc(&pb.counters, CNT_WORDS * sizeof(uint)));
-        HIPCHK(hipMemset(pb.counters, 0, CNT_WORDS * sizeof(uint)));
+        HIPCHK(hipMalloc(&pb.counters, PT_LANES * CNT_WORDS * sizeof(uint)));   // one block of counters per lane
+        HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
@@ -761,7 +769,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     const size_t n = (size_t)lw * lh * viewports;
     if (n == 0) return 0;
     if (n > 0xFFFFFFF0ull) return set_error("trhip_pt_render: launch too large");
-    P.n_launch = (uint)n;
+    P.n_launch = (uint)n; P.id_offset = 0; P.n_ids = (uint)n;
     P.max_sobol_bounces = (uint)(opt.max_bounces > 8 ? 8 : opt.max_bounces);   // shader/sobol_lookup_table.glsl:4-14
     P.sample_counter = frame_counter * (uint)opt.samples_per_pixel;               // src/rt_stage.cc:81
     { uint s = opt.rng_seed; P.rng_seed = s != 0 ? pcg(s) : 0; }                  // src/rt_stage.cc:82
@@ -786,21 +794,26 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         if (int rc = ensure_world_vertices(*scene, stream)) return rc;
         sv.vertices = scene->world_vertices; sv.spans = scene->world_spans;
     }
-    const uint blocks_all = (uint)((n + KB - 1) / KB);
-    // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
-    const uint blocks_q = blocks_all < (256u * 8u) ? blocks_all : 256u * 8u;
     const bool count = count_work != 0;
     const bool timing = detailed_timing != 0;
-    // A/B switch TRHIP_OVERLAP=0: everything on the caller's stream
+    // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
+    // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
+    // want different resources.  Two ways to fill the gaps, both bit-neutral:
+    //  * lanes (default, four = the HIP runtime's hardware queues): the path ids are cut into slices with their own
+    //    queues and counters, and every slice runs its whole bounce loop on its own stream, so one slice's shade overlaps
+    //    another's traversal;
+    //  * TRHIP_LANES=1: one lane, shadow(b) on a side stream overlapping closest(b+1).
+    // Per-kernel timing (trhip_pt_set_profiling) wants kernels that own the chip: one lane, one stream.
+    static const int lanes_env = getenv("TRHIP_LANES") ? atoi(getenv("TRHIP_LANES")) : PT_LANES;
     static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);
-    // per-kernel timing wants kernels that do not share the chip: detailed timing serialises the frame
-    const bool overlap = overlap_enabled && !timing;
-    if (overlap && !impl->side) {
+    const int n_lanes = (!timing && lanes_env >= 2 && n >= 4096) ? (lanes_env > PT_LANES ? PT_LANES : lanes_env) : 1;
+    const bool overlap = overlap_enabled && !timing && n_lanes == 1;
+    if ((overlap || n_lanes > 1) && !impl->side) {
         HIPCHK(hipStreamCreateWithFlags(&impl->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
     }
-    bool shadow_in_flight = false;
+    static const uint grid_cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
@@ -812,47 +825,81 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         impl->pending.push_back(sp);
     };
     HIPCHK(hipEventRecord(ev[0], stream));
-    const int passes = opt.samples_per_pixel / opt.samples_per_pass;
-    for (int pass = 0; pass < passes; ++pass) {
-        P.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
-        for (int s = 0; s < opt.samples_per_pass; ++s) {
-            P.sample_in_pass = (uint)s;
-            timed(T_RAYGEN, stream, [&] {
-                hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, P, pb);
-                hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, stream, pb.counters);
-            });
-            for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
-                const uint* q = bounce == 0 ? nullptr : pb.queue[bounce & 1];
-                uint* qn = pb.queue[(bounce + 1) & 1];
-                timed(T_CLOSEST, stream, [&] {
-                    auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
-                    hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR);
+    for (int l = 2; l < n_lanes; ++l) if (!impl->lane_stream[l]) {
+        HIPCHK(hipStreamCreateWithFlags(&impl->lane_stream[l], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&impl->lane_join[l], hipEventDisableTiming));
+    }
+    if (n_lanes > 1) {   // fork
+        HIPCHK(hipEventRecord(impl->ev_fork, stream));
+        HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
+        for (int l = 2; l < n_lanes; ++l) HIPCHK(hipStreamWaitEvent(impl->lane_stream[l], impl->ev_fork, 0));
+    }
+    const uint per_lane = (uint)((((n + n_lanes - 1) / n_lanes + 63) / 64) * 64);   // whole 8x8 tiles per lane
+    for (int lane = 0; lane < n_lanes; ++lane) {
+        const hipStream_t ls = lane == 0 ? stream : (lane == 1 ? impl->side : impl->lane_stream[lane]);
+        PtParams LP = P;
+        LP.id_offset = (uint)lane * per_lane;
+        if (LP.id_offset >= n) break;
+        LP.n_ids = std::min(per_lane, (uint)n - LP.id_offset);
+        PathBuffers lb = pb;   // the lane's view: shared per-path arrays, its own queues / shadow queue / counters
+        lb.counters = pb.counters + lane * CNT_WORDS;
+        lb.queue[0] = pb.queue[0] + LP.id_offset; lb.queue[1] = pb.queue[1] + LP.id_offset;
+        lb.sh_org_tmax = pb.sh_org_tmax + LP.id_offset; lb.sh_dir_id = pb.sh_dir_id + LP.id_offset;
+        lb.sh_contrib = pb.sh_contrib + LP.id_offset; lb.sh_lobes = pb.sh_lobes + LP.id_offset;
+        const uint blocks_all = (LP.n_ids + KB - 1) / KB;
+        // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
+        const uint blocks_q = blocks_all < grid_cap ? blocks_all : grid_cap;
+        bool shadow_in_flight = false;
+        const int passes = opt.samples_per_pixel / opt.samples_per_pass;
+        for (int pass = 0; pass < passes; ++pass) {
+            LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
+            for (int s = 0; s < opt.samples_per_pass; ++s) {
+                LP.sample_in_pass = (uint)s;
+                timed(T_RAYGEN, ls, [&] {
+                    hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
+                    hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, ls, lb.counters);
                 });
-                if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0)); shadow_in_flight = false; }
-                P.shadow_cnt = shadow_counter(bounce);
-                timed(T_SHADE, stream, [&] {
-                    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
-                    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, P, pb, bounce, q, pb.counters + CNT_CUR, qn);
-                });
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, pb.counters, shadow_counter(bounce + 1));
-                if (bounce < opt.max_bounces - 1) {
-                    hipStream_t ss = stream;
-                    if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
-                        HIPCHK(hipEventRecord(impl->ev_fork, stream));
-                        HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
-                        ss = impl->side;
-                    }
-                    timed(T_SHADOW, ss, [&] {
-                        auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
-                        hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, P, pb);
+                for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
+                    const uint* q = bounce == 0 ? nullptr : lb.queue[bounce & 1];
+                    uint* qn = lb.queue[(bounce + 1) & 1];
+                    timed(T_CLOSEST, ls, [&] {
+                        auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
+                        hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR);
                     });
-                    if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
+                    if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
+                    LP.shadow_cnt = shadow_counter(bounce);
+                    timed(T_SHADE, ls, [&] {
+                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR, qn);
+                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR, qn);
+                    });
+                    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ls, lb.counters, shadow_counter(bounce + 1));
+                    if (bounce < opt.max_bounces - 1) {
+                        hipStream_t ss = ls;
+                        if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
+                            HIPCHK(hipEventRecord(impl->ev_fork, ls));
+                            HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
+                            ss = impl->side;
+                        }
+                        timed(T_SHADOW, ss, [&] {
+                            auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
+                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb);
+                        });
+                        if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
+                    }
                 }
+                if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
+                hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, ls, LP, lb);
             }
-            if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0)); shadow_in_flight = false; }
-            hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, P, pb);
+            timed(T_RESOLVE, ls, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, ls, LP, lb); });
         }
-        timed(T_RESOLVE, stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, P, pb); });
+    }
+    if (n_lanes > 1) {   // join
+        HIPCHK(hipEventRecord(impl->ev_join, impl->side));
+        HIPCHK(hipStreamWaitEvent(stream, impl->ev_join, 0));
+        for (int l = 2; l < n_lanes; ++l) {
+            HIPCHK(hipEventRecord(impl->lane_join[l], impl->lane_stream[l]));
+            HIPCHK(hipStreamWaitEvent(stream, impl->lane_join[l], 0));
+        }
     }
     HIPCHK(hipEventRecord(ev[1], stream));
     HIPCHK(hipGetLastError());
@@ -868,18 +915,20 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
     memset(out, 0, sizeof(*out));
     if (!impl->pb.counters) return 0;
     HIPCHK(hipStreamSynchronize(stream));
-    uint h[CNT_WORDS];
-    HIPCHK(hipMemcpy(h, impl->pb.counters, sizeof(h), hipMemcpyDeviceToHost));
-    auto rd = [&](int i) { return (uint64_t)h[i] | ((uint64_t)h[i + 1] << 32); };
+    uint hl[PT_LANES][CNT_WORDS];
+    HIPCHK(hipMemcpy(hl, impl->pb.counters, sizeof(hl), hipMemcpyDeviceToHost));
+    uint* h = hl[0];
+    auto rd = [&](int i) { uint64_t v = 0; for (int l = 0; l < PT_LANES; ++l) v += (uint64_t)hl[l][i] | ((uint64_t)hl[l][i + 1] << 32); return v; };
     out->closest_rays = rd(CNT_CLOSEST); out->shadow_rays = rd(CNT_SHADOWRAYS); out->node_visits = rd(CNT_NODES);
     out->tri_tests = rd(CNT_TRIS); out->alpha_tests = rd(CNT_ALPHA); out->surface_hits = rd(CNT_SURF);
+    for (int l = 1; l < PT_LANES; ++l) { h[CNT_OVERFLOW] |= hl[l][CNT_OVERFLOW]; h[CNT_MAXSP] = std::max(h[CNT_MAXSP], hl[l][CNT_MAXSP]); h[CNT_MAXVIS] = std::max(h[CNT_MAXVIS], hl[l][CNT_MAXVIS]); }
     out->stack_overflows = h[CNT_OVERFLOW];
     if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] overflow %u src %u; max stack depth %u; max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_OVERFLOW], h[CNT_DBG + 12], h[CNT_MAXSP], h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
     return 0;
 }
 
 int PtStage::reset_counters() {
-    if (impl->pb.counters) HIPCHK(hipMemset(impl->pb.counters, 0, CNT_WORDS * sizeof(uint)));
+    if (impl->pb.counters) HIPCHK(hipMemset(impl->pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
     if (int rc = resolve_pending()) return rc;
     for (int k = 0; k < T_KINDS; ++k) { impl->acc_ms[k] = 0; impl->acc_launches[k] = 0; }
     impl->frames = 0;

@@ -17,7 +17,9 @@ namespace tr {
 #define TR_VOTE 8          // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote)
 #endif
 #define TR_LDS_STACK 16
+#ifndef TR_SPILL_STACK
 #define TR_SPILL_STACK 112
+#endif
 
 struct RayPre {
     f3 org, dir, inv_dir;
