@@ -50,14 +50,14 @@ struct PathBuffers {
     f4* sh_contrib;   // rgb radiance if visible, luminance for the indirect clamp
     f2* sh_lobes;     // lobe weights the contribution is demodulated with
     uint* queue[2];
+    // per lane, four words per bounce b: [4b] live paths entering b, [4b+1] shadow rays of b, [4b+2] / [4b+3] work cursors of
+    // the closest-hit / shadow kernel of b.  Zeroed by k_raygen; nothing has to be rotated between bounces.
+    uint* bounce;
     uint* counters;   // [0] next-queue count, [1] shadow count, [2] overflow flag, [4..] work counters
 };
 
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
        CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORK_CLOSEST = 31, CNT_WORK_SHADOW = 32, CNT_SHADOW_ODD = 33, CNT_WORDS = 34 };
-// the shadow queue length is double-buffered by bounce parity: shadow(b) may still run (side stream) while the main
-// stream has already rotated the other counters for closest(b+1)
-TR_HD int shadow_counter(int bounce) { return (bounce & 1) ? CNT_SHADOW_ODD : CNT_SHADOW; }
 
 struct PtParams {
     trhip_pt_options opt;
@@ -74,7 +74,8 @@ struct PtParams {
     float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
     int nee_point, nee_tri, nee_dir, nee_env;
     int count_work;
-    int shadow_cnt;               // counter word holding this bounce's shadow queue length
+    uint bounce_words;            // size of PathBuffers::bounce for one lane
+    int fused_resolve;            // samples_per_pass == 1: k_resolve forms the sample's colour itself
     trhip_pt_targets T;           // device images; null = target not requested
 };
 
@@ -98,6 +99,7 @@ TR_DEV uint wave_append(uint* counter, bool pred) {
 // ---------------------------------------------------------------------------------------------------
 // path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
 __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
+    if (blockIdx.x == 0) for (uint k = threadIdx.x; k < P.bounce_words; k += KB) pb.bounce[k] = 0;   // queue lengths and work cursors of this sample
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= P.n_ids) return;
     i += P.id_offset;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
     int px, py;
     bool valid = get_pixel_pos(P.L, lx, ly, px, py);
     u4 misc = {0, 0, i, valid ? 0u : 1u};
-    if (P.sample_in_pass == 0) {
+    if (P.sample_in_pass == 0 && !P.fused_resolve) {
         pb.sum_color[i] = F4(0, 0, 0, 1);
         if (pb.sum_diffuse) { pb.sum_diffuse[i] = F4(0); pb.sum_reflection[i] = F4(0); }
     }
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
 template <bool COUNT, bool SOLO>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
-                                                      const uint* count_ptr) {
+                                                      uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = queue ? *count_ptr : P.n_ids;
+    const uint n = queue ? bc[0] : P.n_ids;
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0, max_vis = 0;
     int overflow = 0;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         uint base = 0;
         if (first) base = wave_id * 64u;
         else {
-            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_CLOSEST], 64u);
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[2], 64u);
             base = __shfl(base, 0);
         }
         first = false;
@@ -199,9 +201,9 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb) {
+__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = pb.counters[P.shadow_cnt];
+    const uint n = bc[1];
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
         uint base = 0;
         if (first) base = wave_id * 64u;
         else {
-            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&pb.counters[CNT_WORK_SHADOW], 64u);
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[3], 64u);
             base = __shfl(base, 0);
         }
         first = false;
@@ -375,8 +377,8 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
-                                              const uint* count_ptr, uint* next_queue) {
-    const uint n = queue ? *count_ptr : P.n_ids;
+                                              uint* bc, uint* next_queue) {
+    const uint n = queue ? bc[0] : P.n_ids;
     const uint n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
     uint surf = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
@@ -588,14 +590,14 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             }
         }
         // ---- queue compaction (wave ballots)
-        uint sslot = wave_append(&pb.counters[P.shadow_cnt], want_shadow);
+        uint sslot = wave_append(&bc[1], want_shadow);
         if (want_shadow) {
             pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
             pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
             pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
             pb.sh_lobes[sslot] = sh_w;
         }
-        uint nslot = wave_append(&pb.counters[CNT_NEXT], alive);
+        uint nslot = wave_append(&bc[4], alive);
         if (alive) next_queue[nslot] = id;
     }
     if (COUNT && P.count_work) {
@@ -604,34 +606,26 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
     }
 }
 
-// rotate queue counters between bounces: cur <- next, next <- 0, shadow <- 0
-__global__ void k_advance(uint* counters, int next_shadow_cnt) {
-    counters[CNT_CUR] = counters[CNT_NEXT];
-    counters[CNT_NEXT] = 0;
-    counters[next_shadow_cnt] = 0;   // the queue the NEXT bounce's shade fills; this bounce's stays for k_trace_shadow
-    counters[CNT_WORK_CLOSEST] = 0;
-    counters[CNT_WORK_SHADOW] = 0;
-}
-__global__ void k_clear_shadow(uint* counters) {
-    counters[CNT_SHADOW] = 0; counters[CNT_SHADOW_ODD] = 0; counters[CNT_NEXT] = 0; counters[CNT_WORK_CLOSEST] = 0; counters[CNT_WORK_SHADOW] = 0;
-}
-
 // end of one sample (path_tracer.rgen:105-118): sum_color += first_hit_material.emission + modulate_color(first_hit_material,
 // diffuse, reflection) with material.glsl:57-65; sum_diffuse / sum_reflection when those targets exist
+TR_DEV f4 sample_color(const PtParams& P, f4 d, f4 r, f4 fm, f4 fe) {   // rgb = emission + modulate_color(...), a = first-hit alpha
+    const f3 albedo = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(fm);
+    const float metallic = fm.w;
+    const float approx_fresnel = 0.02f;
+    const f3 dd = F3(d) * albedo * (1 - metallic);
+    const f3 rr = F3(r) * mix3(F3(approx_fresnel), albedo, metallic) / mixf(approx_fresnel, 1.0f, metallic);
+    return F4(F3(fe) + (dd + rr), fe.w);
+}
+
 __global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= P.n_ids) return;
     i += P.id_offset;
     u4 misc = pb.misc[i];
     if (misc.w & 1u) return;
-    const f4 s = pb.sum_color[i], d = pb.diffuse[i], r = pb.reflection[i], fm = pb.first_mat[i], fe = pb.first_emis[i];
-    const f3 albedo = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(fm);
-    const float metallic = fm.w;
-    const float approx_fresnel = 0.02f;
-    const f3 dd = F3(d) * albedo * (1 - metallic);
-    const f3 rr = F3(r) * mix3(F3(approx_fresnel), albedo, metallic) / mixf(approx_fresnel, 1.0f, metallic);
-    const f3 c = F3(fe) + (dd + rr);
-    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, fe.w);
+    const f4 s = pb.sum_color[i], d = pb.diffuse[i], r = pb.reflection[i];
+    const f4 c = sample_color(P, d, r, pb.first_mat[i], pb.first_emis[i]);
+    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, c.w);
     if (pb.sum_diffuse) {
         const f4 sd = pb.sum_diffuse[i], sr = pb.sum_reflection[i];
         pb.sum_diffuse[i] = F4(sd.x + d.x, sd.y + d.y, sd.z + d.z, sd.w + d.w);
@@ -658,6 +652,18 @@ __global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb) {
         if (prev_samples != 0) value = mix4(value, target[idx], keep);
         target[idx] = value;
     };
+    if (P.fused_resolve) {
+        // one sample per pass: the sums are the sample itself (0 + x and x / 1 are exact), k_accumulate_sample is not launched.
+        // A launch id whose pixel is invalid never gets here: get_write_pixel_pos fails with get_pixel_pos.
+        const f4 d = pb.diffuse[i], r = pb.reflection[i];
+        if (P.T.color) {
+            const f4 c = sample_color(P, d, r, pb.first_mat[i], pb.first_emis[i]);
+            accumulate(P.T.color, F4(c.x, c.y, c.z, P.opt.transparent_background ? c.w : 1.0f));
+        }
+        if (P.T.diffuse) accumulate(P.T.diffuse, d);
+        if (P.T.reflection) accumulate(P.T.reflection, r);
+        return;
+    }
     if (P.T.color) {
         const f4 s = pb.sum_color[i];
         accumulate(P.T.color, F4(s.x / spp, s.y / spp, s.z / spp, P.opt.transparent_background ? s.w : 1.0f));
@@ -712,6 +718,8 @@ PtStage::PtStage(DeviceScene* scene, const trhip_pt_options& o) : scene(scene), 
 
 PtStage::~PtStage() {
     free_buffers();
+    if (impl->pb.counters) (void)hipFree(impl->pb.counters);
+    if (impl->pb.bounce) (void)hipFree(impl->pb.bounce);
     if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
     for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
@@ -725,9 +733,9 @@ void PtStage::free_buffers() {
     void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
                     pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    uint* counters = pb.counters;
+    uint *counters = pb.counters, *bounce = pb.bounce;
     pb = PathBuffers{};
-    pb.counters = counters;
+    pb.counters = counters; pb.bounce = bounce;
     impl->capacity = 0;
 }
 
@@ -736,6 +744,7 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     if (!pb.counters) {
         HIPCHK(hipMalloc(&pb.counters, PT_LANES * CNT_WORDS * sizeof(uint)));   // one block of counters per lane
         HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
+        HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * 4u * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
@@ -786,6 +795,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         P.prob_point = point * inv_sum; P.prob_tri = tri * inv_sum; P.prob_dir = dir * inv_sum; P.prob_env = env * inv_sum;
     }
     P.count_work = 1;
+    P.bounce_words = 4u * ((uint)opt.max_bounces + 2u);
+    P.fused_resolve = opt.samples_per_pass == 1;
     P.T = targets;
     if (int rc = ensure_buffers(n, targets.diffuse || targets.reflection)) return rc;
     PathBuffers& pb = impl->pb;
@@ -806,7 +817,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // Per-kernel timing (trhip_pt_set_profiling) wants kernels that own the chip: one lane, one stream.
     static const int lanes_env = getenv("TRHIP_LANES") ? atoi(getenv("TRHIP_LANES")) : PT_LANES;
     static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);
-    const int n_lanes = (!timing && lanes_env >= 2 && n >= 4096) ? (lanes_env > PT_LANES ? PT_LANES : lanes_env) : 1;
+    // Small frames (the shards of a multi-GPU job) are bound by the latency of one ray's dependent fetches per kernel, not
+    // by throughput; extra hardware queues only add dispatch latency there (measured: 1 M paths 1.68 ms on one lane, 1.94 ms
+    // on four; 2 M paths 3.87 ms vs 3.10 ms).
+    static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)1500000;
+    const int n_lanes = (timing || n < lanes_min_paths) ? 1 : std::max(1, std::min(lanes_env, PT_LANES));
     const bool overlap = overlap_enabled && !timing && n_lanes == 1;
     if ((overlap || n_lanes > 1) && !impl->side) {
         HIPCHK(hipStreamCreateWithFlags(&impl->side, hipStreamNonBlocking));
@@ -843,6 +858,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         LP.n_ids = std::min(per_lane, (uint)n - LP.id_offset);
         PathBuffers lb = pb;   // the lane's view: shared per-path arrays, its own queues / shadow queue / counters
         lb.counters = pb.counters + lane * CNT_WORDS;
+        lb.bounce = pb.bounce + (size_t)lane * P.bounce_words;
         lb.queue[0] = pb.queue[0] + LP.id_offset; lb.queue[1] = pb.queue[1] + LP.id_offset;
         lb.sh_org_tmax = pb.sh_org_tmax + LP.id_offset; lb.sh_dir_id = pb.sh_dir_id + LP.id_offset;
         lb.sh_contrib = pb.sh_contrib + LP.id_offset; lb.sh_lobes = pb.sh_lobes + LP.id_offset;
@@ -857,22 +873,19 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                 LP.sample_in_pass = (uint)s;
                 timed(T_RAYGEN, ls, [&] {
                     hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
-                    hipLaunchKernelGGL(k_clear_shadow, dim3(1), dim3(1), 0, ls, lb.counters);
                 });
                 for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                     const uint* q = bounce == 0 ? nullptr : lb.queue[bounce & 1];
                     uint* qn = lb.queue[(bounce + 1) & 1];
                     timed(T_CLOSEST, ls, [&] {
                         auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
-                        hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR);
+                        hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce);
                     });
                     if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
-                    LP.shadow_cnt = shadow_counter(bounce);
                     timed(T_SHADE, ls, [&] {
-                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR, qn);
-                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.counters + CNT_CUR, qn);
+                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce, qn);
+                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce, qn);
                     });
-                    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ls, lb.counters, shadow_counter(bounce + 1));
                     if (bounce < opt.max_bounces - 1) {
                         hipStream_t ss = ls;
                         if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
@@ -882,13 +895,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         }
                         timed(T_SHADOW, ss, [&] {
                             auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
-                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb);
+                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb, lb.bounce + 4 * bounce);
                         });
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                     }
                 }
                 if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
-                hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, ls, LP, lb);
+                if (!LP.fused_resolve) hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, ls, LP, lb);
             }
             timed(T_RESOLVE, ls, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, ls, LP, lb); });
         }
