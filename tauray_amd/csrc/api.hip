@@ -395,7 +395,7 @@ int trhip_pt_reset_counters(trhip_pt* pt) { if (!pt) return set_error("null trhi
 int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_timings(out); }
 
 static LaunchCtx make_launch(const trhip_distribution& d) {
-    LaunchCtx L;
+    LaunchCtx L{};
     uint lw, lh;
     get_ray_count(d, lw, lh);
     L.size_x = d.size_x; L.size_y = d.size_y; L.strategy = d.strategy; L.index = d.index; L.primary = d.primary;

@@ -850,6 +850,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         for (int l = 2; l < n_lanes; ++l) HIPCHK(hipStreamWaitEvent(impl->lane_stream[l], impl->ev_fork, 0));
     }
     const uint per_lane = (uint)((((n + n_lanes - 1) / n_lanes + 63) / 64) * 64);   // whole 8x8 tiles per lane
+    {   // interleave the lanes' tiles when the image is whole tiles and divides evenly (always true for 1080p / 4 lanes)
+        const size_t tiles = n / 64;
+        const bool even = viewports == 1 && (lw & 7u) == 0 && (lh & 7u) == 0 && n_lanes > 1 && tiles % (size_t)n_lanes == 0 &&
+                          (size_t)per_lane * (size_t)n_lanes == n;
+        P.L.tile_lanes = even ? (uint)n_lanes : 1u;
+        P.L.tiles_per_lane = even ? (uint)(tiles / (size_t)n_lanes) : 0u;
+    }
     for (int lane = 0; lane < n_lanes; ++lane) {
         const hipStream_t ls = lane == 0 ? stream : (lane == 1 ? impl->side : impl->lane_stream[lane]);
         PtParams LP = P;

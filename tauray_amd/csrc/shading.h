@@ -495,6 +495,7 @@ struct LaunchCtx {
     int strategy;
     uint index, count, primary;   // count = b (strip bits) for shuffled strips, as uploaded by rt_camera_stage.cc:86-87
     uint launch_w, launch_h;      // gl_LaunchSizeEXT.xy
+    uint tile_lanes, tiles_per_lane;   // > 1: lane l's contiguous id range covers the tiles l, l + lanes, l + 2 lanes, ... of the image
 };
 // Path id -> launch coordinate.  Path ids walk the launch grid in 8x8 tiles (when the width divides by 8) instead of
 // rows, so the 64 rays of a wave start from an 8x8 pixel block: more coherent traversal and texture access on every
@@ -504,7 +505,12 @@ TR_DEV void launch_coord(const LaunchCtx& L, uint i, uint& lx, uint& ly, uint& l
     lz = i / per_layer;
     const uint j = i - lz * per_layer;
     if ((L.launch_w & 7u) == 0u && j < L.launch_w * (L.launch_h & ~7u)) {   // rows past the last full tile row stay row-major
-        const uint tile = j >> 6, k = j & 63u, tiles_x = L.launch_w >> 3;
+        uint tile = j >> 6;
+        const uint k = j & 63u, tiles_x = L.launch_w >> 3;
+        if (L.tile_lanes > 1u) {   // the lanes of a frame (PtStage::render) take interleaved tiles: equal shares of sky, walls and clutter
+            const uint lane = tile / L.tiles_per_lane;
+            tile = (tile - lane * L.tiles_per_lane) * L.tile_lanes + lane;
+        }
         const uint ty = tile / tiles_x, tx = tile - ty * tiles_x;
         lx = (tx << 3) + (k & 7u);
         ly = (ty << 3) + (k >> 3);
