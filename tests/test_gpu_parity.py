@@ -338,6 +338,30 @@ def test_envmap_scene_matches_oracle(R, ctx, oracle):
         assert img[..., :3].mean() > 0.01
 
 
+def test_bench_scene_one_million_triangles(R, ctx, oracle):
+    """BASELINE config 4's scene exactly as bench.py renders it (sponza_teapots: 1 M triangles, glass / metal / diffuse
+    teapots, alpha-tested curtains, sun + emissive quads), at a quarter of the resolution so the oracle finishes in seconds:
+    primary hits bit-equal on the 4-wide PLOC tree vs the oracle's SAH tree, radiance within the fp32 tolerance."""
+    from tauray_amd import scenes
+    W, H = 480, 272
+    scene = scenes.sponza_teapots(width=W, height=H)
+    assert scene.triangle_count > 900_000
+    ss = R.SceneStage(ctx, scene)
+    assert ss.accel["node_count"] == scene.triangle_count - 1
+    osc = oracle.OracleScene(scene)
+    for fid in (5, 9):   # hit distance, (instance, primitive)
+        fs = R.FeatureStage(ctx, ss, fid, _dup((W, H)))
+        buf = ctx.alloc(W * H * 16).zero()
+        fs.run(buf)
+        g, r = buf.download((H, W, 4)), osc.render_feature(fid, W, H)
+        diff = ~((g == r) | (np.isnan(g) & np.isnan(r)))     # misses keep the NaN default value
+        assert not diff.any(), f"feature {fid} on the 1 M triangle scene: {int(diff.any(-1).sum())} pixels differ, max {np.nanmax(np.abs(g - r)):.3e}"
+    kw = dict(max_bounces=4)
+    img = _render_hip(R, ctx, ss, scene, (W, H), **kw)
+    ref = osc.render_pt(oracle.options_for_scene(scene, **kw), W, H)
+    _compare(img, ref, "sponza_teapots 4 bounces")
+
+
 def test_other_projections(R, ctx, test_glb_128, oracle):
     import copy
     from tauray_amd import scene as S
