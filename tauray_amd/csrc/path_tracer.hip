@@ -136,6 +136,79 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One closest-hit ray of queue slot qi (path_tracer.glsl:387-403): trace, store the hit record of the path.
+template <bool COUNT>
+TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, const uint* queue, uint qi, uint n, int* lds_stack,
+                         TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
+    if (qi >= n) return;
+    const uint id = queue ? queue[qi] : qi + P.id_offset;
+    const u4 misc = pb.misc[id];
+    if (misc.w & 1u) return;
+    const f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
+    HitRecord hit;
+    const bool include_lights = !(P.opt.hide_lights && bounce == 0);
+    const uint before = st.nodes;
+    trace_closest_any<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                misc.x, lds_stack, hit, st, overflow);
+    if (COUNT) {
+        const uint vis = st.nodes - before;
+        max_vis = max(max_vis, vis);
+        if (vis > 100000u && vis > atomicMax(&pb.counters[CNT_MAXVIS], vis)) {   // debugging aid: remember a pathological ray
+            float* dbg = reinterpret_cast<float*>(pb.counters + CNT_DBG);
+            dbg[0] = o.x; dbg[1] = o.y; dbg[2] = o.z; dbg[3] = d.x; dbg[4] = d.y; dbg[5] = d.z; dbg[6] = (float)bounce; dbg[7] = (float)id;
+            dbg[8] = o.w; dbg[9] = d.w;
+        }
+    }
+    pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+    rays++;
+}
+
+// One shadow ray of the bounce's shadow queue: contrib *= shadow_ray(...) (path_tracer.glsl:35-52, 462-463) and
+// add_demodulated_color of the result.
+template <bool COUNT>
+TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, TraceStats& st, int& overflow,
+                        uint& rays) {
+    if (qi >= n) return;
+    const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
+    float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow);
+    const uint id = __float_as_uint(d.w);
+    if (vis != 0.0f) {
+        // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
+        float m = c.w * vis;
+        if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
+        const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
+        const f2 w = pb.sh_lobes[qi];
+        // add_demodulated_color; a zero weight adds exactly nothing, so that target is left alone
+        if (w.x != 0.0f) { f4 d4 = pb.diffuse[id]; d4.x += radiance.x * w.x; d4.y += radiance.y * w.x; d4.z += radiance.z * w.x; pb.diffuse[id] = d4; }
+        if (w.y != 0.0f) { f4 r4 = pb.reflection[id]; r4.x += radiance.x * w.y; r4.y += radiance.y * w.y; r4.z += radiance.z * w.y; pb.reflection[id] = r4; }
+    }
+    rays++;
+}
+
+template <bool COUNT>
+TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int overflow, int overflow_tag, uint closest_rays, uint shadow_rays,
+                                 TraceStats st, uint max_vis) {
+    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = (uint)overflow_tag; }
+    if (!P.count_work) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        closest_rays += __shfl_xor(closest_rays, off); shadow_rays += __shfl_xor(shadow_rays, off);
+        if (COUNT) {
+            st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off);
+            st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        add64(pb.counters, CNT_CLOSEST, closest_rays);
+        add64(pb.counters, CNT_SHADOWRAYS, shadow_rays);
+        if (COUNT) {
+            add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha);
+            atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis);
+        }
+    }
+}
+
+// Persistent waves: each wave takes its first 64 rays by wave id (no atomic: avoids a burst of ~7000 dequeues on one word
+// at kernel start) and later chunks from a device-side cursor, which starts past the statically assigned range.
 // SOLO only names the instance launched while detailed timing serialises the frame, so that a profiler lists the
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
 template <bool COUNT, bool SOLO>
@@ -146,9 +219,6 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0, max_vis = 0;
     int overflow = 0;
-    // persistent waves: each wave pulls the next 64 rays from a device-side cursor until the queue is drained
-    // first chunk by wave id (no atomic: avoids a burst of ~7000 dequeues on one word at kernel start), later
-    // chunks from the shared cursor, which starts past the statically assigned range
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
     bool first = true;
     while (true) {
@@ -160,44 +230,9 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         }
         first = false;
         if (base >= n) break;
-        uint qi = base + (threadIdx.x & 63);
-        if (qi >= n) continue;
-        uint id = queue ? queue[qi] : qi + P.id_offset;
-        u4 misc = pb.misc[id];
-        if (misc.w & 1u) continue;
-        f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
-        HitRecord hit;
-        bool include_lights = !(P.opt.hide_lights && bounce == 0);
-        uint before = st.nodes;
-        trace_closest_any<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                misc.x, s_stack + threadIdx.x, hit, st, overflow);
-        if (COUNT) {
-            uint vis = st.nodes - before;
-            max_vis = max(max_vis, vis);
-            if (vis > 100000u && vis > atomicMax(&pb.counters[CNT_MAXVIS], vis)) {   // debugging aid: remember a pathological ray
-                float* dbg = reinterpret_cast<float*>(pb.counters + CNT_DBG);
-                dbg[0] = o.x; dbg[1] = o.y; dbg[2] = o.z; dbg[3] = d.x; dbg[4] = d.y; dbg[5] = d.z; dbg[6] = (float)bounce; dbg[7] = (float)id;
-                dbg[8] = o.w; dbg[9] = d.w;
-            }
-        }
-        pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-        rays++;
+        closest_lane<COUNT>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, st, overflow, max_vis, rays);
     }
-    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 1000 + bounce; }
-    if (P.count_work) {
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_xor(rays, off);
-            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
-        }
-        if (COUNT) {
-            for (int off = 32; off > 0; off >>= 1) { st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off)); }
-            if ((threadIdx.x & 63) == 0) { atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis); }
-        }
-        if ((threadIdx.x & 63) == 0) {
-            add64(pb.counters, CNT_CLOSEST, rays);
-            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
-        }
-    }
+    flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
 }
 
 template <bool COUNT>
@@ -207,8 +242,6 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
-    // first chunk by wave id (no atomic: avoids a burst of ~7000 dequeues on one word at kernel start), later
-    // chunks from the shared cursor, which starts past the statically assigned range
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
     bool first = true;
     while (true) {
@@ -220,34 +253,38 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
         }
         first = false;
         if (base >= n) break;
-        uint qi = base + (threadIdx.x & 63);
-        if (qi >= n) continue;
-        f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
-        float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
-        uint id = __float_as_uint(d.w);
-        if (vis != 0.0f) {
-            // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
-            float m = c.w * vis;
-            if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
-            const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
-            const f2 w = pb.sh_lobes[qi];
-            // add_demodulated_color; a zero weight adds exactly nothing, so that target is left alone
-            if (w.x != 0.0f) { f4 d4 = pb.diffuse[id]; d4.x += radiance.x * w.x; d4.y += radiance.y * w.x; d4.z += radiance.z * w.x; pb.diffuse[id] = d4; }
-            if (w.y != 0.0f) { f4 r4 = pb.reflection[id]; r4.x += radiance.x * w.y; r4.y += radiance.y * w.y; r4.z += radiance.z * w.y; pb.reflection[id] = r4; }
-        }
-        rays++;
+        shadow_lane<COUNT>(sv, P, pb, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, st, overflow, rays);
     }
-    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = 2000; }
-    if (P.count_work) {
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_xor(rays, off);
-            if (COUNT) { st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off); }
+    flush_trace_counters<COUNT>(P, pb, overflow, 2000, 0u, rays, st, 0u);
+}
+
+// Closest-hit rays of bounce b and the shadow rays of bounce b - 1 in one launch.  The two are independent (different
+// state arrays), and in the lane schedule a launch lasts as long as its slowest wave: one launch with one tail instead of
+// two launches with two.  Chunk g of the launch is a closest-hit chunk while g < chunks_c (the longer rays go first), a
+// shadow chunk afterwards.
+__global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+                                                                      uint* bc, uint* bc_prev) {
+    __shared__ int s_stack[TR_STACK_WORDS];
+    const uint nc = bc[0], ns = bc_prev[1];
+    const uint chunks_c = (nc + 63u) >> 6, total = chunks_c + ((ns + 63u) >> 6);
+    TraceStats st = {0, 0, 0, 0};
+    uint closest_rays = 0, shadow_rays = 0, max_vis = 0;
+    int overflow = 0;
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    bool first = true;
+    while (true) {
+        uint g = 0;
+        if (first) g = wave_id;
+        else {
+            if ((threadIdx.x & 63) == 0) g = n_waves + atomicAdd(&bc[2], 1u);
+            g = __shfl(g, 0);
         }
-        if ((threadIdx.x & 63) == 0) {
-            add64(pb.counters, CNT_SHADOWRAYS, rays);
-            if (COUNT) { add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha); }
-        }
+        first = false;
+        if (g >= total) break;
+        if (g < chunks_c) closest_lane<false>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, st, overflow, max_vis, closest_rays);
+        else shadow_lane<false>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, st, overflow, shadow_rays);
     }
+    flush_trace_counters<false>(P, pb, overflow, 3000 + bounce, closest_rays, shadow_rays, st, max_vis);
 }
 
 
@@ -822,7 +859,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // on four; 2 M paths 3.87 ms vs 3.10 ms).
     static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)1500000;
     const int n_lanes = (timing || n < lanes_min_paths) ? 1 : std::max(1, std::min(lanes_env, PT_LANES));
-    const bool overlap = overlap_enabled && !timing && n_lanes == 1;
+    // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
+    static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
+    const bool fused = fused_enabled && !timing && !count;
+    const bool overlap = overlap_enabled && !timing && !fused && n_lanes == 1;
     if ((overlap || n_lanes > 1) && !impl->side) {
         HIPCHK(hipStreamCreateWithFlags(&impl->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
@@ -884,16 +924,22 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                 for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                     const uint* q = bounce == 0 ? nullptr : lb.queue[bounce & 1];
                     uint* qn = lb.queue[(bounce + 1) & 1];
-                    timed(T_CLOSEST, ls, [&] {
-                        auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
-                        hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce);
-                    });
+                    uint* bc = lb.bounce + 4 * bounce;
+                    if (fused && bounce > 0) {
+                        // closest(b) together with shadow(b - 1): one launch, one tail
+                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - 4);
+                    } else {
+                        timed(T_CLOSEST, ls, [&] {
+                            auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
+                            hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
+                        });
+                    }
                     if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
                     timed(T_SHADE, ls, [&] {
-                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce, qn);
-                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, lb.bounce + 4 * bounce, qn);
+                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
-                    if (bounce < opt.max_bounces - 1) {
+                    if (bounce < opt.max_bounces - 1 && !fused) {
                         hipStream_t ss = ls;
                         if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
                             HIPCHK(hipEventRecord(impl->ev_fork, ls));
@@ -902,7 +948,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         }
                         timed(T_SHADOW, ss, [&] {
                             auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
-                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb, lb.bounce + 4 * bounce);
+                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb, bc);
                         });
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                     }
