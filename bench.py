@@ -127,6 +127,19 @@ def main():
         "msample_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
     }
 
+    # ---- frame latency distribution (mean and p50): the same frames again with a host sync after each one,
+    # so unlike `ms_per_step` (back-to-back frames, the metric) this includes the enqueue latency of every frame
+    if world == 1:
+        lat = []
+        for _ in range(min(args.steps, 50)):
+            t1 = time.perf_counter()
+            run_frames(1)
+            ctx.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        result["frame_latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "mean": round(sum(lat) / len(lat), 4), "min": round(lat[0], 4),
+                                      "frames": len(lat), "note": "host sync after every frame"}
+
     # ---- roofline of the dominant kernel (k_trace_closest), rank 0
     if rank == 0 and not args.no_roofline:
         # re-run of the identical frames (same frame indices) with per-kernel HIP events; detailed timing serialises the
