@@ -12,9 +12,9 @@ for W in $WORKLOADS; do
   O=$R/gpurun_out/prof_$TAG/$W; mkdir -p $O
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- \
       python $R/bench.py --steps 20 --warmup 3 --workload $W --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || echo "stats pass failed ($W)"
-  # counter passes: one lane, so that a launch is a whole queue like the launch the roofline refers to (the profiler
-  # serialises kernels under --pmc anyway)
-  B="env TRHIP_LANES=1 python $R/bench.py --steps 5 --warmup 1 --workload $W --no-cpu-baseline --no-roofline"
+  # counter passes: one lane and unfused launches, so that a k_trace_closest launch is a whole queue of one bounce like
+  # the launch the roofline refers to (the profiler serialises kernels under --pmc anyway)
+  B="env TRHIP_LANES=1 TRHIP_FUSED=0 python $R/bench.py --steps 5 --warmup 1 --workload $W --no-cpu-baseline --no-roofline"
   run() { name=$1; shift; timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o t -- $B > $O/$name.log 2>&1 || echo "pass $name failed ($W)"; }
   run fetch FETCH_SIZE
   run write WRITE_SIZE
