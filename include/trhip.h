@@ -83,6 +83,11 @@ int trhip_scene_set_previous_cameras(trhip_device* dev, const void* camera_data,
  * scene, same count and meshes (what scene_stage::update rewrites per frame, src/scene_stage.cc:1066-1116).  The
  * acceleration structure is invalidated: call trhip_scene_build_accel again (full rebuild on the device). */
 int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint32_t count);
+/* After trhip_scene_update_instances: keeps the topology of the last build and recomputes the world triangles, every
+ * child box (level by level, bottom-up) and the tri lights - an acceleration-structure *update* instead of a build
+ * (src/acceleration_structure.cc:376-422).  Results are identical to a rebuild; traversal gets slower as the
+ * transforms drift from the ones the tree was built for. */
+int trhip_scene_refit_accel(trhip_device* dev, trhip_accel_info* out);
 /* Replaces vkCmdBuildAccelerationStructuresKHR (src/acceleration_structure.cc:198,266,421) with an
  * on-device build (pre-transform -> bounds -> Morton -> radix sort -> PLOC clustering -> 4-wide collapse) and
  * runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).  Synchronous. */

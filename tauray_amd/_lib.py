@@ -88,6 +88,7 @@ SYMBOLS = {
     "trhip_scene_set_previous_cameras": (_i, [_vp, _vp, _u32]),
     "trhip_scene_update_instances": (_i, [_vp, _vp, _u32]),
     "trhip_scene_build_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
+    "trhip_scene_refit_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
     "trhip_scene_get_tri_lights": (_i, [_vp, _vp, _u32]),
     "trhip_pt_create": (_i, [_vp, C.POINTER(PtOptionsC), C.POINTER(_vp)]),
     "trhip_pt_destroy": (None, [_vp]),

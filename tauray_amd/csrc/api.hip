@@ -331,6 +331,10 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
 }
+int trhip_scene_refit_accel(trhip_device* dev, trhip_accel_info* out) {
+    DEVCHK(dev);
+    return refit_accel(dev->scene, nullptr, out);
+}
 
 int trhip_scene_get_tri_lights(trhip_device* dev, void* out_host, uint32_t max_count) {
     DEVCHK(dev);

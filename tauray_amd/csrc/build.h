@@ -49,6 +49,12 @@ struct DeviceScene {
     bool accel_built = false;
     uint accel_capacity = 0xFFFFFFFFu;   // triangle count the output buffers were allocated for
     void* scratch = nullptr;             // build temporaries, kept between builds
+    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};   // centroid bounds of the last build
+    // refit support (built on the first trhip_scene_refit_accel after a build): live 4-wide nodes in breadth-first order
+    uint* level_nodes = nullptr;
+    float* node_bounds = nullptr;        // 6 floats per node: union of its child boxes
+    std::vector<uint> level_offsets;     // level l = level_nodes[level_offsets[l] .. level_offsets[l + 1])
+    bool levels_valid = false;
     size_t scratch_bytes = 0;
 
     SceneView view() const {
@@ -70,6 +76,9 @@ struct DeviceScene {
         if (tri_lights) (void)hipFree(tri_lights);
         nodes = nullptr; nodes4 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;
         accel_capacity = 0xFFFFFFFFu;
+        if (level_nodes) (void)hipFree(level_nodes);
+        if (node_bounds) (void)hipFree(node_bounds);
+        level_nodes = nullptr; node_bounds = nullptr; level_offsets.clear(); levels_valid = false;
     }
     void free_all() {
         free_accel();
@@ -81,6 +90,7 @@ struct DeviceScene {
 };
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);
-int ensure_world_vertices(DeviceScene& ds, hipStream_t stream);   // pre_transform.comp per instance
+int ensure_world_vertices(DeviceScene& ds, hipStream_t stream);
+int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);   // same tree, new boxes (after trhip_scene_update_instances)   // pre_transform.comp per instance
 
 }  // namespace tr

@@ -419,12 +419,130 @@ int ensure_world_vertices(DeviceScene& ds, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Refit: the instance transforms changed, the tree keeps its topology (what a BLAS/TLAS *update* does in the reference,
+// src/acceleration_structure.cc:376-422).  World triangles are recomputed in place, then the child boxes of the live
+// nodes are rebuilt level by level from the deepest level up.
+__global__ __launch_bounds__(BT) void k_retransform(SceneView sv, uint n, TriRecord* tris) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n) return;
+    TriRecord t = tris[i];
+    const uint inst = t.inst_flags & 0x7FFFFFFFu;
+    const MeshSpan sp = sv.obj_spans[inst];
+    const uint* ix = sv.indices + sp.index_offset + 3u * t.prim;
+    const Vertex* vb = sv.obj_vertices + sp.vertex_offset;
+    const m4 model = sv.instances[inst].model;
+    const f3 p0 = transform_point(model, vb[ix[0]].pos), p1 = transform_point(model, vb[ix[1]].pos), p2 = transform_point(model, vb[ix[2]].pos);
+    t.v0[0] = p0.x; t.v0[1] = p0.y; t.v0[2] = p0.z;
+    t.v1[0] = p1.x; t.v1[1] = p1.y; t.v1[2] = p1.z;
+    t.v2[0] = p2.x; t.v2[1] = p2.y; t.v2[2] = p2.z;
+    tris[i] = t;
+}
+
+// breadth-first expansion of one level of live nodes (run once per build, on the first refit)
+__global__ __launch_bounds__(BT) void k_expand_level(uint count, const uint* level, const Bvh4Node* nodes4, uint* next, uint* next_count) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= count) return;
+    const Bvh4Node& nd = nodes4[level[i]];
+    for (int c = 0; c < 4; ++c) {
+        const int ch = nd.child[c];
+        if (ch >= 0 && ch != 0x7FFFFFFF) next[atomicAdd(next_count, 1u)] = (uint)ch;
+    }
+}
+
+__global__ __launch_bounds__(BT) void k_refit_level(uint count, const uint* level, Bvh4Node* nodes4, const TriRecord* tris, float* node_bounds) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= count) return;
+    const uint id = level[i];
+    Bvh4Node nd = nodes4[id];
+    float lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    for (int c = 0; c < 4; ++c) {
+        const int ch = nd.child[c];
+        if (ch == 0x7FFFFFFF) continue;
+        float blo[3], bhi[3];
+        if (ch < 0) {
+            const TriRecord& t = tris[~ch];
+            for (int k = 0; k < 3; ++k) { blo[k] = fminf(fminf(t.v0[k], t.v1[k]), t.v2[k]); bhi[k] = fmaxf(fmaxf(t.v0[k], t.v1[k]), t.v2[k]); }
+        } else {
+            for (int k = 0; k < 3; ++k) { blo[k] = node_bounds[6 * (size_t)ch + k]; bhi[k] = node_bounds[6 * (size_t)ch + 3 + k]; }
+        }
+        nd.lox[c] = blo[0]; nd.loy[c] = blo[1]; nd.loz[c] = blo[2]; nd.hix[c] = bhi[0]; nd.hiy[c] = bhi[1]; nd.hiz[c] = bhi[2];
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], blo[k]); hi[k] = fmaxf(hi[k], bhi[k]); }
+    }
+    nodes4[id] = nd;
+    for (int k = 0; k < 3; ++k) { node_bounds[6 * (size_t)id + k] = lo[k]; node_bounds[6 * (size_t)id + 3 + k] = hi[k]; }
+}
+
+int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
+#if !TR_BVH4
+    return set_error("trhip_scene_refit_accel: this build traverses the binary tree; rebuild instead");
+#else
+    const uint n = ds.tri_count;
+    if (!ds.tris || ds.accel_capacity != n || (n > 1 && !ds.nodes4)) return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, stream));
+    SceneView sv = ds.view();
+    const uint n1 = ds.node_count;
+    if (n1 > 0 && !ds.levels_valid) {   // once per build: live nodes by level
+        if (!ds.level_nodes) HIPCHK(hipMalloc(&ds.level_nodes, (size_t)n1 * 4));
+        if (!ds.node_bounds) HIPCHK(hipMalloc(&ds.node_bounds, (size_t)n1 * 24));
+        uint* counter = nullptr;
+        HIPCHK(hipMalloc(&counter, 4));
+        const uint root = 0;
+        HIPCHK(hipMemcpyAsync(ds.level_nodes, &root, 4, hipMemcpyHostToDevice, stream));
+        ds.level_offsets.assign(1, 0u);
+        uint begin = 0, count = 1;
+        while (count > 0) {
+            ds.level_offsets.push_back(begin + count);
+            if (begin + count >= n1) break;   // all node slots used: nothing can follow
+            HIPCHK(hipMemsetAsync(counter, 0, 4, stream));
+            hipLaunchKernelGGL(k_expand_level, dim3((count + BT - 1) / BT), dim3(BT), 0, stream, count, ds.level_nodes + begin, ds.nodes4,
+                               ds.level_nodes + begin + count, counter);
+            uint next = 0;
+            HIPCHK(hipMemcpyAsync(&next, counter, 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            begin += count; count = next;
+            if (ds.level_offsets.size() > 4096) { (void)hipFree(counter); return set_error("trhip_scene_refit_accel: hierarchy too deep"); }
+        }
+        (void)hipFree(counter);
+        ds.levels_valid = true;
+    }
+    if (n > 0) hipLaunchKernelGGL(k_retransform, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv, n, ds.tris);
+    for (size_t l = ds.level_offsets.size(); l-- > 1;) {
+        const uint lo = ds.level_offsets[l - 1], cnt = ds.level_offsets[l] - lo;
+        if (cnt) hipLaunchKernelGGL(k_refit_level, dim3((cnt + BT - 1) / BT), dim3(BT), 0, stream, cnt, ds.level_nodes + lo, ds.nodes4, ds.tris, ds.node_bounds);
+    }
+    HIPCHK(hipGetLastError());
+    ds.accel_built = true;
+    if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0 && ds.tri_lights) {
+        HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
+        SceneView sv2 = ds.view();
+        hipLaunchKernelGGL(k_extract_tri_lights, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
+    }
+    HIPCHK(hipEventRecord(e1, stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->triangle_count = n; info->node_count = ds.node_count; info->node_bytes = 112u; info->tri_light_count = ds.tri_light_count;
+        info->build_ms = ms;
+        for (int k = 0; k < 3; ++k) { info->bounds_min[k] = ds.bounds_lo[k]; info->bounds_max[k] = ds.bounds_hi[k]; }
+    }
+    return 0;
+#endif
+}
+
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     const uint n = ds.tri_count;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));
     ds.accel_built = false;
+    ds.levels_valid = false;   // a new tree: the refit level lists are rebuilt on demand
     SceneView sv = ds.view();
     sv.tri_count = n;
     // Temporaries come out of one scratch arena that survives the call, and the outputs keep their allocation while the
@@ -560,6 +678,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     uint hb[6];
     HIPCHK(hipMemcpy(hb, cbounds, sizeof(hb), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) { ds.bounds_lo[k] = float_unflip(hb[k]); ds.bounds_hi[k] = float_unflip(hb[3 + k]); }
     if (info) {
         info->triangle_count = n;
         info->node_count = ds.node_count;

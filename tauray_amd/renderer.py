@@ -202,13 +202,17 @@ class SceneStage:
         data = np.concatenate([c.pack() for c in cameras])
         check(_lib.lib().trhip_scene_set_previous_cameras(self.ctx.h, data.ctypes.data, len(data)))
 
-    def update_instances(self, instances: np.ndarray):
+    def update_instances(self, instances: np.ndarray, refit: bool = False):
         """Dynamic scenes: new instance records (transforms / materials) for the same meshes, then a full rebuild of the
-        acceleration structure on the device (what scene_stage::update + the TLAS rebuild do per frame)."""
+        acceleration structure on the device (what scene_stage::update + the TLAS rebuild do per frame) or, with
+        `refit`, an update that keeps the tree and recomputes its boxes."""
         inst = np.ascontiguousarray(instances)
         check(_lib.lib().trhip_scene_update_instances(self.ctx.h, inst.ctypes.data, len(inst)))
         info = AccelInfoC()
-        check(_lib.lib().trhip_scene_build_accel(self.ctx.h, C.byref(info)))
+        if refit:
+            check(_lib.lib().trhip_scene_refit_accel(self.ctx.h, C.byref(info)))
+        else:
+            check(_lib.lib().trhip_scene_build_accel(self.ctx.h, C.byref(info)))
         self.accel.update(node_count=info.node_count, build_ms=info.build_ms, tri_light_count=info.tri_light_count,
                           bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
         return self.accel

@@ -535,6 +535,25 @@ def test_dynamic_scene_rebuild_and_motion(R, ctx, oracle):
     ref = osc.render_pt_targets(oracle.options_for_scene(scene, max_bounces=2), 128, 128, ["color", "screen_motion", "instance_id"])
     assert np.array_equal(got["instance_id"], ref["instance_id"])
     assert float(np.abs(got["screen_motion"] - ref["screen_motion"]).max()) <= 1e-5
+    # frame 2: everything moves again, this time the tree is kept and refitted (an acceleration-structure update)
+    for inst, (dx, ang) in ((4, (-0.5, -0.7)), (5, (0.3, 0.5)), (6, (0.0, 1.0))):
+        old = from_glm(scene.instances["model"][inst])
+        c, s_ = np.cos(ang), np.sin(ang)
+        move = np.array([[c, -s_, 0, dx], [s_, c, 0, -0.05], [0, 0, 1, 0.15], [0, 0, 0, 1.0]])
+        new = move @ old
+        scene.instances["model_prev"][inst] = to_glm(old)
+        scene.instances["model"][inst] = to_glm(new)
+        scene.instances["model_normal"][inst] = to_glm(np.linalg.inv(new).T)
+    info = ss.update_instances(scene.instances, refit=True)
+    assert info["build_ms"] > 0
+    osc2 = oracle.OracleScene(scene)
+    for fid in (5, 3, 9):
+        assert np.array_equal(feature(fid, ss), osc2.render_feature(fid, 128, 128)), f"feature {fid} after refit"
+    assert np.array_equal(ss.tri_lights().view(np.uint8), osc2.tri_lights().view(np.uint8)), "tri lights after refit"
+    refit_img = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)
+    _compare(refit_img, osc2.render_pt(oracle.options_for_scene(scene, max_bounces=3), 128, 128), "after refit")
+    ss.update_instances(scene.instances)          # a rebuild gives the same frame, bit for bit
+    assert np.array_equal(refit_img, _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)), "refit vs rebuild"
     # the API refuses a different instance count, and rendering before the rebuild
     with pytest.raises(R.TrhipError):
         R._lib.check(R._lib.lib().trhip_scene_update_instances(ctx.h, scene.instances.ctypes.data, len(scene.instances) - 1))
