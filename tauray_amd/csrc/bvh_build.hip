@@ -479,7 +479,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     return set_error("trhip_scene_refit_accel: this build traverses the binary tree; rebuild instead");
 #else
     const uint n = ds.tri_count;
-    if (!ds.tris || ds.accel_capacity != n || (n > 1 && !ds.nodes4)) return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
+    if (ds.accel_capacity != n || (n > 0 && !ds.tris) || (n > 1 && !ds.nodes4)) return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));

@@ -408,6 +408,9 @@ def test_edge_scenes(R, ctx, oracle):
         img = _render_hip(R, ctx, ss, sc, (64, 64), max_bounces=3)
         ref = oracle.OracleScene(sc).render_pt(oracle.options_for_scene(sc, max_bounces=3), 64, 64)
         _compare(img, ref, what)
+        # the in-place update of the acceleration structure copes with the same corner cases (no nodes, one leaf)
+        ss.update_instances(sc.instances, refit=True)
+        assert np.array_equal(_render_hip(R, ctx, ss, sc, (64, 64), max_bounces=3), img), f"{what}: refit changed the frame"
     assert ss.accel["triangle_count"] == 2
 
 
