@@ -53,11 +53,11 @@ struct PathBuffers {
     // per lane, four words per bounce b: [4b] live paths entering b, [4b+1] shadow rays of b, [4b+2] / [4b+3] work cursors of
     // the closest-hit / shadow kernel of b.  Zeroed by k_raygen; nothing has to be rotated between bounces.
     uint* bounce;
-    uint* counters;   // [0] next-queue count, [1] shadow count, [2] overflow flag, [4..] work counters
+    uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
 
-enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_OVERFLOW = 2, CNT_CUR = 3,
-       CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17, CNT_MAXSP = 30, CNT_WORK_CLOSEST = 31, CNT_WORK_SHADOW = 32, CNT_SHADOW_ODD = 33, CNT_WORDS = 34 };
+enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
+       CNT_MAXSP = 30, CNT_WORDS = 34 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
 
 struct PtParams {
     trhip_pt_options opt;
