@@ -66,6 +66,14 @@ int main(int argc, char** argv)
                 std::string v = val("--filetype=");
                 hopt.output_file_type = v == "raw" ? headless::RAW : (v == "none" ? headless::EMPTY : headless::EXR);
             }
+            else if(starts(a, "--compression="))
+            {
+                static const std::map<std::string, tr::headless::compression_type> comps = {
+                    {"none", tr::headless::NONE}, {"rle", tr::headless::RLE}, {"zips", tr::headless::ZIPS}, {"zip", tr::headless::ZIP}, {"piz", tr::headless::PIZ}};
+                auto it = comps.find(val("--compression="));
+                if(it == comps.end()) throw std::runtime_error("unknown compression " + val("--compression="));
+                hopt.output_compression = it->second;
+            }
             else if(starts(a, "--format="))
             {
                 std::string v = val("--format=");
