@@ -1,10 +1,10 @@
-// On-device LBVH build: the software replacement for the driver's BLAS/TLAS build
-// (reference call sites src/acceleration_structure.cc:198,266,421; recorded by
-// src/scene_stage.cc:1620-1662).  Pipeline:
-//   pre-transform (shader/pre_transform.comp:26-42, positions only) -> centroid bounds ->
-//   63-bit Morton keys -> radix sort (rocPRIM) -> Karras 2012 hierarchy -> atomic bottom-up refit ->
-//   64-byte BVH2 nodes + 48-byte triangle records in Morton order.
-// Also runs extract_tri_lights (shader/extract_tri_lights.comp:17-54).
+// On-device acceleration-structure build: the software replacement for the driver's BLAS/TLAS build
+// (reference call sites src/acceleration_structure.cc:198,266,421; recorded by src/scene_stage.cc:1620-1662).
+//   world triangles (model * vec4(pos, 1), GLSL order) + centroid bounds -> 63-bit Morton keys -> radix sort (rocPRIM)
+//   -> PLOC clustering over the Morton order (or Karras 2012 LBVH + atomic refit, TRHIP_BUILDER=lbvh)
+//   -> depth-first relabelling -> in-place collapse to 4-wide fp32 nodes (128 B) + 48-byte triangle records.
+// trhip_scene_refit_accel keeps the tree and recomputes its boxes level by level.  Also here: extract_tri_lights
+// (shader/extract_tri_lights.comp:17-54) and the pre-transformed vertex copy (shader/pre_transform.comp:26-42).
 #include "build.h"
 
 #include <rocprim/rocprim.hpp>

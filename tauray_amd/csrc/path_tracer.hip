@@ -2,11 +2,11 @@
 // dispatch (src/path_tracer_stage.cc:118-147 -> shader/path_tracer.rgen + hit/miss shader table).
 //
 // One vkCmdTraceRaysKHR pass becomes, per sample:
-//   k_raygen -> for bounce in 0..MAX_BOUNCES-1: k_trace_closest -> k_shade -> k_trace_shadow
-// and k_resolve at the end of the pass.  Path state lives in HBM as float4/uint4 SoA streams; live paths
-// are compacted with wave ballots into id queues between bounces so later bounces launch dense waves.
-// Kernel launches are sized for the worst case and read the live count from device memory: there is no
-// host round trip inside a frame.
+//   k_raygen -> k_trace_closest(0) -> k_shade(0) -> [k_trace_fused(b): closest(b) + shadow(b - 1)] -> k_shade(b) ... -> k_resolve
+// Path state lives in HBM as float4/uint4 SoA streams; live paths are compacted with wave ballots into id queues
+// between bounces so later bounces launch dense waves.  Launches are sized for the worst case and read the live
+// counts from device memory: there is no host round trip inside a frame.  A frame is cut into four lanes (slices of
+// the path ids with their own queues) that run this loop concurrently on their own streams (PtStage::render).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -850,7 +850,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     //  * lanes (default, four = the HIP runtime's hardware queues): the path ids are cut into slices with their own
     //    queues and counters, and every slice runs its whole bounce loop on its own stream, so one slice's shade overlaps
     //    another's traversal;
-    //  * TRHIP_LANES=1: one lane, shadow(b) on a side stream overlapping closest(b+1).
+    //  * TRHIP_LANES=1: one lane; shadow(b) shares the launch of closest(b + 1) (k_trace_fused), or - TRHIP_FUSED=0 - runs
+    //    on a side stream next to it.
     // Per-kernel timing (trhip_pt_set_profiling) wants kernels that own the chip: one lane, one stream.
     static const int lanes_env = getenv("TRHIP_LANES") ? atoi(getenv("TRHIP_LANES")) : PT_LANES;
     static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);

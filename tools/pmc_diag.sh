@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_diag.sh <workload> <tag>   (env TRHIP_BVH_WIDTH etc. inherited) -- run on the GPU box
+# usage: tools/pmc_diag.sh <workload> <tag>   (env switches such as TRHIP_LANES / TRHIP_FUSED / TRHIP_BUILDER are inherited) -- run on the GPU box
 # every pass is wrapped in `timeout`: a rejected counter set makes rocprofv3 hang after its abort.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_$2; mkdir -p $O
