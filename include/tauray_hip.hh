@@ -282,7 +282,7 @@ public:
         tri_light_sampling_mode tri_light_mode = tri_light_sampling_mode::SOLID_ANGLE;
     };
 
-    path_tracer_stage(device& dev, scene_stage& ss, void* color_target, const options& opt)
+    path_tracer_stage(device& dev, scene_stage& ss, void* color_target, const options& opt, bool direct_only = false)
     : dev(&dev), ss(&ss), color(color_target), opt(opt)
     {
         trhip_pt_options o = {};
@@ -297,7 +297,7 @@ public:
         o.use_white_albedo_on_first_bounce = opt.use_white_albedo_on_first_bounce;
         o.transparent_background = opt.transparent_background;
         o.pre_transformed_vertices = opt.pre_transformed_vertices;
-        check(trhip_pt_create(dev.h, &o, &pt));
+        check(direct_only ? trhip_direct_create(dev.h, &o, &pt) : trhip_pt_create(dev.h, &o, &pt));
         reset_distribution_params(opt.distribution);
     }
     path_tracer_stage(const path_tracer_stage&) = delete;
@@ -332,6 +332,15 @@ public:
     void* color;
     options opt;
     trhip_pt* pt = nullptr;
+};
+
+// direct_stage (src/direct_stage.{hh,cc}): first hit + samples_per_pass light samples, same surface as path_tracer_stage.
+// Its reference defaults differ (Blackman-Harris film of radius 1, hybrid tri-light sampling): set them in `options`.
+class direct_stage: public path_tracer_stage
+{
+public:
+    direct_stage(device& dev, scene_stage& ss, void* color_target, const options& opt)
+    : path_tracer_stage(dev, ss, color_target, opt, true) {}
 };
 
 //==============================================================================

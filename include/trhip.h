@@ -142,6 +142,13 @@ typedef struct trhip_timings {        /* hipEvent timers with the reference's st
 } trhip_timings;
 
 int trhip_pt_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out);   /* path_tracer_stage ctor */
+/* direct_stage (src/direct_stage.{hh,cc}, shader/direct.rgen): the first hit of every pixel with sphere lights hidden plus
+ * samples_per_pass light samples from it; no bounces.  Same handle type and the same calls as the path tracer (set
+ * distribution, render, render_targets, counters, timings).  Of the options it reads the sampler, sample counts, film,
+ * projection, light-sampling weights, bounce and tri-light modes, min_ray_dist and transparent_background; MIS, clamping,
+ * regularisation and roulette do not apply (the reference sets no such defines for it) and max_bounces only sizes the
+ * Sobol table. */
+int trhip_direct_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out);
 void trhip_pt_destroy(trhip_pt* pt);
 int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist);  /* rt_camera_stage::reset_distribution_params */
 int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /* reset_accumulated_samples / reset_sample_counter */

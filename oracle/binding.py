@@ -78,6 +78,9 @@ def lib():
         L.oracle_scene_get_tri_lights.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_scene_set_previous_cameras.restype = C.c_int
         L.oracle_scene_set_previous_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.oracle_direct_render_targets.restype = C.c_int
+        L.oracle_direct_render_targets.argtypes = [C.c_void_p, C.POINTER(PtOptionsC), C.POINTER(DistributionC), C.c_uint32, C.c_uint32,
+                                                   C.c_uint32, C.POINTER(PtTargetsC), C.c_uint32, C.c_uint32, C.c_int]
         L.oracle_pt_render_targets.restype = C.c_int
         L.oracle_pt_render_targets.argtypes = [C.c_void_p, C.POINTER(PtOptionsC), C.POINTER(DistributionC), C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.POINTER(PtTargetsC), C.c_uint32, C.c_uint32, C.c_int]
@@ -225,8 +228,8 @@ class OracleScene:
             raise RuntimeError("oracle_scene_set_previous_cameras: camera count mismatch")
 
     def render_pt_targets(self, opt: PtOptionsC, width, height, names, dist: DistributionC = None, viewports=1, frame_counter=0,
-                          samples_accumulated=0, targets=None, target_size=None, threads=0):
-        """oracle_pt_render_targets: returns {name: array[viewports, th, tw, channels]} for the requested gbuffer targets."""
+                          samples_accumulated=0, targets=None, target_size=None, threads=0, direct=False):
+        """oracle_pt_render_targets (or, with `direct`, oracle_direct_render_targets = direct_stage): returns {name: array[viewports, th, tw, channels]} for the requested gbuffer targets."""
         if dist is None:
             dist = DistributionC(width, height, 0, 0, 1, 1)
         tw, th = target_size if target_size else (width, height)
@@ -237,10 +240,10 @@ class OracleScene:
             if n not in out:
                 out[n] = np.zeros((viewports, th, tw, ch), dtype=dt)
             setattr(t, n, out[n].ctypes.data)
-        rc = lib().oracle_pt_render_targets(self.h, C.byref(opt), C.byref(dist), viewports, frame_counter, samples_accumulated,
-                                            C.byref(t), tw, th, threads)
+        fn = lib().oracle_direct_render_targets if direct else lib().oracle_pt_render_targets
+        rc = fn(self.h, C.byref(opt), C.byref(dist), viewports, frame_counter, samples_accumulated, C.byref(t), tw, th, threads)
         if rc != 0:
-            raise RuntimeError("oracle_pt_render_targets failed")
+            raise RuntimeError("oracle render_targets failed")
         return out
 
     def render_feature(self, feature, width, height, dist: DistributionC = None, projection=0, viewport=0,

@@ -1691,35 +1691,12 @@ void ensure_world_vertices(oracle_scene& s) {
     }
 }
 
-// path_tracer.rgen:77-127 + write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
-void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
-                   uint target_w, uint target_h) {
+// write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_* (gbuffer.glsl:18-28,68-78,118-128)
+void write_all_outputs(const pt_ctx& c, const launch_ctx& L, ivec3 wp, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
+                       uint target_w, uint target_h, vec3 col, float alpha, vec4 sum_diffuse, vec4 sum_reflection, float diffuse_div, float reflection_div,
+                       const pt_vertex_data& first_hit_vertex, const sampled_material& first_hit_material) {
     const oracle_scene& s = *c.s;
-    ivec2 pixel;
-    ivec3 wp;
-    if (!get_pixel_pos(L, pixel) || !get_write_pixel_pos(L, wp)) return;
-    const camera_data& cam = s.cameras[L.launch_id.z];
-    pt_vertex_data first_hit_vertex{};
-    sampled_material first_hit_material{};
-    vec3 sum_color = V3(0);
-    vec4 sum_diffuse = V4(0), sum_reflection = V4(0);
     const int spp = c.opt.samples_per_pass;
-    for (int i = 0; i < spp; ++i) {
-        local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples + (uint)i},
-                                                    c.sample_counter, c.rng_seed, c.opt.sampler);
-        vec3 origin, dir;
-        get_world_camera_ray(c, L, pixel, cam, lsampler, origin, dir);
-        vec4 diffuse, reflection;
-        evaluate_ray(c, lsampler, origin, dir, diffuse, reflection, first_hit_vertex, first_hit_material);
-        vec4 old_albedo = first_hit_material.albedo;
-        if (c.opt.use_white_albedo_on_first_bounce) { first_hit_material.albedo.x = first_hit_material.albedo.y = first_hit_material.albedo.z = 1; }
-        sum_color += first_hit_material.emission + modulate_color(first_hit_material, V3(diffuse), V3(reflection));
-        sum_diffuse = sum_diffuse + diffuse;
-        sum_reflection = sum_reflection + reflection;
-        first_hit_material.albedo = old_albedo;
-    }
-    vec3 col = sum_color / (float)spp;
-    const float alpha = c.opt.transparent_background ? first_hit_material.albedo.w : 1.0f;
     if ((uint)wp.x >= target_w || (uint)wp.y >= target_h) return;
     const size_t pix = ((size_t)wp.z * target_h + wp.y) * target_w + wp.x;
     const uint prev_samples = samples_accumulated + previous_samples;
@@ -1755,8 +1732,88 @@ void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, 
         px[0] = value.x; px[1] = value.y; px[2] = value.z; px[3] = value.w;
     };
     accumulate(T.color, V4(col, alpha));
-    accumulate(T.diffuse, sum_diffuse / (float)spp);
-    accumulate(T.reflection, sum_reflection / (float)spp);
+    accumulate(T.diffuse, sum_diffuse / diffuse_div);
+    accumulate(T.reflection, sum_reflection / reflection_div);
+}
+
+// path_tracer.rgen:77-127 + write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_color (gbuffer.glsl:18-28)
+void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
+                   uint target_w, uint target_h) {
+    const oracle_scene& s = *c.s;
+    ivec2 pixel;
+    ivec3 wp;
+    if (!get_pixel_pos(L, pixel) || !get_write_pixel_pos(L, wp)) return;
+    const camera_data& cam = s.cameras[L.launch_id.z];
+    pt_vertex_data first_hit_vertex{};
+    sampled_material first_hit_material{};
+    vec3 sum_color = V3(0);
+    vec4 sum_diffuse = V4(0), sum_reflection = V4(0);
+    const int spp = c.opt.samples_per_pass;
+    for (int i = 0; i < spp; ++i) {
+        local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples + (uint)i},
+                                                    c.sample_counter, c.rng_seed, c.opt.sampler);
+        vec3 origin, dir;
+        get_world_camera_ray(c, L, pixel, cam, lsampler, origin, dir);
+        vec4 diffuse, reflection;
+        evaluate_ray(c, lsampler, origin, dir, diffuse, reflection, first_hit_vertex, first_hit_material);
+        vec4 old_albedo = first_hit_material.albedo;
+        if (c.opt.use_white_albedo_on_first_bounce) { first_hit_material.albedo.x = first_hit_material.albedo.y = first_hit_material.albedo.z = 1; }
+        sum_color += first_hit_material.emission + modulate_color(first_hit_material, V3(diffuse), V3(reflection));
+        sum_diffuse = sum_diffuse + diffuse;
+        sum_reflection = sum_reflection + reflection;
+        first_hit_material.albedo = old_albedo;
+    }
+    vec3 col = sum_color / (float)spp;
+    const float alpha = c.opt.transparent_background ? first_hit_material.albedo.w : 1.0f;
+    write_all_outputs(c, L, wp, previous_samples, samples_accumulated, T, target_w, target_h, col, alpha, sum_diffuse, sum_reflection, (float)spp, (float)spp,
+                      first_hit_vertex, first_hit_material);
+}
+
+// shader/direct.rgen:57-132 (direct_stage): one primary ray with lights hidden, SAMPLES_PER_PASS light samples at its hit
+void direct_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, uint samples_accumulated, const oracle_pt_targets& T,
+                       uint target_w, uint target_h) {
+    const oracle_scene& s = *c.s;
+    ivec2 pixel;
+    ivec3 wp;
+    if (!get_pixel_pos(L, pixel) || !get_write_pixel_pos(L, wp)) return;
+    const camera_data& cam = s.cameras[L.launch_id.z];
+    const int spp = c.opt.samples_per_pass;
+    local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples}, c.sample_counter, c.rng_seed, c.opt.sampler);
+    vec3 origin, dir;
+    get_world_camera_ray(c, L, pixel, cam, lsampler, origin, dir);
+    // evaluate_direct_ray
+    pt_vertex_data first_hit_vertex{};
+    sampled_material first_hit_material{};
+    hit_payload payload;
+    { uvec4& sd = lsampler.rs_seed; payload.random_seed = pcg4d(sd).x; }
+    vec3 color = V3(0);
+    vec4 diffuse = V4(0), reflection = V4(0);
+    float hit_t;
+    trace_closest(s, origin, dir, 0.0f, RAY_MAX_DIST, false /* mask 0xFF ^ 0x02 */, 0, payload, hit_t, *c.tc);
+    intersection_pdf nee_pdf;
+    vec3 light;
+    const bool terminal = !get_intersection_info(c, payload, origin, dir, first_hit_vertex, nee_pdf, first_hit_material, light);
+    color += (light + first_hit_material.emission) * (float)spp;
+    if (!terminal) {
+        mat3 tbn = create_tangent_space(first_hit_vertex.mapped_normal);
+        vec3 shading_view = -dir * tbn;
+        if (shading_view.z < 0.00001f) shading_view = V3(shading_view.x, shading_view.y, std::max(shading_view.z, 0.00001f));
+        shading_view = normalize(shading_view);
+        vec3 diffuse_rgb = V3(0), reflection_rgb = V3(0);
+        for (int i = 0; i < spp; ++i) {
+            bsdf_lobes lobes = {0, 0, 0, 0};
+            vec3 radiance = next_event_estimation(c, generate_ray_sample_uint(lsampler, (uint)i, c.opt.sampler, c.max_sobol_bounces), tbn, shading_view,
+                                                  first_hit_material, first_hit_vertex, lobes);
+            color += radiance * modulate_bsdf(first_hit_material, lobes);
+            add_demodulated_color(lobes, radiance, diffuse_rgb, reflection_rgb);
+            diffuse.w = reflection.w = 1.0f / length(first_hit_vertex.pos - origin);
+        }
+        diffuse = V4(diffuse_rgb, diffuse.w); reflection = V4(reflection_rgb, reflection.w);
+    }
+    // main(): color /= SAMPLES_PER_PASS; diffuse /= SAMPLES_PER_PASS; (reflection is not divided)
+    const float alpha = c.opt.transparent_background ? first_hit_material.albedo.w : 1.0f;
+    write_all_outputs(c, L, wp, previous_samples, samples_accumulated, T, target_w, target_h, color / (float)spp, alpha, diffuse, reflection, (float)spp, 1.0f,
+                      first_hit_vertex, first_hit_material);
 }
 
 uvec2 get_ray_count(const oracle_distribution& d) {   // src/distribution_strategy.cc:33-61
@@ -1831,9 +1888,28 @@ int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle
     return oracle_pt_render_targets(s, opt, dist_in, viewport_count, frame_counter, samples_accumulated, &T, target_w, target_h, threads);
 }
 
+static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
+                               uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
+                               uint32_t target_h, int threads, bool direct);
+
 int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
                              uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
                              uint32_t target_h, int threads) {
+    return render_targets_impl(s, opt, dist_in, viewport_count, frame_counter, samples_accumulated, targets, target_w, target_h, threads, false);
+}
+
+/* direct_stage (src/direct_stage.cc, shader/direct.rgen): no MIS define is set for it, so nee_mis_pdf is the light pdf */
+int oracle_direct_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
+                                 uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
+                                 uint32_t target_h, int threads) {
+    oracle_pt_options o = *opt;
+    o.mis_mode = 0;
+    return render_targets_impl(s, &o, dist_in, viewport_count, frame_counter, samples_accumulated, targets, target_w, target_h, threads, true);
+}
+
+static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
+                               uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
+                               uint32_t target_h, int threads, bool direct) {
     if (viewport_count > s->cameras.size()) return 1;
     if (opt->pre_transformed_vertices) ensure_world_vertices(*s);
     pt_ctx c;
@@ -1868,7 +1944,8 @@ int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, cons
                     for (uint x = 0; x < rays.x; ++x) {
                         launch_ctx L = base;
                         L.launch_id = {x, (uint)y, z};
-                        pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
+                        if (direct) direct_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
+                        else pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
                     }
                 }
 #pragma omp critical

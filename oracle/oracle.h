@@ -111,6 +111,11 @@ typedef struct oracle_pt_targets {
 int oracle_pt_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist,
                              uint32_t viewport_count, uint32_t frame_counter, uint32_t samples_accumulated,
                              const oracle_pt_targets* targets, uint32_t target_w, uint32_t target_h, int threads);
+/* direct_stage (src/direct_stage.cc:30-127, shader/direct.rgen): first hit + samples_per_pass light samples; same options struct
+ * (max_bounces only sizes the Sobol table; MIS, clamping, regularisation, roulette do not apply) */
+int oracle_direct_render_targets(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist,
+                                 uint32_t viewport_count, uint32_t frame_counter, uint32_t samples_accumulated,
+                                 const oracle_pt_targets* targets, uint32_t target_w, uint32_t target_h, int threads);
 
 /* feature_stage (src/feature_stage.cc:33-65): 0 albedo, 1 world normal, 2 view normal,
  * 3 world pos, 4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */

@@ -91,6 +91,7 @@ SYMBOLS = {
     "trhip_scene_refit_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
     "trhip_scene_get_tri_lights": (_i, [_vp, _vp, _u32]),
     "trhip_pt_create": (_i, [_vp, C.POINTER(PtOptionsC), C.POINTER(_vp)]),
+    "trhip_direct_create": (_i, [_vp, C.POINTER(PtOptionsC), C.POINTER(_vp)]),
     "trhip_pt_destroy": (None, [_vp]),
     "trhip_pt_set_distribution": (_i, [_vp, C.POINTER(DistributionC)]),
     "trhip_pt_reset_accumulation": (_i, [_vp, _i]),

@@ -355,6 +355,11 @@ int trhip_pt_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** o
     *out = p;
     return 0;
 }
+int trhip_direct_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt** out) {
+    if (int rc = trhip_pt_create(dev, opt, out)) return rc;
+    (*out)->stage->direct = true;
+    return 0;
+}
 void trhip_pt_destroy(trhip_pt* pt) {
     if (!pt) return;
     (void)hipSetDevice(pt->dev->hip_device);

@@ -49,6 +49,7 @@ struct PathBuffers {
     f4* sh_dir_id;    // direction.xyz, path id bits
     f4* sh_contrib;   // rgb radiance if visible, luminance for the indirect clamp
     f2* sh_lobes;     // lobe weights the contribution is demodulated with
+    f4* sh_cweight;   // direct_stage only: modulate_bsdf(first hit, lobes), the weight of the sample in the colour target
     uint* queue[2];
     // per lane, four words per bounce b: [4b] live paths entering b, [4b+1] shadow rays of b, [4b+2] / [4b+3] work cursors of
     // the closest-hit / shadow kernel of b.  Zeroed by k_raygen; nothing has to be rotated between bounces.
@@ -408,6 +409,35 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
     else l.transmission = 0;
 }
 
+// write_all_outputs, first-sample part (path_tracer.glsl:549-563): albedo, material, normal, position, screen motion and
+// instance id of the first hit
+TR_DEV void write_first_hit_gbuffer(const SceneView& sv, const PtParams& P, uint launch_id, const SurfacePoint& v, const SampledMaterial& mat, bool surface,
+                                    int4 h) {
+    if (P.samples_accumulated + P.previous_samples != 0) return;
+    if (!(P.T.albedo || P.T.material || P.T.normal || P.T.pos || P.T.instance_id || P.T.screen_motion)) return;
+    uint lx, ly, lz;
+    launch_coord(P.L, launch_id, lx, ly, lz);
+    int wx, wy;
+    if (!get_write_pixel_pos(P.L, lx, ly, wx, wy) || (uint)wx >= P.target_w || (uint)wy >= P.target_h) return;
+    const size_t pix = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
+    if (P.T.albedo) reinterpret_cast<f4*>(P.T.albedo)[pix] = mat.albedo;
+    if (P.T.material)   // pack_gbuffer_material (gbuffer.glsl:256-260)
+        reinterpret_cast<f4*>(P.T.material)[pix] = F4(mat.metallic, mat.roughness, (mat.ior_out / mat.ior_in) * 0.25f, mat.transmittance);
+    if (P.T.normal) {   // octahedral_pack (math.glsl:480-485)
+        f3 nn = v.mapped_normal / (fabsf(v.mapped_normal.x) + fabsf(v.mapped_normal.y) + fabsf(v.mapped_normal.z));
+        f2 o = nn.z >= 0.0f ? F2(nn.x, nn.y)
+                            : F2((1 - fabsf(nn.y)) * ((nn.x >= 0.0f ? 1.0f : 0.0f) * 2 - 1), (1 - fabsf(nn.x)) * ((nn.y >= 0.0f ? 1.0f : 0.0f) * 2 - 1));
+        reinterpret_cast<f2*>(P.T.normal)[pix] = o;
+    }
+    if (P.T.pos) reinterpret_cast<f4*>(P.T.pos)[pix] = F4(v.pos, 0);
+    if (P.T.instance_id) reinterpret_cast<int*>(P.T.instance_id)[pix] = surface ? h.x : -1;
+    if (P.T.screen_motion) {   // write_gbuffer_screen_motion (path_tracer.glsl:557-562); lights and misses: prev_pos = pos
+        const f3 prev_pos = surface ? surface_prev_pos(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w)) : v.pos;
+        const f3 m = get_camera_projection(sv.prev_cameras[lz], P.opt.projection, prev_pos);
+        reinterpret_cast<f2*>(P.T.screen_motion)[pix] = F2(m.x, m.y);
+    }
+}
+
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
 #ifndef TR_SHADE_WAVES
 #define TR_SHADE_WAVES 3
@@ -512,33 +542,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
                 pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
                 pb.first_emis[id] = F4(light, mat.albedo.w);
-                const uint prev_samples = P.samples_accumulated + P.previous_samples;
-                if (prev_samples == 0 && P.sample_in_pass == (uint)P.opt.samples_per_pass - 1u &&
-                    (P.T.albedo || P.T.material || P.T.normal || P.T.pos || P.T.instance_id || P.T.screen_motion)) {
-                    // write_all_outputs: only the first sample writes the gbuffer (path_tracer.glsl:549-563)
-                    uint lx, ly, lz;
-                    launch_coord(P.L, misc.z, lx, ly, lz);
-                    int wx, wy;
-                    if (get_write_pixel_pos(P.L, lx, ly, wx, wy) && (uint)wx < P.target_w && (uint)wy < P.target_h) {
-                        const size_t pix = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
-                        if (P.T.albedo) reinterpret_cast<f4*>(P.T.albedo)[pix] = mat.albedo;
-                        if (P.T.material)   // pack_gbuffer_material (gbuffer.glsl:256-260)
-                            reinterpret_cast<f4*>(P.T.material)[pix] = F4(mat.metallic, mat.roughness, (mat.ior_out / mat.ior_in) * 0.25f, mat.transmittance);
-                        if (P.T.normal) {   // octahedral_pack (math.glsl:480-485)
-                            f3 nn = v.mapped_normal / (fabsf(v.mapped_normal.x) + fabsf(v.mapped_normal.y) + fabsf(v.mapped_normal.z));
-                            f2 o = nn.z >= 0.0f ? F2(nn.x, nn.y)
-                                                : F2((1 - fabsf(nn.y)) * ((nn.x >= 0.0f ? 1.0f : 0.0f) * 2 - 1), (1 - fabsf(nn.x)) * ((nn.y >= 0.0f ? 1.0f : 0.0f) * 2 - 1));
-                            reinterpret_cast<f2*>(P.T.normal)[pix] = o;
-                        }
-                        if (P.T.pos) reinterpret_cast<f4*>(P.T.pos)[pix] = F4(v.pos, 0);
-                        if (P.T.instance_id) reinterpret_cast<int*>(P.T.instance_id)[pix] = surface ? h.x : -1;
-                        if (P.T.screen_motion) {   // write_gbuffer_screen_motion (path_tracer.glsl:557-562); lights and misses: prev_pos = pos
-                            const f3 prev_pos = surface ? surface_prev_pos(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w)) : v.pos;
-                            const f3 m = get_camera_projection(sv.prev_cameras[lz], P.opt.projection, prev_pos);
-                            reinterpret_cast<f2*>(P.T.screen_motion)[pix] = F2(m.x, m.y);
-                        }
-                    }
-                }
+                if (P.sample_in_pass == (uint)P.opt.samples_per_pass - 1u) write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
             }
 
             if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
@@ -641,6 +645,185 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
         for (int off = 32; off > 0; off >>= 1) surf += __shfl_xor(surf, off);
         if ((threadIdx.x & 63) == 0) add64(pb.counters, CNT_SURF, surf);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// direct_stage (src/direct_stage.cc:30-127, shader/direct.rgen:57-132): the first hit with lights hidden plus
+// SAMPLES_PER_PASS light samples from it.  k_direct handles light sample `sample` of every path (sample 0 also sets up the
+// first-hit terms); the shadow rays go through the same queue and k_trace_shadow_direct adds the visible ones.  The
+// colour accumulator of the pass lives in first_emis (rgb; a = first-hit alpha).
+template <bool COUNT>
+__global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtParams P, PathBuffers pb, int sample, uint* bc) {
+    const uint n = P.n_ids;
+    const uint n_round = (n + 63u) & ~63u;
+    uint surf = 0;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
+        bool active = qi < n;
+        uint id = 0;
+        u4 misc = {0, 0, 0, 1};
+        if (active) { id = qi + P.id_offset; misc = pb.misc[id]; active = !(misc.w & 1u); }
+        bool want_shadow = false;
+        f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0), sh_cw = F3(0);
+        f2 sh_w = F2(0.0f);
+        float sh_tmax = 0;
+        if (active) {
+            const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id];
+            const int4 h = pb.hit[id];
+            const f3 pos = F3(o4), view = F3(d4);
+            u4 rs = pb.rng[id];
+            // ---- get_intersection_info (path_tracer.glsl:91-201); sphere lights are masked out of the primary ray
+            SampledMaterial mat;
+            mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
+            mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
+            SurfacePoint v;
+            v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
+            f3 light = F3(0);
+            const bool surface = h.x >= 0;
+            if (surface) {
+                if (COUNT && sample == 0) surf++;
+                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode,
+                              P.opt.pre_transformed_vertices != 0, v, mat);
+                mat.albedo.w = 1.0f;
+                if (P.nee_tri) { light = mat.emission; mat.emission = F3(0); }
+            } else {
+                f4 c = sv.environment_factor;
+                if (sv.environment_proj >= 0) {
+                    f2 uv;
+                    uv.y = asinf(-view.y) / TR_PI + 0.5f;
+                    uv.x = atan2f(view.z, view.x) / (2 * TR_PI) + 0.5f;
+                    f4 t = sample_envmap(sv, uv);
+                    c.x *= t.x; c.y *= t.y; c.z *= t.z;
+                }
+                for (uint i = 0; i < sv.directional_light_count; ++i) {
+                    const DirectionalLight dl = sv.directional_lights[i];
+                    if (dl.dir_cutoff >= 1.0f) continue;
+                    float visible = stepf(dl.dir_cutoff, dot(view, -dl.dir));
+                    f3 dc = visible * dl.color / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
+                    if (P.nee_dir) light += dc; else mat.emission += dc;
+                }
+                v.pos = pos;
+                v.mapped_normal = -view;
+                mat.albedo = F4(0);
+                if (P.nee_env) light += F3(c); else mat.emission += F3(c);
+            }
+            const float spp = (float)P.opt.samples_per_pass;
+            f4 color = F4(0), dif = F4(0), ref = F4(0);
+            bool touched = false;
+            if (sample == 0) {
+                const f3 c0 = (light + mat.emission) * spp;   // color += (light + emission) * SAMPLES_PER_PASS
+                color = F4(c0, mat.albedo.w);
+                touched = true;
+                write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
+            }
+            if (surface) {
+                const m3 tbn = create_tangent_space(v.mapped_normal);
+                const f3 shading_view = view_to_tangent_space(view, tbn);
+                u4 coord;
+                {
+                    uint lx, ly, lz;
+                    launch_coord(P.L, misc.z, lx, ly, lz);
+                    int px = 0, py = 0;
+                    if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
+                    coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_counter};
+                }
+                const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
+                                     (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
+                u4 rnd = ray_sample_uint(rs, coord, misc.y, (uint)sample, P.opt.sampler, P.max_sobol_bounces);
+                if (any_nee) {   // next_event_estimation (path_tracer.glsl:302-344) without a MIS define: the light pdf alone
+                    Lobes lobes = {0, 0, 0, 0};
+                    f3 out_dir;
+                    float out_length = 0.0f, light_pdf;
+                    f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
+                    f3 shading_light = mulT(out_dir, tbn);
+                    float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
+                    correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
+                    const bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
+                    const f3 radiance = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
+                    const f3 cw = modulate_bsdf(mat, lobes);
+                    const f2 w = F2(lobes.diffuse + lobes.transmission, lobes.dielectric_reflection + lobes.metallic_reflection);
+                    if (cast) {
+                        want_shadow = true;
+                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = radiance; sh_cw = cw; sh_w = w;
+                    } else {
+                        if (!touched) { color = pb.first_emis[id]; dif = pb.diffuse[id]; ref = pb.reflection[id]; touched = true; }
+                        color.x += radiance.x * cw.x; color.y += radiance.y * cw.y; color.z += radiance.z * cw.z;
+                        dif.x += radiance.x * w.x; dif.y += radiance.y * w.x; dif.z += radiance.z * w.x;
+                        ref.x += radiance.x * w.y; ref.y += radiance.y * w.y; ref.z += radiance.z * w.y;
+                    }
+                }
+                // diffuse.a = reflection.a = 1 / length(first_hit_vertex.pos - pos), set by every sample
+                const float inv_len = 1.0f / length(v.pos - pos);
+                if (touched) { dif.w = inv_len; ref.w = inv_len; }
+                else { pb.diffuse[id].w = inv_len; pb.reflection[id].w = inv_len; }
+                pb.rng[id] = rs;
+            }
+            if (touched) { pb.first_emis[id] = color; pb.diffuse[id] = dif; pb.reflection[id] = ref; }
+        }
+        uint sslot = wave_append(&bc[1], want_shadow);
+        if (want_shadow) {
+            pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
+            pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
+            pb.sh_contrib[sslot] = F4(sh_c, 0);
+            pb.sh_lobes[sslot] = sh_w;
+            pb.sh_cweight[sslot] = F4(sh_cw, 0);
+        }
+    }
+    if (COUNT && P.count_work) {
+        for (int off = 32; off > 0; off >>= 1) surf += __shfl_xor(surf, off);
+        if ((threadIdx.x & 63) == 0) add64(pb.counters, CNT_SURF, surf);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
+    __shared__ int s_stack[TR_STACK_WORDS];
+    const uint n = bc[1];
+    TraceStats st = {0, 0, 0, 0};
+    uint rays = 0;
+    int overflow = 0;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < ((n + 63u) & ~63u); qi += gridDim.x * KB) {
+        if (qi >= n) continue;
+        const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
+        const float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
+        rays++;
+        if (vis == 0.0f) continue;
+        const uint id = __float_as_uint(d.w);
+        const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
+        const f2 w = pb.sh_lobes[qi];
+        const f4 cw = pb.sh_cweight[qi];
+        f4 col = pb.first_emis[id];
+        col.x += radiance.x * cw.x; col.y += radiance.y * cw.y; col.z += radiance.z * cw.z;
+        pb.first_emis[id] = col;
+        if (w.x != 0.0f) { f4 d4 = pb.diffuse[id]; d4.x += radiance.x * w.x; d4.y += radiance.y * w.x; d4.z += radiance.z * w.x; pb.diffuse[id] = d4; }
+        if (w.y != 0.0f) { f4 r4 = pb.reflection[id]; r4.x += radiance.x * w.y; r4.y += radiance.y * w.y; r4.z += radiance.z * w.y; pb.reflection[id] = r4; }
+    }
+    flush_trace_counters<COUNT>(P, pb, overflow, 5000, 0u, rays, st, 0u);
+}
+
+__global__ void k_direct_next_sample(uint* bc) { bc[1] = 0; }   // the shadow queue of the previous light sample is done
+
+// direct.rgen:main: color /= SAMPLES_PER_PASS; diffuse /= SAMPLES_PER_PASS (reflection is not divided); write_all_outputs
+__global__ __launch_bounds__(KB) void k_resolve_direct(PtParams P, PathBuffers pb) {
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= P.n_ids) return;
+    i += P.id_offset;
+    uint lx, ly, lz;
+    launch_coord(P.L, i, lx, ly, lz);
+    int wx, wy;
+    if (!get_write_pixel_pos(P.L, lx, ly, wx, wy)) return;
+    if ((uint)wx >= P.target_w || (uint)wy >= P.target_h) return;
+    const float spp = (float)P.opt.samples_per_pass;
+    const size_t idx = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
+    const uint prev_samples = P.samples_accumulated + P.previous_samples;
+    const float keep = prev_samples != 0 ? (float)prev_samples / (float)((uint)P.opt.samples_per_pass + prev_samples) : 0.0f;
+    auto accumulate = [&](void* image, f4 value) {
+        f4* target = reinterpret_cast<f4*>(image);
+        if (prev_samples != 0) value = mix4(value, target[idx], keep);
+        target[idx] = value;
+    };
+    if (P.T.color) { const f4 c = pb.first_emis[i]; accumulate(P.T.color, F4(c.x / spp, c.y / spp, c.z / spp, P.opt.transparent_background ? c.w : 1.0f)); }
+    if (P.T.diffuse) { const f4 d = pb.diffuse[i]; accumulate(P.T.diffuse, F4(d.x / spp, d.y / spp, d.z / spp, d.w / spp)); }
+    if (P.T.reflection) accumulate(P.T.reflection, pb.reflection[i]);
 }
 
 // end of one sample (path_tracer.rgen:105-118): sum_color += first_hit_material.emission + modulate_color(first_hit_material,
@@ -768,7 +951,7 @@ PtStage::~PtStage() {
 void PtStage::free_buffers() {
     PathBuffers& pb = impl->pb;
     void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
-                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.queue[0], pb.queue[1]};
+                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint *counters = pb.counters, *bounce = pb.bounce;
     pb = PathBuffers{};
@@ -881,6 +1064,44 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         impl->pending.push_back(sp);
     };
     HIPCHK(hipEventRecord(ev[0], stream));
+    if (direct) {   // direct_stage: one lane on the caller's stream (src/direct_stage.cc:104-127)
+        if (!pb.sh_cweight) HIPCHK(hipMalloc(&pb.sh_cweight, impl->capacity * 16));
+        PtParams LP = P;
+        LP.opt.hide_lights = 1;      // the primary ray is traced with mask 0xFF ^ 0x02
+        LP.opt.mis_mode = 0;         // no MIS define in direct_stage: nee_mis_pdf is the light pdf
+        PathBuffers lb = pb;
+        const uint blocks_all = (LP.n_ids + KB - 1) / KB;
+        const uint blocks_q = blocks_all < grid_cap ? blocks_all : grid_cap;
+        const int passes = opt.samples_per_pixel / opt.samples_per_pass;
+        for (int pass = 0; pass < passes; ++pass) {
+            LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
+            LP.sample_in_pass = 0;
+            timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
+            timed(T_CLOSEST, stream, [&] {
+                auto kc = count ? k_trace_closest<true, false> : k_trace_closest<false, false>;
+                hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, 0, (const uint*)nullptr, lb.bounce);
+            });
+            for (int smp = 0; smp < opt.samples_per_pass; ++smp) {
+                if (smp > 0) hipLaunchKernelGGL(k_direct_next_sample, dim3(1), dim3(1), 0, stream, lb.bounce);
+                timed(T_SHADE, stream, [&] {
+                    if (count) hipLaunchKernelGGL(k_direct<true>, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, smp, lb.bounce);
+                    else hipLaunchKernelGGL(k_direct<false>, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, smp, lb.bounce);
+                });
+                timed(T_SHADOW, stream, [&] {
+                    auto ks = count ? k_trace_shadow_direct<true> : k_trace_shadow_direct<false>;
+                    hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, lb.bounce);
+                });
+            }
+            timed(T_RESOLVE, stream, [&] { hipLaunchKernelGGL(k_resolve_direct, dim3(blocks_all), dim3(KB), 0, stream, LP, lb); });
+        }
+        HIPCHK(hipEventRecord(ev[1], stream));
+        HIPCHK(hipGetLastError());
+        timing_pending = true;
+        impl->frames++;
+        frame_counter++;
+        accumulated_samples += (uint)opt.samples_per_pixel;
+        return 0;
+    }
     for (int l = 2; l < n_lanes; ++l) if (!impl->lane_stream[l]) {
         HIPCHK(hipStreamCreateWithFlags(&impl->lane_stream[l], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&impl->lane_join[l], hipEventDisableTiming));

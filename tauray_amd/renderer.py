@@ -260,10 +260,12 @@ def _dist_c(p: DistributionParams) -> DistributionC:
 class PathTracerStage:
     """path_tracer_stage(device&, scene_stage&, const gbuffer_target&, const options&)."""
 
+    _create = "trhip_pt_create"
+
     def __init__(self, ctx: Context, scene_stage: SceneStage, options: PtOptionsC, distribution: Optional[DistributionParams] = None):
         self.ctx, self.ss, self.opt = ctx, scene_stage, options
         h = C.c_void_p()
-        check(_lib.lib().trhip_pt_create(ctx.h, C.byref(options), C.byref(h)))
+        check(getattr(_lib.lib(), self._create)(ctx.h, C.byref(options), C.byref(h)))
         self.h = h.value
         self.distribution = None
         if distribution is not None:
@@ -328,6 +330,12 @@ class PathTracerStage:
             self.close()
         except Exception:
             pass
+
+
+class DirectStage(PathTracerStage):
+    """direct_stage(device&, scene_stage&, const gbuffer_target&, const options&): first hit + samples_per_pass light samples
+    (src/direct_stage.{hh,cc}); same surface as PathTracerStage."""
+    _create = "trhip_direct_create"
 
 
 class FeatureStage:

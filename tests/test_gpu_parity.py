@@ -207,6 +207,43 @@ def test_progressive_accumulation_over_frames(R, ctx, glb128, test_glb_128, orac
     _compare(color.download((1, 128, 128, 4)), ref2, "frame after reset")
 
 
+@pytest.mark.parametrize("name,kw,frames", [
+    ("1-sample", dict(samples_per_pixel=1), 1),
+    ("4-per-pass-sobol", dict(samples_per_pixel=8, samples_per_pass=4, sampler=1), 1),
+    ("accumulated-area-lights", dict(samples_per_pixel=2, samples_per_pass=2, tri_light_mode=0, film=1, film_radius=0.5), 2),
+])
+def test_direct_stage_matches_oracle(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128, name, kw, frames):
+    """direct_stage (src/direct_stage.cc, shader/direct.rgen): first hit with sphere lights hidden + samples_per_pass light
+    samples; colour, demodulated diffuse (divided by the sample count) and reflection (not divided, as the shader has it)
+    and the first-hit AOVs against the oracle."""
+    names = ["color", "diffuse", "reflection", "albedo", "normal", "pos", "instance_id"]
+    opt = R.options_for_scene(test_glb_128, max_bounces=4, **kw)
+    st = R.DirectStage(ctx, glb128, opt, _dup((128, 128)))
+    bufs = {n: ctx.alloc(128 * 128 * R.PathTracerStage.TARGETS[n][0] * 4).zero() for n in names}
+    for _ in range(frames):
+        st.run_targets(bufs)
+    got = {n: np.frombuffer(bufs[n].download((1, 128, 128, R.PathTracerStage.TARGETS[n][0])).tobytes(), dtype=R.PathTracerStage.TARGETS[n][1])
+              .reshape(1, 128, 128, R.PathTracerStage.TARGETS[n][0]) for n in names}
+    c = st.counters()
+    assert c["stack_overflows"] == 0 and c["closest_rays"] > 0 and c["shadow_rays"] > 0
+    st.close()
+    oopt = oracle.options_for_scene(test_glb_128, max_bounces=4, **kw)
+    ref = None
+    spp = kw["samples_per_pixel"]
+    for f in range(frames):
+        ref = oracle_scene_128.render_pt_targets(oopt, 128, 128, names, frame_counter=f, samples_accumulated=spp * f, targets=ref, direct=True)
+    _compare(got["color"], ref["color"], f"direct {name}: color")
+    assert np.array_equal(got["instance_id"], ref["instance_id"])
+    for n, tol in (("albedo", 1e-6), ("normal", 1e-5), ("pos", 1e-5)):
+        assert float(np.abs(got[n] - ref[n]).max()) <= tol * max(1.0, float(np.abs(ref[n]).max())), f"direct {name}: {n}"
+    for n in ("diffuse", "reflection"):
+        rel = np.abs(got[n][..., :3] - ref[n][..., :3]) / (np.abs(ref[n][..., :3]) + 1e-2)
+        assert float((rel.max(-1) > REL_TOL).mean()) <= MAX_BAD_FRACTION, f"direct {name}: {n}"
+        assert float((np.abs(got[n][..., 3] - ref[n][..., 3]) > 1e-4 * (np.abs(ref[n][..., 3]) + 1.0)).mean()) <= MAX_BAD_FRACTION, f"direct {name}: {n} alpha"
+    # sanity: direct light only - darker than the path tracer's image, and not black
+    assert 0.01 < float(got["color"][..., :3].mean())
+
+
 def test_pre_transformed_vertices(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128):
     """PRE_TRANSFORMED_VERTICES (--pre-transform-vertices): shading reads scene_stage's world-space vertex copy
     (shader/pre_transform.comp:26-42) and skips the model / normal-matrix transforms (shader/rt.glsl:18-22)."""
