@@ -51,12 +51,16 @@ struct PathBuffers {
     f2* sh_lobes;     // lobe weights the contribution is demodulated with
     f4* sh_cweight;   // direct_stage only: modulate_bsdf(first hit, lobes), the weight of the sample in the colour target
     uint* queue[2];
-    // per lane, four words per bounce b: [4b] live paths entering b, [4b+1] shadow rays of b, [4b+2] / [4b+3] work cursors of
-    // the closest-hit / shadow kernel of b.  Zeroed by k_raygen; nothing has to be rotated between bounces.
+    // per lane and bounce b (BC_STRIDE words apart): live paths entering b, shadow rays of b, work cursors of the closest-hit /
+    // shadow kernel of b (BC_*).  Zeroed by k_raygen; nothing has to be rotated between bounces.
     uint* bounce;
     uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
 
+// Every counter of PathBuffers::bounce sits in its own 256 bytes: k_shade appends to the shadow queue and to the next
+// bounce's queue with one atomic per wave each, and two hot words in one cache line serialise in the same L2 channel
+// (measured: 0.83 ms instead of 0.56 ms for one k_shade launch of 2 M paths).
+enum { BC_QUEUE = 0, BC_SHADOW = 64, BC_CUR_CLOSEST = 128, BC_CUR_SHADOW = 192, BC_STRIDE = 256 };
 enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
        CNT_MAXSP = 30, CNT_WORDS = 34 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
 
@@ -95,6 +99,30 @@ TR_DEV uint wave_append(uint* counter, bool pred) {
     base = __shfl(base, leader < 0 ? 0 : leader);
     uint rank = __popcll(mask & ((1ull << lane) - 1ull));
     return base + rank;
+}
+
+// Two appends per block iteration with one atomic each per *block*: 2 M paths are 32 k waves, and 32 k atomics on one word
+// take longer than a shade launch should (the word's L2 channel handles them one by one).  Every thread of the block
+// must call this (three __syncthreads).  Slots keep thread order within the block.
+TR_DEV void block_append2(uint* counter_a, bool pred_a, uint& slot_a, uint* counter_b, bool pred_b, uint& slot_b) {
+    __shared__ uint s_cnt[2][KB / 64];
+    __shared__ uint s_base[2];
+    const unsigned long long ma = __ballot(pred_a), mb = __ballot(pred_b);
+    const uint lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[0][wave] = (uint)__popcll(ma); s_cnt[1][wave] = (uint)__popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint total = 0;
+        for (int w = 0; w < KB / 64; ++w) total += s_cnt[threadIdx.x][w];
+        s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? counter_a : counter_b, total) : 0u;
+    }
+    __syncthreads();
+    uint off_a = s_base[0], off_b = s_base[1];
+    for (uint w = 0; w < wave; ++w) { off_a += s_cnt[0][w]; off_b += s_cnt[1][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    slot_a = off_a + (uint)__popcll(ma & below);
+    slot_b = off_b + (uint)__popcll(mb & below);
+    __syncthreads();   // s_cnt / s_base are reused by the next iteration
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -216,7 +244,7 @@ template <bool COUNT, bool SOLO>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = queue ? bc[0] : P.n_ids;
+    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0, max_vis = 0;
     int overflow = 0;
@@ -226,7 +254,8 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         uint base = 0;
         if (first) base = wave_id * 64u;
         else {
-            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[2], 64u);
+            if (n <= n_waves * 64u) break;   // the static first chunks covered the queue: no cursor traffic at all
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[BC_CUR_CLOSEST], 64u);
             base = __shfl(base, 0);
         }
         first = false;
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = bc[1];
+    const uint n = bc[BC_SHADOW];
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
@@ -249,7 +278,8 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
         uint base = 0;
         if (first) base = wave_id * 64u;
         else {
-            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[3], 64u);
+            if (n <= n_waves * 64u) break;
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[BC_CUR_SHADOW], 64u);
             base = __shfl(base, 0);
         }
         first = false;
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint nc = bc[0], ns = bc_prev[1];
+    const uint nc = bc[BC_QUEUE], ns = bc_prev[BC_SHADOW];
     const uint chunks_c = (nc + 63u) >> 6, total = chunks_c + ((ns + 63u) >> 6);
     TraceStats st = {0, 0, 0, 0};
     uint closest_rays = 0, shadow_rays = 0, max_vis = 0;
@@ -277,7 +307,8 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView 
         uint g = 0;
         if (first) g = wave_id;
         else {
-            if ((threadIdx.x & 63) == 0) g = n_waves + atomicAdd(&bc[2], 1u);
+            if (total <= n_waves) break;   // the static first chunks covered both queues
+            if ((threadIdx.x & 63) == 0) g = n_waves + atomicAdd(&bc[BC_CUR_CLOSEST], 1u);
             g = __shfl(g, 0);
         }
         first = false;
@@ -438,6 +469,56 @@ TR_DEV void write_first_hit_gbuffer(const SceneView& sv, const PtParams& P, uint
     }
 }
 
+// The first-hit gbuffer entries of the path tracer, as their own pass right after bounce 0 (only launched when such a
+// target is bound and the frame starts an accumulation): it redoes get_intersection_info for the primary hit so that
+// k_shade, which runs every bounce of every frame, does not carry this code and its registers.
+__global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams P, PathBuffers pb) {
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= P.n_ids) return;
+    const uint id = i + P.id_offset;
+    const u4 misc = pb.misc[id];
+    if (misc.w & 1u) return;
+    const int4 h = pb.hit[id];
+    // after k_shade(0) the path's origin / direction are those of the next ray for surviving paths: the primary ray is
+    // rebuilt from the camera instead
+    uint lx, ly, lz;
+    launch_coord(P.L, misc.z, lx, ly, lz);
+    int px, py;
+    if (!get_pixel_pos(P.L, lx, ly, px, py)) return;
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, lz, P.previous_samples + P.sample_in_pass}, P.sample_counter, P.rng_seed, P.opt.sampler);
+    f2 cam_offset = F2(0.0f);
+    if (P.opt.film != 0) {
+        f4 r = u4_to_unit(pcg4d(ls.rs));
+        if (P.opt.film == 1) cam_offset = F2(r.x, r.y) * 2.0f - 1.0f;
+        else cam_offset = sample_blackman_harris_concentric_disk(F2(r.x, r.y)) * 2.0f;
+        cam_offset = cam_offset * (2.0f * P.opt.film_radius);
+    }
+    f2 dof_u = F2(0.5f);
+    if (P.opt.depth_of_field) { f4 r = u4_to_unit(pcg4d(ls.rs)); dof_u = F2(r.x, r.y); }
+    f3 pos, view;
+    get_screen_camera_ray(P.L, px, py, sv.cameras[lz], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, pos, view);
+    SampledMaterial mat;
+    mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
+    mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
+    SurfacePoint v;
+    v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
+    const bool surface = h.x >= 0;
+    if (surface) {
+        shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, false, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat);
+        mat.albedo.w = 1.0f;
+    } else if (h.y >= 0) {   // sphere light (path_tracer.glsl:139-158)
+        const PointLight pl = sv.point_lights[h.y];
+        v.pos = pos + __int_as_float(h.z) * view;
+        v.mapped_normal = normalize(v.pos - pl.pos);
+        mat.albedo = F4(0, 0, 0, 1);
+    } else {                 // miss (path_tracer.glsl:160-199)
+        v.pos = pos;
+        v.mapped_normal = -view;
+        mat.albedo = F4(0);
+    }
+    write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
+}
+
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
 #ifndef TR_SHADE_WAVES
 #define TR_SHADE_WAVES 3
@@ -445,8 +526,8 @@ TR_DEV void write_first_hit_gbuffer(const SceneView& sv, const PtParams& P, uint
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                               uint* bc, uint* next_queue) {
-    const uint n = queue ? bc[0] : P.n_ids;
-    const uint n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
+    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
+    const uint n_round = (n + (uint)KB - 1u) & ~((uint)KB - 1u);   // whole blocks take part in the appends
     uint surf = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
         bool active = qi < n;
@@ -542,7 +623,6 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
                 pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
                 pb.first_emis[id] = F4(light, mat.albedo.w);
-                if (P.sample_in_pass == (uint)P.opt.samples_per_pass - 1u) write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
             }
 
             if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
@@ -553,13 +633,12 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             if (!terminal) {
                 const m3 tbn = create_tangent_space(v.mapped_normal);
                 const f3 shading_view = view_to_tangent_space(view, tbn);
-                u4 coord;   // only the Sobol-Owen sampler needs the launch coordinate again
-                {
-                    uint i = misc.z;
+                u4 coord = {0, 0, 0, 0};   // only the Sobol-Owen sampler hashes the launch coordinate again (uniform branch)
+                if (P.opt.sampler == SAMPLER_SOBOL_OWEN) {
                     uint lx, ly, lz;
-                    launch_coord(P.L, i, lx, ly, lz);
+                    launch_coord(P.L, misc.z, lx, ly, lz);
                     int px = 0, py = 0;
-                    if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
+                    get_pixel_pos(P.L, lx, ly, px, py);
                     coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_in_pass + P.sample_counter};
                 }
                 // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
@@ -631,14 +710,14 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             }
         }
         // ---- queue compaction (wave ballots)
-        uint sslot = wave_append(&bc[1], want_shadow);
+        uint sslot, nslot;
+        block_append2(&bc[BC_SHADOW], want_shadow, sslot, &bc[BC_STRIDE + BC_QUEUE], alive, nslot);
         if (want_shadow) {
             pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
             pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
             pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
             pb.sh_lobes[sslot] = sh_w;
         }
-        uint nslot = wave_append(&bc[4], alive);
         if (alive) next_queue[nslot] = id;
     }
     if (COUNT && P.count_work) {
@@ -759,7 +838,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
             }
             if (touched) { pb.first_emis[id] = color; pb.diffuse[id] = dif; pb.reflection[id] = ref; }
         }
-        uint sslot = wave_append(&bc[1], want_shadow);
+        uint sslot = wave_append(&bc[BC_SHADOW], want_shadow);
         if (want_shadow) {
             pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
             pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
@@ -777,7 +856,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    const uint n = bc[1];
+    const uint n = bc[BC_SHADOW];
     TraceStats st = {0, 0, 0, 0};
     uint rays = 0;
     int overflow = 0;
@@ -800,7 +879,7 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(Sce
     flush_trace_counters<COUNT>(P, pb, overflow, 5000, 0u, rays, st, 0u);
 }
 
-__global__ void k_direct_next_sample(uint* bc) { bc[1] = 0; }   // the shadow queue of the previous light sample is done
+__global__ void k_direct_next_sample(uint* bc) { bc[BC_SHADOW] = 0; }   // the shadow queue of the previous light sample is done
 
 // direct.rgen:main: color /= SAMPLES_PER_PASS; diffuse /= SAMPLES_PER_PASS (reflection is not divided); write_all_outputs
 __global__ __launch_bounds__(KB) void k_resolve_direct(PtParams P, PathBuffers pb) {
@@ -964,7 +1043,7 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     if (!pb.counters) {
         HIPCHK(hipMalloc(&pb.counters, PT_LANES * CNT_WORDS * sizeof(uint)));   // one block of counters per lane
         HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
-        HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * 4u * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
+        HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * BC_STRIDE * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
@@ -1015,7 +1094,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         P.prob_point = point * inv_sum; P.prob_tri = tri * inv_sum; P.prob_dir = dir * inv_sum; P.prob_env = env * inv_sum;
     }
     P.count_work = 1;
-    P.bounce_words = 4u * ((uint)opt.max_bounces + 2u);
+    P.bounce_words = (uint)BC_STRIDE * ((uint)opt.max_bounces + 2u);
     P.fused_resolve = opt.samples_per_pass == 1;
     P.T = targets;
     if (int rc = ensure_buffers(n, targets.diffuse || targets.reflection)) return rc;
@@ -1045,6 +1124,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     const int n_lanes = (timing || n < lanes_min_paths) ? 1 : std::max(1, std::min(lanes_env, PT_LANES));
     // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
     static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
+    const bool first_hit_targets = targets.albedo || targets.material || targets.normal || targets.pos || targets.instance_id || targets.screen_motion;
     const bool fused = fused_enabled && !timing && !count;
     const bool overlap = overlap_enabled && !timing && !fused && n_lanes == 1;
     if ((overlap || n_lanes > 1) && !impl->side) {
@@ -1146,10 +1226,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                 for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                     const uint* q = bounce == 0 ? nullptr : lb.queue[bounce & 1];
                     uint* qn = lb.queue[(bounce + 1) & 1];
-                    uint* bc = lb.bounce + 4 * bounce;
+                    uint* bc = lb.bounce + BC_STRIDE * bounce;
                     if (fused && bounce > 0) {
                         // closest(b) together with shadow(b - 1): one launch, one tail
-                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - 4);
+                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
                             auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
@@ -1161,6 +1241,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
+                    if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
+                        hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
                     if (bounce < opt.max_bounces - 1 && !fused) {
                         hipStream_t ss = ls;
                         if (overlap) {   // fork: shadow(b) on the side stream, closest(b+1) follows on the caller's stream
