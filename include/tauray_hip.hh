@@ -229,6 +229,22 @@ public:
         check(trhip_scene_build_accel(dev->h, &accel));
     }
 
+    // Per-frame scene changes of scene_stage::update (src/scene_stage.cc:1066-1116, 1543-1612).  `update_acceleration`
+    // keeps the tree and recomputes its boxes (a BLAS/TLAS update) or, with `rebuild`, builds it again on the device.
+    void update_instances(const void* instances_288, uint32_t count) { check(trhip_scene_update_instances(dev->h, instances_288, count)); }
+    void set_previous_cameras(const void* camera_data_320, uint32_t count) { check(trhip_scene_set_previous_cameras(dev->h, camera_data_320, count)); }
+    // mesh(mesh* animation_source) + mesh::skin_data: bind pose (nullptr = the uploaded vertices) and one skin per vertex
+    void set_skin(uint32_t instance, const trhip_skin* skins, uint32_t vertex_count, const void* source_vertices_48 = nullptr)
+    {
+        check(trhip_scene_set_skin(dev->h, instance, source_vertices_48, skins, vertex_count));
+    }
+    // model::update_joints + shader/skinning.comp: column-major mat4 per joint
+    void skin(uint32_t instance, const float* joint_transforms, uint32_t joint_count) { check(trhip_scene_skin(dev->h, instance, joint_transforms, joint_count)); }
+    void update_acceleration(bool rebuild = false)
+    {
+        check(rebuild ? trhip_scene_build_accel(dev->h, &accel) : trhip_scene_refit_accel(dev->h, &accel));
+    }
+
     device* dev;
     trhip_accel_info accel = {};
 };

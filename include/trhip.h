@@ -83,6 +83,19 @@ int trhip_scene_set_previous_cameras(trhip_device* dev, const void* camera_data,
  * scene, same count and meshes (what scene_stage::update rewrites per frame, src/scene_stage.cc:1066-1116).  The
  * acceleration structure is invalidated: call trhip_scene_build_accel again (full rebuild on the device). */
 int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint32_t count);
+/* Skinned meshes.  trhip_scene_set_skin marks the mesh of `instance` as animated: `source` is the bind-pose vertex array
+ * (mesh::get_animation_source(), src/mesh.hh:47,73; NULL = the vertices uploaded for that instance) and `skins` one
+ * {uvec4 joints, vec4 weights} record per vertex (mesh::skin_data, src/mesh.hh:32-36).  trhip_scene_skin runs
+ * shader/skinning.comp over it with `joint_count` column-major mat4 joint transforms (global transform * inverse bind
+ * matrix, model::update_joints src/model.cc:107-118) and rewrites the instance's vertices in the scene, as
+ * scene_stage::record_skinning does per frame (src/scene_stage.cc:1543-1567).  Instances that share the vertex span
+ * move together, like instances of one mesh in the reference.  The acceleration structure is invalidated: follow with
+ * trhip_scene_refit_accel (the BLAS *update* of src/scene_stage.cc:1569-1612) or trhip_scene_build_accel. */
+typedef struct trhip_skin { uint32_t joints[4]; float weights[4]; } trhip_skin;
+int trhip_scene_set_skin(trhip_device* dev, uint32_t instance, const void* source_vertices, const trhip_skin* skins, uint32_t vertex_count);
+int trhip_scene_skin(trhip_device* dev, uint32_t instance, const float* joint_transforms, uint32_t joint_count);
+/* Reads back the (possibly skinned) 48-byte vertices of one instance; for tests and tools. */
+int trhip_scene_get_vertices(trhip_device* dev, uint32_t instance, void* out_host, uint32_t max_count);
 /* After trhip_scene_update_instances: keeps the topology of the last build and recomputes the world triangles, every
  * child box (level by level, bottom-up) and the tri lights - an acceleration-structure *update* instead of a build
  * (src/acceleration_structure.cc:376-422).  Results are identical to a rebuild; traversal gets slower as the

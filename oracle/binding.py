@@ -76,6 +76,8 @@ def lib():
         L.oracle_scene_tri_light_count.restype = C.c_uint32
         L.oracle_scene_tri_light_count.argtypes = [C.c_void_p]
         L.oracle_scene_get_tri_lights.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_skin_vertices.restype = None
+        L.oracle_skin_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_scene_set_previous_cameras.restype = C.c_int
         L.oracle_scene_set_previous_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_direct_render_targets.restype = C.c_int
@@ -287,4 +289,14 @@ def tonemap(img, op=2, exposure=1.0, gamma=2.2):
     img = np.ascontiguousarray(img, dtype=np.float32)
     out = np.zeros_like(img)
     lib().oracle_tonemap(img.ctypes.data, out.ctypes.data, img.size // 4, op, exposure, gamma)
+    return out
+
+
+def skin_vertices(source: np.ndarray, skins: np.ndarray, joint_transforms: np.ndarray) -> np.ndarray:
+    """shader/skinning.comp over one mesh.  `joint_transforms`: (n, 4, 4) matrices as numpy writes them (row-major)."""
+    source = np.ascontiguousarray(source)
+    skins = np.ascontiguousarray(skins)
+    j = np.ascontiguousarray(np.asarray(joint_transforms, dtype=np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+    out = np.zeros_like(source)
+    lib().oracle_skin_vertices(source.ctypes.data, skins.ctypes.data, len(source), j.ctypes.data, len(j), out.ctypes.data)
     return out

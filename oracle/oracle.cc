@@ -1878,6 +1878,50 @@ int oracle_scene_set_previous_cameras(oracle_scene* s, const void* camera_data_a
     return 0;
 }
 uint32_t oracle_scene_tri_light_count(const oracle_scene* s) { return (uint32_t)s->tri_lights.size(); }
+// shader/skinning.comp:44-71 over one mesh.  GLSL's inverse() is the driver's; restated as the cofactor expansion over
+// 2x2 sub-determinants.  Directions use w = 0, so only the upper-left 3x3 of inverse(skin_mat) reaches them and the
+// fourth column of the transpose contributes +0.
+void oracle_skin_vertices(const void* source, const void* skins_in, uint32_t vertex_count, const float* joint_transforms, uint32_t joint_count, void* destination) {
+    struct skin { uint joints[4]; float weights[4]; };
+    const vertex* src_v = (const vertex*)source;
+    const skin* skins = (const skin*)skins_in;
+    const mat4* joints = (const mat4*)joint_transforms;
+    vertex* dst_v = (vertex*)destination;
+    for (uint32_t i = 0; i < vertex_count; ++i) {
+        const skin s = skins[i];
+        mat4 m;
+        for (int c = 0; c < 4; ++c) {
+            vec4 col = joints[s.joints[0] < joint_count ? s.joints[0] : 0].c[c] * s.weights[0];
+            for (int k = 1; k < 4; ++k) col = col + joints[s.joints[k] < joint_count ? s.joints[k] : 0].c[c] * s.weights[k];
+            m.c[c] = col;
+        }
+        auto a = [&](int r, int c) { const vec4& v = m.c[c]; return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+        const float s0 = a(0,0) * a(1,1) - a(1,0) * a(0,1), s1 = a(0,0) * a(1,2) - a(1,0) * a(0,2), s2 = a(0,0) * a(1,3) - a(1,0) * a(0,3);
+        const float s3 = a(0,1) * a(1,2) - a(1,1) * a(0,2), s4 = a(0,1) * a(1,3) - a(1,1) * a(0,3), s5 = a(0,2) * a(1,3) - a(1,2) * a(0,3);
+        const float c5 = a(2,2) * a(3,3) - a(3,2) * a(2,3), c4 = a(2,1) * a(3,3) - a(3,1) * a(2,3), c3 = a(2,1) * a(3,2) - a(3,1) * a(2,2);
+        const float c2 = a(2,0) * a(3,3) - a(3,0) * a(2,3), c1 = a(2,0) * a(3,2) - a(3,0) * a(2,2), c0 = a(2,0) * a(3,1) - a(3,0) * a(2,1);
+        const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+        float inv[3][3];
+        inv[0][0] = ( a(1,1) * c5 - a(1,2) * c4 + a(1,3) * c3) / det;
+        inv[0][1] = (-a(0,1) * c5 + a(0,2) * c4 - a(0,3) * c3) / det;
+        inv[0][2] = ( a(3,1) * s5 - a(3,2) * s4 + a(3,3) * s3) / det;
+        inv[1][0] = (-a(1,0) * c5 + a(1,2) * c2 - a(1,3) * c1) / det;
+        inv[1][1] = ( a(0,0) * c5 - a(0,2) * c2 + a(0,3) * c1) / det;
+        inv[1][2] = (-a(3,0) * s5 + a(3,2) * s2 - a(3,3) * s1) / det;
+        inv[2][0] = ( a(1,0) * c4 - a(1,1) * c2 + a(1,3) * c0) / det;
+        inv[2][1] = (-a(0,0) * c4 + a(0,1) * c2 - a(0,3) * c0) / det;
+        inv[2][2] = ( a(3,0) * s4 - a(3,1) * s2 + a(3,3) * s0) / det;
+        const mat3 it = M3(V3(inv[0][0], inv[0][1], inv[0][2]), V3(inv[1][0], inv[1][1], inv[1][2]), V3(inv[2][0], inv[2][1], inv[2][2]));  // transpose(inverse)
+        const vertex src = src_v[i];
+        vertex dst = src;
+        dst.pos = V3(m * V4(src.pos.x, src.pos.y, src.pos.z, 1.0f));
+        dst.normal = normalize(it * src.normal + V3(0.0f, 0.0f, 0.0f));
+        const vec3 t = normalize(it * V3(src.tangent) + V3(0.0f, 0.0f, 0.0f));
+        dst.tangent = V4(t.x, t.y, t.z, src.tangent.w);
+        dst_v[i] = dst;
+    }
+}
+
 void oracle_scene_get_tri_lights(const oracle_scene* s, void* out) { memcpy(out, s->tri_lights.data(), s->tri_lights.size() * sizeof(tri_light)); }
 
 int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,

@@ -120,6 +120,8 @@ int oracle_direct_render_targets(oracle_scene* s, const oracle_pt_options* opt, 
 /* feature_stage (src/feature_stage.cc:33-65): 0 albedo, 1 world normal, 2 view normal,
  * 3 world pos, 4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */
 /* camera_pair.previous per viewport (defaults to the current cameras) */
+/* shader/skinning.comp over one mesh: 48-byte vertices, {uvec4 joints, vec4 weights} skins, column-major mat4 joints */
+void oracle_skin_vertices(const void* source, const void* skins, uint32_t vertex_count, const float* joint_transforms, uint32_t joint_count, void* destination);
 int oracle_scene_set_previous_cameras(oracle_scene* s, const void* camera_data_array, uint32_t count);
 int oracle_feature_render(oracle_scene* s, int feature, const oracle_distribution* dist, int projection,
                           uint32_t viewport, float min_ray_dist, const float default_value[4],

@@ -324,6 +324,47 @@ int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint3
     return 0;
 }
 
+int trhip_scene_set_skin(trhip_device* dev, uint32_t instance, const void* source_vertices, const trhip_skin* skins, uint32_t vertex_count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    if (instance >= s.instance_count) return set_error("trhip_scene_set_skin: instance out of range");
+    const MeshSpan& sp = s.host_spans[instance];
+    if (vertex_count != sp.vertex_count) return set_error("trhip_scene_set_skin: vertex_count differs from the instance's mesh");
+    if (!skins && vertex_count) return set_error("trhip_scene_set_skin: null skins");
+    HIPCHK(hipDeviceSynchronize());
+    if (s.skin_slots.size() < s.instance_count) s.skin_slots.resize(s.instance_count);
+    DeviceScene::SkinSlot& k = s.skin_slots[instance];
+    if (k.source) { (void)hipFree(k.source); k.source = nullptr; }
+    if (k.skins) { (void)hipFree(k.skins); k.skins = nullptr; }
+    k.vertex_count = vertex_count;
+    if (vertex_count == 0) return 0;
+    HIPCHK(hipMalloc(&k.source, (size_t)vertex_count * sizeof(Vertex)));
+    HIPCHK(hipMalloc(&k.skins, (size_t)vertex_count * sizeof(Skin)));
+    if (source_vertices) HIPCHK(hipMemcpy(k.source, source_vertices, (size_t)vertex_count * sizeof(Vertex), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(k.source, s.vertices + sp.vertex_offset, (size_t)vertex_count * sizeof(Vertex), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(k.skins, skins, (size_t)vertex_count * sizeof(Skin), hipMemcpyHostToDevice));
+    return 0;
+}
+int trhip_scene_skin(trhip_device* dev, uint32_t instance, const float* joint_transforms, uint32_t joint_count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    HIPCHK(hipDeviceSynchronize());   // frames in flight read the vertices
+    if (int rc = skin_instance(s, instance, joint_transforms, joint_count, nullptr)) return rc;
+    s.accel_built = false;
+    if (s.world_vertices) { (void)hipFree(s.world_vertices); s.world_vertices = nullptr; }
+    return 0;
+}
+int trhip_scene_get_vertices(trhip_device* dev, uint32_t instance, void* out_host, uint32_t max_count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    if (instance >= s.instance_count) return set_error("trhip_scene_get_vertices: instance out of range");
+    const MeshSpan& sp = s.host_spans[instance];
+    const uint n = std::min(max_count, sp.vertex_count);
+    HIPCHK(hipDeviceSynchronize());
+    if (n) HIPCHK(hipMemcpy(out_host, s.vertices + sp.vertex_offset, (size_t)n * sizeof(Vertex), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
     if (const char* b = getenv("TRHIP_BUILDER")) dev->scene.builder = std::string(b) == "lbvh" ? 0 : 1;

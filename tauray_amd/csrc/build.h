@@ -80,8 +80,16 @@ struct DeviceScene {
         if (node_bounds) (void)hipFree(node_bounds);
         level_nodes = nullptr; node_bounds = nullptr; level_offsets.clear(); levels_valid = false;
     }
+    // skinned meshes (mesh(mesh* animation_source), src/mesh.hh:47): bind-pose vertices + skin records per instance
+    struct SkinSlot { Vertex* source = nullptr; Skin* skins = nullptr; m4* joints = nullptr; uint joint_capacity = 0; uint vertex_count = 0; };
+    std::vector<SkinSlot> skin_slots;
+    void free_skins() {
+        for (SkinSlot& k : skin_slots) { if (k.source) (void)hipFree(k.source); if (k.skins) (void)hipFree(k.skins); if (k.joints) (void)hipFree(k.joints); }
+        skin_slots.clear();
+    }
     void free_all() {
         free_accel();
+        free_skins();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
                         alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -91,6 +99,7 @@ struct DeviceScene {
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);
 int ensure_world_vertices(DeviceScene& ds, hipStream_t stream);
+int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms, uint joint_count, hipStream_t stream);   // skinning.comp
 int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);   // same tree, new boxes (after trhip_scene_update_instances)   // pre_transform.comp per instance
 
 }  // namespace tr

@@ -420,6 +420,76 @@ int ensure_world_vertices(DeviceScene& ds, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// shader/skinning.comp:44-71, dispatched per skinned mesh by scene_stage::record_skinning (src/scene_stage.cc:1543-1567).
+// skin_mat = sum w_k * joint[k]; positions go through skin_mat, normals and tangents through transpose(inverse(skin_mat)).
+// GLSL leaves the arithmetic of inverse() to the driver; here it is the cofactor expansion over 2x2 sub-determinants
+// (only the upper-left 3x3 of the inverse reaches a direction), identical in oracle/oracle.cc so results match bit for bit.
+// The previous-position buffer the shader also fills is read by the raster path only (shader/forward.vert:28).
+__global__ __launch_bounds__(BT) void k_skinning(uint vertex_count, const Vertex* source, const Skin* skins, const m4* joints, uint joint_count, Vertex* destination) {
+    uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= vertex_count) return;
+    const Skin s = skins[i];
+    float a[4][4];   // a[r][c]
+    for (int c = 0; c < 4; ++c) {
+        f4 col = F4(0);
+        for (int k = 0; k < 4; ++k) {
+            const uint j = s.joints[k] < joint_count ? s.joints[k] : 0u;   // out-of-range joint ids are undefined behaviour in the shader
+            const f4 t = joints[j].c[c] * s.weights[k];
+            col = k == 0 ? t : col + t;
+        }
+        a[0][c] = col.x; a[1][c] = col.y; a[2][c] = col.z; a[3][c] = col.w;
+    }
+    const float s0 = a[0][0] * a[1][1] - a[1][0] * a[0][1], s1 = a[0][0] * a[1][2] - a[1][0] * a[0][2], s2 = a[0][0] * a[1][3] - a[1][0] * a[0][3];
+    const float s3 = a[0][1] * a[1][2] - a[1][1] * a[0][2], s4 = a[0][1] * a[1][3] - a[1][1] * a[0][3], s5 = a[0][2] * a[1][3] - a[1][2] * a[0][3];
+    const float c5 = a[2][2] * a[3][3] - a[3][2] * a[2][3], c4 = a[2][1] * a[3][3] - a[3][1] * a[2][3], c3 = a[2][1] * a[3][2] - a[3][1] * a[2][2];
+    const float c2 = a[2][0] * a[3][3] - a[3][0] * a[2][3], c1 = a[2][0] * a[3][2] - a[3][0] * a[2][2], c0 = a[2][0] * a[3][1] - a[3][0] * a[2][1];
+    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    float inv[3][3];   // inv[r][c], upper-left block of inverse(skin_mat)
+    inv[0][0] = ( a[1][1] * c5 - a[1][2] * c4 + a[1][3] * c3) / det;
+    inv[0][1] = (-a[0][1] * c5 + a[0][2] * c4 - a[0][3] * c3) / det;
+    inv[0][2] = ( a[3][1] * s5 - a[3][2] * s4 + a[3][3] * s3) / det;
+    inv[1][0] = (-a[1][0] * c5 + a[1][2] * c2 - a[1][3] * c1) / det;
+    inv[1][1] = ( a[0][0] * c5 - a[0][2] * c2 + a[0][3] * c1) / det;
+    inv[1][2] = (-a[3][0] * s5 + a[3][2] * s2 - a[3][3] * s1) / det;
+    inv[2][0] = ( a[1][0] * c4 - a[1][1] * c2 + a[1][3] * c0) / det;
+    inv[2][1] = (-a[0][0] * c4 + a[0][1] * c2 - a[0][3] * c0) / det;
+    inv[2][2] = ( a[3][0] * s4 - a[3][1] * s2 + a[3][3] * s0) / det;
+    const Vertex src = source[i];
+    Vertex dst = src;
+    dst.pos = F3(a[0][0] * src.pos.x + a[0][1] * src.pos.y + a[0][2] * src.pos.z + a[0][3],
+                 a[1][0] * src.pos.x + a[1][1] * src.pos.y + a[1][2] * src.pos.z + a[1][3],
+                 a[2][0] * src.pos.x + a[2][1] * src.pos.y + a[2][2] * src.pos.z + a[2][3]);
+    // transpose(inverse(M)) * (d, 0): component r = sum_c inv[c][r] * d_c
+    const f3 n = src.normal, t = F3(src.tangent);
+    // (the w = 0 column of the 4x4 product contributes +0: keeps the sign of a zero component as GLSL has it)
+    dst.normal = normalize(F3(inv[0][0] * n.x + inv[1][0] * n.y + inv[2][0] * n.z + 0.0f, inv[0][1] * n.x + inv[1][1] * n.y + inv[2][1] * n.z + 0.0f,
+                              inv[0][2] * n.x + inv[1][2] * n.y + inv[2][2] * n.z + 0.0f));
+    const f3 tt = normalize(F3(inv[0][0] * t.x + inv[1][0] * t.y + inv[2][0] * t.z + 0.0f, inv[0][1] * t.x + inv[1][1] * t.y + inv[2][1] * t.z + 0.0f,
+                               inv[0][2] * t.x + inv[1][2] * t.y + inv[2][2] * t.z + 0.0f));
+    dst.tangent = F4(tt, src.tangent.w);
+    destination[i] = dst;
+}
+
+int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms, uint joint_count, hipStream_t stream) {
+    if (instance >= ds.skin_slots.size() || !ds.skin_slots[instance].source) return set_error("trhip_scene_skin: instance has no skin (trhip_scene_set_skin)");
+    DeviceScene::SkinSlot& k = ds.skin_slots[instance];
+    if (joint_count == 0 || !joint_transforms) return set_error("trhip_scene_skin: no joint transforms");
+    if (joint_count > k.joint_capacity) {
+        if (k.joints) (void)hipFree(k.joints);
+        k.joints = nullptr; k.joint_capacity = 0;
+        HIPCHK(hipMalloc(&k.joints, (size_t)joint_count * sizeof(m4)));
+        k.joint_capacity = joint_count;
+    }
+    HIPCHK(hipMemcpyAsync(k.joints, joint_transforms, (size_t)joint_count * sizeof(m4), hipMemcpyHostToDevice, stream));
+    const MeshSpan& sp = ds.host_spans[instance];
+    hipLaunchKernelGGL(k_skinning, dim3((k.vertex_count + BT - 1) / BT), dim3(BT), 0, stream, k.vertex_count, k.source, k.skins, k.joints, joint_count,
+                       ds.vertices + sp.vertex_offset);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));   // the host array may be reused by the caller
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Refit: the instance transforms changed, the tree keeps its topology (what a BLAS/TLAS *update* does in the reference,
 // src/acceleration_structure.cc:376-422).  World triangles are recomputed in place, then the child boxes of the live
 // nodes are rebuilt level by level from the deepest level up.

@@ -115,6 +115,7 @@ struct TriLight { f3 pos[3]; uint emission_factor, instance_id, primitive_id; ui
 struct AliasEntry { uint alias_id, probability; float pdf, alias_pdf; };
 struct CameraData { m4 view, view_inverse, view_proj, proj_inverse; f4 origin, dof_params, projection_info, pan; };
 struct MeshSpan { uint vertex_offset, vertex_count, index_offset, triangle_count; };
+struct Skin { uint joints[4]; float weights[4]; };   // mesh::skin_data (src/mesh.hh:32-36), `skin` of shader/skinning.comp:10-14
 struct TextureInfo { uint width, height, texel_offset, pad; };
 #pragma pack(pop)
 static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288, "layout");

@@ -208,6 +208,9 @@ class SceneStage:
         `refit`, an update that keeps the tree and recomputes its boxes."""
         inst = np.ascontiguousarray(instances)
         check(_lib.lib().trhip_scene_update_instances(self.ctx.h, inst.ctypes.data, len(inst)))
+        return self._accel_after_change(refit)
+
+    def _accel_after_change(self, refit: bool):
         info = AccelInfoC()
         if refit:
             check(_lib.lib().trhip_scene_refit_accel(self.ctx.h, C.byref(info)))
@@ -216,6 +219,35 @@ class SceneStage:
         self.accel.update(node_count=info.node_count, build_ms=info.build_ms, tri_light_count=info.tri_light_count,
                           bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
         return self.accel
+
+    def set_skin(self, instance: int, skins: np.ndarray, source: Optional[np.ndarray] = None):
+        """Marks the mesh of `instance` as skinned (mesh::get_animation_source + skin buffer, src/mesh.hh:32-73): `skins` is
+        one SKIN record per vertex, `source` the bind-pose vertices (default: the uploaded ones)."""
+        from .scene import SKIN
+        skins = np.ascontiguousarray(skins, dtype=SKIN)
+        src_ptr = None
+        if source is not None:
+            source = np.ascontiguousarray(source)
+            if len(source) != len(skins):
+                raise ValueError("set_skin: source and skins differ in length")
+            src_ptr = source.ctypes.data
+        check(_lib.lib().trhip_scene_set_skin(self.ctx.h, instance, src_ptr, skins.ctypes.data if len(skins) else None, len(skins)))
+
+    def skin(self, instance: int, joint_transforms: np.ndarray, refit: Optional[bool] = True):
+        """scene_stage::record_skinning (src/scene_stage.cc:1543-1612): shader/skinning.comp over the instance's mesh with
+        the given joint matrices ((n, 4, 4), row-major as numpy writes a matrix; uploaded column-major), then the
+        acceleration-structure update (`refit`), a rebuild (`refit=False`) or nothing (`refit=None`: caller batches)."""
+        j = np.ascontiguousarray(np.asarray(joint_transforms, dtype=np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+        check(_lib.lib().trhip_scene_skin(self.ctx.h, instance, j.ctypes.data, len(j)))
+        return None if refit is None else self._accel_after_change(refit)
+
+    def vertices(self, instance: int) -> np.ndarray:
+        from .scene import VERTEX
+        n = int(self.scene.spans[instance]["vertex_count"])
+        out = np.zeros(n, dtype=VERTEX)
+        if n:
+            check(_lib.lib().trhip_scene_get_vertices(self.ctx.h, instance, out.ctypes.data, n))
+        return out
 
     def tri_lights(self) -> np.ndarray:
         from .scene import TRI_LIGHT

@@ -51,6 +51,7 @@ CAMERA_DATA = np.dtype([
     ("projection_info", f4, 4), ("pan", f4, 4)])
 # Per-instance geometry span inside the concatenated vertex/index arrays.
 MESH_SPAN = np.dtype([("vertex_offset", u4), ("vertex_count", u4), ("index_offset", u4), ("triangle_count", u4)])
+SKIN = np.dtype([("joints", u4, 4), ("weights", f4, 4)])   # mesh::skin_data (src/mesh.hh:32-36)
 # Texture table entry: RGBA8 texels concatenated in one byte array.
 TEXTURE_INFO = np.dtype([("width", u4), ("height", u4), ("texel_offset", u4), ("pad", u4)])
 

@@ -597,3 +597,95 @@ def test_dynamic_scene_rebuild_and_motion(R, ctx, oracle):
     # the API refuses a different instance count, and rendering before the rebuild
     with pytest.raises(R.TrhipError):
         R._lib.check(R._lib.lib().trhip_scene_update_instances(ctx.h, scene.instances.ctypes.data, len(scene.instances) - 1))
+
+
+def _bend_rig(vertices, phase):
+    """A three-joint chain along +y for a mesh: SKIN records from the bind pose, joint matrices for one pose."""
+    from tauray_amd.scene import SKIN
+    y = vertices["pos"][:, 1].astype(np.float64)
+    lo, hi = float(y.min()), float(y.max())
+    t = (y - lo) / max(hi - lo, 1e-6) * 2.0          # 0..2 over the chain
+    skins = np.zeros(len(vertices), dtype=SKIN)
+    j0 = np.clip(np.floor(t), 0, 1).astype(np.uint32)
+    f = np.clip(t - j0, 0.0, 1.0)
+    f = f * f * (3 - 2 * f)
+    skins["joints"][:, 0] = j0; skins["joints"][:, 1] = j0 + 1; skins["joints"][:, 2] = 2; skins["joints"][:, 3] = 0
+    skins["weights"][:, 0] = 1 - f; skins["weights"][:, 1] = f
+
+    def about(pivot_y, ang, shift=(0, 0, 0), scale=1.0):
+        c, s = np.cos(ang), np.sin(ang)
+        r = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @ np.diag([scale, 1.0, scale, 1.0])
+        to, back = np.eye(4), np.eye(4)
+        to[1, 3], back[1, 3] = -pivot_y, pivot_y
+        mv = np.eye(4); mv[:3, 3] = shift
+        return mv @ back @ r @ to
+    mid = 0.5 * (lo + hi)
+    j1 = about(mid, 0.5 * phase, scale=1.0 + 0.2 * phase)
+    j2 = j1 @ about(hi, 0.8 * phase, shift=(0.05 * phase, 0.1 * phase, 0))
+    return skins, np.stack([np.eye(4), j1, j2]).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_skinned_mesh(R, ctx, oracle):
+    """shader/skinning.comp + the acceleration-structure update of scene_stage::record_skinning
+    (src/scene_stage.cc:1543-1612): skinned vertices bit-equal to the oracle's, then the refitted structure renders what
+    an oracle scene built from those vertices renders."""
+    from tauray_amd.gltf import load_glb
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), 128, 128)
+    ss = R.SceneStage(ctx, scene)
+    inst = 4                                                    # the teapot
+    sp = scene.spans[inst]
+    bind = scene.vertices[sp["vertex_offset"]:sp["vertex_offset"] + sp["vertex_count"]].copy()
+    assert np.array_equal(ss.vertices(inst).view(np.uint8), bind.view(np.uint8))
+    with pytest.raises(R.TrhipError):
+        ss.skin(inst, np.eye(4)[None])                          # no skin set yet
+    skins, _ = _bend_rig(bind, 0.0)
+    with pytest.raises(R.TrhipError):
+        ss.set_skin(inst, skins[:-1])                           # one record per vertex of the mesh
+    ss.set_skin(inst, skins)                                    # source = the uploaded vertices
+
+    def feature(fid):
+        fs = R.FeatureStage(ctx, ss, fid, _dup((128, 128)))
+        buf = ctx.alloc(128 * 128 * 16).zero()
+        fs.run(buf)
+        return buf.download((128, 128, 4))
+
+    before = feature(3)
+    frames = []
+    for phase, refit in ((1.0, True), (-0.7, True), (0.4, False)):
+        _, joints = _bend_rig(bind, phase)
+        info = ss.skin(inst, joints, refit=refit)
+        assert info["build_ms"] > 0
+        want = oracle.skin_vertices(bind, skins, joints)
+        assert np.array_equal(ss.vertices(inst).view(np.uint8), want.view(np.uint8)), f"skinned vertices, phase {phase}"
+        osc = oracle.OracleScene(posed_scene(scene, sp, want))
+        for fid in (5, 3, 1, 9):      # distance, world position, world normal, instance id
+            assert np.array_equal(feature(fid), osc.render_feature(fid, 128, 128)), f"feature {fid}, phase {phase}, refit={refit}"
+        img = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)
+        _compare(img, osc.render_pt(oracle.options_for_scene(scene, max_bounces=3), 128, 128), f"skinned frame, phase {phase}")
+        frames.append(img)
+    assert float(np.abs(feature(3) - before)[np.isfinite(before)].max()) > 0.05, "the mesh did not move"
+    # the same pose after a rebuild instead of a refit: same frame, bit for bit
+    _, joints = _bend_rig(bind, -0.7)
+    ss.skin(inst, joints, refit=True)
+    a = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)
+    assert np.array_equal(a, frames[1])
+    ss.skin(inst, joints, refit=False)
+    assert np.array_equal(a, _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)), "refit vs rebuild"
+    # pre-transformed vertices follow the skinned mesh
+    osc = oracle.OracleScene(posed_scene(scene, sp, oracle.skin_vertices(bind, skins, joints)))
+    got = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=2, pre_transformed_vertices=1)
+    _compare(got, osc.render_pt(oracle.options_for_scene(scene, max_bounces=2, pre_transformed_vertices=1), 128, 128), "skinned + pre-transformed")
+    # rendering between trhip_scene_skin and the update is refused
+    ss.skin(inst, joints, refit=None)
+    with pytest.raises(R.TrhipError):
+        _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=1)
+    ss._accel_after_change(True)
+
+
+def posed_scene(scene, sp, vertices):
+    import copy
+    posed = copy.copy(scene)
+    posed.vertices = scene.vertices.copy()
+    posed.vertices[sp["vertex_offset"]:sp["vertex_offset"] + sp["vertex_count"]] = vertices
+    return posed
