@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--sampler", type=int, default=0)
+    ap.add_argument("--views", type=int, default=1, help="camera-grid viewports per frame (45 = the 5x9 light field of config 5)")
+    ap.add_argument("--shard", default="pixels", choices=["pixels", "views", "samples"],
+                    help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -65,9 +68,14 @@ def main():
 
     W, H = args.width, args.height
     scene = scenes.WORKLOADS[args.workload](W, H)
+    if args.views > 1:      # light-field grid (src/tauray.cc:680-727): spacing 0.02, recentering distance 5
+        from tauray_amd.scene import generate_camera_grid
+        gw = 9 if args.views == 45 else args.views
+        scene.cameras = generate_camera_grid(scene.cameras[0], gw, args.views // gw, 0.02, 0.02, 5.0)
     ctx = R.Context(local_rank)
     opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
-    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, rank=rank, world_size=world, viewports=1)
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, rank=rank, world_size=world, viewports=args.views,
+                      shard=args.shard)
     pt = rr.ray_tracer
 
     def sync_all():
@@ -120,11 +128,13 @@ def main():
         "dtype": "f32", "data": "synthetic" if args.workload != "test_glb" else "reference fixture test/test.glb (81 364 triangles)",
         "config": {"workload": args.workload, "triangles": scene.triangle_count, "width": W, "height": H, "bounces": args.bounces,
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
-                   "parallelism": "scanline-sharded x%d + RCCL gather" % world if world > 1 else "single GPU",
+                   "parallelism": ({"pixels": "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
+                                    "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
+                   "views": args.views,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         "rays_per_frame": rays_total // args.steps,
-        "msample_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
+        "msample_per_s": round(W * H * args.views * args.spp * args.steps / elapsed / 1e6, 2),
     }
 
     # ---- frame latency distribution (mean and p50): the same frames again with a host sync after each one,
@@ -172,7 +182,7 @@ def main():
         bytes_per_launch = trace_bytes / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
-                       + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.spp * 16 * args.steps) / args.steps
+                       + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * args.steps) / args.steps
         # HBM traffic of the same kernel from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE + WRITE_SIZE in
         # separate runs).  Lower bound as reported; FETCH_SIZE may under-report by up to 2x on gfx950 (upper bound given too).
         traffic, traffic_range, traffic_src = None, None, None
@@ -205,7 +215,7 @@ def main():
         frames = 0
         t0 = time.perf_counter()
         while True:
-            osc.render_pt(oopt, W, H, frame_counter=frames, threads=cores)
+            osc.render_pt(oopt, W, H, frame_counter=frames, threads=cores, viewports=args.views)
             frames += 1
             if time.perf_counter() - t0 >= args.cpu_seconds:
                 break

@@ -165,6 +165,13 @@ int trhip_direct_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt
 void trhip_pt_destroy(trhip_pt* pt);
 int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist);  /* rt_camera_stage::reset_distribution_params */
 int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /* reset_accumulated_samples / reset_sample_counter */
+/* View and sample sharding across devices (the reference itself only shards pixels,
+ * src/distribution_strategy.cc).  Local layer l of the target shows viewport viewport_base + l * viewport_stride: that
+ * viewport's camera (shader/scene.glsl:176-185) and its RNG stream (the viewport index seeds the sampler,
+ * shader/sampling.glsl:32-45).  Local sample s of a frame is sample sample_base + s * sample_stride of the pixel's
+ * sequence, out of samples_per_pixel * sample_stride per frame (every shard takes the same number).  With these a
+ * shard's pixels are the ones a single device renders for that viewport / those samples.  Defaults 0, 1, 0, 1. */
+int trhip_pt_set_shard(trhip_pt* pt, uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base, uint32_t sample_stride);
 /* One frame: update() + every pass of record_command_buffer_pass (src/path_tracer_stage.cc:118-147).
  * `color` is the device RGBA32F image2DArray [viewports][target_h][target_w] where target size is
  * get_distribution_target_size(dist) (src/distribution_strategy.cc:6-19). */

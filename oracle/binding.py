@@ -78,6 +78,8 @@ def lib():
         L.oracle_scene_get_tri_lights.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_skin_vertices.restype = None
         L.oracle_skin_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.oracle_scene_set_shard.restype = C.c_int
+        L.oracle_scene_set_shard.argtypes = [C.c_void_p] + [C.c_uint32] * 4
         L.oracle_scene_set_previous_cameras.restype = C.c_int
         L.oracle_scene_set_previous_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_direct_render_targets.restype = C.c_int
@@ -275,6 +277,10 @@ class OracleScene:
         out = np.zeros(len(rays), dtype=np.float32)
         lib().oracle_trace_shadow(self.h, len(rays), rays.ctypes.data, out.ctypes.data, threads)
         return out
+
+    def set_shard(self, viewport_base=0, viewport_stride=1, sample_base=0, sample_stride=1):
+        if lib().oracle_scene_set_shard(self.h, viewport_base, viewport_stride, sample_base, sample_stride) != 0:
+            raise RuntimeError("oracle_scene_set_shard: bad shard")
 
     def counters(self):
         c = CountersC()

@@ -441,6 +441,8 @@ struct counters_t { std::atomic<uint64_t> closest{0}, shadow{0}, nodes{0}, tris{
 }  // namespace
 
 struct oracle_scene {
+    // oracle_scene_set_shard: view / sample shard of a multi-device job (mirrors trhip_pt_set_shard)
+    uint shard_vp_base = 0, shard_vp_stride = 1, shard_sample_base = 0, shard_sample_stride = 1;
     std::vector<instance> instances;
     std::vector<mesh_span> spans;
     std::vector<vertex> vertices;
@@ -1187,6 +1189,7 @@ struct launch_ctx {
     oracle_distribution dist;     // `count` already holds b for shuffled strips (rt_camera_stage.cc:86-87)
     uvec3 launch_id;
     uvec2 launch_size;
+    uint viewport = 0;            // the viewport layer launch_id.z shows (differs from it only in a view shard)
 };
 uint permute_region_id(uint i, uint size_x, uint size_y, uint b) {
     uint region_size = ((size_x * size_y) + (1u << b) - 1) >> b;
@@ -1717,7 +1720,7 @@ void write_all_outputs(const pt_ctx& c, const launch_ctx& L, ivec3 wp, uint prev
         if (T.pos) { float* q = T.pos + pix * 4; q[0] = first_hit_vertex.pos.x; q[1] = first_hit_vertex.pos.y; q[2] = first_hit_vertex.pos.z; q[3] = 0; }
         if (T.instance_id) T.instance_id[pix] = first_hit_vertex.instance_id;
         if (T.screen_motion) {   // write_gbuffer_screen_motion(get_camera_projection(get_prev_camera(), prev_pos)): rg32f keeps xy
-            vec3 m = get_camera_projection(s.prev_cameras[L.launch_id.z], c.opt.projection, first_hit_vertex.prev_pos);
+            vec3 m = get_camera_projection(s.prev_cameras[L.viewport], c.opt.projection, first_hit_vertex.prev_pos);
             T.screen_motion[pix * 2] = m.x; T.screen_motion[pix * 2 + 1] = m.y;
         }
     }
@@ -1743,14 +1746,14 @@ void pt_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_samples, 
     ivec2 pixel;
     ivec3 wp;
     if (!get_pixel_pos(L, pixel) || !get_write_pixel_pos(L, wp)) return;
-    const camera_data& cam = s.cameras[L.launch_id.z];
+    const camera_data& cam = s.cameras[L.viewport];
     pt_vertex_data first_hit_vertex{};
     sampled_material first_hit_material{};
     vec3 sum_color = V3(0);
     vec4 sum_diffuse = V4(0), sum_reflection = V4(0);
     const int spp = c.opt.samples_per_pass;
     for (int i = 0; i < spp; ++i) {
-        local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples + (uint)i},
+        local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.viewport, s.shard_sample_base + s.shard_sample_stride * (previous_samples + (uint)i)},
                                                     c.sample_counter, c.rng_seed, c.opt.sampler);
         vec3 origin, dir;
         get_world_camera_ray(c, L, pixel, cam, lsampler, origin, dir);
@@ -1776,9 +1779,9 @@ void direct_invocation(const pt_ctx& c, const launch_ctx& L, uint previous_sampl
     ivec2 pixel;
     ivec3 wp;
     if (!get_pixel_pos(L, pixel) || !get_write_pixel_pos(L, wp)) return;
-    const camera_data& cam = s.cameras[L.launch_id.z];
+    const camera_data& cam = s.cameras[L.viewport];
     const int spp = c.opt.samples_per_pass;
-    local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.launch_id.z, previous_samples}, c.sample_counter, c.rng_seed, c.opt.sampler);
+    local_sampler lsampler = init_local_sampler(uvec4{(uint)pixel.x, (uint)pixel.y, L.viewport, c.s->shard_sample_base + c.s->shard_sample_stride * previous_samples}, c.sample_counter, c.rng_seed, c.opt.sampler);
     vec3 origin, dir;
     get_world_camera_ray(c, L, pixel, cam, lsampler, origin, dir);
     // evaluate_direct_ray
@@ -1922,6 +1925,11 @@ void oracle_skin_vertices(const void* source, const void* skins_in, uint32_t ver
     }
 }
 
+int oracle_scene_set_shard(oracle_scene* s, uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base, uint32_t sample_stride) {
+    if (viewport_stride == 0 || sample_stride == 0 || sample_base >= sample_stride) return 1;
+    s->shard_vp_base = viewport_base; s->shard_vp_stride = viewport_stride; s->shard_sample_base = sample_base; s->shard_sample_stride = sample_stride;
+    return 0;
+}
 void oracle_scene_get_tri_lights(const oracle_scene* s, void* out) { memcpy(out, s->tri_lights.data(), s->tri_lights.size() * sizeof(tri_light)); }
 
 int oracle_pt_render(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
@@ -1954,14 +1962,14 @@ int oracle_direct_render_targets(oracle_scene* s, const oracle_pt_options* opt, 
 static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, const oracle_distribution* dist_in, uint32_t viewport_count,
                                uint32_t frame_counter, uint32_t samples_accumulated, const oracle_pt_targets* targets, uint32_t target_w,
                                uint32_t target_h, int threads, bool direct) {
-    if (viewport_count > s->cameras.size()) return 1;
+    if (viewport_count == 0 || (uint64_t)s->shard_vp_base + (uint64_t)(viewport_count - 1) * s->shard_vp_stride >= s->cameras.size()) return 1;
     if (opt->pre_transformed_vertices) ensure_world_vertices(*s);
     pt_ctx c;
     c.s = s; c.opt = *opt;
     c.max_sobol_bounces = (uint)(opt->max_bounces > 8 ? 8 : opt->max_bounces);   // sobol_lookup_table.glsl:4-14
     c.nee_point = opt->nee_point > 0; c.nee_dir = opt->nee_directional > 0;
     c.nee_env = opt->nee_envmap > 0; c.nee_tri = opt->nee_triangles > 0;
-    c.sample_counter = frame_counter * (uint)opt->samples_per_pixel;              // rt_stage.cc:81, rt_camera_stage.cc:59
+    c.sample_counter = frame_counter * (uint)opt->samples_per_pixel * s->shard_sample_stride;   // rt_stage.cc:81, rt_camera_stage.cc:59
     uint seed = opt->rng_seed;
     c.rng_seed = seed != 0 ? pcg(seed) : 0;                                       // rt_stage.cc:82
     oracle_distribution dist = *dist_in;
@@ -1988,6 +1996,7 @@ static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, co
                     for (uint x = 0; x < rays.x; ++x) {
                         launch_ctx L = base;
                         L.launch_id = {x, (uint)y, z};
+                        L.viewport = s->shard_vp_base + z * s->shard_vp_stride;
                         if (direct) direct_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
                         else pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
                     }

@@ -122,6 +122,8 @@ int oracle_direct_render_targets(oracle_scene* s, const oracle_pt_options* opt, 
 /* camera_pair.previous per viewport (defaults to the current cameras) */
 /* shader/skinning.comp over one mesh: 48-byte vertices, {uvec4 joints, vec4 weights} skins, column-major mat4 joints */
 void oracle_skin_vertices(const void* source, const void* skins, uint32_t vertex_count, const float* joint_transforms, uint32_t joint_count, void* destination);
+/* view / sample shard of the following oracle_pt_render* calls; same meaning as trhip_pt_set_shard */
+int oracle_scene_set_shard(oracle_scene* s, uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base, uint32_t sample_stride);
 int oracle_scene_set_previous_cameras(oracle_scene* s, const void* camera_data_array, uint32_t count);
 int oracle_feature_render(oracle_scene* s, int feature, const oracle_distribution* dist, int projection,
                           uint32_t viewport, float min_ray_dist, const float default_value[4],

@@ -89,6 +89,7 @@ SYMBOLS = {
     "trhip_scene_update_instances": (_i, [_vp, _vp, _u32]),
     "trhip_scene_build_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
     "trhip_scene_refit_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
+    "trhip_pt_set_shard": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "trhip_scene_set_skin": (_i, [_vp, _u32, _vp, _vp, _u32]),
     "trhip_scene_skin": (_i, [_vp, _u32, _vp, _u32]),
     "trhip_scene_get_vertices": (_i, [_vp, _u32, _vp, _u32]),

@@ -415,6 +415,14 @@ int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist) {
     pt->stage->dist = *dist;
     return 0;
 }
+int trhip_pt_set_shard(trhip_pt* pt, uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base, uint32_t sample_stride) {
+    if (!pt) return set_error("trhip_pt_set_shard: null stage");
+    if (viewport_stride == 0 || sample_stride == 0) return set_error("trhip_pt_set_shard: strides must be >= 1");
+    if (sample_base >= sample_stride) return set_error("trhip_pt_set_shard: sample_base must be below sample_stride");
+    pt->stage->shard_vp_base = viewport_base; pt->stage->shard_vp_stride = viewport_stride;
+    pt->stage->shard_sample_base = sample_base; pt->stage->shard_sample_stride = sample_stride;
+    return 0;
+}
 int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter) {
     if (!pt) return set_error("null trhip_pt");
     pt->stage->accumulated_samples = 0;

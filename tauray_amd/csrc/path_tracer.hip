@@ -74,6 +74,8 @@ struct PtParams {
     uint sample_counter, rng_seed;
     uint previous_samples;        // control.previous_samples of the pass
     uint sample_in_pass;
+    uint rng_sample;              // index of this sample in the pixel's sequence: sample_base + sample_stride * (previous_samples + sample_in_pass)
+    uint vp_base, vp_stride;      // local layer l renders viewport vp_base + l * vp_stride (trhip_pt_set_shard)
     uint samples_accumulated;
     uint target_w, target_h;
     float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
@@ -125,6 +127,8 @@ TR_DEV void block_append2(uint* counter_a, bool pred_a, uint& slot_a, uint* coun
     __syncthreads();   // s_cnt / s_base are reused by the next iteration
 }
 
+TR_DEV uint global_viewport(const PtParams& P, uint lz) { return P.vp_base + lz * P.vp_stride; }
+
 // ---------------------------------------------------------------------------------------------------
 // path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
 __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
         if (pb.sum_diffuse) { pb.sum_diffuse[i] = F4(0); pb.sum_reflection[i] = F4(0); }
     }
     if (!valid) { pb.misc[i] = misc; return; }
-    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, lz, P.previous_samples + P.sample_in_pass}, P.sample_counter,
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, P.sample_counter,
                                          P.rng_seed, P.opt.sampler);
     f2 cam_offset = F2(0.0f);
     if (P.opt.film != 0) {   // control.antialiasing == 1
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
     f2 dof_u = F2(0.5f);
     if (P.opt.depth_of_field) { f4 r = u4_to_unit(pcg4d(ls.rs)); dof_u = F2(r.x, r.y); }
     f3 origin, dir;
-    get_screen_camera_ray(P.L, px, py, sv.cameras[lz], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
+    get_screen_camera_ray(P.L, px, py, sv.cameras[global_viewport(P, lz)], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
     misc.x = pcg4d(ls.rs).x;      // payload.random_seed = pcg4d(lsampler.rs.seed).x  (path_tracer.glsl:384)
     misc.y = ls.sobol_index;
     pb.org_pdf[i] = F4(origin, 0.0f);            // bsdf_pdf = 0
@@ -464,7 +468,7 @@ TR_DEV void write_first_hit_gbuffer(const SceneView& sv, const PtParams& P, uint
     if (P.T.instance_id) reinterpret_cast<int*>(P.T.instance_id)[pix] = surface ? h.x : -1;
     if (P.T.screen_motion) {   // write_gbuffer_screen_motion (path_tracer.glsl:557-562); lights and misses: prev_pos = pos
         const f3 prev_pos = surface ? surface_prev_pos(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w)) : v.pos;
-        const f3 m = get_camera_projection(sv.prev_cameras[lz], P.opt.projection, prev_pos);
+        const f3 m = get_camera_projection(sv.prev_cameras[global_viewport(P, lz)], P.opt.projection, prev_pos);
         reinterpret_cast<f2*>(P.T.screen_motion)[pix] = F2(m.x, m.y);
     }
 }
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams
     launch_coord(P.L, misc.z, lx, ly, lz);
     int px, py;
     if (!get_pixel_pos(P.L, lx, ly, px, py)) return;
-    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, lz, P.previous_samples + P.sample_in_pass}, P.sample_counter, P.rng_seed, P.opt.sampler);
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, P.sample_counter, P.rng_seed, P.opt.sampler);
     f2 cam_offset = F2(0.0f);
     if (P.opt.film != 0) {
         f4 r = u4_to_unit(pcg4d(ls.rs));
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams
     f2 dof_u = F2(0.5f);
     if (P.opt.depth_of_field) { f4 r = u4_to_unit(pcg4d(ls.rs)); dof_u = F2(r.x, r.y); }
     f3 pos, view;
-    get_screen_camera_ray(P.L, px, py, sv.cameras[lz], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, pos, view);
+    get_screen_camera_ray(P.L, px, py, sv.cameras[global_viewport(P, lz)], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, pos, view);
     SampledMaterial mat;
     mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
     mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
                     launch_coord(P.L, misc.z, lx, ly, lz);
                     int px = 0, py = 0;
                     get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_in_pass + P.sample_counter};
+                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + P.sample_counter};
                 }
                 // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
                 const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
                     launch_coord(P.L, misc.z, lx, ly, lz);
                     int px = 0, py = 0;
                     if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, lz + P.rng_seed, P.previous_samples + P.sample_counter};
+                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + P.sample_counter};
                 }
                 const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
                                      (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
@@ -1062,7 +1066,8 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
 
 int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
     if (!scene->accel_built) return set_error("trhip_pt_render: call trhip_scene_build_accel first");
-    if (viewports == 0 || viewports > scene->camera_count) return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
+    if (viewports == 0 || (uint64_t)shard_vp_base + (uint64_t)(viewports - 1) * shard_vp_stride >= scene->camera_count)
+        return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
     if (opt.samples_per_pass <= 0 || opt.samples_per_pixel % opt.samples_per_pass != 0)
         return set_error("trhip_pt_render: samples_per_pixel must be a multiple of samples_per_pass");
     if (dist.size_x == 0 || dist.size_y == 0) return set_error("trhip_pt_render: distribution not set");
@@ -1079,7 +1084,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     if (n > 0xFFFFFFF0ull) return set_error("trhip_pt_render: launch too large");
     P.n_launch = (uint)n; P.id_offset = 0; P.n_ids = (uint)n;
     P.max_sobol_bounces = (uint)(opt.max_bounces > 8 ? 8 : opt.max_bounces);   // shader/sobol_lookup_table.glsl:4-14
-    P.sample_counter = frame_counter * (uint)opt.samples_per_pixel;               // src/rt_stage.cc:81
+    // src/rt_stage.cc:81; a sample shard renders every shard_sample_stride-th sample of samples_per_pixel * stride per frame
+    P.sample_counter = frame_counter * (uint)opt.samples_per_pixel * shard_sample_stride;
+    P.vp_base = shard_vp_base; P.vp_stride = shard_vp_stride;
     { uint s = opt.rng_seed; P.rng_seed = s != 0 ? pcg(s) : 0; }                  // src/rt_stage.cc:82
     P.samples_accumulated = accumulated_samples;
     P.target_w = target_w; P.target_h = target_h;
@@ -1156,6 +1163,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         for (int pass = 0; pass < passes; ++pass) {
             LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
             LP.sample_in_pass = 0;
+            LP.rng_sample = shard_sample_base + shard_sample_stride * LP.previous_samples;
             timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
             timed(T_CLOSEST, stream, [&] {
                 auto kc = count ? k_trace_closest<true, false> : k_trace_closest<false, false>;
@@ -1220,6 +1228,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
             for (int s = 0; s < opt.samples_per_pass; ++s) {
                 LP.sample_in_pass = (uint)s;
+                LP.rng_sample = shard_sample_base + shard_sample_stride * (LP.previous_samples + LP.sample_in_pass);
                 timed(T_RAYGEN, ls, [&] {
                     hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
                 });

@@ -22,6 +22,8 @@ public:
     uint frame_counter = 0;          // rt_stage::frame_counter (src/rt_stage.cc:81-86)
     uint accumulated_samples = 0;    // rt_camera_stage::accumulated_samples (src/rt_camera_stage.cc:100)
     int count_work = 0, detailed_timing = 0;
+    // trhip_pt_set_shard: which viewports / samples of the whole job this stage renders (view and sample sharding)
+    uint shard_vp_base = 0, shard_vp_stride = 1, shard_sample_base = 0, shard_sample_stride = 1;
     bool direct = false;             // direct_stage instead of path_tracer_stage (trhip_direct_create)
     hipStream_t last_stream = nullptr;
 

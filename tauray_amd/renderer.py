@@ -70,6 +70,14 @@ def options_for_scene(scene: SceneDesc, **kw) -> PtOptionsC:
     return o
 
 
+def copy_options(o: PtOptionsC, **changes) -> PtOptionsC:
+    c = PtOptionsC()
+    C.memmove(C.byref(c), C.byref(o), C.sizeof(PtOptionsC))
+    for k, v in changes.items():
+        setattr(c, k, v)
+    return c
+
+
 class DeviceBuffer:
     """gpu_buffer-like owner of one device allocation."""
 
@@ -308,6 +316,11 @@ class PathTracerStage:
         check(_lib.lib().trhip_pt_set_distribution(self.h, C.byref(d)))
         self.distribution = distribution
 
+    def set_shard(self, viewport_base=0, viewport_stride=1, sample_base=0, sample_stride=1):
+        """View / sample sharding (trhip_pt_set_shard): local layer l = viewport base + l * stride, local sample s = sample
+        base + s * stride of the pixel's sequence."""
+        check(_lib.lib().trhip_pt_set_shard(self.h, viewport_base, viewport_stride, sample_base, sample_stride))
+
     def reset_accumulated_samples(self):
         check(_lib.lib().trhip_pt_reset_accumulation(self.h, 0))
 
@@ -424,16 +437,40 @@ class RtRenderer:
     """
 
     def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
-                 rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None):
+                 rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None,
+                 shard="pixels"):
+        """`shard`: what the ranks divide among themselves - "pixels" (the reference's distribution strategies, partial frames
+        stitched on rank 0), "views" (viewport v on rank v mod N; nothing is exchanged before output) or "samples" (every
+        rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e)."""
+        if shard not in ("pixels", "views", "samples"):
+            raise ValueError("shard must be pixels, views or samples")
         self.ctx, self.opt, self.size = ctx, options, (int(size[0]), int(size[1]))
-        self.rank, self.world_size, self.viewports = rank, world_size, viewports
-        self.strategy = DISTRIBUTION_DUPLICATE if world_size == 1 else strategy   # src/tauray.cc:519-521
+        self.rank, self.world_size = rank, world_size
+        self.shard = shard if world_size > 1 else "pixels"
+        self.total_viewports = viewports
+        if self.shard == "views":
+            from .transfer import shard_viewports
+            viewports = len(shard_viewports(viewports, rank, world_size))
+        self.viewports = viewports
+        self.strategy = DISTRIBUTION_DUPLICATE if (world_size == 1 or self.shard != "pixels") else strategy   # src/tauray.cc:519-521
         self.accumulate = accumulate
         self.scene_update = SceneStage(ctx, scene)
-        workloads = [1.0 / world_size] * world_size
-        self.dists = self._device_dists(workloads)
+        if self.shard == "pixels":
+            workloads = [1.0 / world_size] * world_size
+            self.dists = self._device_dists(workloads)
+        else:       # every rank owns full-size images
+            self.dists = [DistributionParams(self.size, DISTRIBUTION_DUPLICATE, 0, 1, True)] * world_size
         self.dist = self.dists[rank]
+        if self.shard == "samples":
+            if options.samples_per_pixel % world_size or (options.samples_per_pixel // world_size) % options.samples_per_pass:
+                raise ValueError("sample sharding needs samples_per_pixel divisible by the device count (and the share by samples_per_pass)")
+            options = copy_options(options, samples_per_pixel=options.samples_per_pixel // world_size)
+            self.opt = options
         self.ray_tracer = PathTracerStage(ctx, self.scene_update, options, self.dist)
+        if self.shard == "views":
+            self.ray_tracer.set_shard(viewport_base=rank, viewport_stride=world_size)
+        elif self.shard == "samples":
+            self.ray_tracer.set_shard(sample_base=rank, sample_stride=world_size)
         tw, th = get_distribution_target_size(self.dist)
         self.target_size = (tw, th)
         self.use_torch = (world_size > 1) if use_torch is None else use_torch
@@ -443,8 +480,9 @@ class RtRenderer:
             self._torch = torch
             self.color = torch.zeros((viewports, th, tw, 4), dtype=torch.float32, device=f"cuda:{ctx.hip_device}")
         else:
-            self.color = ctx.alloc(viewports * tw * th * 16).zero()
-        self.stitch = StitchStage(ctx, self.size) if world_size > 1 else None
+            self.color = ctx.alloc(max(viewports, 1) * tw * th * 16).zero()
+        self.stitch = StitchStage(ctx, self.size) if (world_size > 1 and self.shard == "pixels") else None
+        self.all_views = None
         self.tonemap = TonemapStage(ctx, **(tonemap or {}))
         self.display = None
         self.recv_buffers = {}
@@ -480,7 +518,8 @@ class RtRenderer:
     def render_partial(self, stream=None):
         if not self.accumulate:
             self.ray_tracer.reset_accumulated_samples()
-        self.ray_tracer.run(self.color, self.viewports, stream)
+        if self.viewports > 0:      # a view shard can be empty (more devices than views)
+            self.ray_tracer.run(self.color, self.viewports, stream)
 
     def transfer_and_stitch(self):
         """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0."""
@@ -493,16 +532,32 @@ class RtRenderer:
         if self.rank == 0:
             self.stitch.set_blend_ratio(1.0)
 
-    def render(self, tonemap=True):
+    def render(self, tonemap=True, gather_views=False):
         self.render_partial()
         # kernels run on the null stream, which is also torch's current stream: RCCL orders after them
-        self.transfer_and_stitch()
-        if tonemap and self.rank == 0:
-            self.post_process()
+        if self.shard == "views":
+            # every rank finishes its own views (tonemap is per pixel); `gather_views` ships them to the writer on rank 0
+            if tonemap and self.viewports > 0:
+                self.post_process()
+            if gather_views:
+                from .transfer import gather_views_to_display
+                src = self.display if tonemap else self.color
+                self.all_views = gather_views_to_display(src, self.total_viewports, self.rank, self.world_size, self.all_views)
+        elif self.shard == "samples":
+            from .transfer import reduce_samples_to_display
+            reduce_samples_to_display(self.color, self.rank, self.world_size)
+            if tonemap and self.rank == 0:
+                self.post_process()
+        else:
+            self.transfer_and_stitch()
+            if tonemap and self.rank == 0:
+                self.post_process()
         self.accumulated_frames += 1
 
     def post_process(self):
         w, h = self.size
+        if self.viewports == 0:
+            return
         if self.display is None:
             if self.use_torch:
                 self.display = self._torch.empty((self.viewports, h, w, 4), dtype=self._torch.float32, device=self.color.device)

@@ -40,3 +40,55 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
     for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, color, 0)]):
         q.wait()
     return {}
+
+
+def shard_viewports(viewports: int, rank: int, world_size: int) -> List[int]:
+    """View sharding: viewport v belongs to device v mod N."""
+    return list(range(rank, viewports, world_size))
+
+
+def gather_views_to_display(local_views, viewports: int, rank: int, world_size: int, out=None):
+    """Optional last step of a view-sharded frame: the finished views [k, H, W, 4] of every rank travel to rank 0, which
+    returns the full [viewports, H, W, 4] stack (other ranks: None).  One grouped send/recv, no reduction: a view is
+    owned by exactly one rank."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local_views
+    if rank == 0:
+        shape = (viewports,) + tuple(local_views.shape[1:])
+        if out is None or tuple(out.shape) != shape:
+            out = torch.empty(shape, dtype=local_views.dtype, device=local_views.device)
+        mine = shard_viewports(viewports, 0, world_size)
+        if mine:
+            out[mine[0]::world_size] = local_views
+        ops, staged = [], {}
+        for r in range(1, world_size):
+            k = len(shard_viewports(viewports, r, world_size))
+            if k == 0:
+                continue
+            staged[r] = torch.empty((k,) + tuple(local_views.shape[1:]), dtype=local_views.dtype, device=local_views.device)
+            ops.append(dist.P2POp(dist.irecv, staged[r], r))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        for r, buf in staged.items():
+            out[r::world_size] = buf
+        return out
+    if local_views.shape[0] > 0:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_views, 0)]):
+            q.wait()
+    return None
+
+
+def reduce_samples_to_display(color, rank: int, world_size: int):
+    """Sample sharding: every rank holds the mean of its own samples of every pixel, all ranks took the
+    same number; one reduce(sum) to rank 0 (RCCL ring over xGMI), which divides by N.  In place on `color`."""
+    import torch.distributed as dist
+    if world_size == 1:
+        return color
+    dist.reduce(color, dst=0, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        color.mul_(1.0 / world_size)
+        return color
+    return None

@@ -689,3 +689,83 @@ def posed_scene(scene, sp, vertices):
     posed.vertices = scene.vertices.copy()
     posed.vertices[sp["vertex_offset"]:sp["vertex_offset"] + sp["vertex_count"]] = vertices
     return posed
+
+
+@pytest.mark.gpu
+def test_view_and_sample_shards(R, ctx, oracle):
+    """View and sample sharding: a shard's images are exactly the ones a single device renders for those
+    viewports / samples, because cameras and RNG streams are addressed by global viewport and sample index."""
+    import copy
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import generate_camera_grid
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), 96, 64)
+    scene = copy.copy(scene)
+    scene.cameras = generate_camera_grid(scene.cameras[0], 3, 2, 0.3, 0.3, 5.0)            # 6 views
+    ss = R.SceneStage(ctx, scene)
+    size, V = (96, 64), 6
+    kw = dict(max_bounces=3)
+    whole = _render_hip(R, ctx, ss, scene, size, viewports=V, **kw)
+    osc = oracle.OracleScene(scene)
+
+    def shard_render(viewports, frames=1, **shard):
+        opt = R.options_for_scene(scene, **dict(kw, **shard.pop("opt", {})))
+        pt = R.PathTracerStage(ctx, ss, opt, _dup(size))
+        pt.set_shard(**shard)
+        color = ctx.alloc(viewports * size[0] * size[1] * 16).zero()
+        for _ in range(frames):
+            pt.run(color, viewports)
+        img = color.download((viewports, size[1], size[0], 4))
+        pt.close()
+        return img
+
+    for world in (2, 4):
+        for rank in range(world):
+            mine = list(range(rank, V, world))
+            got = shard_render(len(mine), viewport_base=rank, viewport_stride=world)
+            assert np.array_equal(got, whole[mine]), f"view shard {rank}/{world}"
+    osc.set_shard(viewport_base=1, viewport_stride=2)
+    _compare(whole[1::2], osc.render_pt(oracle.options_for_scene(scene, **kw), *size, viewports=3), "view shard vs oracle")
+    osc.set_shard()
+    with pytest.raises(R.TrhipError):
+        shard_render(4, viewport_base=1, viewport_stride=2)         # viewport 7 does not exist
+
+    # samples: 8 spp on one device against 4 shards of 2 spp, two frames accumulated (the sample counter advances by the
+    # whole job's samples per frame)
+    S, world = 8, 4
+    one = _render_hip(R, ctx, ss, scene, size, frames=2, samples_per_pixel=S, **kw)
+    parts = [shard_render(1, frames=2, sample_base=r, sample_stride=world, opt=dict(samples_per_pixel=S // world)) for r in range(world)]
+    mean = np.sum(np.stack(parts).astype(np.float64), axis=0) / world
+    assert float(np.abs(mean[..., :3] - one[..., :3]).max()) <= 2e-6 * max(1.0, float(np.abs(one[..., :3]).max())), "sample shards do not add up"
+    assert not np.array_equal(parts[0], parts[1])
+    # one shard against the oracle's restatement of the same shard
+    osc.set_shard(sample_base=2, sample_stride=4)
+    _compare(shard_render(1, sample_base=2, sample_stride=4, opt=dict(samples_per_pixel=2)),
+             osc.render_pt(oracle.options_for_scene(scene, samples_per_pixel=2, **kw), *size), "sample shard vs oracle")
+    osc.set_shard()
+    with pytest.raises(R.TrhipError):
+        shard_render(1, sample_base=4, sample_stride=4)
+
+
+@pytest.mark.gpu
+def test_rt_renderer_view_shard(R, ctx, oracle):
+    """RtRenderer(shard="views"): rank r of N renders and tonemaps viewports r, r+N, ... with nothing exchanged."""
+    import copy
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import generate_camera_grid
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), 64, 48)
+    scene = copy.copy(scene)
+    scene.cameras = generate_camera_grid(scene.cameras[0], 5, 1, 0.3, 0.3, 5.0)
+    opt = R.options_for_scene(scene, max_bounces=2)
+    single = R.RtRenderer(ctx, scene, opt, (64, 48), viewports=5, use_torch=False)
+    single.render()
+    want_color, want_display = single.download("color"), single.download("display")
+    for world in (2, 3, 7):
+        for rank in range(world):
+            rr = R.RtRenderer(ctx, scene, opt, (64, 48), rank=rank, world_size=world, viewports=5, use_torch=False, shard="views")
+            assert rr.viewports == len(range(rank, 5, world))
+            rr.render()
+            if rr.viewports:
+                assert np.array_equal(rr.download("color"), want_color[rank::world])
+                assert np.array_equal(rr.download("display"), want_display[rank::world])
+    with pytest.raises(ValueError):
+        R.RtRenderer(ctx, scene, R.options_for_scene(scene, samples_per_pixel=3), (64, 48), rank=0, world_size=2, use_torch=False, shard="samples")

@@ -75,3 +75,58 @@ def test_sharded_frame_equals_single_device_frame(tmp_path, world, strategy, ora
     got = np.load(out)
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), f"{(got != ref).any(-1).sum()} pixels differ"
+
+
+def _shard_worker(rank, world, mode, port, out_path):
+    """View / sample sharding with the oracle as the per-rank renderer."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as B
+    from tauray_amd import scene as S
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.transfer import gather_views_to_display, reduce_samples_to_display, shard_viewports
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    scene.cameras = S.generate_camera_grid(scene.cameras[0], VIEWS, 1, 0.3, 0.3, 5.0)
+    osc = B.OracleScene(scene)
+    if mode == "views":
+        mine = shard_viewports(VIEWS, rank, world)
+        osc.set_shard(viewport_base=rank, viewport_stride=world)
+        opt = B.options_for_scene(scene, max_bounces=2)
+        local = osc.render_pt(opt, W, H, viewports=len(mine), threads=2) if mine else np.zeros((0, H, W, 4), np.float32)
+        full = gather_views_to_display(torch.from_numpy(local), VIEWS, rank, world)
+        if rank == 0:
+            np.save(out_path, full.numpy())
+    else:
+        osc.set_shard(sample_base=rank, sample_stride=world)
+        opt = B.options_for_scene(scene, max_bounces=2, samples_per_pixel=SPP // world)
+        local = osc.render_pt(opt, W, H, frame_counter=1, threads=2)
+        total = reduce_samples_to_display(torch.from_numpy(local), rank, world)
+        if rank == 0:
+            np.save(out_path, total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+VIEWS, SPP = 5, 6
+
+
+@pytest.mark.parametrize("world,mode", [(2, "views"), (3, "views"), (6, "views"), (2, "samples"), (3, "samples")])
+def test_view_and_sample_shards_equal_single_device(tmp_path, world, mode, oracle):
+    from tauray_amd import scene as S
+    from tauray_amd.gltf import load_glb
+    out = str(tmp_path / "full.npy")
+    port = 31500 + (os.getpid() + world * 11 + len(mode)) % 2000
+    mp.spawn(_shard_worker, args=(world, mode, port, out), nprocs=world, join=True)
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    scene.cameras = S.generate_camera_grid(scene.cameras[0], VIEWS, 1, 0.3, 0.3, 5.0)
+    osc = oracle.OracleScene(scene)
+    got = np.load(out)
+    if mode == "views":     # more ranks than views (6 > 5): the last rank owns nothing
+        ref = osc.render_pt(oracle.options_for_scene(scene, max_bounces=2), W, H, viewports=VIEWS)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+    else:                   # same samples, summed in a different order
+        ref = osc.render_pt(oracle.options_for_scene(scene, max_bounces=2, samples_per_pixel=SPP), W, H, frame_counter=1)
+        assert float(np.abs(got[..., :3] - ref[..., :3]).max()) <= 2e-6 * max(1.0, float(np.abs(ref[..., :3]).max()))
