@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--views", type=int, default=1, help="camera-grid viewports per frame (45 = the 5x9 light field of config 5)")
     ap.add_argument("--shard", default="pixels", choices=["pixels", "views", "samples"],
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -75,34 +77,34 @@ def main():
     ctx = R.Context(local_rank)
     opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, rank=rank, world_size=world, viewports=args.views,
-                      shard=args.shard)
-    pt = rr.ray_tracer
+                      shard=args.shard, frames_in_flight=args.frames_in_flight)
 
     def sync_all():
-        ctx.sync()
+        rr.sync()
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_frames(n):
+    def run_frames(n, one_at_a_time=False):
         for _ in range(n):
             rr.reset_accumulation()     # offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
             rr.render()
+            if one_at_a_time:           # per-kernel timing wants kernels that own the chip: no second frame next to them
+                rr.sync()
 
     # ---- timed region: W warm-up frames, then exactly K frames between barriers
-    pt.set_profiling(False, False)
+    rr.set_profiling(False, False)
     rr.reset_accumulation(reset_sample_counter=True)
     run_frames(args.warmup)
     sync_all()
-    pt.reset_counters()
+    rr.reset_counters()
     t0 = time.perf_counter()
     run_frames(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
-    counters = pt.counters()
-    timings = pt.timings()
+    counters = rr.counters()
     rays_local = counters["closest_rays"] + counters["shadow_rays"]
 
     if dist is not None:
@@ -130,7 +132,7 @@ def main():
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
                    "parallelism": ({"pixels": "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
-                   "views": args.views,
+                   "views": args.views, "frames_in_flight": args.frames_in_flight,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         "rays_per_frame": rays_total // args.steps,
@@ -144,7 +146,7 @@ def main():
         for _ in range(min(args.steps, 50)):
             t1 = time.perf_counter()
             run_frames(1)
-            ctx.sync()
+            rr.sync()
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
         result["frame_latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "mean": round(sum(lat) / len(lat), 4), "min": round(lat[0], 4),
@@ -154,25 +156,21 @@ def main():
     if rank == 0 and not args.no_roofline:
         # re-run of the identical frames (same frame indices) with per-kernel HIP events; detailed timing serialises the
         # frame (no shadow/closest overlap), so every kernel is measured owning the chip (instance k_trace_closest<false, true>)
-        pt.set_profiling(False, True)
+        rr.set_profiling(False, True)
         rr.reset_accumulation(reset_sample_counter=True)
-        run_frames(args.warmup)
-        ctx.sync()
-        pt.reset_counters()
-        run_frames(args.steps)
-        ctx.sync()
-        timings = pt.timings()
+        run_frames(args.warmup, True)
+        rr.reset_counters()
+        run_frames(args.steps, True)
+        timings = rr.timings()
         launches = max(timings["trace_closest_launches"], 1)
         avg_ms = timings["trace_closest_ms"] / launches
         # counted re-run for the algorithmic byte model
-        pt.set_profiling(True, False)
+        rr.set_profiling(True, False)
         rr.reset_accumulation(reset_sample_counter=True)
         run_frames(args.warmup)
-        ctx.sync()
-        pt.reset_counters()
+        rr.reset_counters()
         run_frames(args.steps)
-        ctx.sync()
-        c = pt.counters()
+        c = rr.counters()
         # bytes per SURVEY.md section 8(d), restricted to what trace kernels touch; the closest-hit kernel's share of
         # node/triangle work is apportioned by ray count (both trace kernels walk the same structure)
         closest_share = c["closest_rays"] / max(c["closest_rays"] + c["shadow_rays"], 1)

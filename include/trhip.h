@@ -35,6 +35,14 @@ int trhip_upload(trhip_device* dev, void* dst_dev, const void* src_host, size_t 
 int trhip_download(trhip_device* dev, void* dst_host, const void* src_dev, size_t bytes, void* stream); /* headless readback, src/headless.cc:292-303 */
 int trhip_memset(trhip_device* dev, void* dst_dev, int value, size_t bytes, void* stream);
 int trhip_sync(trhip_device* dev, void* stream);
+/* Frames in flight (MAX_FRAMES_IN_FLIGHT, src/context.hh:26).  Every call takes the stream it is ordered on; a frame
+ * slot is a stream plus the stages and images it owns, and `dependencies` between stages on different streams
+ * (src/dependency.hh; timeline-semaphore waits in multi_device_stage::run, src/stage.cc:35-76) become
+ * trhip_stream_wait: work enqueued on `stream` after the call starts only when everything enqueued on `on` before the
+ * call has finished.  No host synchronisation.  NULL is the default stream. */
+int trhip_stream_create(trhip_device* dev, void** stream_out);
+int trhip_stream_destroy(trhip_device* dev, void* stream);
+int trhip_stream_wait(trhip_device* dev, void* stream, void* on);
 /* device -> device copy over xGMI (replaces the pinned-host bounce of src/device_transfer.cc:140-290 when all
  * devices live in one process; with one process per GPU the same transfer is an RCCL send/recv) */
 int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream);
@@ -165,6 +173,13 @@ int trhip_direct_create(trhip_device* dev, const trhip_pt_options* opt, trhip_pt
 void trhip_pt_destroy(trhip_pt* pt);
 int trhip_pt_set_distribution(trhip_pt* pt, const trhip_distribution* dist);  /* rt_camera_stage::reset_distribution_params */
 int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /* reset_accumulated_samples / reset_sample_counter */
+/* rt_stage::frame_counter (src/rt_stage.cc:81-86) of the next frame: with one stage per frame slot, slot k of F renders
+ * frames k, k + F, ... and sets the counter before each of them (sample_counter = frame_counter * samples_per_pixel). */
+int trhip_pt_set_frame_counter(trhip_pt* pt, uint32_t frame_counter);
+/* How many slices of a frame the stage runs concurrently on its own streams: 0 = automatic
+ * (four for frames of >= 1.5 M paths), 1 = everything on the caller's stream - the right choice with several frames in
+ * flight, which fill the chip between them. */
+int trhip_pt_set_lanes(trhip_pt* pt, int lanes);
 /* View and sample sharding across devices (the reference itself only shards pixels,
  * src/distribution_strategy.cc).  Local layer l of the target shows viewport viewport_base + l * viewport_stride: that
  * viewport's camera (shader/scene.glsl:176-185) and its RNG stream (the viewport index seeds the sampler,

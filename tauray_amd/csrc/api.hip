@@ -211,6 +211,29 @@ int trhip_download(trhip_device* dev, void* dst, const void* src, size_t bytes, 
 }
 int trhip_memset(trhip_device* dev, void* dst, int value, size_t bytes, void* stream) { DEVCHK(dev); HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream)); return 0; }
 int trhip_sync(trhip_device* dev, void* stream) { DEVCHK(dev); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int trhip_stream_create(trhip_device* dev, void** stream_out) {
+    DEVCHK(dev);
+    if (!stream_out) return set_error("trhip_stream_create: null argument");
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream_out = st;
+    return 0;
+}
+int trhip_stream_destroy(trhip_device* dev, void* stream) {
+    DEVCHK(dev);
+    if (stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipStreamDestroy((hipStream_t)stream)); }
+    return 0;
+}
+int trhip_stream_wait(trhip_device* dev, void* stream, void* on) {
+    DEVCHK(dev);
+    if (stream == on) return 0;
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e, (hipStream_t)on));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    HIPCHK(hipEventDestroy(e));   // released by the runtime once the recorded work has completed
+    return 0;
+}
 int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream) {
     if (!dst_dev || !src_dev) return set_error("null trhip_device");
     DEVCHK(src_dev);
@@ -442,6 +465,17 @@ int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint3
     DEVCHK(pt->dev);
     pt->stage->last_stream = (hipStream_t)stream;
     return pt->stage->render(*targets, target_w, target_h, viewports, (hipStream_t)stream);
+}
+int trhip_pt_set_frame_counter(trhip_pt* pt, uint32_t frame_counter) {
+    if (!pt) return set_error("null trhip_pt");
+    pt->stage->frame_counter = frame_counter;
+    return 0;
+}
+int trhip_pt_set_lanes(trhip_pt* pt, int lanes) {
+    if (!pt) return set_error("null trhip_pt");
+    if (lanes < 0) return set_error("trhip_pt_set_lanes: lanes must be >= 0");
+    pt->stage->lanes = lanes;
+    return 0;
 }
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
     if (!pt) return set_error("null trhip_pt");

@@ -1128,7 +1128,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // by throughput; extra hardware queues only add dispatch latency there (measured: 1 M paths 1.68 ms on one lane, 1.94 ms
     // on four; 2 M paths 3.87 ms vs 3.10 ms).
     static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)1500000;
-    const int n_lanes = (timing || n < lanes_min_paths) ? 1 : std::max(1, std::min(lanes_env, PT_LANES));
+    const int n_lanes = timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(lanes_env, PT_LANES))));
     // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
     static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
     const bool first_hit_targets = targets.albedo || targets.material || targets.normal || targets.pos || targets.instance_id || targets.screen_motion;

@@ -24,6 +24,7 @@ public:
     int count_work = 0, detailed_timing = 0;
     // trhip_pt_set_shard: which viewports / samples of the whole job this stage renders (view and sample sharding)
     uint shard_vp_base = 0, shard_vp_stride = 1, shard_sample_base = 0, shard_sample_stride = 1;
+    int lanes = 0;                   // trhip_pt_set_lanes: 0 = automatic
     bool direct = false;             // direct_stage instead of path_tracer_stage (trhip_direct_create)
     hipStream_t last_stream = nullptr;
 

@@ -138,6 +138,18 @@ class Context:
     def sync(self, stream=None):
         check(_lib.lib().trhip_sync(self.h, stream))
 
+    def create_stream(self) -> int:
+        st = C.c_void_p()
+        check(_lib.lib().trhip_stream_create(self.h, C.byref(st)))
+        return st.value
+
+    def destroy_stream(self, stream):
+        check(_lib.lib().trhip_stream_destroy(self.h, stream))
+
+    def stream_wait(self, stream, on):
+        """Work enqueued on `stream` from now on waits for what is on `on` now (None = the default stream)."""
+        check(_lib.lib().trhip_stream_wait(self.h, stream, on))
+
     def close(self):
         if self.h:
             _lib.lib().trhip_device_destroy(self.h)
@@ -321,6 +333,12 @@ class PathTracerStage:
         base + s * stride of the pixel's sequence."""
         check(_lib.lib().trhip_pt_set_shard(self.h, viewport_base, viewport_stride, sample_base, sample_stride))
 
+    def set_frame_counter(self, frame_counter: int):
+        check(_lib.lib().trhip_pt_set_frame_counter(self.h, frame_counter))
+
+    def set_lanes(self, lanes: int):
+        check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
+
     def reset_accumulated_samples(self):
         check(_lib.lib().trhip_pt_reset_accumulation(self.h, 0))
 
@@ -425,6 +443,16 @@ class TonemapStage:
         check(_lib.lib().trhip_tonemap(self.ctx.h, _ptr(src), _ptr(dst), width, height, layers, C.byref(self.info), stream))
 
 
+class _FrameSlot:
+    """What one frame in flight owns: its stage (path buffers, counters), its images and the stream it is ordered on."""
+
+    def __init__(self):
+        self.pt = None
+        self.color = None
+        self.display = None
+        self.stream = None
+
+
 class RtRenderer:
     """rt_renderer<path_tracer_stage> for one rank of an N-GPU job.
 
@@ -434,16 +462,26 @@ class RtRenderer:
     xGMI): non-display ranks `send` their partial, the display rank `recv`s it straight into device
     memory and runs the stitch kernel - replacing the GPU->pinned host->GPU copies of
     src/device_transfer.cc:21-347.
+
+    `frames_in_flight` (MAX_FRAMES_IN_FLIGHT = 2 in the reference, src/context.hh:26): that many frame slots, each with its
+    own stage, images and stream; frame i goes to slot i mod F and starts while the previous frames are still running, so
+    the tails of one frame's kernels are filled by the next frame.  The exchange between ranks, the stitch and the tonemap
+    of a multi-GPU frame stay on the default stream (= torch's current stream, where RCCL orders itself); only the path
+    tracing runs ahead on the slot streams.
     """
 
     def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
                  rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None,
-                 shard="pixels"):
+                 shard="pixels", frames_in_flight=1):
         """`shard`: what the ranks divide among themselves - "pixels" (the reference's distribution strategies, partial frames
         stitched on rank 0), "views" (viewport v on rank v mod N; nothing is exchanged before output) or "samples" (every
         rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e)."""
         if shard not in ("pixels", "views", "samples"):
             raise ValueError("shard must be pixels, views or samples")
+        if frames_in_flight < 1:
+            raise ValueError("frames_in_flight must be >= 1")
+        if frames_in_flight > 1 and accumulate:
+            raise ValueError("accumulating frames depend on each other: frames_in_flight must be 1")
         self.ctx, self.opt, self.size = ctx, options, (int(size[0]), int(size[1]))
         self.rank, self.world_size = rank, world_size
         self.shard = shard if world_size > 1 else "pixels"
@@ -466,11 +504,6 @@ class RtRenderer:
                 raise ValueError("sample sharding needs samples_per_pixel divisible by the device count (and the share by samples_per_pass)")
             options = copy_options(options, samples_per_pixel=options.samples_per_pixel // world_size)
             self.opt = options
-        self.ray_tracer = PathTracerStage(ctx, self.scene_update, options, self.dist)
-        if self.shard == "views":
-            self.ray_tracer.set_shard(viewport_base=rank, viewport_stride=world_size)
-        elif self.shard == "samples":
-            self.ray_tracer.set_shard(sample_base=rank, sample_stride=world_size)
         tw, th = get_distribution_target_size(self.dist)
         self.target_size = (tw, th)
         self.use_torch = (world_size > 1) if use_torch is None else use_torch
@@ -478,15 +511,43 @@ class RtRenderer:
         if self.use_torch:
             import torch
             self._torch = torch
-            self.color = torch.zeros((viewports, th, tw, 4), dtype=torch.float32, device=f"cuda:{ctx.hip_device}")
-        else:
-            self.color = ctx.alloc(max(viewports, 1) * tw * th * 16).zero()
+        self.frames_in_flight = frames_in_flight
+        self.slots = []
+        for k in range(frames_in_flight):
+            slot = _FrameSlot()
+            slot.pt = PathTracerStage(ctx, self.scene_update, options, self.dist)
+            if self.shard == "views":
+                slot.pt.set_shard(viewport_base=rank, viewport_stride=world_size)
+            elif self.shard == "samples":
+                slot.pt.set_shard(sample_base=rank, sample_stride=world_size)
+            if frames_in_flight > 1:
+                slot.pt.set_lanes(1)             # the frames in flight fill the chip between them
+                slot.stream = ctx.create_stream()
+            if self.use_torch:
+                slot.color = self._torch.zeros((viewports, th, tw, 4), dtype=self._torch.float32, device=f"cuda:{ctx.hip_device}")
+            else:
+                slot.color = ctx.alloc(max(viewports, 1) * tw * th * 16).zero()
+            self.slots.append(slot)
+        self.current = self.slots[0]
         self.stitch = StitchStage(ctx, self.size) if (world_size > 1 and self.shard == "pixels") else None
         self.all_views = None
         self.tonemap = TonemapStage(ctx, **(tonemap or {}))
-        self.display = None
         self.recv_buffers = {}
         self.accumulated_frames = 0
+        self.frame_index = 0
+
+    # the stage / images of the most recent frame (the only ones there are with frames_in_flight = 1)
+    @property
+    def ray_tracer(self) -> PathTracerStage:
+        return self.current.pt
+
+    @property
+    def color(self):
+        return self.current.color
+
+    @property
+    def display(self):
+        return self.current.display
 
     def _device_dists(self, ratios) -> List[DistributionParams]:
         out, cumulative = [], 0.0
@@ -497,32 +558,77 @@ class RtRenderer:
         return out
 
     def set_scene(self, scene: SceneDesc):
+        self.sync()
         self.scene_update.set_scene(scene)
 
+    def sync(self):
+        """Waits for every frame in flight."""
+        for slot in self.slots:
+            if slot.stream is not None:
+                self.ctx.sync(slot.stream)
+        self.ctx.sync()
+
     def reset_accumulation(self, reset_sample_counter=False):
-        self.ray_tracer.reset_accumulated_samples()
+        for slot in self.slots:
+            slot.pt.reset_accumulated_samples()
+            if reset_sample_counter:
+                slot.pt.reset_sample_counter()
         if reset_sample_counter:
-            self.ray_tracer.reset_sample_counter()
+            self.frame_index = 0
         self.accumulated_frames = 0
+
+    def set_profiling(self, count_work=False, detailed_timing=False):
+        for slot in self.slots:
+            slot.pt.set_profiling(count_work, detailed_timing)
+
+    def reset_counters(self):
+        self.sync()
+        for slot in self.slots:
+            slot.pt.reset_counters()
+
+    def counters(self) -> dict:
+        """Work counters summed over the frame slots."""
+        self.sync()
+        total = {}
+        for slot in self.slots:
+            for k, v in slot.pt.counters().items():
+                total[k] = max(total.get(k, 0), v) if k == "stack_overflows" else total.get(k, 0) + v
+        return total
+
+    def timings(self) -> dict:
+        self.sync()
+        total = {}
+        for slot in self.slots:
+            for k, v in slot.pt.timings().items():
+                total[k] = total.get(k, 0) + v
+        return total
 
     def set_device_workloads(self, ratios):
         """rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183): only for shuffled strips."""
         if self.strategy in (DISTRIBUTION_SCANLINE, DISTRIBUTION_DUPLICATE):
             return
+        self.sync()
         self.dists = self._device_dists(ratios)
         self.dist = self.dists[self.rank]
-        self.ray_tracer.reset_distribution_params(self.dist)
-        if self.rank != 0:
-            self.ray_tracer.reset_accumulated_samples()
+        for slot in self.slots:
+            slot.pt.reset_distribution_params(self.dist)
+            if self.rank != 0:
+                slot.pt.reset_accumulated_samples()
 
     def render_partial(self, stream=None):
+        """The path-tracing part of the next frame on its slot (`stream` overrides the slot's stream)."""
+        slot = self.slots[self.frame_index % self.frames_in_flight]
+        self.current = slot
         if not self.accumulate:
-            self.ray_tracer.reset_accumulated_samples()
+            slot.pt.reset_accumulated_samples()
+        if self.frames_in_flight > 1:
+            slot.pt.set_frame_counter(self.frame_index)      # one stage per slot: slot k renders frames k, k + F, ...
+        self.frame_index += 1
         if self.viewports > 0:      # a view shard can be empty (more devices than views)
-            self.ray_tracer.run(self.color, self.viewports, stream)
+            slot.pt.run(slot.color, self.viewports, stream if stream is not None else slot.stream)
 
     def transfer_and_stitch(self):
-        """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0."""
+        """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0 (default stream)."""
         if self.world_size == 1:
             return
         from .transfer import gather_to_display
@@ -534,7 +640,18 @@ class RtRenderer:
 
     def render(self, tonemap=True, gather_views=False):
         self.render_partial()
-        # kernels run on the null stream, which is also torch's current stream: RCCL orders after them
+        slot = self.current
+        if self.world_size == 1:
+            if tonemap:
+                self.post_process(slot.stream)       # the whole frame stays on its slot's stream
+            self.accumulated_frames += 1
+            return
+        # Several ranks.  Everything after the path tracing runs on the default stream, which is also torch's current
+        # stream: RCCL orders itself after the kernels enqueued there.  With frames in flight the default stream first
+        # waits for this slot's path tracing, and the slot's stream afterwards waits for the default stream, so that the
+        # next frame of this slot does not overwrite images that are still being sent, stitched or tonemapped.
+        if slot.stream is not None:
+            self.ctx.stream_wait(None, slot.stream)
         if self.shard == "views":
             # every rank finishes its own views (tonemap is per pixel); `gather_views` ships them to the writer on rank 0
             if tonemap and self.viewports > 0:
@@ -552,21 +669,25 @@ class RtRenderer:
             self.transfer_and_stitch()
             if tonemap and self.rank == 0:
                 self.post_process()
+        if slot.stream is not None:
+            self.ctx.stream_wait(slot.stream, None)
         self.accumulated_frames += 1
 
-    def post_process(self):
+    def post_process(self, stream=None):
         w, h = self.size
         if self.viewports == 0:
             return
-        if self.display is None:
+        slot = self.current
+        if slot.display is None:
             if self.use_torch:
-                self.display = self._torch.empty((self.viewports, h, w, 4), dtype=self._torch.float32, device=self.color.device)
+                slot.display = self._torch.empty((self.viewports, h, w, 4), dtype=self._torch.float32, device=slot.color.device)
             else:
-                self.display = self.ctx.alloc(self.viewports * w * h * 16)
-        self.tonemap.run(self.color, self.display, w, h, self.viewports)
+                slot.display = self.ctx.alloc(self.viewports * w * h * 16)
+        self.tonemap.run(slot.color, slot.display, w, h, self.viewports, stream)
 
     def download(self, which="color") -> np.ndarray:
-        self.ctx.sync()
+        """The most recent frame's partial colour target or tonemapped display image."""
+        self.sync()
         buf = self.color if which == "color" else self.display
         if which == "color":
             tw, th = self.target_size
@@ -576,3 +697,12 @@ class RtRenderer:
             self._torch.cuda.synchronize()
             return buf.cpu().numpy()
         return buf.download((self.viewports, th, tw, 4), np.float32)
+
+    def close(self):
+        self.sync()
+        for slot in self.slots:
+            slot.pt.close()
+            if slot.stream is not None:
+                self.ctx.destroy_stream(slot.stream)
+                slot.stream = None
+        self.slots = []

@@ -769,3 +769,38 @@ def test_rt_renderer_view_shard(R, ctx, oracle):
                 assert np.array_equal(rr.download("display"), want_display[rank::world])
     with pytest.raises(ValueError):
         R.RtRenderer(ctx, scene, R.options_for_scene(scene, samples_per_pixel=3), (64, 48), rank=0, world_size=2, use_torch=False, shard="samples")
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_are_the_same_frames(R, ctx):
+    """Frame slots (MAX_FRAMES_IN_FLIGHT, src/context.hh:26): frame i on slot i mod F, started before the previous frames
+    have finished, is bit for bit the frame a one-frame-at-a-time renderer produces for index i."""
+    from tauray_amd.gltf import load_glb
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), 160, 96)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    serial = R.RtRenderer(ctx, scene, opt, (160, 96), use_torch=False)
+    want = []
+    for _ in range(7):
+        serial.render()
+        want.append((serial.download("color"), serial.download("display")))
+    assert not np.array_equal(want[0][0], want[1][0])
+    cs = serial.counters()
+    serial.close()
+    for F in (2, 3):
+        rr = R.RtRenderer(ctx, scene, opt, (160, 96), use_torch=False, frames_in_flight=F)
+        for i in range(7):          # no host synchronisation between frames
+            rr.render()
+        rr.sync()
+        for back in range(F):       # the last F frames are still in their slots
+            i = 6 - back
+            slot = rr.slots[i % F]
+            assert np.array_equal(slot.color.download((1, 96, 160, 4)), want[i][0]), f"F={F}: frame {i}"
+            assert np.array_equal(slot.display.download((1, 96, 160, 4)), want[i][1]), f"F={F}: tonemapped frame {i}"
+        c = rr.counters()
+        assert c["closest_rays"] == cs["closest_rays"] and c["shadow_rays"] == cs["shadow_rays"] and c["stack_overflows"] == 0
+        rr.reset_accumulation(reset_sample_counter=True)
+        rr.render()
+        assert np.array_equal(rr.download("color"), want[0][0])
+        rr.close()
+    with pytest.raises(ValueError):
+        R.RtRenderer(ctx, scene, opt, (160, 96), use_torch=False, frames_in_flight=2, accumulate=True)
