@@ -140,7 +140,12 @@ public:
 
     void* alloc(size_t bytes) { void* p = nullptr; check(trhip_malloc(h, bytes, &p)); return p; }
     void free(void* p) { trhip_free(h, p); }
-    void sync() { check(trhip_sync(h, nullptr)); }
+    void sync(void* stream = nullptr) { check(trhip_sync(h, stream)); }
+    // Frame slots: a stream per frame in flight (MAX_FRAMES_IN_FLIGHT, src/context.hh:26); `dependencies` between stages on
+    // different streams (src/dependency.hh) = stream_wait: `stream` continues once everything now on `on` has finished.
+    void* create_stream() { void* st = nullptr; check(trhip_stream_create(h, &st)); return st; }
+    void destroy_stream(void* stream) { check(trhip_stream_destroy(h, stream)); }
+    void stream_wait(void* stream, void* on) { check(trhip_stream_wait(h, stream, on)); }
 
     trhip_device* h = nullptr;
     int hip_device;
@@ -327,11 +332,20 @@ public:
         trhip_distribution d = to_abi(distribution);
         check(trhip_pt_set_distribution(pt, &d));
     }
-    // stage::run: enqueue the frame (all passes) on the device's stream
-    void run()
+    // one stage per frame slot: slot k of F renders frames k, k + F, ... (rt_stage::frame_counter, src/rt_stage.cc:81-86)
+    void set_frame_counter(uint32_t frame_counter) { check(trhip_pt_set_frame_counter(pt, frame_counter)); }
+    // slices of a frame run concurrently inside the stage: 0 = automatic, 1 = none (several frames in flight instead)
+    void set_lanes(int lanes) { check(trhip_pt_set_lanes(pt, lanes)); }
+    // view / sample shard of a multi-device job: global viewport and sample addressing
+    void set_shard(uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base = 0, uint32_t sample_stride = 1)
+    {
+        check(trhip_pt_set_shard(pt, viewport_base, viewport_stride, sample_base, sample_stride));
+    }
+    // stage::run: enqueue the frame (all passes) on `stream` (default: the device's stream)
+    void run(void* stream = nullptr)
     {
         uvec2 ts = get_distribution_target_size(opt.distribution);
-        check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count, nullptr));
+        check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count, stream));
     }
     // the same frame into a gbuffer (src/gbuffer.hh: the entries path_tracer.rgen writes); null members are skipped
     using gbuffer_target = trhip_pt_targets;
@@ -374,10 +388,10 @@ public:
         bool alpha_grid_background = false;
     };
     tonemap_stage(device& dev, const options& opt): dev(&dev), opt(opt) {}
-    void run(const void* in, void* out, uvec2 size, uint32_t layers)
+    void run(const void* in, void* out, uvec2 size, uint32_t layers, void* stream = nullptr)
     {
         trhip_tonemap_info info = {(int32_t)opt.tonemap_operator, opt.exposure, opt.gamma, opt.alpha_grid_background ? 16 : 0};
-        check(trhip_tonemap(dev->h, in, out, size.x, size.y, layers, &info, nullptr));
+        check(trhip_tonemap(dev->h, in, out, size.x, size.y, layers, &info, stream));
     }
     device* dev;
     options opt;
