@@ -42,6 +42,9 @@ def parse():
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
+    ap.add_argument("--save-display", default=None, help="rank 0 writes the last tonemapped frame to this .npy file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -50,6 +53,9 @@ def parse():
 
 def main():
     args = parse()
+    if os.environ.get("TRHIP_BENCH_WATCHDOG"):      # rehearsals: dump every thread's stack and exit instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["TRHIP_BENCH_WATCHDOG"]), exit=True)
     from tauray_amd import renderer as R
     from tauray_amd import scenes
     from tauray_amd.distribution import DISTRIBUTION_SCANLINE
@@ -61,10 +67,13 @@ def main():
         import torch
         import torch.distributed as dist
         rank = int(os.environ.get("RANK", "0"))
-        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", str(rank)))
         world = int(os.environ.get("WORLD_SIZE", str(world)))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         local_rank = 0
 
@@ -153,7 +162,8 @@ def main():
                                       "frames": len(lat), "note": "host sync after every frame"}
 
     # ---- roofline of the dominant kernel (k_trace_closest), rank 0
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank takes part (a frame of a multi-GPU job ends in an exchange between the ranks); rank 0's kernels are reported.
         # re-run of the identical frames (same frame indices) with per-kernel HIP events; detailed timing serialises the
         # frame (no shadow/closest overlap), so every kernel is measured owning the chip (instance k_trace_closest<false, true>)
         rr.set_profiling(False, True)
@@ -225,6 +235,13 @@ def main():
             "ms_per_frame": round(dt / frames * 1e3, 1),
         }
 
+    if args.save_display:       # frame 0 again on every rank, outside all timing
+        rr.set_profiling(False, False)
+        rr.reset_accumulation(reset_sample_counter=True)
+        rr.render()
+        sync_all()
+        if rank == 0:
+            np.save(args.save_display, rr.download("display"))
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -13,6 +13,15 @@ from typing import Dict, List
 from .distribution import DistributionParams, get_distribution_target_size
 
 
+def _settle(t):
+    """gloo reads and writes device memory from the host without looking at any stream (rehearsals of the N > 1 path on
+    one GPU, tools/rehearse_multi_rank.sh): drain the device before and after its transfers.  RCCL is stream-ordered."""
+    import torch
+    import torch.distributed as dist
+    if getattr(t, "is_cuda", False) and dist.get_backend() == "gloo":
+        torch.cuda.synchronize()
+
+
 def partial_shape(dist: DistributionParams, viewports: int):
     w, h = get_distribution_target_size(dist)
     return (viewports, h, w, 4)
@@ -25,6 +34,7 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
     import torch.distributed as dist
     if world_size == 1:
         return {}
+    _settle(color)
     if rank == 0:
         ops = []
         for r in range(1, world_size):
@@ -36,9 +46,11 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
             ops.append(dist.P2POp(dist.irecv, buf, r))
         for q in dist.batch_isend_irecv(ops):
             q.wait()
+        _settle(color)
         return {r: recv_buffers[r] for r in range(1, world_size)}
     for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, color, 0)]):
         q.wait()
+    _settle(color)
     return {}
 
 
@@ -55,6 +67,7 @@ def gather_views_to_display(local_views, viewports: int, rank: int, world_size: 
     import torch.distributed as dist
     if world_size == 1:
         return local_views
+    _settle(local_views)
     if rank == 0:
         shape = (viewports,) + tuple(local_views.shape[1:])
         if out is None or tuple(out.shape) != shape:
@@ -72,6 +85,7 @@ def gather_views_to_display(local_views, viewports: int, rank: int, world_size: 
         if ops:
             for q in dist.batch_isend_irecv(ops):
                 q.wait()
+        _settle(local_views)
         for r, buf in staged.items():
             out[r::world_size] = buf
         return out
@@ -87,7 +101,9 @@ def reduce_samples_to_display(color, rank: int, world_size: int):
     import torch.distributed as dist
     if world_size == 1:
         return color
+    _settle(color)
     dist.reduce(color, dst=0, op=dist.ReduceOp.SUM)
+    _settle(color)
     if rank == 0:
         color.mul_(1.0 / world_size)
         return color
