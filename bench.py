@@ -133,7 +133,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_total / elapsed / 1e6
     result = {
-        "metric": "Mray/s (closest-hit + shadow rays traced) @1920x1080, 4 bounces, 1 spp",
+        "metric": "Mray/s (closest-hit + shadow rays traced) @%dx%d, %d bounces, %d spp" % (W, H, args.bounces, args.spp),
         "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.workload != "test_glb" else "reference fixture test/test.glb (81 364 triangles)",
