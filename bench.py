@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Hardware queues the HIP runtime spreads streams over (default 4).  Six frame slots of a small shard want their own queue
+# each; measured neutral for full frames.  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -40,8 +43,9 @@ def parse():
     ap.add_argument("--views", type=int, default=1, help="camera-grid viewports per frame (45 = the 5x9 light field of config 5)")
     ap.add_argument("--shard", default="pixels", choices=["pixels", "views", "samples"],
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
+                         "0 = 3 for one or two GPUs, 6 beyond (small shards are latency-bound: tools/shard_share_probe.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--save-display", default=None, help="rank 0 writes the last tonemapped frame to this .npy file")
@@ -60,6 +64,8 @@ def main():
     from tauray_amd import scenes
     from tauray_amd.distribution import DISTRIBUTION_SCANLINE
 
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 3 if args.gpus <= 2 else 6
     world = args.gpus
     rank = 0
     dist = None
