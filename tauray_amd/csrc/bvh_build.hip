@@ -649,6 +649,8 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         if (n > 0) HIPCHK(hipMalloc(&ds.tris, (size_t)n * sizeof(TriRecord)));
         if (n1 > 0) {
 #if TR_BVH4
+            // traversal addresses a node's planes with 32-bit byte offsets (node << 7 | plane)
+            if ((uint64_t)n1 * sizeof(Bvh4Node) > 0xFFFFFFFFull) return set_error("trhip_scene_build_accel: more than 2^25 nodes");
             HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node)));
 #else
             HIPCHK(hipMalloc(&ds.nodes, n1 * sizeof(BvhNode)));

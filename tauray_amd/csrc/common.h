@@ -140,7 +140,8 @@ static_assert(sizeof(BvhNode) == 64, "node layout");
 // 4-wide node, one 128-byte line: child boxes in SoA (one dwordx4 per plane), child references as in BvhNode
 // (>= 0 inner node, < 0 ~triangle).  Empty slots hold an inverted box (lo = +inf, hi = -inf) and are never hit.
 struct alignas(128) Bvh4Node {
-    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];   // per axis lo at 32*axis, hi 16 bytes later: a ray reads its near plane at
+                                                            // 32*axis + 16*(direction < 0) and its far plane at that offset ^ 16
     int child[4];
     int pad[4];
 };

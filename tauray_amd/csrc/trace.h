@@ -25,6 +25,7 @@ struct RayPre {
     f3 org, dir, inv_dir;
     int kx, ky, kz;
     float Sx, Sy, Sz;
+    uint nox, noy, noz;   // byte offsets of the near x / y / z planes inside a Bvh4Node (far plane: offset ^ 16)
 };
 
 TR_DEV RayPre make_ray(f3 org, f3 dir) {
@@ -40,6 +41,9 @@ TR_DEV RayPre make_ray(f3 org, f3 dir) {
     r.Sy = comp(dir, ky) / comp(dir, kz);
     r.Sz = 1.0f / comp(dir, kz);
     r.inv_dir = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    r.nox = (__float_as_uint(r.inv_dir.x) >> 31) << 4;
+    r.noy = ((__float_as_uint(r.inv_dir.y) >> 31) << 4) | 32u;
+    r.noz = ((__float_as_uint(r.inv_dir.z) >> 31) << 4) | 64u;
     return r;
 }
 
@@ -295,23 +299,36 @@ TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float
 // 4-wide fp32 BVH: half the dependent node fetches of the binary tree for about the same box-test arithmetic.
 struct Hit4 { float t[4]; int c[4]; };
 
-TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* np, float tmin, float tmax, Hit4& h) {
-    const f4 lox = *reinterpret_cast<const f4*>(np->lox), loy = *reinterpret_cast<const f4*>(np->loy), loz = *reinterpret_cast<const f4*>(np->loz);
-    const f4 hix = *reinterpret_cast<const f4*>(np->hix), hiy = *reinterpret_cast<const f4*>(np->hiy), hiz = *reinterpret_cast<const f4*>(np->hiz);
-    const int4 ch = *reinterpret_cast<const int4*>(np->child);
-    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
-    h.c[0] = ch.x; h.c[1] = ch.y; h.c[2] = ch.z; h.c[3] = ch.w;
+// The ray's direction signs pick the near and the far plane of every axis at load time (per-lane byte offsets into the
+// 128-byte node), so the slab test needs no min / max to order them: per child 6 sub, 6 mul, max + max3, min3 + pad + min,
+// one compare.  NaNs (0 * inf: origin on a plane of an axis the ray does not move along) are dropped by min / max, i.e.
+// that axis does not constrain the interval.  Empty slots hold an inverted infinite box: their near distance is +inf (or
+// their far distance -inf) for every ray, so they never pass and need no test of their own.
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h) {
+    const char* base = reinterpret_cast<const char*>(nodes);
+    const uint t = (uint)node << 7;
+    const uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
+    const f4 nxv = *reinterpret_cast<const f4*>(base + (size_t)ax), fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
+    const f4 nyv = *reinterpret_cast<const f4*>(base + (size_t)ay), fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
+    const f4 nzv = *reinterpret_cast<const f4*>(base + (size_t)az), fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
+    const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
+    const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
+    const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
+    int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float tx0 = (lx[k] - r.org.x) * r.inv_dir.x, tx1 = (hx[k] - r.org.x) * r.inv_dir.x;
-        float ty0 = (ly[k] - r.org.y) * r.inv_dir.y, ty1 = (hy[k] - r.org.y) * r.inv_dir.y;
-        float tz0 = (lz[k] - r.org.z) * r.inv_dir.z, tz1 = (hz[k] - r.org.z) * r.inv_dir.z;
-        float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-        float t1 = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000003576278687f, tmax);
-        // empty slots carry the sentinel child (their inverted box would pass the min/max slab test)
-        h.t[k] = (t0 <= t1 && h.c[k] != 0x7FFFFFFF) ? t0 : __builtin_huge_valf();
+        const float tx0 = (nx[k] - r.org.x) * r.inv_dir.x, tx1 = (fx[k] - r.org.x) * r.inv_dir.x;
+        const float ty0 = (ny[k] - r.org.y) * r.inv_dir.y, ty1 = (fy[k] - r.org.y) * r.inv_dir.y;
+        const float tz0 = (nz[k] - r.org.z) * r.inv_dir.z, tz1 = (fz[k] - r.org.z) * r.inv_dir.z;
+        const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin));
+        // far planes widened by 1 + 2*gamma(3) so rounding can never cull a true hit
+        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1) * 1.0000003576278687f, tmax);
+        h.t[k] = t0 <= t1 ? t0 : __builtin_huge_valf();
     }
+    // keeps the load of the child ids next to the plane loads: left alone, the compiler sinks it into the "some child is hit"
+    // branch, one more dependent round trip per node
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
 }
 
 #define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
@@ -340,7 +357,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
 #endif
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect(r, sv.nodes4 + node, tmin, best_t, h);
+                box4_intersect(r, sv.nodes4, node, tmin, best_t, h);
                 if (COUNT) st.nodes++;
                 TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                 if (h.t[0] < __builtin_huge_valf()) {
@@ -413,7 +430,7 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     while (true) {
         if (node >= 0) {
             Hit4 h;
-            box4_intersect(r, sv.nodes4 + node, tmin, tmax, h);
+            box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
             if (COUNT) st.nodes++;
             int next = 0x7FFFFFFF;
 #pragma unroll
