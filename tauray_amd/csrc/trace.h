@@ -110,18 +110,22 @@ struct LaneStack {
     int sp;
     int overflow;       // count of dropped pushes (an int in a VGPR, not a wave-level predicate)
     TR_DEV void init(int* base) { lds = base; sp = 0; overflow = 0; }
+    // The common case costs a compare, an address and the ds_write.  Past the end of the spill array pushes land on its last
+    // slot and are counted: the traversal still terminates (sp stays balanced) and the frame is reported as invalid.
     TR_DEV void push(int* spill, int v) {
-        const bool ok = sp < TR_LDS_STACK + TR_SPILL_STACK;
         if (sp < TR_LDS_STACK) lds[sp * TR_BLOCK] = v;
-        else if (ok) spill[sp - TR_LDS_STACK] = v;
-        overflow += ok ? 0 : 1;
-        sp += ok ? 1 : 0;
+        else {
+            const int k = sp - TR_LDS_STACK;
+            if (k >= TR_SPILL_STACK) overflow++;
+            spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1] = v;
+        }
+        sp++;
     }
     TR_DEV int pop(const int* spill) {
         sp--;
         int v = lds[(sp < TR_LDS_STACK ? sp : 0) * TR_BLOCK];
         asm volatile("" : "+v"(v));   // pin the ds_read: no select-of-pointers + flat_load
-        if (sp >= TR_LDS_STACK) v = spill[sp - TR_LDS_STACK];
+        if (sp >= TR_LDS_STACK) v = spill[sp - TR_LDS_STACK < TR_SPILL_STACK ? sp - TR_LDS_STACK : TR_SPILL_STACK - 1];
         return v;
     }
 };
@@ -307,7 +311,10 @@ struct Hit4 { float t[4]; int c[4]; };
 TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h) {
     const char* base = reinterpret_cast<const char*>(nodes);
     const uint t = (uint)node << 7;
-    const uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
+    uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
+    // opaque to the optimiser: once it splits the known +32 / +64 out of ay / az as immediate offsets, it addresses the far
+    // planes with 64-bit adds instead of the base + 32-bit offset form
+    asm volatile("" : "+v"(ay), "+v"(az));
     const f4 nxv = *reinterpret_cast<const f4*>(base + (size_t)ax), fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
     const f4 nyv = *reinterpret_cast<const f4*>(base + (size_t)ay), fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
     const f4 nzv = *reinterpret_cast<const f4*>(base + (size_t)az), fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
