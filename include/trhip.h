@@ -233,6 +233,12 @@ int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void
 int trhip_stitch(trhip_device* dev, const trhip_distribution* partial_dist, const void* partial_dev,
                  uint32_t partial_w, uint32_t partial_h, void* primary_dev, uint32_t viewports,
                  float blend_ratio, void* stream);
+/* The partial images of all non-primary devices in one launch (the reference dispatches the stitch shader once per
+ * device, src/stitch_stage.cc:150-196): `count` entries of what trhip_stitch takes.  With blend_ratio < 1 the partials
+ * must not overlap, which the distribution strategies guarantee. */
+int trhip_stitch_batch(trhip_device* dev, uint32_t count, const trhip_distribution* partial_dists, const void* const* partials_dev,
+                       const uint32_t* partial_ws, const uint32_t* partial_hs, void* primary_dev, uint32_t viewports,
+                       float blend_ratio, void* stream);
 
 /* ---- tonemap_stage (src/tonemap_stage.cc:139-164, shader/tonemap*.comp) */
 typedef struct trhip_tonemap_info {

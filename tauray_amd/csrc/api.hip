@@ -116,6 +116,35 @@ __global__ __launch_bounds__(KB) void k_stitch(LaunchCtx L, const f4* partial, u
     primary[o] = c;
 }
 
+// the same for up to TR_STITCH_BATCH partial images in one launch (blockIdx.y = partial)
+#define TR_STITCH_BATCH 15
+struct StitchBatch { LaunchCtx L[TR_STITCH_BATCH]; const f4* partial[TR_STITCH_BATCH]; uint pw[TR_STITCH_BATCH], ph[TR_STITCH_BATCH]; };
+__global__ __launch_bounds__(KB) void k_stitch_batch(StitchBatch B, f4* primary, uint viewports, float blend_ratio) {
+    const uint e = blockIdx.y;
+    const LaunchCtx L = B.L[e];
+    const uint pw = B.pw[e], ph = B.ph[e];
+    const f4* partial = B.partial[e];
+    uint per_view = L.strategy == 2 ? L.launch_w : pw * ph;
+    uint i = blockIdx.x * KB + threadIdx.x;
+    if (i >= per_view * viewports) return;
+    uint z = i / per_view, p = i % per_view;
+    uint sx, sy, ox, oy;
+    if (L.strategy == 2) {
+        uint j = permute_region_id(L.index + p, L.size_x, L.size_y, L.count);
+        if (j >= L.size_x * L.size_y) return;
+        sx = p % L.size_x; sy = p / L.size_x;
+        ox = j % L.size_x; oy = j / L.size_x;
+    } else {
+        sx = p % pw; sy = p / pw;
+        ox = sx; oy = sy * L.count + L.index;
+        if (oy >= L.size_y) return;
+    }
+    f4 c = partial[((size_t)z * ph + sy) * pw + sx];
+    size_t o = ((size_t)z * L.size_y + oy) * L.size_x + ox;
+    if (blend_ratio < 1.0f) c = mix4(primary[o], c, blend_ratio);
+    primary[o] = c;
+}
+
 // tonemap_stage: shader/tonemap.glsl:35-55 + tonemap_{gamma,filmic,reinhard,reinhard_luminance}.comp
 __global__ __launch_bounds__(KB) void k_tonemap(const f4* in, f4* out, uint w, uint h, uint layers, int op, float exposure, float gamma, int grid) {
     size_t i = (size_t)blockIdx.x * KB + threadIdx.x;
@@ -543,6 +572,31 @@ int trhip_stitch(trhip_device* dev, const trhip_distribution* pd, const void* pa
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_stitch, dim3((uint)((n + KB - 1) / KB)), dim3(KB), 0, (hipStream_t)stream, L, (const f4*)partial_dev, pw, ph,
                        (f4*)primary_dev, viewports, blend_ratio);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int trhip_stitch_batch(trhip_device* dev, uint32_t count, const trhip_distribution* pds, const void* const* partials_dev, const uint32_t* pws,
+                       const uint32_t* phs, void* primary_dev, uint32_t viewports, float blend_ratio, void* stream) {
+    DEVCHK(dev);
+    if (count == 0) return 0;
+    if (!pds || !partials_dev || !pws || !phs) return set_error("trhip_stitch_batch: null argument");
+    for (uint32_t first = 0; first < count; first += TR_STITCH_BATCH) {
+        const uint32_t m = std::min<uint32_t>(TR_STITCH_BATCH, count - first);
+        StitchBatch B{};
+        size_t n_max = 0;
+        for (uint32_t k = 0; k < m; ++k) {
+            const trhip_distribution& pd = pds[first + k];
+            if (pd.strategy == 0) return set_error("trhip_stitch_batch: needs scanline or shuffled-strips partials");
+            B.L[k] = make_launch(pd);
+            B.partial[k] = (const f4*)partials_dev[first + k]; B.pw[k] = pws[first + k]; B.ph[k] = phs[first + k];
+            const size_t per_view = pd.strategy == 2 ? B.L[k].launch_w : (size_t)B.pw[k] * B.ph[k];
+            n_max = std::max(n_max, per_view * viewports);
+        }
+        if (n_max == 0) continue;
+        hipLaunchKernelGGL(k_stitch_batch, dim3((uint)((n_max + KB - 1) / KB), m), dim3(KB), 0, (hipStream_t)stream, B, (f4*)primary_dev, viewports,
+                           blend_ratio);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -432,6 +432,23 @@ class StitchStage:
         check(_lib.lib().trhip_stitch(self.ctx.h, C.byref(d), _ptr(partial), pw, ph, _ptr(primary), viewports, self.blend_ratio, stream))
 
 
+    def run_all(self, partial_dists, partials, primary, viewports=1, stream=None):
+        """Every partial image in one launch (trhip_stitch_batch)."""
+        n = len(partial_dists)
+        if n == 0:
+            return
+        key = tuple((id(p), d.index, d.count, d.strategy) for d, p in zip(partial_dists, partials))
+        if getattr(self, "_batch_key", None) != key:      # argument arrays are rebuilt only when the partials change
+            ds = (DistributionC * n)(*[_dist_c(d) for d in partial_dists])
+            ptrs = (C.c_void_p * n)(*[_ptr(p) for p in partials])
+            sizes = [get_distribution_target_size(d) for d in partial_dists]
+            pws = (C.c_uint32 * n)(*[w for w, _ in sizes])
+            phs = (C.c_uint32 * n)(*[h for _, h in sizes])
+            self._batch_key, self._batch_args = key, (ds, ptrs, pws, phs)
+        ds, ptrs, pws, phs = self._batch_args
+        check(_lib.lib().trhip_stitch_batch(self.ctx.h, n, ds, ptrs, pws, phs, _ptr(primary), viewports, self.blend_ratio, stream))
+
+
 class TonemapStage:
     """tonemap_stage (filmic default, exposure 1, gamma 2.2; alpha grid only when not headless)."""
 
@@ -633,8 +650,9 @@ class RtRenderer:
             return
         from .transfer import gather_to_display
         partials = gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers)
-        for r, buf in partials.items():
-            self.stitch.run_one(self.dists[r], buf, self.color, self.viewports)
+        if partials:
+            peers = sorted(partials)
+            self.stitch.run_all([self.dists[r] for r in peers], [partials[r] for r in peers], self.color, self.viewports)
         if self.rank == 0:
             self.stitch.set_blend_ratio(1.0)
 

@@ -36,14 +36,17 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
         return {}
     _settle(color)
     if rank == 0:
-        ops = []
+        ops = recv_buffers.get("ops")       # the receive list of the previous frame, while the shapes stay what they were
+        fresh = ops is None
         for r in range(1, world_size):
             shape = partial_shape(dists[r], viewports)
             buf = recv_buffers.get(r)
             if buf is None or tuple(buf.shape) != shape:
-                buf = torch.empty(shape, dtype=torch.float32, device=color.device)
-                recv_buffers[r] = buf
-            ops.append(dist.P2POp(dist.irecv, buf, r))
+                recv_buffers[r] = torch.empty(shape, dtype=torch.float32, device=color.device)
+                fresh = True
+        if fresh:
+            ops = [dist.P2POp(dist.irecv, recv_buffers[r], r) for r in range(1, world_size)]
+            recv_buffers["ops"] = ops
         for q in dist.batch_isend_irecv(ops):
             q.wait()
         _settle(color)

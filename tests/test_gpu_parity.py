@@ -329,19 +329,26 @@ def test_fake_device_sharding_is_bitwise_identical(R, ctx, glb128, test_glb_128,
         cum += 1.0 / world
     opt = R.options_for_scene(test_glb_128, max_bounces=3)
     primary = ctx.alloc(W * H * 16).zero()
+    primary2 = ctx.alloc(W * H * 16).zero()
     stitch = R.StitchStage(ctx, (W, H))
+    parts = []
     for i, d in enumerate(dists):
         pt = R.PathTracerStage(ctx, glb128, opt, d)
         if i == 0:
             pt.run(primary)
+            pt.reset_accumulated_samples(); pt.reset_sample_counter()
+            pt.run(primary2)
         else:
             tw, th = D.get_distribution_target_size(d)
             part = ctx.alloc(tw * th * 16).zero()
             pt.run(part)
             stitch.run_one(d, part, primary)
+            parts.append(part)
         pt.close()
     got = primary.download((1, H, W, 4))
     assert np.array_equal(got, full), f"{(got != full).any(-1).sum()} pixels differ"
+    stitch.run_all(dists[1:], parts, primary2)          # all partials in one launch (trhip_stitch_batch)
+    assert np.array_equal(primary2.download((1, H, W, 4)), full)
 
 
 def test_viewports_and_camera_grid(R, ctx, test_glb_128, oracle):
