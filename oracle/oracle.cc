@@ -695,8 +695,10 @@ inline bool box_intersect(const ray_pre& r, vec3 bmin, vec3 bmax, float tmin, fl
         float inv = idx(r.inv_dir, a);
         float tn = (idx(bmin, a) - idx(r.org, a)) * inv;
         float tf = (idx(bmax, a) - idx(r.org, a)) * inv;
-        if (tn > tf) { float x = tn; tn = tf; tf = x; }
+        if (std::signbit(inv)) { float x = tn; tn = tf; tf = x; }   // by the direction's sign: comparing would mis-order a NaN
         tf *= 1.0000003576278687f;   // 1 + 2*gamma(3): conservative far plane
+        // 0 * inf = NaN when the origin lies exactly on a plane of an axis the ray does not move along: the ray is inside
+        // that slab (on its boundary), so the axis does not constrain the interval
         t0 = tn > t0 ? tn : t0;
         t1 = tf < t1 ? tf : t1;
         if (t0 > t1) return false;

@@ -90,10 +90,13 @@ TR_DEV bool box_intersect(const RayPre& r, const float* lo, const float* hi, flo
     float tx0 = (lo[0] - r.org.x) * r.inv_dir.x, tx1 = (hi[0] - r.org.x) * r.inv_dir.x;
     float ty0 = (lo[1] - r.org.y) * r.inv_dir.y, ty1 = (hi[1] - r.org.y) * r.inv_dir.y;
     float tz0 = (lo[2] - r.org.z) * r.inv_dir.z, tz1 = (hi[2] - r.org.z) * r.inv_dir.z;
-    float nx = fminf(tx0, tx1), fx = fmaxf(tx0, tx1);
-    float ny = fminf(ty0, ty1), fy = fmaxf(ty0, ty1);
-    float nz = fminf(tz0, tz1), fz = fmaxf(tz0, tz1);
-    // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a zero-direction axis)
+    // near / far by the direction's sign, not by comparing: 0 * inf = NaN (origin on a plane of an axis the ray does not move
+    // along) must leave the axis unconstrained, and min / max would order a NaN against -inf the wrong way round
+    const bool sx = r.nox & 16u, sy = r.noy & 16u, sz = r.noz & 16u;
+    float nx = sx ? tx1 : tx0, fx = sx ? tx0 : tx1;
+    float ny = sy ? ty1 : ty0, fy = sy ? ty0 : ty1;
+    float nz = sz ? tz1 : tz0, fz = sz ? tz0 : tz1;
+    // fminf/fmaxf below drop NaNs
     float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
     // far planes widened by 1 + 2*gamma(3) so rounding can never cull a true hit
     float t1 = fminf(fminf(fminf(fx, fy), fz) * 1.0000003576278687f, tmax);

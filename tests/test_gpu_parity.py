@@ -116,6 +116,45 @@ def test_closest_hit_queries_bit_exact(R, ctx, glb128, oracle_scene_128):
         assert 0.5 < hit.mean() <= 1.0   # the room is open towards the camera
 
 
+def test_axis_aligned_rays_on_box_planes(R, ctx, glb128, test_glb_128, oracle_scene_128):
+    """Rays that do not move along one or two axes (+0 and -0 components), starting exactly on coordinates the geometry
+    uses: the slab test then multiplies 0 by infinity on those axes and picks near / far planes by the sign of a zero.
+    Hits must still equal the oracle's, whose traversal orders the planes with min / max instead."""
+    from tauray_amd.scene import from_glm
+    rng = np.random.default_rng(11)
+    n = 60_000
+    verts = test_glb_128.vertices
+    sp = test_glb_128.spans
+    pos = []
+    for i in range(len(sp)):       # world-space vertex positions
+        v = verts["pos"][sp["vertex_offset"][i]:sp["vertex_offset"][i] + sp["vertex_count"][i]]
+        m = from_glm(test_glb_128.instances["model"][i])
+        pos.append((np.c_[v, np.ones(len(v), np.float32)] @ np.asarray(m).T)[:, :3])
+    pos = np.concatenate(pos).astype(np.float32)
+    org = pos[rng.integers(0, len(pos), size=n)].copy()
+    keep = rng.integers(0, 3, size=n)                       # one coordinate stays exactly on a vertex coordinate
+    jitter = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    jitter[np.arange(n), keep] = 0
+    org += jitter
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    zero = rng.integers(0, 3, size=n)
+    d[np.arange(n), zero] = np.where(rng.uniform(size=n) < 0.5, np.float32(0.0), np.float32(-0.0))
+    two = rng.uniform(size=n) < 0.3                         # a third of the rays move along a single axis
+    zero2 = (zero + 1 + rng.integers(0, 2, size=n)) % 3
+    d[np.arange(n)[two], zero2[two]] = np.float32(-0.0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    g = glb128.trace_closest(rays, None, include_lights=False)
+    o = oracle_scene_128.trace_closest(rays, None, include_lights=False)
+    assert np.array_equal(g["instance_id"], o["instance_id"]) and np.array_equal(g["primitive_id"], o["primitive_id"])
+    assert np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32))
+    assert (g["instance_id"] >= 0).mean() > 0.3
+    srays = rays.copy()
+    srays[:, 7] = rng.uniform(0.05, 3.0, size=n)
+    gs, os_ = glb128.trace_shadow(srays), oracle_scene_128.trace_shadow(srays)
+    assert np.array_equal(gs == 0, os_ == 0) and np.allclose(gs, os_, atol=1e-6)
+
+
 def test_shadow_queries(R, ctx, glb128, oracle_scene_128):
     rng = np.random.default_rng(8)
     n = 100_000
