@@ -644,12 +644,15 @@ class RtRenderer:
         if self.viewports > 0:      # a view shard can be empty (more devices than views)
             slot.pt.run(slot.color, self.viewports, stream if stream is not None else slot.stream)
 
-    def transfer_and_stitch(self):
-        """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0 (default stream)."""
+    def transfer_and_stitch(self, own_slot=None):
+        """device_transfer + stitch_stage over RCCL: gather partial frames on rank 0 (default stream).  `own_slot`: the display
+        rank's slot whose path tracing the stitch (not the receives) has to wait for."""
         if self.world_size == 1:
             return
         from .transfer import gather_to_display
         partials = gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers)
+        if own_slot is not None and own_slot.stream is not None:
+            self.ctx.stream_wait(None, own_slot.stream)
         if partials:
             peers = sorted(partials)
             self.stitch.run_all([self.dists[r] for r in peers], [partials[r] for r in peers], self.color, self.viewports)
@@ -668,7 +671,10 @@ class RtRenderer:
         # stream: RCCL orders itself after the kernels enqueued there.  With frames in flight the default stream first
         # waits for this slot's path tracing, and the slot's stream afterwards waits for the default stream, so that the
         # next frame of this slot does not overwrite images that are still being sent, stitched or tonemapped.
-        if slot.stream is not None:
+        # The display rank of a pixel-sharded frame receives into buffers of its own: its receives need not wait for its own
+        # path tracing, only the stitch into its image does.
+        display_of_pixels = self.shard == "pixels" and self.rank == 0
+        if slot.stream is not None and not display_of_pixels:
             self.ctx.stream_wait(None, slot.stream)
         if self.shard == "views":
             # every rank finishes its own views (tonemap is per pixel); `gather_views` ships them to the writer on rank 0
@@ -684,7 +690,7 @@ class RtRenderer:
             if tonemap and self.rank == 0:
                 self.post_process()
         else:
-            self.transfer_and_stitch()
+            self.transfer_and_stitch(slot if display_of_pixels else None)
             if tonemap and self.rank == 0:
                 self.post_process()
         if slot.stream is not None:
