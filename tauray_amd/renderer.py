@@ -723,6 +723,8 @@ class RtRenderer:
         return buf.download((self.viewports, th, tw, 4), np.float32)
 
     def close(self):
+        if not self.slots:
+            return
         self.sync()
         for slot in self.slots:
             slot.pt.close()
@@ -730,3 +732,10 @@ class RtRenderer:
                 self.ctx.destroy_stream(slot.stream)
                 slot.stream = None
         self.slots = []
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
