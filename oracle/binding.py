@@ -159,9 +159,19 @@ def options_for_scene(scene, **kw) -> PtOptionsC:
 
 
 class OracleScene:
-    def __init__(self, scene):
+    def __init__(self, scene, node_globals=None):
+        """`node_globals`: pose of the joint nodes of a scene with skinned meshes (default: the file's rest pose)."""
         L = lib()
         self._keep = []
+        if getattr(scene, "skinned", None):
+            import copy
+            posed = copy.copy(scene)
+            posed.vertices = scene.vertices.copy()
+            for sk in scene.skinned:
+                sp = scene.spans[sk.instance]
+                lo, hi = int(sp["vertex_offset"]), int(sp["vertex_offset"]) + int(sp["vertex_count"])
+                posed.vertices[lo:hi] = skin_vertices(scene.vertices[lo:hi], sk.skins, scene.joint_transforms(sk, node_globals))
+            scene = posed
         infos, texels = scene.texture_table()
         cams = scene.camera_data()
         non_opaque = scene.potentially_transparent().astype(np.uint8)

@@ -5,7 +5,8 @@ Host mirror of the reference's loader for the subset the path tracer needs
 meshes), followed by the instance flattening of scene_stage
 (src/scene_stage.cc:664-819: one instance per (model, vertex group), in node
 traversal order).  Supports KHR_lights_punctual, KHR_materials_transmission,
-KHR_materials_ior, KHR_materials_emissive_strength and Tauray's TR_data.
+KHR_materials_ior, KHR_materials_emissive_strength, Tauray's TR_data and skins
+(JOINTS_0 / WEIGHTS_0 + inverse bind matrices; animation clips are not played).
 """
 from __future__ import annotations
 
@@ -268,13 +269,22 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 _calculate_normals(v, idx)
             if "TANGENT" not in at:
                 _calculate_tangents(v, idx)
-            groups.append((mat, v, idx))
+            skin = None
+            if "JOINTS_0" in at:        # mesh::skin_data, weights renormalised (src/gltf.cc:722-731)
+                skin = np.zeros(len(pos), dtype=S.SKIN)
+                skin["joints"] = g.accessor(at["JOINTS_0"]).astype(np.uint32)[:, :4]
+                if "WEIGHTS_0" in at:
+                    w = g.accessor(at["WEIGHTS_0"]).astype(np.float32)[:, :4]
+                    ws = ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
+                    skin["weights"] = w / ws[:, None]
+            groups.append((mat, v, idx, skin))
         models.append(groups)
 
     inst_list, span_list, vert_list, idx_list = [], [], [], []
     point_lights, spot_lights, dir_lights, cameras = [], [], [], []
     voff = ioff = 0
     light_meta = {"angle": 0.0, "radius": 0.0}
+    node_globals, skinned_pending = {}, []
 
     def visit(node_index, parent):
         nonlocal voff, ioff
@@ -291,13 +301,19 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
             local = S.trs_matrix(node.get("translation", (0, 0, 0)), node.get("rotation", (0, 0, 0, 1)),
                                  node.get("scale", (1, 1, 1)))
         glob = parent @ local
+        node_globals[node_index] = glob
 
         if "mesh" in node:
             sto = 0.0
             if tr and "mesh" in tr:
                 sto = float(tr["mesh"].get("shadow_terminator_offset", 0.0))
-            for mat, v, idx in models[node["mesh"]]:
-                inst_list.append(S.make_instance(glob, mat, sto))
+            for mat, v, idx, skin in models[node["mesh"]]:
+                if "skin" in node and skin is not None:
+                    # glTF places skinned meshes at the origin; the loader enforces it (src/gltf.cc:777-784)
+                    skinned_pending.append((len(inst_list), node["skin"], skin))
+                    inst_list.append(S.make_instance(np.eye(4), mat, sto))
+                else:
+                    inst_list.append(S.make_instance(glob, mat, sto))
                 span_list.append((voff, len(v), ioff, len(idx) // 3))
                 vert_list.append(v)
                 idx_list.append(idx)
@@ -360,4 +376,13 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
         directional_lights=np.concatenate(dir_lights) if dir_lights else np.zeros(0, dtype=S.DIRECTIONAL_LIGHT),
         textures=textures, envmap=None, environment_factor=(0, 0, 0, 0), cameras=cameras,
         name=path.split("/")[-1])
+    desc.node_globals = node_globals
+    for inst, skin_index, skin in skinned_pending:
+        sk = j["skins"][skin_index]
+        joints = list(sk["joints"])
+        if "inverseBindMatrices" in sk:
+            ibm = g.accessor(sk["inverseBindMatrices"]).astype(np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)   # column-major in the file
+        else:
+            ibm = np.stack([np.eye(4)] * len(joints))
+        desc.skinned.append(S.SkinnedMesh(instance=inst, skins=skin, joint_nodes=joints, inverse_bind=ibm))
     return desc.finalize(gather_emissive_triangles)

@@ -204,14 +204,26 @@ class SceneStage:
         d.non_opaque = p(non_opaque)
         d.gather_emissive_triangles = 1 if getattr(scene, "tri_light_count", 0) > 0 else 0
         check(L.trhip_scene_upload(self.ctx.h, C.byref(d)))
+        self.scene = scene
+        # skinned meshes: the uploaded vertices are the bind pose; pose them with the file's rest pose before the build
+        # (the reference runs skinning.comp on the first scene update, src/scene_stage.cc:1543-1567)
+        for sk in getattr(scene, "skinned", []):
+            self.set_skin(sk.instance, sk.skins)
+            self.skin(sk.instance, scene.joint_transforms(sk), refit=None)
         info = AccelInfoC()
         check(L.trhip_scene_build_accel(self.ctx.h, C.byref(info)))
-        self.scene = scene
         self.accel = dict(triangle_count=info.triangle_count, node_count=info.node_count,
                           tri_light_count=info.tri_light_count, build_ms=info.build_ms,
                           bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max),
                           node_bytes=info.node_bytes)
         return self.accel
+
+    def pose(self, node_globals: dict, refit: bool = True):
+        """New global transforms of the joint nodes (an animation step of the caller's): every skinned mesh is skinned again
+        and the acceleration structure updated."""
+        for sk in self.scene.skinned:
+            self.skin(sk.instance, self.scene.joint_transforms(sk, node_globals), refit=None)
+        return self._accel_after_change(refit)
 
     def update_cameras(self, cameras):
         data = np.concatenate([c.pack() for c in cameras])

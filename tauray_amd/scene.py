@@ -287,6 +287,17 @@ def build_alias_table(envmap: np.ndarray) -> np.ndarray:
 
 
 @dataclass
+class SkinnedMesh:
+    """A skinned vertex group of the scene (mesh::get_skin + model::get_joints, src/mesh.hh:32-36, src/model.hh): its
+    instance, one SKIN record per vertex of that instance, and per joint the glTF node that drives it and the inverse
+    bind matrix (mathematical 4x4)."""
+    instance: int
+    skins: np.ndarray            # SKIN[vertex_count]
+    joint_nodes: List[int]
+    inverse_bind: np.ndarray     # (n, 4, 4)
+
+
+@dataclass
 class SceneDesc:
     """Everything `trhip_scene_upload` takes: the flattened scene of
     scene_stage::update (src/scene_stage.cc:1026-1496)."""
@@ -301,6 +312,13 @@ class SceneDesc:
     environment_factor: tuple = (0.0, 0.0, 0.0, 0.0)
     cameras: List[Camera] = field(default_factory=list)
     name: str = "scene"
+    skinned: List["SkinnedMesh"] = field(default_factory=list)     # vertices of these instances are the bind pose
+    node_globals: dict = field(default_factory=dict)               # glTF node index -> global transform of the rest pose
+
+    def joint_transforms(self, sk: "SkinnedMesh", node_globals: Optional[dict] = None) -> np.ndarray:
+        """model::update_joints (src/model.cc:107-118): joint node's global transform * inverse bind matrix, (n, 4, 4)."""
+        g = node_globals if node_globals is not None else self.node_globals
+        return np.stack([np.asarray(g[n], dtype=np.float64) @ sk.inverse_bind[i] for i, n in enumerate(sk.joint_nodes)]).astype(np.float32)
 
     @property
     def triangle_count(self) -> int:

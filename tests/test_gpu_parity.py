@@ -850,3 +850,40 @@ def test_frames_in_flight_are_the_same_frames(R, ctx):
         rr.close()
     with pytest.raises(ValueError):
         R.RtRenderer(ctx, scene, opt, (160, 96), use_torch=False, frames_in_flight=2, accumulate=True)
+
+
+@pytest.mark.gpu
+def test_skinned_glb_scene(R, ctx, oracle):
+    """A glTF file with a skin (tests/golden/skinned.glb): the scene stage poses the mesh with the file's rest pose on upload,
+    `pose()` moves the joints; frames equal the oracle's for the same joint transforms."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import trs_matrix
+    scene = load_glb(os.path.join(GOLDEN, "skinned.glb"), 128, 128)
+    ss = R.SceneStage(ctx, scene)
+    sk = scene.skinned[0]
+    sp = scene.spans[sk.instance]
+    bind = scene.vertices[sp["vertex_offset"]:sp["vertex_offset"] + sp["vertex_count"]]
+    assert np.array_equal(ss.vertices(0).view(np.uint8), oracle.skin_vertices(bind, sk.skins, scene.joint_transforms(sk)).view(np.uint8))
+
+    def feature(fid):
+        fs = R.FeatureStage(ctx, ss, fid, _dup((128, 128)))
+        buf = ctx.alloc(128 * 128 * 16).zero()
+        fs.run(buf)
+        return buf.download((128, 128, 4))
+
+    def check(osc, what):
+        for fid in (5, 3, 1, 9):
+            assert np.array_equal(feature(fid), osc.render_feature(fid, 128, 128), equal_nan=True), f"feature {fid}, {what}"   # misses are NaN
+        _compare(_render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3),
+                 osc.render_pt(oracle.options_for_scene(scene, max_bounces=3), 128, 128), what)
+
+    check(oracle.OracleScene(scene), "rest pose")
+    rest_ids = feature(9)[..., 0]
+    assert (rest_ids == 0).sum() > 100, "the tube is not in view"
+    # an animation step of the caller's: joint 1 swings the other way, joint 2 curls
+    g = dict(scene.node_globals)
+    g[3] = g[2] @ trs_matrix((0, 1, 0), (0, 0, np.sin(-0.35), np.cos(-0.35)))
+    g[4] = g[3] @ trs_matrix((0, 1, 0), (np.sin(0.3), 0, 0, np.cos(0.3)))
+    ss.pose(g)
+    check(oracle.OracleScene(scene, node_globals=g), "new pose")
+    assert (feature(9)[..., 0] != rest_ids).sum() > 50, "the pose did not change the image"

@@ -338,3 +338,46 @@ def test_skinning_against_float64(oracle):
     # a joint id past the array falls back to joint 0 (undefined in the shader; defined here so that nothing is read out of bounds)
     wild = one_hot.copy(); wild["joints"][:, 0] = 1000
     assert np.array_equal(oracle.skin_vertices(src, wild, joints).view(np.uint8), oracle.skin_vertices(src, one_hot, joints).view(np.uint8))
+
+
+def test_skinned_glb_loader(oracle):
+    """tests/golden/skinned.glb (tools/make_skinned_glb.py): skins, renormalised weights, the skinned mesh moved to the
+    origin, joint transforms = global transform * inverse bind matrix - recomputed here from the generator's parameters."""
+    import os
+    from conftest import GOLDEN
+    from tauray_amd.gltf import load_glb
+    scene = load_glb(os.path.join(GOLDEN, "skinned.glb"), 128, 128)
+    assert len(scene.skinned) == 1 and scene.skinned[0].instance == 0 and scene.skinned[0].joint_nodes == [2, 3, 4]
+    sk = scene.skinned[0]
+    assert np.array_equal(np.asarray(scene.instances["model"][0]), np.eye(4, dtype=np.float32)), "skinned meshes sit at the origin"
+    assert np.allclose(sk.skins["weights"].sum(axis=1), 1.0, atol=1e-6) and len(sk.skins) == scene.spans["vertex_count"][0]
+
+    def rz(deg):
+        c, s = math.cos(math.radians(deg)), math.sin(math.radians(deg))
+        return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+
+    def tr(x, y, z):
+        m = np.eye(4); m[:3, 3] = (x, y, z); return m
+
+    g0 = tr(0.3, 0.0, -0.2) @ tr(0, 0, 0) @ rz(0.0)
+    g1 = g0 @ tr(0, 1, 0) @ rz(30.0)
+    g2 = g1 @ tr(0, 1, 0) @ rz(40.0)
+    want = np.stack([g0 @ tr(0, 0, 0), g1 @ tr(0, -1, 0), g2 @ tr(0, -2, 0)])
+    got = scene.joint_transforms(sk)
+    assert np.allclose(got, want, atol=1e-6)
+    # the top ring hangs on joint 2 alone: a bind-pose vertex (x, 2, z) goes to g2 * (x, 0, z)
+    lo = int(scene.spans["vertex_offset"][0]); n = int(scene.spans["vertex_count"][0])
+    bind = scene.vertices[lo:lo + n]
+    posed = oracle.skin_vertices(bind, sk.skins, got)
+    top = np.where(bind["pos"][:, 1] == 2.0)[0]
+    assert len(top) == 24
+    for i in top:
+        e = g2 @ np.array([bind["pos"][i][0], 0.0, bind["pos"][i][2], 1.0])
+        assert np.allclose(posed["pos"][i], e[:3], atol=2e-6)
+    # and the bottom ring stays where the skeleton's root puts it
+    bottom = np.where(bind["pos"][:, 1] == 0.0)[0]
+    assert np.allclose(posed["pos"][bottom], bind["pos"][bottom] + np.array([0.3, 0.0, -0.2], np.float32), atol=1e-6)
+    # the oracle scene is built from the posed vertices
+    osc = oracle.OracleScene(scene)
+    ids = osc.render_feature(9, 64, 64)[..., 0]
+    assert (ids == 0).sum() > 20 and (ids == 1).sum() > 100
