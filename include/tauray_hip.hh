@@ -431,6 +431,10 @@ public:
     {
         tonemap_stage::options tonemap;
         bool accumulate = false;
+        // Frame slots on a single device (MAX_FRAMES_IN_FLIGHT = 2 in the reference, src/context.hh:26): frame i renders
+        // and tonemaps on the stream of slot i % N while its predecessors are still running; `display` and
+        // finish_frame() refer to the frame render() was last called for, frame_slots[k] to the others.
+        int max_frames_in_flight = 1;
     };
 
     // `devices`: HIP device index per logical device (repeat an index for --fake-devices); device 0 displays.
@@ -461,12 +465,39 @@ public:
             if(i != 0) d.gbuffer_copy = per_device[0].dev->alloc(d.target_bytes);   // receive buffer on the display device
         }
         display_bytes = size_t(size.x) * size.y * 16 * this->opt.active_viewport_count;
-        display = per_device[0].dev->alloc(display_bytes);
+        display = own_display = per_device[0].dev->alloc(display_bytes);
         tonemap = std::make_unique<tonemap_stage>(*per_device[0].dev, this->opt.tonemap);
+        if(this->opt.max_frames_in_flight > 1)
+        {
+            if(devices.size() != 1 || this->opt.accumulate)
+                throw std::runtime_error("rt_renderer: frames in flight need a single device and no accumulation");
+            per_device_data& d = per_device[0];
+            for(int k = 0; k < this->opt.max_frames_in_flight; ++k)
+            {
+                frame_slot fs;
+                fs.stream = d.dev->create_stream();
+                fs.color = d.dev->alloc(d.target_bytes);
+                fs.display = d.dev->alloc(display_bytes);
+                check(trhip_memset(d.dev->h, fs.color, 0, d.target_bytes, nullptr));
+                path_tracer_stage::options po = this->opt;
+                po.distribution = d.dist;
+                fs.ray_tracer = std::make_unique<path_tracer_stage>(*d.dev, *d.scene_update, fs.color, po);
+                fs.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
+                frame_slots.push_back(std::move(fs));
+            }
+            d.dev->sync();
+        }
     }
 
     ~rt_renderer()
     {
+        for(auto& fs: frame_slots)
+        {
+            per_device[0].dev->sync(fs.stream);
+            fs.ray_tracer.reset();
+            per_device[0].dev->free(fs.color); per_device[0].dev->free(fs.display);
+            per_device[0].dev->destroy_stream(fs.stream);
+        }
         for(auto& d: per_device) d.dev->sync();
         for(size_t i = 0; i < per_device.size(); ++i)
         {
@@ -474,7 +505,7 @@ public:
             if(per_device[i].gbuffer_copy) per_device[0].dev->free(per_device[i].gbuffer_copy);
             per_device[i].dev->free(per_device[i].color);
         }
-        per_device[0].dev->free(display);
+        per_device[0].dev->free(own_display);
     }
 
     void reset_accumulation(bool reset_sample_counter = false)
@@ -484,12 +515,31 @@ public:
             d.ray_tracer->reset_accumulated_samples();
             if(reset_sample_counter) d.ray_tracer->reset_sample_counter();
         }
+        if(reset_sample_counter) frame_index = 0;
         accumulated_frames = 0;
     }
+
+    // waits for the frame of the last render() call (all of it: path tracing and tonemap)
+    void finish_frame() { for(auto& d: per_device) d.dev->sync(); if(current_slot >= 0) per_device[0].dev->sync(frame_slots[current_slot].stream); }
+    void finish_slot(int k) { per_device[0].dev->sync(frame_slots[k].stream); }
 
     // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap
     void render()
     {
+        if(!frame_slots.empty())
+        {   // one stage per slot: slot k renders frames k, k + N, ... (rt_stage::frame_counter is set per frame)
+            current_slot = (int)(frame_index % frame_slots.size());
+            frame_slot& fs = frame_slots[current_slot];
+            fs.ray_tracer->reset_accumulated_samples();
+            fs.ray_tracer->set_frame_counter(frame_index);
+            fs.ray_tracer->run(fs.stream);
+            tonemap->run(fs.color, fs.display, size, (uint32_t)opt.active_viewport_count, fs.stream);
+            display = fs.display;
+            frame_index++;
+            accumulated_frames++;
+            return;
+        }
+        frame_index++;
         if(!opt.accumulate) for(auto& d: per_device) d.ray_tracer->reset_accumulated_samples();
         for(auto& d: per_device) d.ray_tracer->run();
         device& display_device = *per_device[0].dev;
@@ -545,9 +595,20 @@ public:
         size_t target_bytes = 0;
     };
     std::vector<per_device_data> per_device;
+    struct frame_slot
+    {
+        void* stream = nullptr;
+        std::unique_ptr<path_tracer_stage> ray_tracer;
+        void* color = nullptr;
+        void* display = nullptr;
+    };
+    std::vector<frame_slot> frame_slots;   // empty unless options.max_frames_in_flight > 1
+    int current_slot = -1;
+    uint32_t frame_index = 0;
     uvec2 size;
     options opt;
-    void* display = nullptr;          // tonemapped RGBA32F on the display device
+    void* display = nullptr;          // tonemapped RGBA32F on the display device (of the most recent frame)
+    void* own_display = nullptr;
     size_t display_bytes = 0;
     std::unique_ptr<tonemap_stage> tonemap;
     unsigned accumulated_frames = 0;

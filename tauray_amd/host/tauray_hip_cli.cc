@@ -6,7 +6,7 @@
 //              [--frames=1] [--fake-devices=N | --devices=0,1,...] [--distribution-strategy=scanline|shuffled-strips]
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
-//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0]
+//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1]
 #include <cstdlib>
 #include <iostream>
 #include <map>
@@ -24,7 +24,7 @@ int main(int argc, char** argv)
     {
         std::string scene_path, prefix = "capture";
         uvec2 size{1280, 720};
-        int frames = 1, warmup = 0, fake_devices = 1;
+        int frames = 1, warmup = 0, fake_devices = 1, frames_in_flight = 1;
         std::vector<int> devices;
         bool timing = false;
         rt_renderer::options opt;
@@ -47,6 +47,7 @@ int main(int argc, char** argv)
             else if(starts(a, "--samples-per-pass=")) opt.samples_per_pass = std::stoi(val("--samples-per-pass="));
             else if(starts(a, "--frames=")) { frames = std::stoi(val("--frames=")); hopt.single_frame = frames == 1; }
             else if(starts(a, "--warmup-frames=")) warmup = std::stoi(val("--warmup-frames="));
+            else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
             else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
             else if(starts(a, "--exposure=")) opt.tonemap.exposure = std::stof(val("--exposure="));
@@ -110,9 +111,31 @@ int main(int argc, char** argv)
         opt.samples_per_pass = std::min(opt.samples_per_pass, opt.samples_per_pixel);
         opt.active_viewport_count = 1;
 
+        opt.max_frames_in_flight = frames_in_flight;
         rt_renderer rr(devices, scene, size, opt);
         hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = 1;
         headless out(hopt);
+        if(frames_in_flight > 1)
+        {   // frame f renders while the frames before it are read back, compressed and written (the reference overlaps
+            // its save workers with the next frames the same way, src/headless.cc:349-422)
+            std::vector<int> in_slot(frames_in_flight, -1);
+            auto retire = [&](int k) {
+                if(in_slot[k] < 0) return;
+                rr.finish_slot(k);
+                out.save(*rr.per_device[0].dev, rr.frame_slots[k].display, (unsigned)in_slot[k]);
+                in_slot[k] = -1;
+            };
+            for(int f = -warmup; f < frames; ++f)
+            {
+                const int k = (int)(rr.frame_index % (uint32_t)frames_in_flight);
+                retire(k);                               // the slot's previous frame must be on disk before it is reused
+                rr.render();
+                in_slot[k] = f < 0 ? -1 : f;
+                if(f < 0) rr.finish_slot(k);
+            }
+            for(int n = 0; n < frames_in_flight; ++n) retire((int)((rr.frame_index + n) % (uint32_t)frames_in_flight));
+            return 0;
+        }
         for(int f = -warmup; f < frames; ++f)
         {
             auto t0 = std::chrono::high_resolution_clock::now();

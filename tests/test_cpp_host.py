@@ -258,3 +258,19 @@ def test_headless_naming_and_exr_layout(tmp_path, scene_dump):
     subprocess.check_call([CLI, scene_dump, "--width=16", "--height=8", "--max-ray-depth=1", f"--headless={rgba}", "--format=rgba32", "--compression=none"])
     names, ch, comp = read_simple_exr(rgba + ".exr")
     assert comp == 0 and names == ["A", "B", "G", "R"] and (ch["A"] == 1).all()
+
+
+@pytest.mark.gpu
+def test_cpp_frames_in_flight_write_the_same_files(tmp_path, scene_dump):
+    """tr::rt_renderer with frame slots (options.max_frames_in_flight): frame f renders while earlier frames are read back and
+    written; every file is byte-identical to the one-frame-at-a-time run's."""
+    common = [CLI, scene_dump, "--width=96", "--height=64", "--max-ray-depth=3", "--frames=7", "--filetype=raw", "--warmup-frames=2"]
+    a, b = str(tmp_path / "serial"), str(tmp_path / "slots")
+    subprocess.check_call(common + [f"--headless={a}"])
+    subprocess.check_call(common + [f"--headless={b}", "--frames-in-flight=3"])
+    for f in range(7):
+        x, y = open(f"{a}{f}.raw", "rb").read(), open(f"{b}{f}.raw", "rb").read()
+        assert len(x) == 96 * 64 * 16 and x == y, f"frame {f} differs"
+    assert open(f"{a}0.raw", "rb").read() != open(f"{a}1.raw", "rb").read()
+    r = subprocess.run(common + [f"--headless={b}", "--frames-in-flight=2", "--fake-devices=2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "single device" in r.stderr
