@@ -215,6 +215,10 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_range": traffic_range, "traffic_source": traffic_src,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            # what a frame cannot avoid moving even with a perfectly cached tree: ray + hit records written and read once, one
+            # framebuffer write
+            "frame_compulsory_GBps": round(((c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * args.steps)
+                                           / args.steps / (ms_per_step * 1e-3) / 1e9, 1),
             "kernel_ms_per_frame": {k: round(timings[k + "_ms"] / args.steps, 4) for k in ("trace_closest", "trace_shadow", "shade", "raygen", "resolve")},
             "node_visits_per_ray": round(c["node_visits"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
             "tri_tests_per_ray": round(c["tri_tests"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
