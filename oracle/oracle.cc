@@ -696,13 +696,14 @@ inline bool box_intersect(const ray_pre& r, vec3 bmin, vec3 bmax, float tmin, fl
         float tn = (idx(bmin, a) - idx(r.org, a)) * inv;
         float tf = (idx(bmax, a) - idx(r.org, a)) * inv;
         if (std::signbit(inv)) { float x = tn; tn = tf; tf = x; }   // by the direction's sign: comparing would mis-order a NaN
-        tf *= 1.0000003576278687f;   // 1 + 2*gamma(3): conservative far plane
         // 0 * inf = NaN when the origin lies exactly on a plane of an axis the ray does not move along: the ray is inside
         // that slab (on its boundary), so the axis does not constrain the interval
         t0 = tn > t0 ? tn : t0;
         t1 = tf < t1 ? tf : t1;
-        if (t0 > t1) return false;
     }
+    // entry against min(exit, tmax) widened by a pad that covers the rounding of the slab distances and the error of the
+    // triangle test's distance (a different expression): the closest hit must not depend on the shape of the tree
+    if (t0 > t1 * 1.000004f) return false;
     tnear = t0;
     return true;
 }

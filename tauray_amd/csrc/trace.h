@@ -16,6 +16,11 @@ namespace tr {
 #ifndef TR_VOTE
 #define TR_VOTE 8          // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote)
 #endif
+// The slab test compares a box's entry distance with min(exit distance, current closest hit / tmax) * TR_SLAB_PAD.  The pad
+// covers the rounding of both slab distances and, on the tmax side, the error of the distance the triangle test computes
+// (a different expression): without it a box can be culled against a hit that one of its own triangles would have beaten
+// by a few ulps, and which of two nearly coincident surfaces wins then depends on the shape of the tree.
+#define TR_SLAB_PAD 1.000004f
 #define TR_LDS_STACK 16
 #ifndef TR_SPILL_STACK
 #define TR_SPILL_STACK 112
@@ -98,8 +103,7 @@ TR_DEV bool box_intersect(const RayPre& r, const float* lo, const float* hi, flo
     float nz = sz ? tz1 : tz0, fz = sz ? tz0 : tz1;
     // fminf/fmaxf below drop NaNs
     float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-    // far planes widened by 1 + 2*gamma(3) so rounding can never cull a true hit
-    float t1 = fminf(fminf(fminf(fx, fy), fz) * 1.0000003576278687f, tmax);
+    float t1 = fminf(fminf(fminf(fx, fy), fz), tmax) * TR_SLAB_PAD;
     tnear = t0;
     return t0 <= t1;
 }
@@ -331,8 +335,7 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, flo
         const float ty0 = (ny[k] - r.org.y) * r.inv_dir.y, ty1 = (fy[k] - r.org.y) * r.inv_dir.y;
         const float tz0 = (nz[k] - r.org.z) * r.inv_dir.z, tz1 = (fz[k] - r.org.z) * r.inv_dir.z;
         const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin));
-        // far planes widened by 1 + 2*gamma(3) so rounding can never cull a true hit
-        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1) * 1.0000003576278687f, tmax);
+        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
         h.t[k] = t0 <= t1 ? t0 : __builtin_huge_valf();
     }
     // keeps the load of the child ids next to the plane loads: left alone, the compiler sinks it into the "some child is hit"

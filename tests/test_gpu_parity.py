@@ -887,3 +887,60 @@ def test_skinned_glb_scene(R, ctx, oracle):
     ss.pose(g)
     check(oracle.OracleScene(scene, node_globals=g), "new pose")
     assert (feature(9)[..., 0] != rest_ids).sum() > 50, "the pose did not change the image"
+
+
+@pytest.mark.gpu
+def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
+    """BASELINE config 4 at its full size (sponza_teapots, 1920x1080, 4 bounces), through properties that need no oracle: the
+    frame does not depend on the tree (PLOC vs LBVH build, refit vs rebuild), on how it is sharded (8 shuffled-strip shards,
+    stitched in one launch) or on how many frames are in flight."""
+    from tauray_amd import scenes
+    from tauray_amd import distribution as D
+    W, H = 1920, 1080
+    scene = scenes.sponza_teapots(W, H)
+    ss = R.SceneStage(ctx, scene)
+    assert ss.accel["triangle_count"] > 900_000
+    a = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all() and a[..., :3].min() >= 0 and a[..., :3].mean() > 1e-3
+    ploc_nodes = ss.accel["node_count"]
+    # another tree over the same triangles: every hit is the same hit, so the frame is bit-identical
+    monkeypatch.setenv("TRHIP_BUILDER", "lbvh")
+    ss.update_instances(scene.instances)
+    b = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
+    assert np.array_equal(b, a), f"LBVH tree vs PLOC tree: {int((b != a).any(-1).sum())} pixels differ"
+    monkeypatch.setenv("TRHIP_BUILDER", "ploc")
+    ss.update_instances(scene.instances)
+    assert ss.accel["node_count"] == ploc_nodes
+    ss.update_instances(scene.instances, refit=True)
+    assert np.array_equal(_render_hip(R, ctx, ss, scene, (W, H), max_bounces=4), a), "refitted tree"
+    # 8 shuffled-strip shards, all partials stitched by one launch
+    opt = R.options_for_scene(scene, max_bounces=4)
+    primary = ctx.alloc(W * H * 16).zero()
+    dists = [D.get_device_distribution_params((W, H), D.DISTRIBUTION_SHUFFLED_STRIPS, i / 8, 1 / 8, i, 8, i == 0) for i in range(8)]
+    parts = []
+    for i, d in enumerate(dists):
+        pt = R.PathTracerStage(ctx, ss, opt, d)
+        if i == 0:
+            pt.run(primary)
+        else:
+            tw, th = D.get_distribution_target_size(d)
+            parts.append(ctx.alloc(tw * th * 16).zero())
+            pt.run(parts[-1])
+        pt.close()
+    R.StitchStage(ctx, (W, H)).run_all(dists[1:], parts, primary)
+    assert np.array_equal(primary.download((1, H, W, 4)), a), "8 strip shards"
+    del parts
+    # three frames in flight: frame 0 of the slots is the frame above, frame 2 equals a serial renderer's frame 2
+    pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+    serial = ctx.alloc(W * H * 16).zero()
+    for _ in range(3):
+        pt.reset_accumulated_samples()
+        pt.run(serial)
+    frame2 = serial.download((1, H, W, 4))
+    pt.close()
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), use_torch=False, frames_in_flight=3)     # uploads the same scene again
+    for _ in range(3):
+        rr.render()
+    rr.sync()
+    assert np.array_equal(rr.slots[0].color.download((1, H, W, 4)), a) and np.array_equal(rr.slots[2].color.download((1, H, W, 4)), frame2)
+    rr.close()
