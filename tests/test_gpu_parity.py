@@ -930,6 +930,14 @@ def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     R.StitchStage(ctx, (W, H)).run_all(dists[1:], parts, primary)
     assert np.array_equal(primary.download((1, H, W, 4)), a), "8 strip shards"
     del parts
+    # one lane or two instead of the automatic four concurrent slices of the frame
+    for lanes in (1, 2):
+        pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+        pt.set_lanes(lanes)
+        buf = ctx.alloc(W * H * 16).zero()
+        pt.run(buf)
+        assert np.array_equal(buf.download((1, H, W, 4)), a), f"{lanes} lane(s)"
+        pt.close()
     # three frames in flight: frame 0 of the slots is the frame above, frame 2 equals a serial renderer's frame 2
     pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
     serial = ctx.alloc(W * H * 16).zero()
