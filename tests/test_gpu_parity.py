@@ -439,6 +439,22 @@ def test_bench_scene_one_million_triangles(R, ctx, oracle):
         g, r = buf.download((H, W, 4)), osc.render_feature(fid, W, H)
         diff = ~((g == r) | (np.isnan(g) & np.isnan(r)))     # misses keep the NaN default value
         assert not diff.any(), f"feature {fid} on the 1 M triangle scene: {int(diff.any(-1).sum())} pixels differ, max {np.nanmax(np.abs(g - r)):.3e}"
+    # incoherent rays from inside the atrium (what bounces 1+ look like), stochastic alpha on: hits bit-equal
+    rng = np.random.default_rng(21)
+    n = 100_000
+    lo, hi = np.array(ss.accel["bounds_min"], np.float32), np.array(ss.accel["bounds_max"], np.float32)
+    org = (lo + (hi - lo) * rng.uniform(0.05, 0.95, size=(n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], axis=1)
+    seeds = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    g, o = ss.trace_closest(rays, seeds), osc.trace_closest(rays, seeds)
+    assert np.array_equal(g["instance_id"], o["instance_id"]) and np.array_equal(g["primitive_id"], o["primitive_id"])
+    assert np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32)) and (g["instance_id"] >= 0).mean() > 0.9
+    srays = rays.copy()
+    srays[:, 7] = rng.uniform(0.1, 20.0, size=n)
+    gs, os_ = ss.trace_shadow(srays), osc.trace_shadow(srays)
+    assert np.array_equal(gs == 0, os_ == 0) and np.allclose(gs, os_, atol=1e-6)
     kw = dict(max_bounces=4)
     img = _render_hip(R, ctx, ss, scene, (W, H), **kw)
     ref = osc.render_pt(oracle.options_for_scene(scene, **kw), W, H)
