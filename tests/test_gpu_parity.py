@@ -512,6 +512,31 @@ def test_edge_scenes(R, ctx, oracle):
         assert np.array_equal(_render_hip(R, ctx, ss, sc, (64, 64), max_bounces=3), img), f"{what}: refit changed the frame"
     assert ss.accel["triangle_count"] == 2
 
+    # coincident surfaces: the same two-triangle quad three times (two instances at the same place with different materials,
+    # the third with its triangles listed twice).  Equal hit distances go to the lower (instance, primitive) in both
+    # implementations, whatever order the trees present the candidates in.
+    quad = np.zeros(4, dtype=S.VERTEX)
+    quad["pos"] = [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)]
+    quad["normal"] = (0, 0, 1)
+    quad["tangent"] = (1, 0, 0, 1)
+    mats = [S.make_material(albedo=c + (1,), metallic=0.0, roughness=0.6) for c in ((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9))]
+    insts = np.concatenate([S.make_instance(np.eye(4), m) for m in mats])
+    verts = np.concatenate([quad, quad, quad])
+    idx = np.array([0, 1, 2, 0, 2, 3] + [0, 1, 2, 0, 2, 3] + [0, 2, 3, 0, 1, 2, 0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    spans = np.array([(0, 4, 0, 2), (4, 4, 6, 2), (8, 4, 12, 4)], dtype=S.MESH_SPAN)
+    sc = S.SceneDesc(instances=insts, spans=spans, vertices=verts, indices=idx, point_lights=light, cameras=[cam]).finalize(True)
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    for fid in (9, 5, 0):       # instance id, distance, albedo
+        fs = R.FeatureStage(ctx, ss, fid, _dup((64, 64)))
+        buf = ctx.alloc(64 * 64 * 16).zero()
+        fs.run(buf)
+        assert np.array_equal(buf.download((64, 64, 4)), osc.render_feature(fid, 64, 64), equal_nan=True), f"coincident quads, feature {fid}"
+        if fid == 9:
+            ids = buf.download((64, 64, 4))[..., 0]
+            assert set(np.unique(ids[np.isfinite(ids)])) == {0.0}, "the lowest instance wins every tie"
+    _compare(_render_hip(R, ctx, ss, sc, (64, 64), max_bounces=3), osc.render_pt(oracle.options_for_scene(sc, max_bounces=3), 64, 64), "coincident quads")
+
 
 def test_tonemap_operators(R, ctx, oracle):
     rng = np.random.default_rng(4)
