@@ -993,3 +993,26 @@ def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     rr.sync()
     assert np.array_equal(rr.slots[0].color.download((1, H, W, 4)), a) and np.array_equal(rr.slots[2].color.download((1, H, W, 4)), frame2)
     rr.close()
+
+
+@pytest.mark.gpu
+def test_maximum_size_frame(R, ctx):
+    """An 8K frame (7680x4320: 33 M paths, ~8 GB of path state on a 288 GB device): deterministic, and two scanline shards
+    stitched together give the same bits; 32-bit path ids and queue counters have room for 128 such frames."""
+    from tauray_amd import scenes
+    from tauray_amd import distribution as D
+    W, H = 7680, 4320
+    scene = scenes.test_glb(W, H)
+    ss = R.SceneStage(ctx, scene)
+    kw = dict(max_bounces=2)
+    a = _render_hip(R, ctx, ss, scene, (W, H), **kw)
+    assert a.shape == (1, H, W, 4) and np.isfinite(a).all() and (a[..., 3] == 1).all() and a[..., :3].mean() > 1e-3
+    opt = R.options_for_scene(scene, **kw)
+    dists = [D.get_device_distribution_params((W, H), D.DISTRIBUTION_SCANLINE, i / 2, 1 / 2, i, 2, i == 0) for i in range(2)]
+    primary = ctx.alloc(W * H * 16).zero()
+    pt = R.PathTracerStage(ctx, ss, opt, dists[0]); pt.run(primary); pt.close()
+    tw, th = D.get_distribution_target_size(dists[1])
+    part = ctx.alloc(tw * th * 16).zero()
+    pt = R.PathTracerStage(ctx, ss, opt, dists[1]); pt.run(part); pt.close()
+    R.StitchStage(ctx, (W, H)).run_all(dists[1:], [part], primary)
+    assert np.array_equal(primary.download((1, H, W, 4)), a)
