@@ -609,6 +609,15 @@ def test_full_size_properties(R, ctx):
     pt.run(acc); pt.reset_accumulated_samples(); pt.run(acc); f1 = acc.download((1, H, W, 4))
     assert np.array_equal(f0, a)
     assert np.allclose(both[..., :3], 0.5 * (f0[..., :3] + f1[..., :3]), rtol=1e-6, atol=1e-7)
+    # four accumulated 1-spp frames are the four passes of one 4-spp frame: same sample indices (sample_counter =
+    # frame * spp, src/rt_stage.cc:81), same running mean (gbuffer.glsl:18-28)
+    pt.reset_accumulated_samples(); pt.reset_sample_counter()
+    for _ in range(4):
+        pt.run(acc)
+    four_frames = acc.download((1, H, W, 4))
+    pt.close()
+    one_frame = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4, samples_per_pixel=4, samples_per_pass=1)
+    assert np.array_equal(four_frames, one_frame)
 
 
 def test_dynamic_scene_rebuild_and_motion(R, ctx, oracle):
