@@ -1025,3 +1025,29 @@ def test_maximum_size_frame(R, ctx):
     pt = R.PathTracerStage(ctx, ss, opt, dists[1]); pt.run(part); pt.close()
     R.StitchStage(ctx, (W, H)).run_all(dists[1:], [part], primary)
     assert np.array_equal(primary.download((1, H, W, 4)), a)
+
+
+@pytest.mark.gpu
+def test_long_accumulation_is_the_mean_of_its_frames(R, ctx):
+    """BASELINE config 3 accumulates 4096 samples per pixel: the running mean of gbuffer.glsl:18-28 over many frames must stay
+    the mean of the frames.  512 accumulated 1-spp frames against the float64 mean of the same 512 frames rendered one by one."""
+    from tauray_amd.gltf import load_glb
+    W, H, N = 48, 32, 512
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    ss = R.SceneStage(ctx, scene)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+    acc = ctx.alloc(W * H * 16).zero()
+    for _ in range(N):
+        pt.run(acc)
+    running = acc.download((1, H, W, 4)).astype(np.float64)
+    pt.reset_accumulated_samples(); pt.reset_sample_counter()
+    total = np.zeros((1, H, W, 4))
+    for _ in range(N):
+        pt.reset_accumulated_samples()
+        pt.run(acc)
+        total += acc.download((1, H, W, 4))
+    pt.close()
+    mean = total / N
+    assert np.abs(running[..., :3] - mean[..., :3]).max() <= 2e-5 * max(1.0, mean[..., :3].max())
+    assert (running[..., 3] == 1).all()
