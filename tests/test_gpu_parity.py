@@ -1051,3 +1051,67 @@ def test_long_accumulation_is_the_mean_of_its_frames(R, ctx):
     mean = total / N
     assert np.abs(running[..., :3] - mean[..., :3]).max() <= 2e-5 * max(1.0, mean[..., :3].max())
     assert (running[..., 3] == 1).all()
+
+
+@pytest.mark.gpu
+def test_sharded_gbuffer_direct_and_feature_stages(R, ctx):
+    """Pixel sharding of everything that renders: a scanline / strip shard of the gbuffer targets, of direct_stage and of
+    feature_stage holds exactly the pixels the unsharded image has at those positions (every stage keys its random streams
+    and its write position by the absolute pixel, shader/rt.glsl:170-231)."""
+    from tauray_amd import distribution as D
+    from tauray_amd.gltf import load_glb
+    W, H = 256, 144
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    ss = R.SceneStage(ctx, scene)
+    names = ["color", "diffuse", "reflection", "albedo", "normal", "pos", "instance_id"]
+    opt = R.options_for_scene(scene, max_bounces=3)
+
+    def targets(stage_cls, d, options):
+        pt = stage_cls(ctx, ss, options, d)
+        tw, th = D.get_distribution_target_size(d)
+        bufs = {n: ctx.alloc(tw * th * R.PathTracerStage.TARGETS[n][0] * 4).zero() for n in names}
+        pt.run_targets(bufs)
+        out = {n: np.frombuffer(bufs[n].download((1, th, tw, R.PathTracerStage.TARGETS[n][0])).tobytes(),
+                                dtype=R.PathTracerStage.TARGETS[n][1]).reshape(th, tw, -1) for n in names}
+        pt.close()
+        return out
+
+    def positions(d):
+        """absolute pixel of every element of a non-primary shard's target, row-major"""
+        tw, th = D.get_distribution_target_size(d)
+        if d.strategy == D.DISTRIBUTION_SCANLINE:
+            ys = np.arange(th) * d.count + d.index
+            return np.repeat(ys, tw), np.tile(np.arange(tw), th), np.repeat(ys < H, tw)
+        b = D.calculate_shuffled_strips_b((W, H))
+        p = np.arange(tw * th)
+        j = np.array([D.permute_region_id(d.index + int(q), d.size, b) if q < d.count else W * H for q in p])
+        ok = j < W * H
+        j = np.where(ok, j, 0)
+        return j // W, j % W, ok
+
+    dopt = R.options_for_scene(scene, max_bounces=3, samples_per_pixel=2, samples_per_pass=2)
+    for stage_cls, options, what in ((R.PathTracerStage, opt, "path tracer"), (R.DirectStage, dopt, "direct stage")):
+        full = targets(stage_cls, _dup((W, H)), options)
+        for strategy, world in ((D.DISTRIBUTION_SCANLINE, 3), (D.DISTRIBUTION_SHUFFLED_STRIPS, 4)):
+            for rank in range(1, world):
+                d = D.get_device_distribution_params((W, H), strategy, rank / world, 1 / world, rank, world, False)
+                part = targets(stage_cls, d, options)
+                ys, xs, ok = positions(d)
+                for n in names:
+                    got = part[n].reshape(-1, part[n].shape[-1])[ok]
+                    want = full[n][ys[ok], xs[ok]]
+                    assert np.array_equal(got, want, equal_nan=True), f"{what}, strategy {strategy}, rank {rank}/{world}, target {n}"
+    # feature_stage the same way
+    for fid in (3, 9):
+        fs = R.FeatureStage(ctx, ss, fid, _dup((W, H)))
+        buf = ctx.alloc(W * H * 16).zero()
+        fs.run(buf)
+        full = buf.download((H, W, 4))
+        d = D.get_device_distribution_params((W, H), D.DISTRIBUTION_SCANLINE, 2 / 3, 1 / 3, 2, 3, False)
+        tw, th = D.get_distribution_target_size(d)
+        fs = R.FeatureStage(ctx, ss, fid, d)
+        buf = ctx.alloc(tw * th * 16).zero()
+        fs.run(buf)
+        part = buf.download((th, tw, 4))
+        ys, xs, ok = positions(d)
+        assert np.array_equal(part.reshape(-1, 4)[ok], full[ys[ok], xs[ok]], equal_nan=True), f"feature {fid} shard"
