@@ -937,6 +937,19 @@ def test_skinned_glb_scene(R, ctx, oracle):
     ss.pose(g)
     check(oracle.OracleScene(scene, node_globals=g), "new pose")
     assert (feature(9)[..., 0] != rest_ids).sum() > 50, "the pose did not change the image"
+    # an emissive skinned mesh: its triangles are light sources whose records follow the pose (extract_tri_lights.comp runs
+    # after skinning.comp in scene_stage::update)
+    scene.instances["mat"]["emission_factor"][sk.instance] = (2.0, 1.0, 0.4, 1.0)
+    scene.finalize(True)
+    ss = R.SceneStage(ctx, scene)
+    for pose, refit in ((None, None), (g, True), (g, False)):
+        if pose is not None:
+            ss.pose(pose, refit=refit)
+        osc = oracle.OracleScene(scene, node_globals=pose)
+        assert ss.accel["tri_light_count"] == 768
+        assert np.array_equal(ss.tri_lights().view(np.uint8), osc.tri_lights().view(np.uint8)), f"tri lights, pose {pose is not None}, refit {refit}"
+        _compare(_render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3),
+                 osc.render_pt(oracle.options_for_scene(scene, max_bounces=3), 128, 128), "emissive skinned mesh")
 
 
 @pytest.mark.gpu
