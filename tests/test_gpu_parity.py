@@ -630,6 +630,7 @@ def test_dynamic_scene_rebuild_and_motion(R, ctx, oracle):
     scene = load_glb(os.path.join(GOLDEN, "test.glb"), 128, 128)
     ss = R.SceneStage(ctx, scene)
     first = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=2)
+    _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=2, pre_transformed_vertices=1)    # builds the world-space vertex copy
 
     def feature(fid, sstage):
         fs = R.FeatureStage(ctx, sstage, fid, _dup((128, 128)))
@@ -688,6 +689,9 @@ def test_dynamic_scene_rebuild_and_motion(R, ctx, oracle):
     assert np.array_equal(ss.tri_lights().view(np.uint8), osc2.tri_lights().view(np.uint8)), "tri lights after refit"
     refit_img = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)
     _compare(refit_img, osc2.render_pt(oracle.options_for_scene(scene, max_bounces=3), 128, 128), "after refit")
+    # the pre-transformed vertex copy is rebuilt for the new transforms (it was made for the old ones by the first frames)
+    pre_before = _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=2, pre_transformed_vertices=1)
+    _compare(pre_before, osc2.render_pt(oracle.options_for_scene(scene, max_bounces=2, pre_transformed_vertices=1), 128, 128), "pre-transformed after refit")
     ss.update_instances(scene.instances)          # a rebuild gives the same frame, bit for bit
     assert np.array_equal(refit_img, _render_hip(R, ctx, ss, scene, (128, 128), max_bounces=3)), "refit vs rebuild"
     # the API refuses a different instance count, and rendering before the rebuild
