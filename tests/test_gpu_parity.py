@@ -1132,3 +1132,41 @@ def test_sharded_gbuffer_direct_and_feature_stages(R, ctx):
         part = buf.download((th, tw, 4))
         ys, xs, ok = positions(d)
         assert np.array_equal(part.reshape(-1, 4)[ok], full[ys[ok], xs[ok]], equal_nan=True), f"feature {fid} shard"
+
+
+@pytest.mark.gpu
+def test_ragged_shards(R, ctx):
+    """More devices than scanlines, strips that do not divide the image, one-pixel frames: shards may be empty or ragged
+    and the stitched frame still equals the unsharded one."""
+    from tauray_amd import distribution as D
+    from tauray_amd.gltf import load_glb
+    for (W, H), world, strategy in (((16, 5), 8, D.DISTRIBUTION_SCANLINE), ((37, 11), 7, D.DISTRIBUTION_SHUFFLED_STRIPS), ((1, 1), 3, D.DISTRIBUTION_SCANLINE),
+                                    ((130, 3), 5, D.DISTRIBUTION_SHUFFLED_STRIPS)):
+        scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+        ss = R.SceneStage(ctx, scene)
+        full = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=2)
+        opt = R.options_for_scene(scene, max_bounces=2)
+        dists, cum = [], 0.0
+        for i in range(world):
+            dists.append(D.get_device_distribution_params((W, H), strategy, cum, 1.0 / world, i, world, i == 0))
+            cum += 1.0 / world
+        primary = ctx.alloc(W * H * 16).zero()
+        parts, pd = [], []
+        for i, d in enumerate(dists):
+            tw, th = D.get_distribution_target_size(d)
+            pt = R.PathTracerStage(ctx, ss, opt, d)
+            if i == 0:
+                pt.run(primary)
+            else:
+                buf = ctx.alloc(max(tw * th, 1) * 16).zero()
+                if tw * th > 0:
+                    pt.run(buf)
+                parts.append(buf); pd.append(d)
+            pt.close()
+        R.StitchStage(ctx, (W, H)).run_all(pd, parts, primary)
+        assert np.array_equal(primary.download((1, H, W, 4)), full), f"{W}x{H} over {world} devices, strategy {strategy}"
+        # the renderer object of the last rank (possibly an empty shard) renders without the exchange
+        rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=world - 1, world_size=world, use_torch=False)
+        rr.render_partial()
+        rr.sync()
+        rr.close()
