@@ -609,6 +609,9 @@ inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; 
 vec4 sample_texture(const oracle_scene& s, int tex_id, vec2 uv) {
     const texture_info& ti = s.tex_infos[tex_id];
     int w = (int)ti.width, h = (int)ti.height;
+    // a texture unit returns a texel for any coordinate; non-finite ones are defined as 0 (see csrc/texture.h)
+    if (!(fabsf(uv.x) < INFINITY)) uv.x = 0.0f;
+    if (!(fabsf(uv.y) < INFINITY)) uv.y = 0.0f;
     float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
@@ -1408,6 +1411,9 @@ bool get_intersection_info(const pt_ctx& c, const hit_payload& payload, vec3 ori
     mat = sampled_material{};
     mat.metallic = 1;
     mat.albedo = V4(0);
+    // the other members stay unwritten in the GLSL for lights and misses; the material gbuffer target packs ior_out / ior_in,
+    // so both implementations define them: roughness 0, transmittance 0, ior 1 / 1
+    mat.ior_in = 1.0f; mat.ior_out = 1.0f;
     v = pt_vertex_data{};
     if (payload.instance_id >= 0) {
         c.tc->surface++;

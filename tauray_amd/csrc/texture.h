@@ -21,6 +21,10 @@ TR_DEV f4 bilerp(f4 c00, f4 c10, f4 c01, f4 c11, float fx, float fy) {
 TR_DEV f4 sample_texture(const SceneView& sv, int tex_id, f2 uv) {
     const TextureInfo ti = sv.tex_infos[tex_id];
     int w = (int)ti.width, h = (int)ti.height;
+    // a texture unit returns a texel for any coordinate; non-finite ones (the uv of a light sample on a triangle seen
+    // edge-on, whose weight is zero anyway) are defined as 0 here so that 0 * texel stays 0
+    if (!(fabsf(uv.x) < __builtin_huge_valf())) uv.x = 0.0f;
+    if (!(fabsf(uv.y) < __builtin_huge_valf())) uv.y = 0.0f;
     float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;

@@ -1170,3 +1170,54 @@ def test_ragged_shards(R, ctx):
         rr.render_partial()
         rr.sync()
         rr.close()
+
+
+@pytest.mark.gpu
+def test_texture_edge_cases(R, ctx, oracle):
+    """Textures that are not powers of two (3x5, 1x1, 7x2), texture coordinates far outside [0, 1] (repeat wrapping,
+    negative values), all four material textures at once (albedo with alpha, metallic-roughness, normal map, emission)."""
+    from tauray_amd import scene as S
+    rng = np.random.default_rng(5)
+    texs = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in ((3, 5), (1, 1), (7, 2), (4, 4))]
+    texs[0][..., 3] = rng.integers(0, 2, size=(5, 3)) * 255        # alpha-tested albedo
+    texs[2][..., 2] = 255                                          # a normal map pointing mostly outwards
+    quad = np.zeros(4, dtype=S.VERTEX)
+    quad["pos"] = [(-1.5, -1.5, 0), (1.5, -1.5, 0), (1.5, 1.5, 0), (-1.5, 1.5, 0)]
+    quad["normal"] = (0, 0, 1)
+    quad["tangent"] = (1, 0, 0, 1)
+    quad["uv"] = [(-2.3, -1.7), (3.7, -1.7), (3.7, 2.9), (-2.3, 2.9)]
+    back = quad.copy()
+    back["pos"][:, 2] = -1.0
+    back["uv"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    mat = S.make_material(albedo=(0.9, 0.8, 0.7, 1.0), metallic=0.7, roughness=0.8, emission=(0.3, 0.2, 0.1), albedo_tex=0, mr_tex=1, normal_tex=2,
+                          emission_tex=3, double_sided=True)
+    plain = S.make_material(albedo=(0.5, 0.5, 0.9, 1.0), metallic=0.0, roughness=0.7)
+    cam = S.Camera(fov=60, aspect=1.0)
+    cam.transform = S.trs_matrix((0.1, -0.05, 3))
+    sc = S.SceneDesc(instances=np.concatenate([S.make_instance(np.eye(4), mat), S.make_instance(np.eye(4), plain)]),
+                     spans=np.array([(0, 4, 0, 2), (4, 4, 6, 2)], dtype=S.MESH_SPAN), vertices=np.concatenate([quad, back]),
+                     indices=np.array([0, 1, 2, 0, 2, 3] * 2, dtype=np.uint32), point_lights=S.make_point_light((20, 20, 20), (0.5, 0.8, 2.5), 0.1),
+                     textures=texs, cameras=[cam]).finalize(True)
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    for fid, tol in ((9, 0.0), (5, 0.0), (1, 0.0), (0, 1e-6)):   # instance id (alpha test picks front or back), distance, normal, albedo
+        fs = R.FeatureStage(ctx, ss, fid, _dup((96, 96)))
+        buf = ctx.alloc(96 * 96 * 16).zero()
+        fs.run(buf)
+        g, r = buf.download((96, 96, 4)), osc.render_feature(fid, 96, 96)
+        if tol == 0.0:
+            assert np.array_equal(g, r, equal_nan=True), f"feature {fid}"
+        else:
+            assert np.array_equal(np.isnan(g), np.isnan(r)) and np.nanmax(np.abs(g - r)) <= tol, f"feature {fid}"
+    ids = osc.render_feature(9, 96, 96)[..., 0]
+    # the feature renderer's any-hit uses a fixed cutoff of 1e-4 (shader/rt_feature.rahit:17): only where the filtered alpha is
+    # exactly zero does the back quad show
+    assert (ids == 0).sum() > 500 and (ids == 1).sum() > 100, "the alpha-tested texture should show both quads"
+    img, ref = _render_hip(R, ctx, ss, sc, (192, 192), max_bounces=3), osc.render_pt(oracle.options_for_scene(sc, max_bounces=3), 192, 192)
+    rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
+    print("textured quad: pixels outside tolerance", float((rel.max(-1) > REL_TOL).mean()), "bit-equal", float((img == ref).all(-1).mean()))
+    _compare(img, ref, "textured quad")
+    got = _render_targets_hip(R, ctx, ss, sc, (96, 96), ["albedo", "material", "normal"], max_bounces=2)
+    ref = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 96, 96, ["albedo", "material", "normal"])
+    for n in ("albedo", "material", "normal"):
+        assert np.allclose(got[n], ref[n], atol=2e-6, equal_nan=True), n
