@@ -1865,8 +1865,10 @@ oracle_scene* oracle_scene_create(const oracle_scene_desc* d) {
     size_t texel_count = 0;
     for (auto& ti : s->tex_infos) texel_count = std::max(texel_count, (size_t)ti.texel_offset + (size_t)ti.width * ti.height);
     s->texels.assign(d->texels, d->texels + texel_count * 4);
-    s->environment_factor = V4(d->environment_factor[0], d->environment_factor[1], d->environment_factor[2], d->environment_factor[3]);
+    // scene_metadata (src/scene_stage.cc:1341-1352): the factor is the environment map's; without a map it is zero, proj -1
+    s->environment_factor = V4(0.0f);
     if (d->envmap && d->envmap_width && d->envmap_height) {
+        s->environment_factor = V4(d->environment_factor[0], d->environment_factor[1], d->environment_factor[2], d->environment_factor[3]);
         s->env_w = d->envmap_width; s->env_h = d->envmap_height;
         size_t n = (size_t)s->env_w * s->env_h;
         s->envmap.assign((const vec4*)d->envmap, (const vec4*)d->envmap + n);

@@ -1221,3 +1221,75 @@ def test_texture_edge_cases(R, ctx, oracle):
     ref = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 96, 96, ["albedo", "material", "normal"])
     for n in ("albedo", "material", "normal"):
         assert np.allclose(got[n], ref[n], atol=2e-6, equal_nan=True), n
+
+
+def _zoo_scene(materials=None, point=(0, 1, 2), directional=(0, 1), env=True):
+    """Corner values of the material model and every light class at once (see test_material_and_light_zoo)."""
+    from tauray_amd import scene as S
+    quad = np.zeros(4, dtype=S.VERTEX)
+    quad["pos"] = [(-0.45, -0.45, 0), (0.45, -0.45, 0), (0.45, 0.45, 0), (-0.45, 0.45, 0)]
+    quad["normal"] = (0, 0, 1)
+    quad["tangent"] = (1, 0, 0, 1)
+    quad["uv"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    mats = [
+        S.make_material(albedo=(0.9, 0.9, 0.9, 1), metallic=1.0, roughness=0.0),                       # mirror
+        S.make_material(albedo=(0.9, 0.6, 0.2, 1), metallic=1.0, roughness=0.35),
+        # (ior exactly 1.0 is left out: transmission then divides by (eta * cos_d + cos_o)^2 = 0 and the reference itself yields
+        # NaN, shader/ggx.glsl:350-372; see DESIGN.md)
+        S.make_material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=0.0, transmittance=1.0, ior=1.05, double_sided=True),
+        S.make_material(albedo=(0.9, 1, 0.9, 1), metallic=0.0, roughness=0.0, transmittance=1.0, ior=0.7, double_sided=True),
+        S.make_material(albedo=(1, 0.9, 0.9, 1), metallic=0.0, roughness=0.2, transmittance=0.8, ior=2.4, double_sided=True),
+        S.make_material(albedo=(0, 0, 0, 1), metallic=0.0, roughness=1.0),
+        S.make_material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0),
+        S.make_material(albedo=(0.2, 0.4, 0.9, 1), metallic=0.5, roughness=0.001),                     # just above the delta threshold
+        S.make_material(albedo=(0.7, 0.7, 0.2, 0.5), metallic=0.0, roughness=0.5, double_sided=True),   # half-transparent by albedo alpha
+    ]
+    if materials is not None:
+        mats = [mats[k] for k in materials]
+    insts, verts, spans, idx = [], [], [], []
+    for i, m in enumerate(mats):
+        x, y = (i % 3 - 1) * 1.0, (i // 3 - 1) * 1.0
+        flip = np.diag([1.0, 1.0, -1.0, 1.0]) if i in (5, 6) else np.eye(4)     # two single-sided panels face away from the camera
+        t = S.trs_matrix((x, y, 0.1 * (i % 2))) @ flip
+        insts.append(S.make_instance(t, m))
+        spans.append((4 * i, 4, 6 * i, 2))
+        verts.append(quad)
+        idx += [0, 1, 2, 0, 2, 3]
+    back = quad.copy(); back["pos"] *= 8
+    insts.append(S.make_instance(S.trs_matrix((0, 0, -1.5)), S.make_material(albedo=(0.6, 0.6, 0.6, 1), metallic=0.0, roughness=0.8)))
+    spans.append((4 * len(mats), 4, 6 * len(mats), 2)); verts.append(back); idx += [0, 1, 2, 0, 2, 3]
+    lights = np.concatenate([
+        S.make_point_light((30, 30, 30), (0.3, 0.4, 2.0), 0.0),                                   # radius 0: a delta light
+        S.make_point_light((10, 6, 3), (-1.2, 1.0, 1.2), 0.25),                                   # a sphere the camera can see
+        S.make_spotlight((40, 40, 60), (1.5, -1.0, 2.5), (-0.5, 0.3, -1.0), 0.05, 25.0, 3.0),
+    ])
+    dls = np.concatenate([S.make_directional_light((2.0, 1.9, 1.7), (-0.3, -0.5, -1.0), 0.0),     # angle 0: never hit directly
+                          S.make_directional_light((0.5, 0.6, 0.9), (0.4, -0.2, -1.0), 5.0)])
+    cam = S.Camera(fov=55, aspect=1.0)
+    cam.transform = S.trs_matrix((0.15, 0.1, 4.2))
+    lights = lights[list(point)] if len(point) else np.zeros(0, dtype=S.POINT_LIGHT)
+    dls = dls[list(directional)] if len(directional) else np.zeros(0, dtype=S.DIRECTIONAL_LIGHT)
+    return S.SceneDesc(instances=np.concatenate(insts), spans=np.array(spans, dtype=S.MESH_SPAN), vertices=np.concatenate(verts),
+                       indices=np.array(idx, dtype=np.uint32), point_lights=lights, directional_lights=dls,
+                       envmap=np.ones((2, 4, 4), dtype=np.float32) if env else None,      # a uniform environment: a constant map times a factor
+                       environment_factor=(0.3, 0.35, 0.4, 1.0) if env else (0, 0, 0, 0), cameras=[cam]).finalize(True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_material_and_light_zoo(R, ctx, oracle, sampler):
+    """Corner values of the material model and every light class at once: mirror (roughness 0), rough metal, glass with
+    ior 1.05 / 0.7 / 2.4 and roughness 0, black and white diffuse, single-sided panels seen from behind, a radius-0 point
+    light, a spotlight, directional lights of angle 0 and 5 degrees, a uniform environment, a lit sphere light in view."""
+    sc = _zoo_scene()
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    for kw in (dict(max_bounces=6, sampler=sampler), dict(max_bounces=4, sampler=sampler, samples_per_pixel=2, regularization_gamma=0.5)):
+        img = _render_hip(R, ctx, ss, sc, (160, 160), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(sc, **kw), 160, 160)
+        assert np.isfinite(ref).all(), "the oracle produced a non-finite pixel"
+        _compare(img, ref, f"zoo {kw}")
+    got = _render_targets_hip(R, ctx, ss, sc, (160, 160), ["material", "albedo", "instance_id"], max_bounces=2)
+    want = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 160, 160, ["material", "albedo", "instance_id"])
+    assert np.array_equal(got["instance_id"], want["instance_id"])
+    assert np.allclose(got["material"], want["material"], atol=1e-6) and np.allclose(got["albedo"], want["albedo"], atol=1e-6)
