@@ -1293,3 +1293,64 @@ def test_material_and_light_zoo(R, ctx, oracle, sampler):
     want = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 160, 160, ["material", "albedo", "instance_id"])
     assert np.array_equal(got["instance_id"], want["instance_id"])
     assert np.allclose(got["material"], want["material"], atol=1e-6) and np.allclose(got["albedo"], want["albedo"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_odd_frame_sizes_and_scales(R, ctx, oracle):
+    """Frame sizes that are not whole 8x8 tiles, with and without concurrent lanes; extreme aspect ratios; the same scene a
+    thousand times larger and a thousand times smaller (hit distances scale, the 1e-4 ray offset does not)."""
+    import copy
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import from_glm, to_glm
+    # 2.08 M paths: four lanes by default, but 1923 x 1081 is not a whole number of tiles
+    W, H = 1923, 1081
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    ss = R.SceneStage(ctx, scene)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    frames = []
+    for lanes in (0, 1, 3):
+        pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+        pt.set_lanes(lanes)
+        buf = ctx.alloc(W * H * 16).zero()
+        pt.run(buf)
+        frames.append(buf.download((1, H, W, 4)))
+        pt.close()
+    assert np.isfinite(frames[0]).all() and np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    for (w, h) in ((1920, 1), (1, 1080), (7, 1300), (65, 63)):
+        sc = load_glb(os.path.join(GOLDEN, "test.glb"), w, h)
+        ss = R.SceneStage(ctx, sc)
+        img = _render_hip(R, ctx, ss, sc, (w, h), max_bounces=2)
+        if w * h <= 65 * 63:
+            _compare(img, oracle.OracleScene(sc).render_pt(oracle.options_for_scene(sc, max_bounces=2), w, h), f"{w}x{h}")
+        else:
+            assert img.shape == (1, h, w, 4) and np.isfinite(img).all()
+    # scale the world (instances, lights, camera) by k: distances and positions scale, everything else stays
+    base = load_glb(os.path.join(GOLDEN, "test.glb"), 96, 96)
+    for k in (1e3, 1e-3):
+        sc = copy.copy(base)
+        sc.instances = base.instances.copy()
+        S = np.diag([k, k, k, 1.0])
+        for i in range(len(sc.instances)):
+            m = S @ from_glm(base.instances["model"][i])
+            sc.instances["model"][i] = to_glm(m)
+            sc.instances["model_prev"][i] = to_glm(m)
+            sc.instances["model_normal"][i] = to_glm(np.linalg.inv(m).T)
+        sc.point_lights = base.point_lights.copy()
+        sc.point_lights["pos"] *= k
+        sc.point_lights["radius"] *= k
+        sc.point_lights["color"] *= k * k
+        sc.cameras = copy.deepcopy(base.cameras)
+        for c in sc.cameras:
+            t = np.asarray(c.transform, dtype=np.float64).copy()
+            t[:3, 3] *= k
+            c.transform = t
+            c.near *= k; c.far *= k
+        ss = R.SceneStage(ctx, sc)
+        osc = oracle.OracleScene(sc)
+        for fid in (5, 9, 3):
+            fs = R.FeatureStage(ctx, ss, fid, _dup((96, 96)), min_ray_dist=1e-4 * min(k, 1.0))
+            buf = ctx.alloc(96 * 96 * 16).zero()
+            fs.run(buf)
+            assert np.array_equal(buf.download((96, 96, 4)), osc.render_feature(fid, 96, 96, min_ray_dist=1e-4 * min(k, 1.0)), equal_nan=True), f"scale {k}, feature {fid}"
+        kw = dict(max_bounces=3, min_ray_dist=1e-4 * k)
+        _compare(_render_hip(R, ctx, ss, sc, (96, 96), **kw), osc.render_pt(oracle.options_for_scene(sc, **kw), 96, 96), f"scale {k}")
