@@ -1354,3 +1354,41 @@ def test_odd_frame_sizes_and_scales(R, ctx, oracle):
             assert np.array_equal(buf.download((96, 96, 4)), osc.render_feature(fid, 96, 96, min_ray_dist=1e-4 * min(k, 1.0)), equal_nan=True), f"scale {k}, feature {fid}"
         kw = dict(max_bounces=3, min_ray_dist=1e-4 * k)
         _compare(_render_hip(R, ctx, ss, sc, (96, 96), **kw), osc.render_pt(oracle.options_for_scene(sc, **kw), 96, 96), f"scale {k}")
+
+
+@pytest.mark.gpu
+def test_many_instances_of_one_mesh(R, ctx, oracle):
+    """4 096 instances that share one vertex / index span (instancing), every one with its own transform and material, a few
+    of them emissive: instance lookup, per-instance tri-light ranges and the per-instance pre-transformed copy."""
+    from tauray_amd import scene as S
+    rng = np.random.default_rng(9)
+    n = 4096
+    tet = np.zeros(4, dtype=S.VERTEX)
+    tet["pos"] = [(0, 0, 0.15), (0.14, 0, -0.07), (-0.07, 0.12, -0.07), (-0.07, -0.12, -0.07)]
+    nn = tet["pos"] / np.linalg.norm(tet["pos"], axis=1, keepdims=True)
+    tet["normal"] = nn
+    tet["tangent"] = (1, 0, 0, 1)
+    idx = np.array([0, 1, 2, 0, 2, 3, 0, 3, 1, 1, 3, 2], dtype=np.uint32)
+    insts = []
+    for i in range(n):
+        g = np.array([i % 16, (i // 16) % 16, i // 256], dtype=np.float64)
+        t = S.trs_matrix((g - (7.5, 7.5, 7.5)) * 0.45 + rng.uniform(-0.05, 0.05, 3), rng.normal(size=4), rng.uniform(0.6, 1.4, 3))
+        emis = (3.0, 2.0, 1.0) if i % 97 == 0 else (0, 0, 0)
+        insts.append(S.make_instance(t, S.make_material(albedo=tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,), metallic=float(i % 3 == 0), roughness=float(rng.uniform(0.1, 1.0)),
+                                                         emission=emis, double_sided=True)))
+    cam = S.Camera(fov=50, aspect=1.0)
+    cam.transform = S.trs_matrix((0.3, 0.2, 9.0))
+    sc = S.SceneDesc(instances=np.concatenate(insts), spans=np.array([(0, 4, 0, 4)] * n, dtype=S.MESH_SPAN), vertices=tet, indices=idx,
+                     point_lights=S.make_point_light((300, 300, 300), (0, 6, 8), 0.3), cameras=[cam]).finalize(True)
+    assert sc.triangle_count == 4 * n
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    assert ss.accel["tri_light_count"] == 4 * len(range(0, n, 97))
+    assert np.array_equal(ss.tri_lights().view(np.uint8), osc.tri_lights().view(np.uint8))
+    for fid in (9, 5, 1):
+        fs = R.FeatureStage(ctx, ss, fid, _dup((128, 128)))
+        buf = ctx.alloc(128 * 128 * 16).zero()
+        fs.run(buf)
+        assert np.array_equal(buf.download((128, 128, 4)), osc.render_feature(fid, 128, 128), equal_nan=True), f"feature {fid}"
+    for kw in (dict(max_bounces=3), dict(max_bounces=3, pre_transformed_vertices=1)):
+        _compare(_render_hip(R, ctx, ss, sc, (128, 128), **kw), osc.render_pt(oracle.options_for_scene(sc, **kw), 128, 128), f"instanced {kw}")
