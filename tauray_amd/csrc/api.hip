@@ -289,10 +289,20 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
         for (uint k = 0; k < 3 * sp.triangle_count; ++k)
             if (d->indices[sp.index_offset + k] >= sp.vertex_count) return set_error("trhip_scene_upload: vertex index out of range");
         prefix[i + 1] = prefix[i] + sp.triangle_count;
+        {   // a non-finite transform would put NaN boxes into the tree (the driver's behaviour for them is undefined too)
+            const float* mm = reinterpret_cast<const float*>(&insts[i].model);
+            for (int k = 0; k < 16; ++k) if (!std::isfinite(mm[k])) return set_error("trhip_scene_upload: non-finite instance transform");
+        }
         const Material& m = insts[i].mat;
         int texs[4] = {m.albedo_tex_id, m.metallic_roughness_tex_id, m.normal_tex_id, m.emission_tex_id};
         for (int t : texs) if (t >= (int)d->texture_count) return set_error("trhip_scene_upload: texture id out of range");
         if (insts[i].light_base_id >= 0) tri_lights = std::max(tri_lights, (uint)insts[i].light_base_id + sp.triangle_count);
+    }
+    {
+        const Vertex* vv = (const Vertex*)d->vertices;
+        for (uint i = 0; i < d->vertex_count; ++i)
+            if (!(std::isfinite(vv[i].pos.x) && std::isfinite(vv[i].pos.y) && std::isfinite(vv[i].pos.z)))
+                return set_error("trhip_scene_upload: non-finite vertex position");
     }
     if (upload_array(s.instances, d->instances, d->instance_count)) return 1;
     if (upload_array(s.spans, d->spans, d->instance_count)) return 1;

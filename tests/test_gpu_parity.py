@@ -570,6 +570,16 @@ def test_api_errors(R, ctx, test_glb_128):
     bad.indices[5] = 10**6
     with pytest.raises(R.TrhipError, match="out of range"):
         R.SceneStage(c2, bad)
+    bad = copy.copy(test_glb_128)
+    bad.vertices = test_glb_128.vertices.copy()
+    bad.vertices["pos"][100, 1] = np.nan
+    with pytest.raises(R.TrhipError, match="non-finite vertex"):
+        R.SceneStage(c2, bad)
+    bad = copy.copy(test_glb_128)
+    bad.instances = test_glb_128.instances.copy()
+    bad.instances["model"][2][1, 3] = np.inf
+    with pytest.raises(R.TrhipError, match="non-finite instance"):
+        R.SceneStage(c2, bad)
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs 2 and 4)
