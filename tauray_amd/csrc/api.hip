@@ -377,6 +377,10 @@ int trhip_scene_update_instances(trhip_device* dev, const void* instances, uint3
     DeviceScene& s = dev->scene;
     if (count != s.instance_count) return set_error("trhip_scene_update_instances: count differs from the uploaded instances");
     if (count && !instances) return set_error("trhip_scene_update_instances: null instances");
+    for (uint32_t i = 0; i < count; ++i) {
+        const float* mm = reinterpret_cast<const float*>(&((const Instance*)instances)[i].model);
+        for (int k = 0; k < 16; ++k) if (!std::isfinite(mm[k])) return set_error("trhip_scene_update_instances: non-finite instance transform");
+    }
     HIPCHK(hipDeviceSynchronize());
     if (count) HIPCHK(hipMemcpy(s.instances, instances, (size_t)count * sizeof(Instance), hipMemcpyHostToDevice));
     // transforms changed: the acceleration structure, the tri lights and the pre-transformed vertex copy are stale
@@ -410,6 +414,8 @@ int trhip_scene_set_skin(trhip_device* dev, uint32_t instance, const void* sourc
 int trhip_scene_skin(trhip_device* dev, uint32_t instance, const float* joint_transforms, uint32_t joint_count) {
     DEVCHK(dev);
     DeviceScene& s = dev->scene;
+    for (size_t k = 0; joint_transforms && k < (size_t)joint_count * 16; ++k)
+        if (!std::isfinite(joint_transforms[k])) return set_error("trhip_scene_skin: non-finite joint transform");
     HIPCHK(hipDeviceSynchronize());   // frames in flight read the vertices
     if (int rc = skin_instance(s, instance, joint_transforms, joint_count, nullptr)) return rc;
     s.accel_built = false;
