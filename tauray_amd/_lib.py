@@ -5,6 +5,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# Hardware queues the HIP runtime spreads its streams over (default 4): frame slots beyond three only pay off with more
+# (DESIGN.md section 5).  Read by the runtime when it starts, so it has to be in the environment before the library loads.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRHIP_LIB", os.path.join(_HERE, "libtrhip.so"))   # TRHIP_LIB: A/B builds while tuning
 
