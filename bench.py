@@ -111,6 +111,10 @@ def main():
 
     # ---- timed region: W warm-up frames, then exactly K frames between barriers
     rr.set_profiling(False, False)
+    # Not part of the W warm-up steps: a fresh box takes a few hundred milliseconds of work to reach its clocks and to fault
+    # in every buffer, more than W = 3 frames of 2 ms give it.  A fixed frame count keeps the ranks of a multi-GPU job in step.
+    run_frames(120)
+    sync_all()
     rr.reset_accumulation(reset_sample_counter=True)
     run_frames(args.warmup)
     sync_all()
