@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--save-display", default=None, help="rank 0 writes the last tonemapped frame to this .npy file")
+    ap.add_argument("--prewarm", type=int, default=120, help="untimed frames before the warm-up steps (clocks, page faults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -113,7 +114,7 @@ def main():
     rr.set_profiling(False, False)
     # Not part of the W warm-up steps: a fresh box takes a few hundred milliseconds of work to reach its clocks and to fault
     # in every buffer, more than W = 3 frames of 2 ms give it.  A fixed frame count keeps the ranks of a multi-GPU job in step.
-    run_frames(120)
+    run_frames(args.prewarm)
     sync_all()
     rr.reset_accumulation(reset_sample_counter=True)
     run_frames(args.warmup)
