@@ -45,7 +45,7 @@ def parse():
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
-                         "0 = 4 for one or two GPUs, 6 beyond (small shards are latency-bound: tools/shard_share_probe.py)")
+                         "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--save-display", default=None, help="rank 0 writes the last tonemapped frame to this .npy file")
@@ -66,7 +66,7 @@ def main():
     from tauray_amd.distribution import DISTRIBUTION_SCANLINE
 
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 4 if args.gpus <= 2 else 6
+        args.frames_in_flight = 4
     world = args.gpus
     rank = 0
     dist = None
