@@ -1,7 +1,7 @@
 # Rehearsal of the N > 1 bench path on a one-GPU box: all ranks on device 0, gloo instead of RCCL.  usage: bash tools/rehearse_multi_rank.sh [F ...]
 cd $GRAFT_REPO_ROOT
 export TRHIP_BENCH_WATCHDOG=60
-for f in ${@:-1 3}; do
+for f in ${@:-1 4}; do
 timeout 120 python bench.py --steps 5 --frames-in-flight $f --no-cpu-baseline --no-roofline --save-display /tmp/disp1.npy > /dev/null
 for n in 2 3; do
 echo "== F=$f N=$n"
