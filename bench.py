@@ -11,6 +11,13 @@ save are outside the timed region (reference README "Benchmarking", docs/MANUAL.
 Prints ONE JSON line (rank 0).  `value` = rays actually traced (closest-hit + shadow, device counters) per second
 over all GPUs.  With N > 1 the frame is sharded by interleaved scanlines (DISTRIBUTION_SCANLINE) and the partial
 frames are gathered on rank 0 over RCCL: total work is fixed, so scaling is "strong".
+
+The K timed frames are K distinct frames (frame index = sample counter), four of them in flight at a time on their own
+streams like the reference's frame slots (--frames-in-flight); the region is closed by a
+synchronisation of every stream (+ barrier), so `ms_per_step` is elapsed / K and `frame_latency_ms` is what one frame
+takes with a host sync after each.  Before the W warm-up steps --prewarm untimed frames bring a cold box to its clocks.
+The `roofline` object is measured in a separate serialised re-run (one frame at a time, per-kernel HIP events), the
+`cpu_baseline` by the CPU oracle on the host cores.
 """
 import argparse
 import json
