@@ -1247,8 +1247,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     }
                     if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
                     timed(T_SHADE, ls, [&] {
-                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        // k_shade holds three waves per SIMD (768 resident blocks): a grid of 1024 blocks strides over the queue with
+                        // a shorter tail than 2048 when frames overlap (test.glb -2.5 %, the larger scenes unchanged)
+                        static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 1024u;
+                        const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
+                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
