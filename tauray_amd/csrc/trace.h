@@ -12,7 +12,9 @@
 
 namespace tr {
 
+#ifndef TR_BLOCK
 #define TR_BLOCK 256
+#endif
 #ifndef TR_VOTE
 #define TR_VOTE 8          // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote)
 #endif
