@@ -551,6 +551,16 @@ def test_tonemap_operators(R, ctx, oracle):
         assert np.allclose(got, ref, rtol=2e-6, atol=1e-6), f"operator {op}"
     R.TonemapStage(ctx, op=2, alpha_grid_background=True).run(src, dst, 47, 33, 2)
     assert np.isfinite(dst.download(x.shape)).all()
+    # values a renderer can hand over: zero, negative, huge, infinite and NaN radiance (the operators clamp to [0, 1000]
+    # before their curve, shader/tonemap.glsl:35-55; what a NaN becomes is whatever min / max make of it in both)
+    y = x.copy()
+    y[0, 0, :8, :3] = [[0, 0, 0], [-1, -0.5, -1e-3], [1e30, 1e20, 5e4], [np.inf, 1, 0], [np.nan, 0.5, 0.25], [1000, 1000, 1000], [1e-30, 1e-38, 1e-45], [0.004, 0.0039, 0.0041]]
+    src.upload(y)
+    for op in range(5):
+        R.TonemapStage(ctx, op=op, exposure=1.0, gamma=2.2).run(src, dst, 47, 33, 2)
+        got, ref = dst.download(y.shape), oracle.tonemap(y, op=op, exposure=1.0, gamma=2.2)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), f"operator {op}: NaNs in different places"
+        assert np.allclose(got, ref, rtol=2e-6, atol=1e-6, equal_nan=True), f"operator {op}, special values"
 
 
 def test_api_errors(R, ctx, test_glb_128):
