@@ -1412,3 +1412,26 @@ def test_many_instances_of_one_mesh(R, ctx, oracle):
         assert np.array_equal(buf.download((128, 128, 4)), osc.render_feature(fid, 128, 128), equal_nan=True), f"feature {fid}"
     for kw in (dict(max_bounces=3), dict(max_bounces=3, pre_transformed_vertices=1)):
         _compare(_render_hip(R, ctx, ss, sc, (128, 128), **kw), osc.render_pt(oracle.options_for_scene(sc, **kw), 128, 128), f"instanced {kw}")
+
+
+@pytest.mark.gpu
+def test_all_features_on_the_zoo_scene(R, ctx, oracle):
+    """feature_stage's ten features on a scene with misses, mirrored instances, single-sided back faces, alpha and a previous
+    camera: equal to the oracle's (albedo within the powf difference of the two maths libraries)."""
+    import copy
+    sc = _zoo_scene()
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    prev = copy.deepcopy(sc.cameras)
+    prev[0].transform = np.asarray(prev[0].transform) @ np.array([[1, 0, 0, 0.1], [0, 1, 0, 0.05], [0, 0, 1, -0.2], [0, 0, 0, 1.0]])
+    ss.set_previous_cameras(prev)
+    osc.set_previous_cameras(prev)
+    for fid in range(10):
+        for default in ((np.nan,) * 4, (0.0, -1.0, 2.0, 7.0)):
+            fs = R.FeatureStage(ctx, ss, fid, _dup((144, 112)), default_value=default)
+            buf = ctx.alloc(144 * 112 * 16).zero()
+            fs.run(buf)
+            g, r = buf.download((112, 144, 4)), osc.render_feature(fid, 144, 112, default_value=default)
+            assert np.array_equal(np.isnan(g), np.isnan(r)), f"feature {fid}"
+            tol = 1e-6 if fid in (0, 6, 7, 8) else 0.0
+            assert np.nanmax(np.abs(g - r)) <= tol * max(1.0, float(np.nanmax(np.abs(r)))), f"feature {fid}: {np.nanmax(np.abs(g - r))}"
