@@ -857,6 +857,14 @@ def test_view_and_sample_shards(R, ctx, oracle):
     mean = np.sum(np.stack(parts).astype(np.float64), axis=0) / world
     assert float(np.abs(mean[..., :3] - one[..., :3]).max()) <= 2e-6 * max(1.0, float(np.abs(one[..., :3]).max())), "sample shards do not add up"
     assert not np.array_equal(parts[0], parts[1])
+    # the Sobol samplers address their sequences by the same global sample index
+    for sampler in (1, 2, 3):
+        one_s = _render_hip(R, ctx, ss, scene, size, samples_per_pixel=4, sampler=sampler, **kw)
+        parts_s = [shard_render(1, sample_base=r, sample_stride=2, opt=dict(samples_per_pixel=2, sampler=sampler)) for r in range(2)]
+        mean_s = np.sum(np.stack(parts_s).astype(np.float64), axis=0) / 2
+        assert float(np.abs(mean_s[..., :3] - one_s[..., :3]).max()) <= 2e-6 * max(1.0, float(np.abs(one_s[..., :3]).max())), f"sampler {sampler}"
+        got_v = shard_render(3, viewport_base=1, viewport_stride=2, opt=dict(sampler=sampler))
+        assert np.array_equal(got_v, _render_hip(R, ctx, ss, scene, size, viewports=V, sampler=sampler, **kw)[1::2]), f"view shard, sampler {sampler}"
     # one shard against the oracle's restatement of the same shard
     osc.set_shard(sample_base=2, sample_stride=4)
     _compare(shard_render(1, sample_base=2, sample_stride=4, opt=dict(samples_per_pixel=2)),
