@@ -1443,3 +1443,33 @@ def test_all_features_on_the_zoo_scene(R, ctx, oracle):
             assert np.array_equal(np.isnan(g), np.isnan(r)), f"feature {fid}"
             tol = 1e-6 if fid in (0, 6, 7, 8) else 0.0
             assert np.nanmax(np.abs(g - r)) <= tol * max(1.0, float(np.nanmax(np.abs(r)))), f"feature {fid}: {np.nanmax(np.abs(g - r))}"
+
+
+@pytest.mark.gpu
+def test_random_option_combinations(R, ctx, oracle):
+    """Differential test over option combinations nobody wrote down: 48 seeded draws from the whole option space (sampler, film,
+    MIS, bounce mode, tri-light mode, NEE weights, clamping, regularisation, roulette, hidden lights, white first-bounce albedo,
+    transparent background, samples per pixel and per pass, depth of field, pre-transformed vertices, seed) on the zoo scene."""
+    sc = _zoo_scene()
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    rng = np.random.default_rng(2024)
+    for k in range(48):
+        per_pass = int(rng.choice([1, 1, 2, 3]))
+        kw = dict(
+            max_bounces=int(rng.integers(1, 7)), sampler=int(rng.integers(0, 4)), film=int(rng.integers(0, 3)), film_radius=float(rng.choice([0.5, 1.0, 1.5])),
+            mis_mode=int(rng.integers(0, 3)), bounce_mode=int(rng.integers(0, 3)), tri_light_mode=int(rng.integers(0, 3)),
+            nee_point=float(rng.choice([0.0, 1.0, 2.5])), nee_directional=float(rng.choice([0.0, 1.0, 0.3])), nee_envmap=float(rng.choice([0.0, 1.0])),
+            indirect_clamping=float(rng.choice([0.0, 0.0, 5.0])), regularization_gamma=float(rng.choice([0.0, 0.0, 0.3])),
+            russian_roulette_delta=float(rng.choice([0.0, 0.0, 1.5])), hide_lights=int(rng.integers(0, 2)),
+            use_white_albedo_on_first_bounce=int(rng.integers(0, 2)), transparent_background=int(rng.integers(0, 2)),
+            samples_per_pass=per_pass, samples_per_pixel=per_pass * int(rng.integers(1, 3)), depth_of_field=int(rng.integers(0, 2)),
+            pre_transformed_vertices=int(rng.integers(0, 2)), rng_seed=int(rng.choice([0, 0, 77])))
+        frames = int(rng.integers(1, 3))
+        img = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, **kw)
+        opt = oracle.options_for_scene(sc, **kw)
+        ref = None
+        for f in range(frames):
+            ref = osc.render_pt(opt, 96, 96, frame_counter=f, samples_accumulated=f * kw["samples_per_pixel"], color=ref)
+        assert np.isfinite(ref).all(), f"draw {k}: the oracle produced a non-finite pixel with {kw}"
+        _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s)")
