@@ -1473,3 +1473,71 @@ def test_random_option_combinations(R, ctx, oracle):
             ref = osc.render_pt(opt, 96, 96, frame_counter=f, samples_accumulated=f * kw["samples_per_pixel"], color=ref)
         assert np.isfinite(ref).all(), f"draw {k}: the oracle produced a non-finite pixel with {kw}"
         _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_triangle_soups(R, ctx, oracle, seed):
+    """Hit parity on geometry no modeller would export: 20 000 random triangles of wildly different sizes (1e-3 .. 1e2), needles,
+    zero-area triangles, exact duplicates, coplanar overlapping sheets, a few non-opaque instances; closest-hit and shadow
+    queries from inside and outside the cloud, with and without stochastic alpha."""
+    from tauray_amd import scene as S
+    rng = np.random.default_rng(seed)
+    n = 20_000
+    centre = rng.normal(size=(n, 3)) * rng.choice([0.5, 3.0, 30.0], size=(n, 1))
+    size = 10.0 ** rng.uniform(-3, 2, size=(n, 1, 1))
+    tri = centre[:, None, :] + rng.normal(size=(n, 3, 3)) * size
+    needles = rng.choice(n, 500, replace=False)
+    tri[needles, 2] = tri[needles, 1] + (tri[needles, 1] - tri[needles, 0]) * 1e-4 + rng.normal(size=(500, 3)) * 1e-6
+    degenerate = rng.choice(n, 300, replace=False)
+    tri[degenerate, 2] = tri[degenerate, 0]                                  # zero area
+    dup = rng.choice(n, 400, replace=False)
+    tri[dup] = tri[(dup + 1) % n]                                            # exact duplicates of other triangles
+    # coplanar, overlapping in the plane z = 0.25.  Kept below a few units across: the distance the triangle test computes
+    # for a 100-unit triangle hit from 3 mm away is good to ~4e-4 only, far more than the slab test's pad, and which of such
+    # sheets wins then depends on the traversal order in both implementations (DESIGN.md section 3)
+    sheet = rng.choice(np.where(size[:, 0, 0] < 1.0)[0], 600, replace=False)
+    tri[sheet, :, 2] = 0.25
+    tri = tri.astype(np.float32)
+    verts = np.zeros(3 * n, dtype=S.VERTEX)
+    verts["pos"] = tri.reshape(-1, 3)
+    verts["normal"] = (0, 0, 1)
+    verts["tangent"] = (1, 0, 0, 1)
+    parts = 8
+    per = n // parts
+    insts, spans = [], []
+    for k in range(parts):
+        alpha = 0.4 if k in (2, 5) else 1.0
+        insts.append(S.make_instance(np.eye(4), S.make_material(albedo=(0.5, 0.5, 0.5, alpha), metallic=0.0, roughness=0.5, double_sided=True)))
+        spans.append((3 * per * k, 3 * per, 3 * per * k, per))
+    cam = S.Camera(fov=60, aspect=1.0)
+    cam.transform = S.trs_matrix((0, 0, 100))
+    sc = S.SceneDesc(instances=np.concatenate(insts), spans=np.array(spans, dtype=S.MESH_SPAN), vertices=verts,
+                     indices=np.tile(np.arange(3 * per, dtype=np.uint32), parts), cameras=[cam]).finalize(True)
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    m = 60_000
+    org = np.concatenate([rng.normal(size=(m // 2, 3)) * 2.0, rng.normal(size=(m // 2, 3)) * 60.0]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d[m // 2:] = -org[m // 2:] + rng.normal(size=(m // 2, 3)).astype(np.float32) * 5      # outside rays aim at the cloud
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((m, 1), 1e-4, np.float32), d, np.full((m, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    seeds = rng.integers(0, 2**32, size=m, dtype=np.uint64).astype(np.uint32)
+    for sd in (seeds, None):
+        g, o = ss.trace_closest(rays, sd), osc.trace_closest(rays, sd)
+        same = (g["instance_id"] == o["instance_id"]) & (g["primitive_id"] == o["primitive_id"]) & (g["t"].view(np.uint32) == o["t"].view(np.uint32))
+        # The only disagreement allowed: a different member of the coplanar sheet at (nearly) the same distance.  The triangle
+        # test's distance is good to ~1e-4 for rays that start a millimetre from a sheet, so which of the overlapping
+        # triangles reports the smallest one depends on the order the trees offer them in; everything else must be equal.
+        sheet_set = np.zeros(n, dtype=bool); sheet_set[sheet] = True
+        for i in np.where(~same)[0]:
+            kg, ko = int(g["instance_id"][i]) * per + int(g["primitive_id"][i]), int(o["instance_id"][i]) * per + int(o["primitive_id"][i])
+            assert g["instance_id"][i] >= 0 and o["instance_id"][i] >= 0 and sheet_set[kg] and sheet_set[ko], f"ray {i}: {g[i]} vs {o[i]}"
+            assert abs(float(g["t"][i]) - float(o["t"][i])) <= 1e-3 * float(o["t"][i]), f"ray {i}: {g[i]} vs {o[i]}"
+        assert (~same).sum() <= m // 10_000, f"{int((~same).sum())} of {m} closest hits differ"
+        assert (g["instance_id"] >= 0).mean() > 0.3
+    srays = rays.copy()
+    srays[:, 7] = rng.uniform(0.5, 80.0, size=m)
+    gs, os_ = ss.trace_shadow(srays), osc.trace_shadow(srays)
+    assert np.array_equal(gs == 0, os_ == 0) and np.allclose(gs, os_, atol=1e-6)
+    assert ss.accel["triangle_count"] == n
