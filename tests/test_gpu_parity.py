@@ -1541,3 +1541,18 @@ def test_random_triangle_soups(R, ctx, oracle, seed):
     gs, os_ = ss.trace_shadow(srays), osc.trace_shadow(srays)
     assert np.array_equal(gs == 0, os_ == 0) and np.allclose(gs, os_, atol=1e-6)
     assert ss.accel["triangle_count"] == n
+    if seed == 1:      # and whole paths through it: lit, finite, equal to the oracle within the usual tolerance
+        import copy
+        lit = copy.copy(sc)
+        lit.point_lights = S.make_point_light((3e6, 3e6, 3e6), (100, 300, 400), 5.0)      # outside the cloud, like the camera
+        lit.envmap = np.ones((2, 4, 4), dtype=np.float32)
+        lit.environment_factor = (0.2, 0.25, 0.3, 1.0)
+        lit.cameras = [copy.deepcopy(cam)]
+        lit.cameras[0].fov = 35
+        lit.cameras[0].transform = S.trs_matrix((5, 10, 420))
+        ss = R.SceneStage(ctx, lit)
+        osc = oracle.OracleScene(lit)
+        kw = dict(max_bounces=4, samples_per_pixel=2)
+        img, ref = _render_hip(R, ctx, ss, lit, (128, 128), **kw), osc.render_pt(oracle.options_for_scene(lit, **kw), 128, 128)
+        assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
+        _compare(img, ref, "paths through the soup")
