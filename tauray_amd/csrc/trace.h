@@ -22,7 +22,9 @@ namespace tr {
 // covers the rounding of both slab distances and, on the tmax side, the error of the distance the triangle test computes
 // (a different expression): without it a box can be culled against a hit that one of its own triangles would have beaten
 // by a few ulps, and which of two nearly coincident surfaces wins then depends on the shape of the tree.
+#ifndef TR_SLAB_PAD
 #define TR_SLAB_PAD 1.000004f
+#endif
 #define TR_LDS_STACK 16
 #ifndef TR_SPILL_STACK
 #define TR_SPILL_STACK 112
