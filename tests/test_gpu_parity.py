@@ -1556,3 +1556,38 @@ def test_random_triangle_soups(R, ctx, oracle, seed):
         img, ref = _render_hip(R, ctx, ss, lit, (128, 128), **kw), osc.render_pt(oracle.options_for_scene(lit, **kw), 128, 128)
         assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
         _compare(img, ref, "paths through the soup")
+
+
+@pytest.mark.gpu
+def test_refit_sequences_equal_rebuilds(R, ctx):
+    """Twelve random instance-transform updates in a row with skinning steps in between, once with nothing but refits (the
+    tree of the first build gets staler every step) and once rebuilding at every step: the same frames, bit for bit."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import from_glm, to_glm, trs_matrix
+
+    def sequence(refit):
+        rng = np.random.default_rng(12)
+        scene = load_glb(os.path.join(GOLDEN, "test.glb"), 96, 96)
+        ss = R.SceneStage(ctx, scene)
+        sp = scene.spans[4]
+        bind = scene.vertices[sp["vertex_offset"]:sp["vertex_offset"] + sp["vertex_count"]].copy()
+        skins, _ = _bend_rig(bind, 0.0)
+        ss.set_skin(4, skins)
+        base = [from_glm(scene.instances["model"][i]) for i in range(len(scene.instances))]
+        frames = []
+        for step in range(12):
+            for i in rng.choice(np.arange(4, len(scene.instances)), size=2, replace=False):
+                m = trs_matrix(rng.uniform(-0.4, 0.4, 3), rng.normal(size=4) * (0.2, 0.2, 0.2, 1.0) + (0, 0, 0, 1), rng.uniform(0.7, 1.3, 3)) @ base[i]
+                scene.instances["model_prev"][i] = scene.instances["model"][i]
+                scene.instances["model"][i] = to_glm(m)
+                scene.instances["model_normal"][i] = to_glm(np.linalg.inv(m).T)
+            ss.update_instances(scene.instances, refit=refit)
+            if step % 3 == 1:
+                ss.skin(4, _bend_rig(bind, float(rng.uniform(-1, 1)))[1], refit=refit)
+            frames.append(_render_hip(R, ctx, ss, scene, (96, 96), max_bounces=3))
+        return frames
+
+    a, b = sequence(True), sequence(False)
+    for step, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), f"step {step}"
+    assert not np.array_equal(a[0], a[-1])
