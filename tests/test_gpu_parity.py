@@ -1591,3 +1591,54 @@ def test_refit_sequences_equal_rebuilds(R, ctx):
     for step, (x, y) in enumerate(zip(a, b)):
         assert np.array_equal(x, y), f"step {step}"
     assert not np.array_equal(a[0], a[-1])
+
+
+@pytest.mark.gpu
+def test_random_cameras(R, ctx, oracle):
+    """Twenty seeded cameras on the zoo scene: perspective with pan (fov offsets) and depth of field (circular and polygonal
+    apertures), orthographic windows off the axis, equirectangular with partial fields of view, rolled and tilted transforms,
+    wide and narrow aspect ratios: ray generation and the whole frame against the oracle."""
+    import copy
+    from tauray_amd import scene as S
+    base = _zoo_scene()
+    rng = np.random.default_rng(31)
+    for k in range(20):
+        sc = copy.copy(base)
+        cam = S.Camera()
+        kind = k % 3
+        w, h = [(96, 96), (160, 64), (48, 120)][int(rng.integers(0, 3))]
+        dof = 0
+        if kind == 0:
+            cam.projection = S.PROJ_PERSPECTIVE
+            cam.fov = float(rng.uniform(20, 110))
+            cam.fov_offset = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))
+            if k % 2 == 0:
+                cam.set_focus(float(rng.uniform(0.5, 4)), float(rng.uniform(2, 6)), int(rng.choice([0, 3, 6])), float(rng.uniform(0, 90)), 0.036)
+                dof = 1
+        elif kind == 1:
+            cam.projection = S.PROJ_ORTHOGRAPHIC
+            cx, cy, hw = rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(1.0, 2.5)
+            cam.ortho = (cx - hw, cx + hw, cy - hw, cy + hw, 0.01, 50.0)
+        else:
+            cam.projection = S.PROJ_EQUIRECTANGULAR
+            cam.equirect_fov = (float(rng.uniform(90, 360)), float(rng.uniform(60, 180)))
+        cam.transform = S.trs_matrix(rng.uniform(-0.5, 0.5, 3) + (0, 0, 4.0), rng.normal(size=4) * (0.15, 0.15, 0.3, 1.0) + (0, 0, 0, 1.5))
+        cam.set_aspect(w / h)
+        sc.cameras = [cam]
+        ss = R.SceneStage(ctx, sc)
+        osc = oracle.OracleScene(sc)
+        kw = dict(max_bounces=3, depth_of_field=dof, projection=cam.projection, film=int(rng.integers(0, 3)))
+        img = _render_hip(R, ctx, ss, sc, (w, h), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(sc, **kw), w, h)
+        assert np.isfinite(ref).all(), f"camera {k}"
+        _compare(img, ref, f"camera {k} (kind {kind}, {w}x{h}, dof {dof})")
+        fs = R.FeatureStage(ctx, ss, 5, _dup((w, h)), projection=cam.projection)
+        buf = ctx.alloc(w * h * 16).zero()
+        fs.run(buf)
+        g, r = buf.download((h, w, 4)), osc.render_feature(5, w, h, projection=cam.projection)
+        if kind != 2:
+            assert np.array_equal(g, r, equal_nan=True), f"camera {k}: primary hit distances"
+        else:       # equirectangular rays go through sin / cos, which differ by ulps between the two maths libraries
+            both = np.isfinite(g[..., 0]) & np.isfinite(r[..., 0])
+            assert (np.isfinite(g[..., 0]) != np.isfinite(r[..., 0])).mean() <= 2e-3
+            assert (np.abs(g[both] - r[both]) > 1e-4 * np.abs(r[both]) + 1e-5).mean() <= 2e-3, f"camera {k}: primary hit distances"
