@@ -1642,3 +1642,39 @@ def test_random_cameras(R, ctx, oracle):
             both = np.isfinite(g[..., 0]) & np.isfinite(r[..., 0])
             assert (np.isfinite(g[..., 0]) != np.isfinite(r[..., 0])).mean() <= 2e-3
             assert (np.abs(g[both] - r[both]) > 1e-4 * np.abs(r[both]) + 1e-5).mean() <= 2e-3, f"camera {k}: primary hit distances"
+
+
+@pytest.mark.gpu
+def test_random_lights(R, ctx, oracle):
+    """Sixteen seeded light rigs on the zoo scene: up to five point / spot lights (radius 0 .. 0.6, cones of 3 .. 80 degrees,
+    falloff exponents 0 .. 8, some inside geometry or behind the camera), up to three directional lights (angles 0 .. 25
+    degrees), with and without the environment map, tri-light modes and MIS modes drawn along."""
+    import copy
+    from tauray_amd import scene as S
+    base = _zoo_scene()
+    rng = np.random.default_rng(77)
+    for k in range(16):
+        sc = copy.copy(base)
+        pls = []
+        for _ in range(int(rng.integers(0, 6))):
+            col = tuple(rng.uniform(2, 60, 3))
+            pos = tuple(rng.uniform(-2.5, 2.5, 2)) + (float(rng.uniform(-1.0, 5.0)),)
+            radius = float(rng.choice([0.0, 0.0, rng.uniform(0.02, 0.6)]))
+            if rng.uniform() < 0.5:
+                pls.append(S.make_point_light(col, pos, radius))
+            else:
+                pls.append(S.make_spotlight(col, pos, tuple(rng.normal(size=3)), radius, float(rng.uniform(3, 80)), float(rng.uniform(0, 8))))
+        dls = [S.make_directional_light(tuple(rng.uniform(0.2, 3, 3)), tuple(rng.normal(size=3) * (1, 1, 0.3) + (0, 0, -1)), float(rng.choice([0.0, rng.uniform(0.1, 25)])))
+               for _ in range(int(rng.integers(0, 4)))]
+        sc.point_lights = np.concatenate(pls) if pls else np.zeros(0, dtype=S.POINT_LIGHT)
+        sc.directional_lights = np.concatenate(dls) if dls else np.zeros(0, dtype=S.DIRECTIONAL_LIGHT)
+        if k % 3 == 0:
+            sc.envmap, sc.environment_factor = None, (0, 0, 0, 0)
+        ss = R.SceneStage(ctx, sc)
+        osc = oracle.OracleScene(sc)
+        kw = dict(max_bounces=int(rng.integers(2, 5)), mis_mode=int(rng.integers(0, 3)), tri_light_mode=int(rng.integers(0, 3)), hide_lights=int(rng.integers(0, 2)),
+                  sampler=int(rng.integers(0, 2)))
+        img = _render_hip(R, ctx, ss, sc, (112, 112), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(sc, **kw), 112, 112)
+        assert np.isfinite(ref).all(), f"rig {k}: the oracle produced a non-finite pixel"
+        _compare(img, ref, f"rig {k}: {len(pls)} point / spot, {len(dls)} directional, {kw}")
