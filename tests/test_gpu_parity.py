@@ -1678,3 +1678,39 @@ def test_random_lights(R, ctx, oracle):
         ref = osc.render_pt(oracle.options_for_scene(sc, **kw), 112, 112)
         assert np.isfinite(ref).all(), f"rig {k}: the oracle produced a non-finite pixel"
         _compare(img, ref, f"rig {k}: {len(pls)} point / spot, {len(dls)} directional, {kw}")
+
+
+@pytest.mark.gpu
+def test_random_materials(R, ctx, oracle):
+    """Twelve seeded draws of all nine panel materials of the zoo scene: metallic and roughness anywhere in [0, 1] (with
+    exact zeros and ones), transmittance, ior in [0.5, 3] away from 1, albedo alpha, emission (emissive panels become tri
+    lights), single- and double-sided, normal factors - whole frames and the material gbuffer targets against the oracle."""
+    import copy
+    from tauray_amd import scene as S
+    base = _zoo_scene()
+    rng = np.random.default_rng(5150)
+    corner = lambda: float(rng.choice([0.0, 1.0, rng.uniform(0, 1), rng.uniform(0, 1)]))
+    for k in range(12):
+        sc = copy.copy(base)
+        sc.instances = base.instances.copy()
+        for i in range(9):
+            ior = float(rng.uniform(0.5, 3.0))
+            if abs(ior - 1.0) < 0.03:
+                ior = 1.3
+            emis = tuple(rng.uniform(0, 4, 3)) if rng.uniform() < 0.25 else (0, 0, 0)
+            sc.instances["mat"][i] = S.make_material(albedo=tuple(rng.uniform(0, 1, 3)) + (float(rng.choice([1.0, 1.0, rng.uniform(0.1, 0.9)])),),
+                                                     metallic=corner(), roughness=corner(), emission=emis,
+                                                     transmittance=float(rng.choice([0.0, 0.0, 1.0, rng.uniform(0, 1)])), ior=ior,
+                                                     normal_factor=float(rng.uniform(0.5, 1.5)), double_sided=bool(rng.integers(0, 2)))
+        sc.finalize(True)
+        ss = R.SceneStage(ctx, sc)
+        osc = oracle.OracleScene(sc)
+        assert np.array_equal(ss.tri_lights().view(np.uint8), osc.tri_lights().view(np.uint8))
+        kw = dict(max_bounces=int(rng.integers(2, 6)), sampler=int(rng.integers(0, 2)), tri_light_mode=int(rng.integers(0, 3)))
+        img = _render_hip(R, ctx, ss, sc, (112, 112), **kw)
+        ref = osc.render_pt(oracle.options_for_scene(sc, **kw), 112, 112)
+        assert np.isfinite(ref).all(), f"draw {k}: the oracle produced a non-finite pixel"
+        _compare(img, ref, f"draw {k}: {kw}")
+        got = _render_targets_hip(R, ctx, ss, sc, (112, 112), ["material", "albedo"], max_bounces=2)
+        want = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 112, 112, ["material", "albedo"])
+        assert np.allclose(got["material"], want["material"], atol=1e-6) and np.allclose(got["albedo"], want["albedo"], atol=1e-6), f"draw {k}"
