@@ -501,7 +501,7 @@ class RtRenderer:
 
     def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
                  rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None,
-                 shard="pixels", frames_in_flight=1):
+                 shard="pixels", frames_in_flight=1, stage_cls=None):
         """`shard`: what the ranks divide among themselves - "pixels" (the reference's distribution strategies, partial frames
         stitched on rank 0), "views" (viewport v on rank v mod N; nothing is exchanged before output) or "samples" (every
         rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e)."""
@@ -544,7 +544,7 @@ class RtRenderer:
         self.slots = []
         for k in range(frames_in_flight):
             slot = _FrameSlot()
-            slot.pt = PathTracerStage(ctx, self.scene_update, options, self.dist)
+            slot.pt = (stage_cls or PathTracerStage)(ctx, self.scene_update, options, self.dist)   # rt_renderer<Pipeline>: path_tracer_stage or direct_stage
             if self.shard == "views":
                 slot.pt.set_shard(viewport_base=rank, viewport_stride=world_size)
             elif self.shard == "samples":

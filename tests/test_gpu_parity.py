@@ -932,6 +932,15 @@ def test_frames_in_flight_are_the_same_frames(R, ctx):
         rr.close()
     with pytest.raises(ValueError):
         R.RtRenderer(ctx, scene, opt, (160, 96), use_torch=False, frames_in_flight=2, accumulate=True)
+    # rt_renderer<direct_stage>: the same renderer around the other pipeline, one frame at a time and with slots
+    dopt = R.options_for_scene(scene, max_bounces=3, samples_per_pixel=2, samples_per_pass=2)
+    a = R.RtRenderer(ctx, scene, dopt, (160, 96), use_torch=False, stage_cls=R.DirectStage)
+    b = R.RtRenderer(ctx, scene, dopt, (160, 96), use_torch=False, stage_cls=R.DirectStage, frames_in_flight=3)
+    for i in range(4):
+        a.render(); b.render()
+        assert np.array_equal(a.download("display"), b.download("display")), f"direct stage, frame {i}"
+    assert not np.array_equal(a.download("color"), want[3][0])
+    a.close(); b.close()
 
 
 @pytest.mark.gpu
