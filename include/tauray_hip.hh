@@ -422,9 +422,12 @@ public:
 };
 
 //==============================================================================
-// rt_renderer<path_tracer_stage>: all devices in one process, like the reference
+// rt_renderer<Pipeline> (src/rt_renderer.hh:28-77): all devices in one process, like the reference.  Pipeline is
+// path_tracer_stage or direct_stage (the reference instantiates the template for those, src/rt_renderer.cc:410-412);
+// `rt_renderer` and `direct_renderer` below are the two instantiations (src/rt_renderer.hh:75-77).
 //==============================================================================
-class rt_renderer
+template<typename Pipeline>
+class basic_rt_renderer
 {
 public:
     struct options: path_tracer_stage::options
@@ -438,7 +441,7 @@ public:
     };
 
     // `devices`: HIP device index per logical device (repeat an index for --fake-devices); device 0 displays.
-    rt_renderer(const std::vector<int>& devices, const scene_data& scene, uvec2 size, options opt)
+    basic_rt_renderer(const std::vector<int>& devices, const scene_data& scene, uvec2 size, options opt)
     : size(size), opt(opt)
     {
         if(devices.empty()) throw std::runtime_error("rt_renderer needs at least one device");
@@ -461,7 +464,7 @@ public:
             check(trhip_memset(d.dev->h, d.color, 0, d.target_bytes, nullptr));
             path_tracer_stage::options po = this->opt;
             po.distribution = d.dist;
-            d.ray_tracer = std::make_unique<path_tracer_stage>(*d.dev, *d.scene_update, d.color, po);
+            d.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, d.color, po);
             if(i != 0) d.gbuffer_copy = per_device[0].dev->alloc(d.target_bytes);   // receive buffer on the display device
         }
         display_bytes = size_t(size.x) * size.y * 16 * this->opt.active_viewport_count;
@@ -481,7 +484,7 @@ public:
                 check(trhip_memset(d.dev->h, fs.color, 0, d.target_bytes, nullptr));
                 path_tracer_stage::options po = this->opt;
                 po.distribution = d.dist;
-                fs.ray_tracer = std::make_unique<path_tracer_stage>(*d.dev, *d.scene_update, fs.color, po);
+                fs.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, fs.color, po);
                 fs.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
                 frame_slots.push_back(std::move(fs));
             }
@@ -489,7 +492,7 @@ public:
         }
     }
 
-    ~rt_renderer()
+    ~basic_rt_renderer()
     {
         for(auto& fs: frame_slots)
         {
@@ -588,7 +591,7 @@ public:
     {
         std::unique_ptr<device> dev;
         std::unique_ptr<scene_stage> scene_update;
-        std::unique_ptr<path_tracer_stage> ray_tracer;
+        std::unique_ptr<Pipeline> ray_tracer;
         distribution_params dist;
         void* color = nullptr;
         void* gbuffer_copy = nullptr;
@@ -598,7 +601,7 @@ public:
     struct frame_slot
     {
         void* stream = nullptr;
-        std::unique_ptr<path_tracer_stage> ray_tracer;
+        std::unique_ptr<Pipeline> ray_tracer;
         void* color = nullptr;
         void* display = nullptr;
     };
@@ -613,6 +616,8 @@ public:
     std::unique_ptr<tonemap_stage> tonemap;
     unsigned accumulated_frames = 0;
 };
+using rt_renderer = basic_rt_renderer<path_tracer_stage>;       // path_tracer_renderer
+using direct_renderer = basic_rt_renderer<direct_stage>;        // direct_renderer
 
 //==============================================================================
 // headless (src/headless.{hh,cc}): readback + writers.  EXR: scanline, uncompressed, channels B,G,R[,A] like the

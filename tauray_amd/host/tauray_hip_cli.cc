@@ -6,7 +6,7 @@
 //              [--frames=1] [--fake-devices=N | --devices=0,1,...] [--distribution-strategy=scanline|shuffled-strips]
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
-//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1]
+//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1] [--renderer=path-tracer|direct]
 #include <cstdlib>
 #include <iostream>
 #include <map>
@@ -25,6 +25,7 @@ int main(int argc, char** argv)
         std::string scene_path, prefix = "capture";
         uvec2 size{1280, 720};
         int frames = 1, warmup = 0, fake_devices = 1, frames_in_flight = 1;
+        std::string renderer = "path-tracer";
         std::vector<int> devices;
         bool timing = false;
         rt_renderer::options opt;
@@ -47,6 +48,11 @@ int main(int argc, char** argv)
             else if(starts(a, "--samples-per-pass=")) opt.samples_per_pass = std::stoi(val("--samples-per-pass="));
             else if(starts(a, "--frames=")) { frames = std::stoi(val("--frames=")); hopt.single_frame = frames == 1; }
             else if(starts(a, "--warmup-frames=")) warmup = std::stoi(val("--warmup-frames="));
+            else if(starts(a, "--renderer="))
+            {
+                renderer = val("--renderer=");
+                if(renderer != "path-tracer" && renderer != "direct") throw std::runtime_error("unknown renderer " + renderer + " (path-tracer, direct)");
+            }
             else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
             else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
@@ -112,9 +118,11 @@ int main(int argc, char** argv)
         opt.active_viewport_count = 1;
 
         opt.max_frames_in_flight = frames_in_flight;
-        rt_renderer rr(devices, scene, size, opt);
         hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = 1;
         headless out(hopt);
+        // --renderer picks the pipeline rt_renderer<Pipeline> is instantiated with (src/tauray.cc:355-421: path-tracer, direct)
+        auto run = [&](auto& rr) -> int
+        {
         if(frames_in_flight > 1)
         {   // frame f renders while the frames before it are read back, compressed and written (the reference overlaps
             // its save workers with the next frames the same way, src/headless.cc:349-422)
@@ -155,6 +163,17 @@ int main(int argc, char** argv)
             out.save(*rr.per_device[0].dev, rr.display, (unsigned)f);
         }
         return 0;
+        };
+        if(renderer == "direct")
+        {
+            direct_renderer::options dopt;
+            static_cast<path_tracer_stage::options&>(dopt) = opt;
+            dopt.tonemap = opt.tonemap; dopt.accumulate = opt.accumulate; dopt.max_frames_in_flight = opt.max_frames_in_flight;
+            direct_renderer rr(devices, scene, size, dopt);
+            return run(rr);
+        }
+        rt_renderer rr(devices, scene, size, opt);
+        return run(rr);
     }
     catch(std::exception& e)
     {

@@ -236,6 +236,19 @@ def test_cpp_renderer_matches_python_mirror_and_fake_devices(tmp_path, scene_dum
         assert "[path tracing (1 viewports)]" in r.stdout and "HOST:" in r.stdout
         got = np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4)
         assert np.array_equal(got, ref), tag
+    # rt_renderer<direct_stage> (tr::direct_renderer, --renderer=direct) against the Python DirectStage
+    dopt = R.options_for_scene(test_glb_128, max_bounces=4, samples_per_pixel=2, samples_per_pass=2)
+    dt = R.DirectStage(ctx, ss, dopt, DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    color.zero()
+    dt.run(color)
+    R.TonemapStage(ctx).run(color, disp, W, H)
+    ref = disp.download((H, W, 4))
+    for tag, extra in (("direct", []), ("direct_fake2", ["--fake-devices=2", "--distribution-strategy=scanline"]), ("direct_slots", ["--frames-in-flight=2"])):
+        prefix = str(tmp_path / tag)
+        subprocess.check_call([CLI] + common + [f"--headless={prefix}", "--renderer=direct", "--samples-per-pixel=2", "--samples-per-pass=2"] + extra)
+        assert np.array_equal(np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4), ref), tag
+    r = subprocess.run([CLI] + common + ["--renderer=whitted"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown renderer" in r.stderr
 
 
 @pytest.mark.gpu
