@@ -20,6 +20,9 @@ static bool starts(const std::string& s, const std::string& p) { return s.compar
 
 int main(int argc, char** argv)
 {
+    // hardware queues of the HIP runtime (default 4): more than three frame slots only pay off with more; read when the
+    // runtime starts, i.e. before the first call into libtrhip
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     try
     {
         std::string scene_path, prefix = "capture";
