@@ -65,9 +65,12 @@ def parse():
 
 def main():
     args = parse()
-    if os.environ.get("TRHIP_BENCH_WATCHDOG"):      # rehearsals: dump every thread's stack and exit instead of hanging
+    # A multi-rank run that stops making progress (a peer died, an exchange deadlocked) dumps every thread's stack and exits
+    # instead of hanging until somebody kills it; a whole run takes a minute or two.  TRHIP_BENCH_WATCHDOG overrides (seconds).
+    watchdog = int(os.environ.get("TRHIP_BENCH_WATCHDOG", "900" if args.gpus > 1 else "0"))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["TRHIP_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     from tauray_amd import renderer as R
     from tauray_amd import scenes
     from tauray_amd.distribution import DISTRIBUTION_SCANLINE
