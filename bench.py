@@ -86,6 +86,8 @@ def main():
         rank = int(os.environ.get("RANK", "0"))
         local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", str(rank)))
         world = int(os.environ.get("WORLD_SIZE", str(world)))
+        if torch.cuda.device_count() > 0:
+            local_rank %= torch.cuda.device_count()     # a launcher that narrows *_VISIBLE_DEVICES per rank leaves one device, index 0
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
