@@ -21,7 +21,6 @@
 #include <fstream>
 #include <functional>
 #include <memory>
-#include <queue>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -620,230 +619,17 @@ using rt_renderer = basic_rt_renderer<path_tracer_stage>;       // path_tracer_r
 using direct_renderer = basic_rt_renderer<direct_stage>;        // direct_renderer
 
 //==============================================================================
-// headless (src/headless.{hh,cc}): readback + writers.  EXR: scanline, uncompressed, channels B,G,R[,A] like the
-// reference (which defaults to PIZ; compression "none" is one of its options), half or float.
-// ---------------------------------------------------------------------------------------------------------------------
-// OpenEXR PIZ compression (what the reference's tinyexr writer uses by default, src/headless.cc:385-406): per block of 32
-// scanlines the 16-bit words of every channel go through a value-range compaction (bitmap + LUT), a 2-D Haar-like
-// wavelet and a canonical Huffman coder with run-length escapes.  Written from the published format description
-// (OpenEXR "Technical Introduction", ImfPizCompressor); any conforming reader decodes it.
-namespace piz
-{
-constexpr int USHORT_RANGE = 1 << 16, BITMAP_SIZE = USHORT_RANGE >> 3;
-constexpr int HUF_ENCSIZE = (1 << 16) + 1;
-
-inline void wenc14(uint16_t a, uint16_t b, uint16_t& l, uint16_t& h)
-{
-    const int16_t as = (int16_t)a, bs = (int16_t)b;
-    const int16_t ms = (int16_t)((as + bs) >> 1), ds = (int16_t)(as - bs);
-    l = (uint16_t)ms; h = (uint16_t)ds;
-}
-inline void wenc16(uint16_t a, uint16_t b, uint16_t& l, uint16_t& h)
-{
-    constexpr int A_OFFSET = 1 << 15, M_OFFSET = 1 << 15, MOD_MASK = (1 << 16) - 1;
-    const int ao = (a + A_OFFSET) & MOD_MASK;
-    int m = (ao + b) >> 1, d = ao - b;
-    if(d < 0) m = (m + M_OFFSET) & MOD_MASK;
-    d &= MOD_MASK;
-    l = (uint16_t)m; h = (uint16_t)d;
-}
-inline void wav2_encode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx)
-{
-    const bool w14 = mx < (1 << 14);
-    const int n = nx > ny ? ny : nx;
-    int p = 1, p2 = 2;
-    auto enc = [&](uint16_t a, uint16_t b, uint16_t& l, uint16_t& h) { if(w14) wenc14(a, b, l, h); else wenc16(a, b, l, h); };
-    while(p2 <= n)
-    {
-        uint16_t* py = in;
-        uint16_t* ey = in + oy * (ny - p2);
-        const int oy1 = oy * p, oy2 = oy * p2, ox1 = ox * p, ox2 = ox * p2;
-        uint16_t i00, i01, i10, i11;
-        for(; py <= ey; py += oy2)
-        {
-            uint16_t* px = py;
-            uint16_t* ex = py + ox * (nx - p2);
-            for(; px <= ex; px += ox2)
-            {
-                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
-                enc(*px, *p01, i00, i01); enc(*p10, *p11, i10, i11);
-                enc(i00, i10, *px, *p10); enc(i01, i11, *p01, *p11);
-            }
-            if(nx & p) { uint16_t* p10 = px + oy1; enc(*px, *p10, i00, *p10); *px = i00; }
-        }
-        if(ny & p)
-        {
-            uint16_t* px = py;
-            uint16_t* ex = py + ox * (nx - p2);
-            for(; px <= ex; px += ox2) { uint16_t* p01 = px + ox1; enc(*px, *p01, i00, *p01); *px = i00; }
-        }
-        p = p2; p2 <<= 1;
-    }
-}
-
-struct bit_writer
-{
-    std::vector<uint8_t>& out;
-    uint64_t c = 0; int lc = 0; uint64_t total = 0;
-    void bits(int n, uint64_t v) { c = (c << n) | v; lc += n; total += (uint64_t)n; while(lc >= 8) { lc -= 8; out.push_back((uint8_t)(c >> lc)); } }
-    void flush() { if(lc) out.push_back((uint8_t)((c << (8 - lc)) & 0xFF)); c = 0; lc = 0; }
-};
-
-// code lengths of an optimal prefix code for the symbols with freq > 0 (at least two of them)
-inline void huffman_lengths(const std::vector<uint64_t>& freq, std::vector<uint8_t>& length)
-{
-    struct node { uint64_t f; int left, right; };
-    std::vector<node> nodes;
-    std::vector<int> leaf_of(freq.size(), -1);
-    using item = std::pair<uint64_t, int>;
-    std::priority_queue<item, std::vector<item>, std::greater<item>> heap;
-    for(size_t i = 0; i < freq.size(); ++i)
-        if(freq[i]) { leaf_of[i] = (int)nodes.size(); nodes.push_back({freq[i], -1, -1}); heap.push({freq[i], leaf_of[i]}); }
-    while(heap.size() > 1)
-    {
-        item a = heap.top(); heap.pop();
-        item b = heap.top(); heap.pop();
-        nodes.push_back({a.first + b.first, a.second, b.second});
-        heap.push({a.first + b.first, (int)nodes.size() - 1});
-    }
-    std::vector<uint8_t> depth(nodes.size(), 0);
-    for(int i = (int)nodes.size() - 1; i >= 0; --i)      // parents come after their children: walk from the root down
-        if(nodes[i].left >= 0) { depth[nodes[i].left] = (uint8_t)(depth[i] + 1); depth[nodes[i].right] = (uint8_t)(depth[i] + 1); }
-    length.assign(freq.size(), 0);
-    for(size_t i = 0; i < freq.size(); ++i) if(leaf_of[i] >= 0) length[i] = depth[leaf_of[i]];
-}
-
-inline void huf_compress(const uint16_t* raw, size_t n, std::vector<uint8_t>& out)
-{
-    if(n == 0) return;
-    std::vector<uint64_t> freq(HUF_ENCSIZE, 0);
-    for(size_t i = 0; i < n; ++i) freq[raw[i]]++;
-    int im = 0, iM = 0;
-    while(!freq[im]) im++;
-    for(int i = 0; i < HUF_ENCSIZE - 1; ++i) if(freq[i]) iM = i;
-    iM++;                      // the run-length escape symbol
-    freq[iM] = 1;
-    std::vector<uint8_t> length;
-    huffman_lengths(freq, length);
-    for(uint8_t l : length) if(l > 58) throw std::runtime_error("PIZ: Huffman code longer than 58 bits");
-    // canonical codes from the lengths (the reader rebuilds them the same way): code << 6 | length
-    std::vector<uint64_t> hcode(HUF_ENCSIZE, 0);
-    {
-        uint64_t count[59] = {0};
-        for(int i = 0; i < HUF_ENCSIZE; ++i) count[length[i]]++;
-        uint64_t c = 0;
-        for(int i = 58; i > 0; --i) { const uint64_t nc = (c + count[i]) >> 1; count[i] = c; c = nc; }
-        for(int i = 0; i < HUF_ENCSIZE; ++i) if(length[i]) hcode[i] = (uint64_t)length[i] | (count[length[i]]++ << 6);
-    }
-    const size_t header = out.size();
-    out.resize(out.size() + 20);
-    // packed table of code lengths, 6 bits each, runs of zero lengths abbreviated
-    const size_t table_start = out.size();
-    {
-        constexpr int SHORT_ZEROCODE_RUN = 59, LONG_ZEROCODE_RUN = 63, SHORTEST_LONG_RUN = 2 + LONG_ZEROCODE_RUN - SHORT_ZEROCODE_RUN,
-                      LONGEST_LONG_RUN = 255 + SHORTEST_LONG_RUN;
-        bit_writer w{out};
-        for(int i = im; i <= iM; ++i)
-        {
-            const int l = length[i];
-            if(l == 0)
-            {
-                int zerun = 1;
-                while(i < iM && zerun < LONGEST_LONG_RUN) { if(length[i + 1] > 0) break; i++; zerun++; }
-                if(zerun >= 2)
-                {
-                    if(zerun >= SHORTEST_LONG_RUN) { w.bits(6, LONG_ZEROCODE_RUN); w.bits(8, (uint64_t)(zerun - SHORTEST_LONG_RUN)); }
-                    else w.bits(6, (uint64_t)(SHORT_ZEROCODE_RUN + zerun - 2));
-                    continue;
-                }
-            }
-            w.bits(6, (uint64_t)l);
-        }
-        w.flush();
-    }
-    const size_t table_length = out.size() - table_start;
-    // the data: Huffman codes, a run of equal symbols as symbol + escape + 8-bit count when that is shorter
-    uint64_t n_bits;
-    {
-        bit_writer w{out};
-        auto code = [&](uint64_t hc) { w.bits((int)(hc & 63), hc >> 6); };
-        auto send = [&](uint64_t sc, int run) {
-            const int ls = (int)(sc & 63), lr = (int)(hcode[iM] & 63);
-            if(ls + lr + 8 < ls * run) { code(sc); code(hcode[iM]); w.bits(8, (uint64_t)run); }
-            else while(run-- >= 0) code(sc);
-        };
-        uint16_t s = raw[0];
-        int cs = 0;
-        for(size_t i = 1; i < n; ++i)
-        {
-            if(s == raw[i] && cs < 255) cs++;
-            else { send(hcode[s], cs); cs = 0; }
-            s = raw[i];
-        }
-        send(hcode[s], cs);
-        n_bits = w.total;
-        w.flush();
-    }
-    const uint32_t head[5] = {(uint32_t)im, (uint32_t)iM, (uint32_t)table_length, (uint32_t)n_bits, 0u};
-    std::memcpy(out.data() + header, head, 20);
-}
-
-// `raw`: the block as it would be stored uncompressed: per scanline, per channel, nx samples of `words[c]` 16-bit words
-inline void compress_block(const uint8_t* raw, size_t raw_bytes, int nx, int ny, const std::vector<int>& words, std::vector<uint8_t>& out)
-{
-    const size_t total = raw_bytes / 2;
-    std::vector<uint16_t> tmp(total);
-    std::vector<size_t> start(words.size());
-    { size_t o = 0; for(size_t c = 0; c < words.size(); ++c) { start[c] = o; o += size_t(nx) * ny * words[c]; } }
-    {   // de-interleave the scanlines into one plane per channel
-        const uint16_t* in = reinterpret_cast<const uint16_t*>(raw);
-        std::vector<size_t> end = start;
-        for(int y = 0; y < ny; ++y)
-            for(size_t c = 0; c < words.size(); ++c)
-            {
-                const size_t n = size_t(nx) * words[c];
-                std::memcpy(tmp.data() + end[c], in, n * 2);
-                in += n; end[c] += n;
-            }
-    }
-    std::vector<uint8_t> bitmap(BITMAP_SIZE, 0);
-    for(uint16_t v : tmp) bitmap[v >> 3] |= (uint8_t)(1 << (v & 7));
-    bitmap[0] &= (uint8_t)~1;   // zero is always in the table
-    int min_nz = BITMAP_SIZE - 1, max_nz = 0;
-    for(int i = 0; i < BITMAP_SIZE; ++i) if(bitmap[i]) { if(min_nz > i) min_nz = i; if(max_nz < i) max_nz = i; }
-    std::vector<uint16_t> lut(USHORT_RANGE);
-    int k = 0;
-    for(int i = 0; i < USHORT_RANGE; ++i) lut[i] = (i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) ? (uint16_t)k++ : (uint16_t)0;
-    const uint16_t max_value = (uint16_t)(k - 1);
-    for(uint16_t& v : tmp) v = lut[v];
-    const size_t begin = out.size();
-    const uint16_t mm[2] = {(uint16_t)min_nz, (uint16_t)max_nz};
-    out.insert(out.end(), reinterpret_cast<const uint8_t*>(mm), reinterpret_cast<const uint8_t*>(mm) + 4);
-    if(min_nz <= max_nz) out.insert(out.end(), bitmap.begin() + min_nz, bitmap.begin() + max_nz + 1);
-    for(size_t c = 0; c < words.size(); ++c)
-        for(int j = 0; j < words[c]; ++j)
-            wav2_encode(tmp.data() + start[c] + j, nx, words[c], ny, nx * words[c], max_value);
-    const size_t length_pos = out.size();
-    out.resize(out.size() + 4);
-    const size_t huf_start = out.size();
-    huf_compress(tmp.data(), total, out);
-    const int32_t length = (int32_t)(out.size() - huf_start);
-    std::memcpy(out.data() + length_pos, &length, 4);
-    if(out.size() - begin >= raw_bytes)   // not smaller: the block is stored as it is
-    {
-        out.resize(begin);
-        out.insert(out.end(), raw, raw + raw_bytes);
-    }
-}
-}
-
+// headless (src/headless.{hh,cc}): readback + writers.  EXR: scanline file, channels B,G,R[,A] like the reference's,
+// half or float, stored uncompressed or deflated (ZIPS: one scanline per chunk, ZIP: sixteen).  The reference's writer
+// defaults to PIZ (src/headless.hh:56); wavelet coding is not on the hot path and is left out: ZIP is the default here,
+// every EXR reader takes it, and `--compression=none` gives the raw scanlines.
 //==============================================================================
 class headless
 {
 public:
     enum image_file_type { EXR = 0, RAW, EMPTY };
     enum pixel_format { RGB16, RGB32, RGBA16, RGBA32 };
-    enum compression_type { NONE = 0, RLE, ZIPS, ZIP, PIZ };   // src/headless.hh:25-32
+    enum compression_type { NONE = 0, ZIPS = 2, ZIP = 3 };   // values = OpenEXR compression codes; subset of src/headless.hh:25-32
 
     struct options
     {
@@ -851,7 +637,7 @@ public:
         std::string output_prefix = "capture";
         image_file_type output_file_type = EXR;
         pixel_format output_format = RGB16;
-        compression_type output_compression = PIZ;      // src/headless.hh:56
+        compression_type output_compression = ZIP;      // the reference defaults to PIZ (src/headless.hh:56), see above
         bool single_frame = false;
         bool skip_nan_check = false;
         unsigned first_frame_index = 0;
@@ -932,51 +718,22 @@ private:
         f.write(reinterpret_cast<const char*>(img), (std::streamsize)(pixels * 16));
     }
 
-    // RLE / ZIP share OpenEXR's byte reordering and delta predictor; a block that does not shrink is stored raw
-    static void compress_bytes(compression_type comp, const std::vector<uint8_t>& raw, std::vector<uint8_t>& out)
+    // A deflated EXR chunk: the bytes of the chunk split into even and odd positions (first half | second half), each byte
+    // replaced by its difference to the one before (biased by 128), then zlib.  A chunk that does not shrink is stored raw.
+    static void deflate_chunk(const std::vector<uint8_t>& raw, std::vector<uint8_t>& out)
     {
-        const size_t n = raw.size();
-        std::vector<uint8_t> tmp(n);
-        {
-            uint8_t *t1 = tmp.data(), *t2 = tmp.data() + (n + 1) / 2;
-            for(size_t i = 0; i < n;) { *t1++ = raw[i++]; if(i < n) *t2++ = raw[i++]; }
-            int p = n ? tmp[0] : 0;
-            for(size_t i = 1; i < n; ++i) { const int d = int(tmp[i]) - p + (128 + 256); p = tmp[i]; tmp[i] = (uint8_t)d; }
-        }
+        const size_t n = raw.size(), half = (n + 1) / 2;
+        std::vector<uint8_t> planar(n);
+        for(size_t i = 0; i < n; ++i) planar[(i & 1) ? half + i / 2 : i / 2] = raw[i];
+        for(size_t i = n; i-- > 1;) planar[i] = (uint8_t)(planar[i] - planar[i - 1] + 128);
         out.clear();
-        if(comp == RLE)
-        {
-            constexpr ptrdiff_t MIN_RUN = 3, MAX_RUN = 127;
-            const int8_t* in = reinterpret_cast<const int8_t*>(tmp.data());
-            const int8_t *end = in + n, *run_start = in, *run_end = in + 1;
-            while(run_start < end)
-            {
-                while(run_end < end && *run_start == *run_end && run_end - run_start - 1 < MAX_RUN) ++run_end;
-                if(run_end - run_start >= MIN_RUN)
-                {
-                    out.push_back((uint8_t)(int8_t)((run_end - run_start) - 1)); out.push_back((uint8_t)*run_start);
-                    run_start = run_end;
-                }
-                else
-                {
-                    while(run_end < end && ((run_end + 1 >= end || *run_end != *(run_end + 1)) || (run_end + 2 >= end || *(run_end + 1) != *(run_end + 2))) &&
-                          run_end - run_start < MAX_RUN) ++run_end;
-                    out.push_back((uint8_t)(int8_t)(run_start - run_end));
-                    while(run_start < run_end) out.push_back((uint8_t)*run_start++);
-                }
-                ++run_end;
-            }
-        }
-        else
-        {
 #ifdef TAURAY_HIP_WITH_ZLIB
-            uLongf len = compressBound((uLong)n);
-            out.resize(len);
-            if(compress(out.data(), &len, tmp.data(), (uLong)n) != Z_OK) throw std::runtime_error("EXR: zlib compress failed");
-            out.resize(len);
+        uLongf len = compressBound((uLong)n);
+        out.resize(len);
+        if(compress(out.data(), &len, planar.data(), (uLong)n) != Z_OK) throw std::runtime_error("EXR: zlib compress failed");
+        out.resize(len);
 #endif
-        }
-        if(out.size() >= n) out = raw;
+        if(out.empty() || out.size() >= n) out = raw;
     }
 
     void write_exr(const std::string& filename, const float* img) const
@@ -1000,14 +757,14 @@ private:
             put_i32(half ? 1 : 2); uint8_t plinear[4] = {0, 0, 0, 0}; put(plinear, 4); put_i32(1); put_i32(1);
         }
         uint8_t zero = 0; put(&zero, 1);
-        // OpenEXR compression codes: 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ; scanlines per chunk 1, 1, 1, 16, 32
-        static const uint8_t exr_code[5] = {0, 1, 2, 3, 4};
-        static const uint32_t block_lines[5] = {1, 1, 1, 16, 32};
-        compression_type comp = opt.output_compression;
+        const compression_type comp = opt.output_compression;
+        if(comp != NONE && comp != ZIPS && comp != ZIP) throw std::runtime_error("EXR: unsupported compression");
+        const uint8_t exr_code = (uint8_t)comp;
+        const uint32_t lines = comp == ZIP ? 16u : 1u;      // scanlines per chunk
 #ifndef TAURAY_HIP_WITH_ZLIB
         if(comp == ZIP || comp == ZIPS) throw std::runtime_error("EXR zip compression needs a build with TAURAY_HIP_WITH_ZLIB");
 #endif
-        attr("compression", "compression", 1); put(&exr_code[comp], 1);
+        attr("compression", "compression", 1); put(&exr_code, 1);
         int32_t box[4] = {0, 0, (int32_t)opt.size.x - 1, (int32_t)opt.size.y - 1};
         attr("dataWindow", "box2i", 16); put(box, 16);
         attr("displayWindow", "box2i", 16); put(box, 16);
@@ -1017,12 +774,10 @@ private:
         attr("screenWindowCenter", "v2f", 8); put(origin, 8);
         attr("screenWindowWidth", "float", 4); put(&one, 4);
         put(&zero, 1);
-        const uint32_t lines = block_lines[comp];
         const uint32_t n_blocks = (opt.size.y + lines - 1) / lines;
         const size_t table_pos = out.size();
         out.resize(out.size() + 8 * size_t(n_blocks));
         std::vector<uint8_t> raw, packed;
-        const std::vector<int> words(size_t(nch), half ? 1 : 2);
         for(uint32_t b = 0; b < n_blocks; ++b)
         {
             const uint32_t y0 = b * lines, y1 = std::min(opt.size.y, y0 + lines);
@@ -1036,9 +791,8 @@ private:
                         else raw.insert(raw.end(), (uint8_t*)&v, (uint8_t*)&v + 4);
                     }
             packed.clear();
-            if(comp == PIZ) piz::compress_block(raw.data(), raw.size(), (int)opt.size.x, (int)(y1 - y0), words, packed);
-            else if(comp == RLE || comp == ZIP || comp == ZIPS) compress_bytes(comp, raw, packed);
-            else packed = raw;
+            if(comp == NONE) packed = raw;
+            else deflate_chunk(raw, packed);
             uint64_t off = out.size();
             std::memcpy(out.data() + table_pos + 8 * size_t(b), &off, 8);
             put_i32((int32_t)y0); put_i32((int32_t)packed.size());
