@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the path_tracer_stage hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload test_glb|sponza_class|sponza_teapots]
+    python bench.py --gpus N --steps K --warmup W [--workload sponza_teapots|sponza_class|test_glb]
+
+With N > 1 and no launcher in the environment (no RANK) the script starts its own ranks: it re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one process per GPU.
+The default workload is sponza_teapots (BASELINE config 4's 1 M-triangle scene, the one north_star's target is stated on) for
+every N; test_glb is BASELINE config 2.
 
 A "step" is one frame: every pass of path_tracer_stage over one 1920x1080 image (1 spp, 4 bounces, all other
 options at the reference's CLI defaults), followed by the multi-GPU gather/stitch and the tonemap - the
@@ -41,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="test_glb", choices=["test_glb", "sponza_class", "sponza_teapots"])
+    ap.add_argument("--workload", default="sponza_teapots", choices=["test_glb", "sponza_class", "sponza_teapots"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=4)
@@ -60,11 +65,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, meet in one all-reduce, print the world size and stop (checks the launcher path without a GPU)")
+    ap.add_argument("--sustained-frames", type=int, default=400,
+                    help="N = 1: a second, longer timed region of this many frames reported as `sustained` (K = 20 frames are 0.1 s; "
+                         "0 switches it off)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node and hand over their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     # A multi-rank run that stops making progress (a peer died, an exchange deadlocked) dumps every thread's stack and exits
     # instead of hanging until somebody kills it; a whole run takes a minute or two.  TRHIP_BENCH_WATCHDOG overrides (seconds).
     watchdog = int(os.environ.get("TRHIP_BENCH_WATCHDOG", "900" if args.gpus > 1 else "0"))
@@ -86,6 +112,14 @@ def main():
         rank = int(os.environ.get("RANK", "0"))
         local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", str(rank)))
         world = int(os.environ.get("WORLD_SIZE", str(world)))
+        if args.rendezvous_only:
+            dist.init_process_group(args.dist_backend if args.dist_backend != "nccl" or torch.cuda.is_available() else "gloo")
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            dist.all_reduce(t)
+            if rank == 0:
+                print(json.dumps({"rendezvous": world, "rank_sum": int(t.item())}))
+            dist.destroy_process_group()
+            return
         if torch.cuda.device_count() > 0:
             local_rank %= torch.cuda.device_count()     # a launcher that narrows *_VISIBLE_DEVICES per rank leaves one device, index 0
         torch.cuda.set_device(local_rank)
@@ -164,7 +198,7 @@ def main():
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
                    "parallelism": ({"pixels": "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
-                   "views": args.views, "frames_in_flight": args.frames_in_flight,
+                   "views": args.views, "frames_in_flight": args.frames_in_flight, "prewarm_frames": args.prewarm,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         "rays_per_frame": rays_total // args.steps,
@@ -183,6 +217,19 @@ def main():
         lat.sort()
         result["frame_latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "mean": round(sum(lat) / len(lat), 4), "min": round(lat[0], 4),
                                       "frames": len(lat), "note": "host sync after every frame"}
+        # SURVEY.md 8(d) / BASELINE.md define ms/frame as host wall time around one render() including the stream sync: the same
+        # metric by that definition (one frame at a time, no frames in flight), beside the pipelined `value`
+        p50 = lat[len(lat) // 2]
+        result["ms_per_frame_sync"] = round(p50, 4)
+        result["value_sync_per_frame"] = round(result["rays_per_frame"] / (p50 * 1e-3) / 1e6, 2)
+        if args.sustained_frames > 0:      # a timed region long enough for a 1 Hz utilisation sampler to see
+            sync_all()
+            t1 = time.perf_counter()
+            run_frames(args.sustained_frames)
+            sync_all()
+            dt = time.perf_counter() - t1
+            result["sustained"] = {"frames": args.sustained_frames, "ms_per_frame": round(dt / args.sustained_frames * 1e3, 4),
+                                   "value": round(result["rays_per_frame"] * args.sustained_frames / dt / 1e6, 2), "unit": "Mray/s"}
 
     # ---- roofline of the dominant kernel (k_trace_closest), rank 0
     if not args.no_roofline:
@@ -216,7 +263,7 @@ def main():
                        + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * args.steps) / args.steps
         # HBM traffic of the same kernel from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE + WRITE_SIZE in
         # separate runs).  Lower bound as reported; FETCH_SIZE may under-report by up to 2x on gfx950 (upper bound given too).
-        traffic, traffic_range, traffic_src = None, None, None
+        traffic, traffic_range, traffic_src, valu = None, None, None, None
         try:
             import glob, json as _json
             for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_summary.json")), reverse=True):
@@ -224,12 +271,17 @@ def main():
                 if "hbm_traffic_bytes_per_launch_range" in k:
                     traffic_range = k["hbm_traffic_bytes_per_launch_range"]
                     traffic, traffic_src = traffic_range[0], os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))
+                    # HBM is not what binds this kernel (the tree is served by L2 / Infinity Cache): the VALU counters of the
+                    # same committed passes say what does
+                    valu = {"issue_busy": k.get("valu_issue_busy"), "lane_utilisation": k.get("valu_lane_utilisation"),
+                            "wait_fraction": k.get("wait_fraction"), "source": traffic_src}
                     break
         except Exception:
             pass
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_range": traffic_range, "traffic_source": traffic_src,
+            "valu": valu,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             # what a frame cannot avoid moving even with a perfectly cached tree: ray + hit records written and read once, one

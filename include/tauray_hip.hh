@@ -77,6 +77,12 @@ inline uvec2 get_distribution_target_size(const distribution_params& p)
     return get_distribution_render_size(p);
 }
 
+inline uvec2 get_distribution_target_max_size(const distribution_params& p)   // src/distribution_strategy.cc:21-31
+{
+    if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS) return p.size;
+    return get_distribution_target_size(p);
+}
+
 inline uvec2 get_ray_count(const distribution_params& p)
 {
     if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS) return uvec2{p.count, 1};
@@ -411,7 +417,7 @@ public:
     const std::vector<double>& update(const std::vector<double>& times)
     {
         double sum_speed = 0;
-        for(size_t i = 0; i < workloads.size(); ++i) sum_speed += std::max(workloads[i] / times[i], 0.0);
+        for(size_t i = 0; i < workloads.size(); ++i) sum_speed += std::max(workloads[i] / times[i], 0.0);   // a zero time gives inf: no update
         if(sum_speed > 0 && std::isfinite(sum_speed))
             for(size_t i = 0; i < workloads.size(); ++i)
                 workloads[i] = workloads[i] * 0.9 + (workloads[i] / times[i]) / sum_speed * 0.1;
@@ -424,6 +430,14 @@ public:
 // rt_renderer<Pipeline> (src/rt_renderer.hh:28-77): all devices in one process, like the reference.  Pipeline is
 // path_tracer_stage or direct_stage (the reference instantiates the template for those, src/rt_renderer.cc:410-412);
 // `rt_renderer` and `direct_renderer` below are the two instantiations (src/rt_renderer.hh:75-77).
+//
+// render() never blocks the host, like the reference's (src/rt_renderer.cc:84-133, src/stage.cc:35-76): every device has
+// one stream per frame slot; a device's path tracing and the peer copy of its partial frame go onto its slot stream, the
+// display device's slot stream waits for those streams (trhip_stream_wait_peer = the `dependencies` the reference hands
+// from stage to stage), then stitches every partial in one launch and tonemaps.  The next frame of a slot starts on a
+// non-display device only after the display device has stitched the slot's previous frame (the receive buffer is free
+// again) - a stream dependency as well.  Frame slots (MAX_FRAMES_IN_FLIGHT, src/context.hh:26) work with any number of
+// devices.
 //==============================================================================
 template<typename Pipeline>
 class basic_rt_renderer
@@ -433,9 +447,9 @@ public:
     {
         tonemap_stage::options tonemap;
         bool accumulate = false;
-        // Frame slots on a single device (MAX_FRAMES_IN_FLIGHT = 2 in the reference, src/context.hh:26): frame i renders
-        // and tonemaps on the stream of slot i % N while its predecessors are still running; `display` and
-        // finish_frame() refer to the frame render() was last called for, frame_slots[k] to the others.
+        // Frame slots: frame i renders, is gathered and tonemapped on the streams of slot i % N while its predecessors are
+        // still running; `display` and finish_frame() refer to the frame render() was last called for, frame_slots[k] to
+        // the others.
         int max_frames_in_flight = 1;
     };
 
@@ -445,9 +459,14 @@ public:
     {
         if(devices.empty()) throw std::runtime_error("rt_renderer needs at least one device");
         if(devices.size() == 1) this->opt.distribution.strategy = DISTRIBUTION_DUPLICATE;   // src/tauray.cc:519-521
+        const int n_slots = std::max(this->opt.max_frames_in_flight, 1);
+        if(n_slots > 1 && this->opt.accumulate)
+            throw std::runtime_error("rt_renderer: accumulating frames depend on each other, frames in flight must be 1");
         per_device.resize(devices.size());
         std::vector<double> ratios(devices.size(), 1.0 / devices.size());
         double cumulative = 0;
+        const size_t layers = this->opt.active_viewport_count;
+        display_bytes = size_t(size.x) * size.y * 16 * layers;
         for(size_t i = 0; i < devices.size(); ++i)
         {
             per_device_data& d = per_device[i];
@@ -457,116 +476,111 @@ public:
             d.dist = get_device_distribution_params(size, this->opt.distribution.strategy, cumulative, ratios[i], (unsigned)i,
                                                     (unsigned)devices.size(), i == 0);
             cumulative += ratios[i];
-            uvec2 ts = get_distribution_target_size(d.dist);
-            d.target_bytes = size_t(ts.x) * ts.y * 16 * this->opt.active_viewport_count;
-            d.color = d.dev->alloc(d.target_bytes);
-            check(trhip_memset(d.dev->h, d.color, 0, d.target_bytes, nullptr));
-            path_tracer_stage::options po = this->opt;
-            po.distribution = d.dist;
-            d.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, d.color, po);
-            if(i != 0) d.gbuffer_copy = per_device[0].dev->alloc(d.target_bytes);   // receive buffer on the display device
-        }
-        display_bytes = size_t(size.x) * size.y * 16 * this->opt.active_viewport_count;
-        display = own_display = per_device[0].dev->alloc(display_bytes);
-        tonemap = std::make_unique<tonemap_stage>(*per_device[0].dev, this->opt.tonemap);
-        if(this->opt.max_frames_in_flight > 1)
-        {
-            if(devices.size() != 1 || this->opt.accumulate)
-                throw std::runtime_error("rt_renderer: frames in flight need a single device and no accumulation");
-            per_device_data& d = per_device[0];
-            for(int k = 0; k < this->opt.max_frames_in_flight; ++k)
+            // non-primary targets are allocated for the largest share set_device_workloads can hand the device
+            // (get_distribution_target_max_size, src/rt_renderer.cc init_resources)
+            const uvec2 ms = get_distribution_target_max_size(d.dist);
+            d.max_bytes = size_t(ms.x) * ms.y * 16 * layers;
+            d.slots.resize((size_t)n_slots);
+            for(slot_data& sl: d.slots)
             {
-                frame_slot fs;
-                fs.stream = d.dev->create_stream();
-                fs.color = d.dev->alloc(d.target_bytes);
-                fs.display = d.dev->alloc(display_bytes);
-                check(trhip_memset(d.dev->h, fs.color, 0, d.target_bytes, nullptr));
+                sl.stream = d.dev->create_stream();
+                sl.color = d.dev->alloc(d.max_bytes);
+                check(trhip_memset(d.dev->h, sl.color, 0, d.max_bytes, nullptr));
                 path_tracer_stage::options po = this->opt;
                 po.distribution = d.dist;
-                fs.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, fs.color, po);
-                fs.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
-                frame_slots.push_back(std::move(fs));
+                sl.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, sl.color, po);
+                if(n_slots > 1) sl.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
+                if(i != 0) sl.gbuffer_copy = per_device[0].dev->alloc(d.max_bytes);   // receive buffer on the display device
             }
             d.dev->sync();
         }
+        frame_slots.resize((size_t)n_slots);
+        for(frame_slot& fs: frame_slots) fs.display = per_device[0].dev->alloc(display_bytes);
+        display = frame_slots[0].display;
+        tonemap = std::make_unique<tonemap_stage>(*per_device[0].dev, this->opt.tonemap);
     }
 
     ~basic_rt_renderer()
     {
-        for(auto& fs: frame_slots)
-        {
-            per_device[0].dev->sync(fs.stream);
-            fs.ray_tracer.reset();
-            per_device[0].dev->free(fs.color); per_device[0].dev->free(fs.display);
-            per_device[0].dev->destroy_stream(fs.stream);
-        }
-        for(auto& d: per_device) d.dev->sync();
+        finish_all();
         for(size_t i = 0; i < per_device.size(); ++i)
-        {
-            per_device[i].ray_tracer.reset();
-            if(per_device[i].gbuffer_copy) per_device[0].dev->free(per_device[i].gbuffer_copy);
-            per_device[i].dev->free(per_device[i].color);
-        }
-        per_device[0].dev->free(own_display);
+            for(slot_data& sl: per_device[i].slots)
+            {
+                sl.ray_tracer.reset();
+                if(sl.gbuffer_copy) per_device[0].dev->free(sl.gbuffer_copy);
+                per_device[i].dev->free(sl.color);
+                per_device[i].dev->destroy_stream(sl.stream);
+            }
+        for(frame_slot& fs: frame_slots) per_device[0].dev->free(fs.display);
     }
 
     void reset_accumulation(bool reset_sample_counter = false)
     {
         for(auto& d: per_device)
-        {
-            d.ray_tracer->reset_accumulated_samples();
-            if(reset_sample_counter) d.ray_tracer->reset_sample_counter();
-        }
+            for(slot_data& sl: d.slots)
+            {
+                sl.ray_tracer->reset_accumulated_samples();
+                if(reset_sample_counter) sl.ray_tracer->reset_sample_counter();
+            }
         if(reset_sample_counter) frame_index = 0;
         accumulated_frames = 0;
     }
 
-    // waits for the frame of the last render() call (all of it: path tracing and tonemap)
-    void finish_frame() { for(auto& d: per_device) d.dev->sync(); if(current_slot >= 0) per_device[0].dev->sync(frame_slots[current_slot].stream); }
-    void finish_slot(int k) { per_device[0].dev->sync(frame_slots[k].stream); }
+    // waits for the frame of the last render() call (all of it: path tracing, gather, stitch and tonemap end on the
+    // display device's slot stream)
+    void finish_frame() { if(current_slot >= 0) finish_slot(current_slot); }
+    void finish_slot(int k) { per_device[0].dev->sync(per_device[0].slots[(size_t)k].stream); }
+    void finish_all()
+    {
+        for(auto& d: per_device) { for(slot_data& sl: d.slots) d.dev->sync(sl.stream); d.dev->sync(); }
+    }
 
-    // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap
+    // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap.  Enqueues only.
     void render()
     {
-        if(!frame_slots.empty())
-        {   // one stage per slot: slot k renders frames k, k + N, ... (rt_stage::frame_counter is set per frame)
-            current_slot = (int)(frame_index % frame_slots.size());
-            frame_slot& fs = frame_slots[current_slot];
-            fs.ray_tracer->reset_accumulated_samples();
-            fs.ray_tracer->set_frame_counter(frame_index);
-            fs.ray_tracer->run(fs.stream);
-            tonemap->run(fs.color, fs.display, size, (uint32_t)opt.active_viewport_count, fs.stream);
-            display = fs.display;
-            frame_index++;
-            accumulated_frames++;
-            return;
-        }
-        frame_index++;
-        if(!opt.accumulate) for(auto& d: per_device) d.ray_tracer->reset_accumulated_samples();
-        for(auto& d: per_device) d.ray_tracer->run();
+        const size_t k = frame_index % frame_slots.size();
+        current_slot = (int)k;
+        const uint32_t layers = (uint32_t)opt.active_viewport_count;
         device& display_device = *per_device[0].dev;
-        for(size_t i = 1; i < per_device.size(); ++i)
+        void* const display_stream = per_device[0].slots[k].stream;
+        for(size_t i = 0; i < per_device.size(); ++i)
         {
             per_device_data& d = per_device[i];
-            d.dev->sync();
-            check(trhip_copy_peer(display_device.h, d.gbuffer_copy, d.dev->h, d.color, d.target_bytes, nullptr));
-            d.dev->sync();
+            slot_data& sl = d.slots[k];
+            if(!opt.accumulate) sl.ray_tracer->reset_accumulated_samples();
+            if(frame_slots.size() > 1) sl.ray_tracer->set_frame_counter(frame_index);   // one stage per slot: slot k renders frames k, k + N, ...
+            if(i != 0)   // the slot's previous frame has been stitched on the display device: its receive buffer is free
+                check(trhip_stream_wait_peer(d.dev->h, sl.stream, display_device.h, display_stream));
+            sl.ray_tracer->run(sl.stream);
+            if(i != 0) check(trhip_copy_peer(display_device.h, sl.gbuffer_copy, d.dev->h, sl.color, d.target_bytes(layers), sl.stream));
         }
-        for(size_t i = 1; i < per_device.size(); ++i)
+        if(per_device.size() > 1)
         {
-            per_device_data& d = per_device[i];
-            uvec2 ts = get_distribution_target_size(d.dist);
-            trhip_distribution pd = to_abi(d.dist);
-            check(trhip_stitch(display_device.h, &pd, d.gbuffer_copy, ts.x, ts.y, per_device[0].color,
-                               (uint32_t)opt.active_viewport_count, 1.0f, nullptr));
+            std::vector<trhip_distribution> dists;
+            std::vector<const void*> partials;
+            std::vector<uint32_t> ws, hs;
+            for(size_t i = 1; i < per_device.size(); ++i)
+            {
+                per_device_data& d = per_device[i];
+                check(trhip_stream_wait_peer(display_device.h, display_stream, d.dev->h, d.slots[k].stream));
+                const uvec2 ts = get_distribution_target_size(d.dist);
+                dists.push_back(to_abi(d.dist)); partials.push_back(d.slots[k].gbuffer_copy); ws.push_back(ts.x); hs.push_back(ts.y);
+            }
+            check(trhip_stitch_batch(display_device.h, (uint32_t)dists.size(), dists.data(), partials.data(), ws.data(), hs.data(),
+                                     per_device[0].slots[k].color, layers, stitch_blend_ratio, display_stream));
+            stitch_blend_ratio = 1.0f;      // src/rt_renderer.cc:122
         }
-        tonemap->run(per_device[0].color, display, size, (uint32_t)opt.active_viewport_count);
+        display = frame_slots[k].display;
+        tonemap->run(per_device[0].slots[k].color, display, size, layers, display_stream);
+        frame_index++;
         accumulated_frames++;
     }
 
+    // rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183): only shuffled strips can be re-balanced
     void set_device_workloads(const std::vector<double>& ratios)
     {
         if(opt.distribution.strategy != DISTRIBUTION_SHUFFLED_STRIPS) return;
+        finish_all();
         double cumulative = 0;
         for(size_t i = 0; i < per_device.size(); ++i)
         {
@@ -574,46 +588,54 @@ public:
             per_device[i].dist = get_device_distribution_params(size, opt.distribution.strategy, cumulative, ratio, (unsigned)i,
                                                                 (unsigned)per_device.size(), i == 0);
             cumulative += ratio;
-            per_device[i].ray_tracer->reset_distribution_params(per_device[i].dist);
-            if(i != 0) per_device[i].ray_tracer->reset_accumulated_samples();
+            for(slot_data& sl: per_device[i].slots)
+            {
+                sl.ray_tracer->reset_distribution_params(per_device[i].dist);
+                if(i != 0) sl.ray_tracer->reset_accumulated_samples();
+            }
         }
+        // the non-primary devices start over with one sample: blend their pixels into what the display device has
+        // accumulated instead of replacing it (src/rt_renderer.cc:176-181)
+        if(opt.accumulate && per_device.size() > 1) stitch_blend_ratio = 1.0f / float(accumulated_frames + 1);
     }
 
+    // "path tracing" timers of the most recent frame, one per device (waits for them)
     std::vector<double> get_path_tracing_times()
     {
         std::vector<double> t;
-        for(auto& d: per_device) t.push_back(d.ray_tracer->get_duration_ms());
+        const size_t k = current_slot < 0 ? 0 : (size_t)current_slot;
+        for(auto& d: per_device) t.push_back(d.slots[k].ray_tracer->get_duration_ms());
         return t;
     }
 
+    struct slot_data
+    {
+        void* stream = nullptr;
+        std::unique_ptr<Pipeline> ray_tracer;
+        void* color = nullptr;          // the device's (partial) colour target of this slot
+        void* gbuffer_copy = nullptr;   // non-primary devices: where the partial lands on the display device
+    };
     struct per_device_data
     {
         std::unique_ptr<device> dev;
         std::unique_ptr<scene_stage> scene_update;
-        std::unique_ptr<Pipeline> ray_tracer;
         distribution_params dist;
-        void* color = nullptr;
-        void* gbuffer_copy = nullptr;
-        size_t target_bytes = 0;
+        size_t max_bytes = 0;
+        std::vector<slot_data> slots;
+        size_t target_bytes(size_t layers) const { const uvec2 ts = get_distribution_target_size(dist); return size_t(ts.x) * ts.y * 16 * layers; }
     };
     std::vector<per_device_data> per_device;
-    struct frame_slot
-    {
-        void* stream = nullptr;
-        std::unique_ptr<Pipeline> ray_tracer;
-        void* color = nullptr;
-        void* display = nullptr;
-    };
-    std::vector<frame_slot> frame_slots;   // empty unless options.max_frames_in_flight > 1
+    struct frame_slot { void* display = nullptr; };   // tonemapped RGBA32F on the display device
+    std::vector<frame_slot> frame_slots;   // options.max_frames_in_flight of them (at least one)
     int current_slot = -1;
     uint32_t frame_index = 0;
     uvec2 size;
     options opt;
-    void* display = nullptr;          // tonemapped RGBA32F on the display device (of the most recent frame)
-    void* own_display = nullptr;
+    void* display = nullptr;          // frame_slots[current_slot].display
     size_t display_bytes = 0;
     std::unique_ptr<tonemap_stage> tonemap;
     unsigned accumulated_frames = 0;
+    float stitch_blend_ratio = 1.0f;
 };
 using rt_renderer = basic_rt_renderer<path_tracer_stage>;       // path_tracer_renderer
 using direct_renderer = basic_rt_renderer<direct_stage>;        // direct_renderer

@@ -43,6 +43,10 @@ int trhip_sync(trhip_device* dev, void* stream);
 int trhip_stream_create(trhip_device* dev, void** stream_out);
 int trhip_stream_destroy(trhip_device* dev, void* stream);
 int trhip_stream_wait(trhip_device* dev, void* stream, void* on);
+/* The same dependency between streams of two devices of one process (the timeline semaphores the reference exports
+ * between devices, src/device_transfer.cc:318-347, src/rt_renderer.cc:98-127): work enqueued on `stream` of `dev` after
+ * the call starts only when everything enqueued on `on` of `on_dev` before the call has finished. */
+int trhip_stream_wait_peer(trhip_device* dev, void* stream, trhip_device* on_dev, void* on);
 /* device -> device copy over xGMI (replaces the pinned-host bounce of src/device_transfer.cc:140-290 when all
  * devices live in one process; with one process per GPU the same transfer is an RCCL send/recv) */
 int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream);

@@ -97,6 +97,7 @@ SYMBOLS = {
     "trhip_stream_create": (_i, [_vp, C.POINTER(C.c_void_p)]),
     "trhip_stream_destroy": (_i, [_vp, _vp]),
     "trhip_stream_wait": (_i, [_vp, _vp, _vp]),
+    "trhip_stream_wait_peer": (_i, [_vp, _vp, _vp, _vp]),
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
     "trhip_pt_set_shard": (_i, [_vp, _u32, _u32, _u32, _u32]),

@@ -263,6 +263,18 @@ int trhip_stream_wait(trhip_device* dev, void* stream, void* on) {
     HIPCHK(hipEventDestroy(e));   // released by the runtime once the recorded work has completed
     return 0;
 }
+int trhip_stream_wait_peer(trhip_device* dev, void* stream, trhip_device* on_dev, void* on) {
+    if (!dev || !on_dev) return set_error("null trhip_device");
+    if (dev->hip_device == on_dev->hip_device && stream == on) return 0;
+    DEVCHK(on_dev);       // the event belongs to the device whose stream records it
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e, (hipStream_t)on));
+    DEVCHK(dev);
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    HIPCHK(hipEventDestroy(e));
+    return 0;
+}
 int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream) {
     if (!dst_dev || !src_dev) return set_error("null trhip_device");
     DEVCHK(src_dev);

@@ -105,8 +105,14 @@ class LoadBalancer:
         self.workloads = [(max(x, 0.0) + add) / s for x in w]
 
     def update(self, path_tracing_times):
-        speeds = [max(w / t, 0.0) if t > 0 else 0.0 for w, t in zip(self.workloads, path_tracing_times)]
-        sum_speed = sum(speeds)
+        # speed = share / time; a zero time (empty share, missing timer) is an infinite speed, the sum is then not finite and
+        # the update is skipped, as in src/load_balancer.cc:12-32
+        def speed(w, t):
+            if t == 0:
+                return math.inf if w > 0 else (math.nan if w == 0 else -math.inf)
+            return w / t
+        speeds = [speed(w, t) for w, t in zip(self.workloads, path_tracing_times)]
+        sum_speed = sum(max(v, 0.0) if not math.isnan(v) else v for v in speeds)
         if sum_speed > 0 and math.isfinite(sum_speed):
-            self.workloads = [w * 0.9 + (w / t) / sum_speed * 0.1 for w, t in zip(self.workloads, path_tracing_times)]
+            self.workloads = [w * 0.9 + v / sum_speed * 0.1 for w, v in zip(self.workloads, speeds)]
         return self.workloads

@@ -31,6 +31,7 @@ int main(int argc, char** argv)
         std::string renderer = "path-tracer";
         std::vector<int> devices;
         bool timing = false;
+        std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
         headless::options hopt;
@@ -55,6 +56,17 @@ int main(int argc, char** argv)
             {
                 renderer = val("--renderer=");
                 if(renderer != "path-tracer" && renderer != "direct") throw std::runtime_error("unknown renderer " + renderer + " (path-tracer, direct)");
+            }
+            else if(starts(a, "--device-workloads="))
+            {
+                std::string v = val("--device-workloads=");
+                for(size_t p0 = 0; p0 <= v.size();)
+                {
+                    size_t p1 = v.find(',', p0);
+                    if(p1 == std::string::npos) p1 = v.size();
+                    workloads.push_back(std::stod(v.substr(p0, p1 - p0)));
+                    p0 = p1 + 1;
+                }
             }
             else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
@@ -126,6 +138,11 @@ int main(int argc, char** argv)
         // --renderer picks the pipeline rt_renderer<Pipeline> is instantiated with (src/tauray.cc:355-421: path-tracer, direct)
         auto run = [&](auto& rr) -> int
         {
+        if(!workloads.empty())
+        {
+            if(workloads.size() != rr.per_device.size()) throw std::runtime_error("--device-workloads needs one ratio per device");
+            rr.set_device_workloads(workloads);
+        }
         if(frames_in_flight > 1)
         {   // frame f renders while the frames before it are read back, compressed and written (the reference overlaps
             // its save workers with the next frames the same way, src/headless.cc:349-422)
@@ -152,7 +169,7 @@ int main(int argc, char** argv)
             auto t0 = std::chrono::high_resolution_clock::now();
             rr.reset_accumulation();                   // offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
             rr.render();
-            for(auto& d: rr.per_device) d.dev->sync();
+            rr.finish_frame();
             auto t1 = std::chrono::high_resolution_clock::now();
             if(f < 0) continue;
             if(timing)

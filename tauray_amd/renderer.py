@@ -501,18 +501,30 @@ class RtRenderer:
 
     def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
                  rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None,
-                 shard="pixels", frames_in_flight=1, stage_cls=None):
+                 shard="pixels", frames_in_flight=1, stage_cls=None, exchange=None):
         """`shard`: what the ranks divide among themselves - "pixels" (the reference's distribution strategies, partial frames
         stitched on rank 0), "views" (viewport v on rank v mod N; nothing is exchanged before output) or "samples" (every
-        rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e)."""
+        rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e).
+        `exchange`: what carries the partial frames of a pixel-sharded job to rank 0 - None = torch.distributed (RCCL), or a
+        transfer.LocalExchange shared by the ranks of one process (device-to-device copies on the default stream)."""
         if shard not in ("pixels", "views", "samples"):
             raise ValueError("shard must be pixels, views or samples")
         if frames_in_flight < 1:
             raise ValueError("frames_in_flight must be >= 1")
         if frames_in_flight > 1 and accumulate:
             raise ValueError("accumulating frames depend on each other: frames_in_flight must be 1")
+        if shard == "samples" and accumulate and world_size > 1:
+            # the reduce sums the ranks' running means into rank 0's target in place: a second accumulated frame would blend
+            # new samples into an already reduced mean
+            raise ValueError("sample sharding reduces into the colour target: it cannot accumulate across frames")
         self.ctx, self.opt, self.size = ctx, options, (int(size[0]), int(size[1]))
         self.rank, self.world_size = rank, world_size
+        self.exchange = exchange
+        if exchange is not None:
+            if shard != "pixels":
+                raise ValueError("an in-process exchange carries pixel shards only")
+            exchange.attach(rank, ctx)
+            use_torch = False if use_torch is None else use_torch
         self.shard = shard if world_size > 1 else "pixels"
         self.total_viewports = viewports
         if self.shard == "views":
@@ -552,10 +564,7 @@ class RtRenderer:
             if frames_in_flight > 1:
                 slot.pt.set_lanes(1)             # the frames in flight fill the chip between them
                 slot.stream = ctx.create_stream()
-            if self.use_torch:
-                slot.color = self._torch.zeros((viewports, th, tw, 4), dtype=self._torch.float32, device=f"cuda:{ctx.hip_device}")
-            else:
-                slot.color = ctx.alloc(max(viewports, 1) * tw * th * 16).zero()
+            slot.color = self._alloc_color(viewports, tw, th)
             self.slots.append(slot)
         self.current = self.slots[0]
         self.stitch = StitchStage(ctx, self.size) if (world_size > 1 and self.shard == "pixels") else None
@@ -577,6 +586,11 @@ class RtRenderer:
     @property
     def display(self):
         return self.current.display
+
+    def _alloc_color(self, viewports, tw, th):
+        if self.use_torch:
+            return self._torch.zeros((viewports, th, tw, 4), dtype=self._torch.float32, device=f"cuda:{self.ctx.hip_device}")
+        return self.ctx.alloc(max(viewports * tw * th, 1) * 16).zero()
 
     def _device_dists(self, ratios) -> List[DistributionParams]:
         out, cumulative = [], 0.0
@@ -639,10 +653,21 @@ class RtRenderer:
         self.sync()
         self.dists = self._device_dists(ratios)
         self.dist = self.dists[self.rank]
+        new_size = get_distribution_target_size(self.dist)
         for slot in self.slots:
             slot.pt.reset_distribution_params(self.dist)
             if self.rank != 0:
                 slot.pt.reset_accumulated_samples()
+                if new_size != self.target_size:
+                    # A non-primary target has the size of the share (the partial frame that travels is the whole image):
+                    # a new share is a new image.  The reference allocates get_distribution_target_max_size once instead
+                    # (src/rt_renderer.cc init_resources); either way the kernels are bounded by the allocated size.
+                    slot.color = self._alloc_color(self.viewports, *new_size)
+        self.target_size = new_size
+        self.recv_buffers.pop("ops", None)      # the display rank's receive list is rebuilt for the new shapes
+        if self.accumulate and self.stitch is not None:
+            # the other devices start over with one sample: blend it into what has accumulated (src/rt_renderer.cc:176-181)
+            self.stitch.set_blend_ratio(1.0 / (self.accumulated_frames + 1))
 
     def render_partial(self, stream=None):
         """The path-tracing part of the next frame on its slot (`stream` overrides the slot's stream)."""
@@ -661,8 +686,11 @@ class RtRenderer:
         rank's slot whose path tracing the stitch (not the receives) has to wait for."""
         if self.world_size == 1:
             return
-        from .transfer import gather_to_display
-        partials = gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers)
+        if self.exchange is not None:
+            partials = self.exchange.gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers, self.ctx)
+        else:
+            from .transfer import gather_to_display
+            partials = gather_to_display(self.color, self.dists, self.rank, self.world_size, self.viewports, self.recv_buffers)
         if own_slot is not None and own_slot.stream is not None:
             self.ctx.stream_wait(None, own_slot.stream)
         if partials:

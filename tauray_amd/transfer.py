@@ -57,6 +57,46 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
     return {}
 
 
+class LocalExchange:
+    """The same exchange for several ranks that live in ONE process on one or more devices (the reference's own
+    arrangement, and `--fake-devices`): a "send" is a device-to-device copy enqueued on the default stream into the display
+    rank's receive buffer for that peer (trhip_copy_peer, which is what an RCCL send/recv pair amounts to over xGMI), a
+    "receive" is nothing at all - the default stream already orders the copy before the stitch.  No host synchronisation
+    anywhere: a frame is correct only if the renderer's stream dependencies around the exchange are
+    (tests/test_gpu_parity.py::test_in_process_ranks_exchange_is_stream_ordered).  Call order per frame: every non-display
+    rank's render(), then rank 0's."""
+
+    def __init__(self, world_size: int):
+        self.world_size = world_size
+        self.mailbox = {}       # peer -> (DeviceBuffer on the display device, shape)
+        self.display_ctx = None
+
+    def attach(self, rank: int, ctx):
+        if rank == 0:
+            self.display_ctx = ctx
+
+    def gather_to_display(self, color, dists: List[DistributionParams], rank: int, world_size: int, viewports: int, recv_buffers, ctx):
+        from . import _lib
+        if world_size == 1:
+            return {}
+        if rank == 0:
+            return {r: self.mailbox[r][0] for r in range(1, world_size) if r in self.mailbox}
+        if self.display_ctx is None:
+            raise RuntimeError("LocalExchange: the display rank has to be created first")
+        shape = partial_shape(dists[rank], viewports)
+        nbytes = shape[0] * shape[1] * shape[2] * 16
+        box = self.mailbox.get(rank)
+        if box is None or box[1] != shape:
+            self.display_ctx.sync()     # a stitch of the previous shape may still read the old buffer
+            box = (self.display_ctx.alloc(max(nbytes, 16)), shape)
+            self.mailbox[rank] = box
+        if nbytes:
+            rc = _lib.lib().trhip_copy_peer(self.display_ctx.h, box[0].data_ptr(), ctx.h, color.data_ptr(), nbytes, None)
+            if rc:
+                raise RuntimeError(_lib.lib().trhip_last_error().decode())
+        return {}
+
+
 def shard_viewports(viewports: int, rank: int, world_size: int) -> List[int]:
     """View sharding: viewport v belongs to device v mod N."""
     return list(range(rank, viewports, world_size))

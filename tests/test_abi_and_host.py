@@ -152,3 +152,21 @@ def test_procedural_scenes_are_deterministic():
     assert a.envmap is not None and len(a.directional_lights) == 1 and a.tri_light_count == 4
     frac_alpha = a.spans["triangle_count"][a.potentially_transparent()].sum() / a.triangle_count
     assert 0.01 < frac_alpha < 0.15
+
+
+def test_load_balancer_follows_the_reference():
+    """load_balancer (src/load_balancer.cc:12-52): EMA towards the measured speeds; a zero "path tracing" time makes the speed
+    sum non-finite and the update is skipped instead of raising."""
+    from tauray_amd.distribution import LoadBalancer
+    lb = LoadBalancer(3)
+    assert lb.workloads == pytest.approx([1 / 3] * 3)
+    w = lb.update([1.0, 2.0, 4.0])
+    speeds = np.array([1 / 3, 1 / 6, 1 / 12])
+    assert w == pytest.approx(list(np.array([1 / 3] * 3) * 0.9 + speeds / speeds.sum() * 0.1))
+    assert sum(w) == pytest.approx(1.0)
+    before = list(w)
+    assert lb.update([1.0, 0.0, 2.0]) == before          # inf speed: skipped
+    lb2 = LoadBalancer(2, [1.0, 0.0])
+    assert lb2.workloads == [1.0, 0.0]
+    assert lb2.update([1.0, 0.0]) == [1.0, 0.0]           # 0 / 0 = NaN: skipped
+    assert LoadBalancer(3, [2.0, 2.0]).workloads == pytest.approx([0.5, 0.5, 0.0])

@@ -184,5 +184,28 @@ def test_cpp_frames_in_flight_write_the_same_files(tmp_path, scene_dump):
         x, y = open(f"{a}{f}.raw", "rb").read(), open(f"{b}{f}.raw", "rb").read()
         assert len(x) == 96 * 64 * 16 and x == y, f"frame {f} differs"
     assert open(f"{a}0.raw", "rb").read() != open(f"{a}1.raw", "rb").read()
-    r = subprocess.run(common + [f"--headless={b}", "--frames-in-flight=2", "--fake-devices=2"], capture_output=True, text=True)
-    assert r.returncode != 0 and "single device" in r.stderr
+    # frame slots across devices (src/rt_renderer.cc:84-133 never blocks the host): eight fake devices, four slots, both
+    # distribution strategies - the same bytes as one device, one frame at a time
+    for tag, extra in (("scan", ["--fake-devices=8", "--frames-in-flight=4", "--distribution-strategy=scanline"]),
+                       ("strips", ["--fake-devices=8", "--frames-in-flight=4", "--distribution-strategy=shuffled-strips"]),
+                       ("two", ["--fake-devices=2", "--frames-in-flight=2"])):
+        c = str(tmp_path / tag)
+        subprocess.check_call(common + [f"--headless={c}"] + extra)
+        for f in range(7):
+            assert open(f"{a}{f}.raw", "rb").read() == open(f"{c}{f}.raw", "rb").read(), f"{tag}: frame {f} differs"
+
+
+@pytest.mark.gpu
+def test_cpp_set_device_workloads_resizes_the_shares(tmp_path, scene_dump):
+    """rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183) with shuffled strips: shares that grow past the even
+    split (the non-primary targets are allocated with get_distribution_target_max_size) still give the single-device frame."""
+    common = [CLI, scene_dump, "--width=96", "--height=64", "--max-ray-depth=3", "--frames=3", "--filetype=raw"]
+    a = str(tmp_path / "one")
+    subprocess.check_call(common + [f"--headless={a}"])
+    for tag, w in (("grow_last", "0.1,0.2,0.7"), ("grow_mid", "0.05,0.9,0.05"), ("starve", "0.5,0.0,0.5")):
+        b = str(tmp_path / tag)
+        subprocess.check_call(common + [f"--headless={b}", "--fake-devices=3", "--distribution-strategy=shuffled-strips", f"--device-workloads={w}"])
+        for f in range(3):
+            assert open(f"{a}{f}.raw", "rb").read() == open(f"{b}{f}.raw", "rb").read(), f"{tag}: frame {f} differs"
+    r = subprocess.run(common + [f"--headless={a}", "--fake-devices=2", "--device-workloads=1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "one ratio per device" in r.stderr

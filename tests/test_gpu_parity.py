@@ -1723,3 +1723,98 @@ def test_random_materials(R, ctx, oracle):
         got = _render_targets_hip(R, ctx, ss, sc, (112, 112), ["material", "albedo"], max_bounces=2)
         want = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 112, 112, ["material", "albedo"])
         assert np.allclose(got["material"], want["material"], atol=1e-6) and np.allclose(got["albedo"], want["albedo"], atol=1e-6), f"draw {k}"
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Several ranks of one process exchanging partial frames with nothing but stream order between them
+
+
+def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=None, break_waits=False):
+    """`world` RtRenderer ranks on fake devices (one Context each on HIP device 0) joined by a transfer.LocalExchange: sends
+    are device-to-device copies on the default stream, there is no host synchronisation between or inside frames, and
+    every frame's display image is copied to a history buffer in stream order.  Returns [frames, H, W, 4]."""
+    from tauray_amd import _lib
+    from tauray_amd.transfer import LocalExchange
+    W, H = size
+    ex = LocalExchange(world)
+    ctxs = [R.Context(0) for _ in range(world)]
+    rrs = [R.RtRenderer(ctxs[r], scene, opt, size, strategy=strategy, rank=r, world_size=world, exchange=ex, frames_in_flight=F)
+           for r in range(world)]
+    if workloads is not None:
+        for rr in rrs:
+            rr.set_device_workloads(workloads)
+    if break_waits:      # negative control: the non-display ranks' sends no longer wait for their path tracing
+        for c in ctxs[1:]:
+            c.stream_wait = lambda stream, on: None
+    hist = ctxs[0].alloc(frames * W * H * 16).zero()
+    ctxs[0].sync()
+    for f in range(frames):
+        for r in list(range(1, world)) + [0]:
+            rrs[r].render()
+        rc = _lib.lib().trhip_copy_peer(ctxs[0].h, hist.data_ptr() + f * W * H * 16, ctxs[0].h, rrs[0].display.data_ptr(), W * H * 16, None)
+        assert rc == 0
+    for rr in rrs:
+        rr.sync()
+    out = hist.download((frames, H, W, 4))
+    for rr in rrs:
+        assert rr.counters()["stack_overflows"] == 0
+        rr.close()
+    return out
+
+
+def _single_rank_frames(R, ctx, scene, opt, size, frames):
+    rr = R.RtRenderer(ctx, scene, opt, size, use_torch=False)
+    out = []
+    for _ in range(frames):
+        rr.render()
+        out.append(rr.download("display")[0])
+    rr.close()
+    return np.stack(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,strategy,F", [(3, 1, 4), (4, 2, 4), (2, 1, 1), (8, 1, 3)])
+def test_in_process_ranks_exchange_is_stream_ordered(R, ctx, world, strategy, F):
+    """The bracket of stream dependencies around the exchange in RtRenderer.render (path tracing on the slot stream ->
+    default stream: send / stitch / tonemap -> slot stream) is all that orders 50 consecutive frames with four in flight:
+    every stitched, tonemapped frame equals the single-rank frame of the same index bit for bit.  The reference's
+    counterpart is the timeline-semaphore chain of src/rt_renderer.cc:84-133."""
+    from tauray_amd.gltf import load_glb
+    W, H, frames = 160, 96, 50
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    ref = _single_rank_frames(R, ctx, scene, opt, (W, H), frames)
+    assert not np.array_equal(ref[0], ref[1])      # the sample counter advances: frames are distinguishable
+    got = _in_process_job(R, scene, opt, (W, H), world, strategy, F, frames)
+    wrong = [f for f in range(frames) if not np.array_equal(got[f], ref[f])]
+    assert not wrong, f"frames {wrong[:10]} differ from the single-rank frames"
+
+
+@pytest.mark.gpu
+def test_in_process_exchange_without_its_waits_is_caught(R, ctx):
+    """Negative control for the test above: with the non-display ranks' stream dependencies removed their sends overtake
+    their path tracing and ship stale pixels - the comparison notices."""
+    from tauray_amd.gltf import load_glb
+    W, H, frames = 480, 272, 12
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    opt = R.options_for_scene(scene, max_bounces=4)
+    ref = _single_rank_frames(R, ctx, scene, opt, (W, H), frames)
+    got = _in_process_job(R, scene, opt, (W, H), 2, 1, 4, frames, break_waits=True)
+    assert any(not np.array_equal(got[f], ref[f]) for f in range(frames))
+
+
+@pytest.mark.gpu
+def test_set_device_workloads_resizes_python_shares(R, ctx):
+    """RtRenderer.set_device_workloads (src/rt_renderer.cc:135-183): shares that grow past the even split get new targets and
+    receive buffers of the new size; the stitched frame is still the single-rank frame (the old code kept the
+    images of the even split and wrote past them)."""
+    from tauray_amd.gltf import load_glb
+    W, H, frames = 96, 64, 4
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    ref = _single_rank_frames(R, ctx, scene, opt, (W, H), frames)
+    for workloads in ([0.1, 0.2, 0.7], [0.05, 0.9, 0.05], [0.5, 0.0, 0.5]):
+        got = _in_process_job(R, scene, opt, (W, H), 3, 2, 1, frames, workloads=workloads)
+        assert np.array_equal(got, ref), workloads
+    with pytest.raises(ValueError):
+        R.RtRenderer(ctx, scene, R.options_for_scene(scene, samples_per_pixel=2), (W, H), rank=0, world_size=2, use_torch=False, shard="samples", accumulate=True)
