@@ -8,6 +8,7 @@
 
 #include "pt.h"
 #include "trace.h"
+#include "trace_quad.h"
 
 namespace tr {
 
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     get_screen_camera_ray(L, px, py, cam, projection, false, F2(0), F2(0.5f), origin, dir);
     f3 ray_origin = projection == 2 ? origin : F3(cam.origin);   // rt_feature.rgen:35 traces from cam.origin
     HitRecord hit;
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     int overflow = 0;
     trace_closest_any<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
     if (overflow) *overflow_flag = 1;
@@ -67,28 +68,53 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
 }
 
 // ray-level hooks
+// TOP: through the treetop in LDS, like the frame's trace kernels (so that the ray-level parity tests cover that path).
+// Whole waves walk the ray list together and use the wave-level traversal with its quad-cooperative tail (trace_quad.h),
+// which is what the frame's closest-hit kernels run.
+template <bool TOP>
 __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
-                                                      HitRecord* out, uint* overflow_flag) {
+                                                      HitRecord* out, uint* overflow_flag, int* qspill) {
     __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
+    __shared__ int s_owner[(KB / 64) * 16];
+    if (TOP) load_treetop(sv, s_top);
     int* my_stack = s_stack + threadIdx.x;
+    QuadCtx qc;
+    qc.wave_stack = s_stack + (threadIdx.x & ~63u);
+    qc.owner_tab = s_owner + (threadIdx.x >> 6) * 16u;
+    qc.spill = qspill + ((size_t)blockIdx.x * (KB / 64) + (threadIdx.x >> 6)) * (16u * TR_QSPILL);
     int overflow = 0;
-    TraceStats st = {0, 0, 0, 0};
-    for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
-        const float* r = rays + (size_t)i * 8;
+    TraceStats st = {};
+    for (uint base = blockIdx.x * KB; base < n; base += gridDim.x * KB) {
+        const uint i = base + threadIdx.x;
+        const bool valid = i < n;
+        float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) for (int k = 0; k < 8; ++k) r[k] = rays[(size_t)i * 8 + k];
+        const uint seed = (valid && seeds) ? seeds[i] : 0u;
         HitRecord hit;
-        if (seeds) trace_closest_any<0, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seeds[i], my_stack, hit, st, overflow);
-        else trace_closest_any<1, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow);
-        out[i] = hit;
+#if TR_BVH4 && TR_QUAD_SWITCH > 0
+        if (seeds) trace_closest_wave4<0, false, TOP>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, qc, s_top, hit, st, overflow);
+        else trace_closest_wave4<1, false, TOP>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, qc, s_top, hit, st, overflow);
+#else
+        if (valid) {
+            if (seeds) trace_closest_any<0, false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, hit, st, overflow, s_top);
+            else trace_closest_any<1, false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow, s_top);
+        }
+#endif
+        if (valid) out[i] = hit;
     }
     if (overflow) *overflow_flag = 1;
 }
+template <bool TOP>
 __global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
     __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
+    if (TOP) load_treetop(sv, s_top);
     int overflow = 0;
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
-        out[i] = trace_shadow_any<false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow);
+        out[i] = trace_shadow_any<false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow, s_top);
     }
     if (overflow) *overflow_flag = 1;
 }
@@ -195,7 +221,9 @@ struct trhip_device {
     int hip_device = 0;
     DeviceScene scene;
     uint* overflow_flag = nullptr;
+    int* qspill = nullptr;          // deep-stack slice per wave of a k_query_closest launch (trace_quad.h)
 };
+constexpr uint QUERY_BLOCKS = 2048;
 struct trhip_pt {
     trhip_device* dev;
     PtStage* stage;
@@ -228,6 +256,7 @@ void trhip_device_destroy(trhip_device* dev) {
     (void)hipDeviceSynchronize();
     dev->scene.free_all();
     if (dev->overflow_flag) (void)hipFree(dev->overflow_flag);
+    if (dev->qspill) (void)hipFree(dev->qspill);
     delete dev;
 }
 int trhip_malloc(trhip_device* dev, size_t bytes, void** out) { DEVCHK(dev); HIPCHK(hipMalloc(out, bytes ? bytes : 16)); return 0; }
@@ -573,9 +602,11 @@ int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, con
     DEVCHK(dev);
     if (!dev->scene.accel_built) return set_error("trhip_trace_closest: call trhip_scene_build_accel first");
     if (n == 0) return 0;
-    uint blocks = std::min((n + KB - 1) / KB, 2048u);
-    hipLaunchKernelGGL(k_query_closest, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
-                       (const uint*)seeds_dev, include_lights, (HitRecord*)hits_dev, dev->overflow_flag);
+    uint blocks = std::min((n + KB - 1) / KB, QUERY_BLOCKS);
+    if (!dev->qspill) HIPCHK(hipMalloc(&dev->qspill, (size_t)QUERY_BLOCKS * (KB / 64) * 16u * TR_QSPILL * sizeof(int)));
+    const bool top = TR_BVH4 && dev->scene.view().treetop != nullptr;
+    hipLaunchKernelGGL(top ? k_query_closest<true> : k_query_closest<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+                       (const uint*)seeds_dev, include_lights, (HitRecord*)hits_dev, dev->overflow_flag, dev->qspill);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -584,7 +615,8 @@ int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void
     if (!dev->scene.accel_built) return set_error("trhip_trace_shadow: call trhip_scene_build_accel first");
     if (n == 0) return 0;
     uint blocks = std::min((n + KB - 1) / KB, 2048u);
-    hipLaunchKernelGGL(k_query_shadow, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+    const bool top = TR_BVH4 && dev->scene.view().treetop != nullptr;
+    hipLaunchKernelGGL(top ? k_query_shadow<true> : k_query_shadow<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
                        (float*)visibility_dev, dev->overflow_flag);
     HIPCHK(hipGetLastError());
     return 0;

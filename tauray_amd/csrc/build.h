@@ -39,6 +39,8 @@ struct DeviceScene {
     // built by trhip_scene_build_accel
     BvhNode* nodes = nullptr;
     Bvh4Node* nodes4 = nullptr;
+    f4* treetop = nullptr;               // top four levels of nodes4 for the LDS of the trace kernels (TR_TOP_SLOTS)
+    bool use_treetop = true;             // TRHIP_TREETOP=0: trace kernels fetch every node from nodes4
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
     uint node_count = 0, tri_light_count = 0;
@@ -63,6 +65,7 @@ struct DeviceScene {
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
         v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4;
+        v.treetop = (use_treetop && accel_built && node_count > 0) ? treetop : nullptr;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
@@ -72,6 +75,8 @@ struct DeviceScene {
     void free_accel() {
         if (nodes) (void)hipFree(nodes);
         if (nodes4) (void)hipFree(nodes4);
+        if (treetop) (void)hipFree(treetop);
+        treetop = nullptr;
         if (tris) (void)hipFree(tris);
         if (tri_lights) (void)hipFree(tri_lights);
         nodes = nullptr; nodes4 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;

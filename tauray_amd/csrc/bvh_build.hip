@@ -544,6 +544,49 @@ __global__ __launch_bounds__(BT) void k_refit_level(uint count, const uint* leve
     for (int k = 0; k < 3; ++k) { node_bounds[6 * (size_t)id + k] = lo[k]; node_bounds[6 * (size_t)id + 3 + k] = hi[k]; }
 }
 
+// The top four levels of the 4-wide tree in the plane-major layout the trace kernels keep in LDS (common.h, TR_TOP_SLOTS).
+// One block; level by level, one thread per slot.  Slots the tree does not fill keep inverted boxes and are never referenced.
+__global__ __launch_bounds__(128) void k_build_treetop(const Bvh4Node* nodes4, uint node_count, f4* top) {
+    __shared__ int slot_node[TR_TOP_SLOTS];
+    const uint t = threadIdx.x;
+    if (t < TR_TOP_SLOTS) {
+        slot_node[t] = (t == 0 && node_count > 0) ? 0 : -1;
+        const float inf = __builtin_huge_valf();
+        for (int p = 0; p < 6; ++p) top[p * TR_TOP_SLOTS + t] = (p & 1) ? F4(-inf) : F4(inf);
+        int4 e = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF);
+        reinterpret_cast<int4*>(top)[6 * TR_TOP_SLOTS + t] = e;
+    }
+    __syncthreads();
+    for (uint first = 0, count = 1; first < TR_TOP_SLOTS; first += count, count *= 4) {
+        if (t >= first && t < first + count && slot_node[t] >= 0) {
+            const Bvh4Node nd = nodes4[slot_node[t]];
+            const float* rows[6] = {nd.lox, nd.hix, nd.loy, nd.hiy, nd.loz, nd.hiz};
+            for (int p = 0; p < 6; ++p) top[p * TR_TOP_SLOTS + t] = F4(rows[p][0], rows[p][1], rows[p][2], rows[p][3]);
+            int ref[4];
+            for (int k = 0; k < 4; ++k) {
+                const int c = nd.child[k];
+                ref[k] = c;
+                if (t < TR_TOP_INNER && c >= 0 && c != 0x7FFFFFFF) { slot_node[4 * t + 1 + k] = c; ref[k] = TR_TOP_FLAG | (int)(4 * t + 1 + k); }
+            }
+            reinterpret_cast<int4*>(top)[6 * TR_TOP_SLOTS + t] = make_int4(ref[0], ref[1], ref[2], ref[3]);
+        }
+        __syncthreads();
+    }
+}
+
+static int build_treetop(DeviceScene& ds, hipStream_t stream) {
+#if TR_BVH4
+    // off unless TRHIP_TREETOP=1: measured slower (profiles/r2/treetop_ab.json)
+    static const bool enabled = getenv("TRHIP_TREETOP") && atoi(getenv("TRHIP_TREETOP")) != 0;
+    ds.use_treetop = enabled;
+    if (!ds.nodes4 || ds.node_count == 0) return 0;
+    if (!ds.treetop) HIPCHK(hipMalloc(&ds.treetop, TR_TOP_WORDS * sizeof(float)));
+    hipLaunchKernelGGL(k_build_treetop, dim3(1), dim3(128), 0, stream, ds.nodes4, ds.node_count, ds.treetop);
+    HIPCHK(hipGetLastError());
+#endif
+    return 0;
+}
+
 int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 #if !TR_BVH4
     return set_error("trhip_scene_refit_accel: this build traverses the binary tree; rebuild instead");
@@ -585,6 +628,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         if (cnt) hipLaunchKernelGGL(k_refit_level, dim3((cnt + BT - 1) / BT), dim3(BT), 0, stream, cnt, ds.level_nodes + lo, ds.nodes4, ds.tris, ds.node_bounds);
     }
     HIPCHK(hipGetLastError());
+    if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
     if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0 && ds.tri_lights) {
         HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
@@ -732,6 +776,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         }
         HIPCHK(hipGetLastError());
     }
+    if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
     // tri lights
     ds.tri_light_count = 0;

@@ -147,6 +147,16 @@ struct alignas(128) Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
 
+// Treetop: the top four levels of the 4-wide tree (1 + 4 + 16 + 64 = 85 slots of an implicit complete 4-ary layout, the
+// children of slot s are slots 4 s + 1 ..) copied into the LDS of every trace block.  Stored plane by plane
+// (plane p of slot s at 16 * (p * TR_TOP_SLOTS + s) bytes: planes 0..5 = lox, hix, loy, hiy, loz, hiz rows of the node,
+// plane 6 = child references) so that lanes reading the same plane of different slots hit different LDS banks.  A child
+// reference with TR_TOP_FLAG set names a treetop slot; the references of the last treetop level are global node ids.
+#define TR_TOP_SLOTS 85
+#define TR_TOP_INNER 21          // slots 0..20 (levels 0..2) have their children in the treetop
+#define TR_TOP_FLAG 0x40000000
+#define TR_TOP_WORDS (7 * TR_TOP_SLOTS * 4)
+
 // 48-byte world-space triangle record, stored in Morton (leaf) order.
 //   inst_flags: bits 0..30 instance id, bit 31 = non-opaque (runs the any-hit path)
 struct alignas(16) TriRecord {
@@ -177,6 +187,7 @@ struct SceneView {
     const BvhNode* nodes;
     const TriRecord* tris;
     const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)
+    const f4* treetop;           // TR_TOP_WORDS floats, see TR_TOP_SLOTS; null = none (queries start at node 0 of nodes4)
     f4 environment_factor;
     int environment_proj;
     uint instance_count, point_light_count, directional_light_count, tri_light_count;

@@ -14,6 +14,7 @@
 
 #include "pt.h"
 #include "trace.h"
+#include "trace_quad.h"
 
 namespace tr {
 
@@ -54,6 +55,7 @@ struct PathBuffers {
     // per lane and bounce b (BC_STRIDE words apart): live paths entering b, shadow rays of b, work cursors of the closest-hit /
     // shadow kernel of b (BC_*).  Zeroed by k_raygen; nothing has to be rotated between bounces.
     uint* bounce;
+    int* qspill;      // deep stack entries of the quad-cooperative tail of the closest-hit waves (trace_quad.h): 16 * TR_QSPILL words per wave of a launch
     uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
 
@@ -62,7 +64,7 @@ struct PathBuffers {
 // (measured: 0.83 ms instead of 0.56 ms for one k_shade launch of 2 M paths).
 enum { BC_QUEUE = 0, BC_SHADOW = 64, BC_CUR_CLOSEST = 128, BC_CUR_SHADOW = 192, BC_STRIDE = 256 };
 enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
-       CNT_MAXSP = 30, CNT_WORDS = 34 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
+       CNT_MAXSP = 30, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_WORDS = 48 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
 
 struct PtParams {
     trhip_pt_options opt;
@@ -169,20 +171,28 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
 }
 
 // ---------------------------------------------------------------------------------------------------
-// One closest-hit ray of queue slot qi (path_tracer.glsl:387-403): trace, store the hit record of the path.
-template <bool COUNT>
+// The closest-hit rays of queue slots base .. base + 63 (path_tracer.glsl:387-403), one wave: trace, store the hit records of
+// the paths.  Every lane of the wave calls this; the traversal re-deals the last rays of the chunk over quads (trace_quad.h).
+template <bool COUNT, bool TOP>
 TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, const uint* queue, uint qi, uint n, int* lds_stack,
-                         TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
-    if (qi >= n) return;
-    const uint id = queue ? queue[qi] : qi + P.id_offset;
-    const u4 misc = pb.misc[id];
-    if (misc.w & 1u) return;
-    const f4 o = pb.org_pdf[id], d = pb.dir_reg[id];
+                         const QuadCtx& qc, const float* top, TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
+    bool valid = qi < n;
+    uint id = 0;
+    u4 misc = {0, 0, 0, 1};
+    if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; valid = !(misc.w & 1u); }
+    f4 o = F4(0), d = F4(0);
+    if (valid) { o = pb.org_pdf[id]; d = pb.dir_reg[id]; }
     HitRecord hit;
     const bool include_lights = !(P.opt.hide_lights && bounce == 0);
     const uint before = st.nodes;
-    trace_closest_any<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                misc.x, lds_stack, hit, st, overflow);
+#if TR_BVH4 && TR_QUAD_SWITCH > 0
+    trace_closest_wave4<0, COUNT, TOP>(sv, valid, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights, misc.x,
+                                       lds_stack, qc, top, hit, st, overflow);
+#else
+    if (valid) trace_closest_any<0, COUNT, TOP>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                                misc.x, lds_stack, hit, st, overflow, top);
+#endif
+    if (!valid) return;
     if (COUNT) {
         const uint vis = st.nodes - before;
         max_vis = max(max_vis, vis);
@@ -196,14 +206,31 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     rays++;
 }
 
-// One shadow ray of the bounce's shadow queue: contrib *= shadow_ray(...) (path_tracer.glsl:35-52, 462-463) and
-// add_demodulated_color of the result.
-template <bool COUNT>
-TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, TraceStats& st, int& overflow,
-                        uint& rays) {
-    if (qi >= n) return;
-    const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
-    float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow);
+// LDS and global scratch of a wave's quad tail
+TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb) {
+    QuadCtx qc;
+    const uint wave = threadIdx.x >> 6;
+    qc.wave_stack = s_stack + (threadIdx.x & ~63u);
+    qc.owner_tab = s_owner + wave * 16u;
+    qc.spill = pb.qspill + ((size_t)blockIdx.x * (KB / 64) + wave) * (16u * TR_QSPILL);
+    return qc;
+}
+
+// The shadow rays of slots base .. base + 63 of the bounce's shadow queue, one wave: contrib *= shadow_ray(...)
+// (path_tracer.glsl:35-52, 462-463) and add_demodulated_color of the result.  Every lane of the wave calls this.
+template <bool COUNT, bool TOP>
+TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, const QuadCtx& qc, const float* top,
+                        TraceStats& st, int& overflow, uint& rays) {
+    const bool valid = qi < n;
+    f4 o = F4(0), d = F4(0), c = F4(0);
+    if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; c = pb.sh_contrib[qi]; }
+#if TR_BVH4 && TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
+    float vis = trace_shadow_wave4<COUNT, TOP>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, top, st, overflow);
+#else
+    float vis = 1.0f;
+    if (valid) vis = trace_shadow_any<COUNT, TOP>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow, top);
+#endif
+    if (!valid) return;
     const uint id = __float_as_uint(d.w);
     if (vis != 0.0f) {
         // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
@@ -227,6 +254,9 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
         closest_rays += __shfl_xor(closest_rays, off); shadow_rays += __shfl_xor(shadow_rays, off);
         if (COUNT) {
             st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off);
+            st.ph_node += __shfl_xor(st.ph_node, off); st.ph_tri += __shfl_xor(st.ph_tri, off); st.ph_node16 += __shfl_xor(st.ph_node16, off);
+            st.ph_node8 += __shfl_xor(st.ph_node8, off); st.lv_node16 += __shfl_xor(st.lv_node16, off);
+            st.ph_qnode += __shfl_xor(st.ph_qnode, off); st.ph_qtri += __shfl_xor(st.ph_qtri, off);
             st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off));
         }
     }
@@ -235,6 +265,9 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
         add64(pb.counters, CNT_SHADOWRAYS, shadow_rays);
         if (COUNT) {
             add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha);
+            add64(pb.counters, CNT_PH_NODE, st.ph_node); add64(pb.counters, CNT_PH_TRI, st.ph_tri); add64(pb.counters, CNT_PH_NODE16, st.ph_node16);
+            add64(pb.counters, CNT_PH_NODE8, st.ph_node8); add64(pb.counters, CNT_LV_NODE16, st.lv_node16);
+            add64(pb.counters, CNT_PH_QNODE, st.ph_qnode); add64(pb.counters, CNT_PH_QTRI, st.ph_qtri);
             atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis);
         }
     }
@@ -244,12 +277,17 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
 // at kernel start) and later chunks from a device-side cursor, which starts past the statically assigned range.
 // SOLO only names the instance launched while detailed timing serialises the frame, so that a profiler lists the
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
-template <bool COUNT, bool SOLO>
+// TOP: the block keeps the top four levels of the tree in LDS (load_treetop) and traversals start there.
+template <bool COUNT, bool SOLO, bool TOP>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
+    __shared__ int s_owner[(KB / 64) * 16];
+    if (TOP) load_treetop(sv, s_top);
+    const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     uint rays = 0, max_vis = 0;
     int overflow = 0;
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
@@ -264,16 +302,21 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         }
         first = false;
         if (base >= n) break;
-        closest_lane<COUNT>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, st, overflow, max_vis, rays);
+        closest_lane<COUNT, TOP>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, s_top, st, overflow, max_vis, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
+// With the treetop in LDS six blocks fit a CU (26 KB each): ask for the registers of six waves, not of eight.
+template <bool COUNT, bool TOP>
+__global__ __launch_bounds__(KB, TOP ? (TR_SHADOW_WAVES < 6 ? TR_SHADOW_WAVES : 6) : TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
+    __shared__ int s_owner[(KB / 64) * 16];
+    if (TOP) load_treetop(sv, s_top);
+    const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = bc[BC_SHADOW];
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     uint rays = 0;
     int overflow = 0;
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
@@ -288,7 +331,7 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
         }
         first = false;
         if (base >= n) break;
-        shadow_lane<COUNT>(sv, P, pb, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, st, overflow, rays);
+        shadow_lane<COUNT, TOP>(sv, P, pb, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, s_top, st, overflow, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 2000, 0u, rays, st, 0u);
 }
@@ -297,12 +340,17 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
 // state arrays), and in the lane schedule a launch lasts as long as its slowest wave: one launch with one tail instead of
 // two launches with two.  Chunk g of the launch is a closest-hit chunk while g < chunks_c (the longer rays go first), a
 // shadow chunk afterwards.
+template <bool TOP>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
     __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
+    __shared__ int s_owner[(KB / 64) * 16];
+    if (TOP) load_treetop(sv, s_top);
+    const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint nc = bc[BC_QUEUE], ns = bc_prev[BC_SHADOW];
     const uint chunks_c = (nc + 63u) >> 6, total = chunks_c + ((ns + 63u) >> 6);
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     uint closest_rays = 0, shadow_rays = 0, max_vis = 0;
     int overflow = 0;
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
@@ -317,8 +365,8 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView 
         }
         first = false;
         if (g >= total) break;
-        if (g < chunks_c) closest_lane<false>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, st, overflow, max_vis, closest_rays);
-        else shadow_lane<false>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, st, overflow, shadow_rays);
+        if (g < chunks_c) closest_lane<false, TOP>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, qc, s_top, st, overflow, max_vis, closest_rays);
+        else shadow_lane<false, TOP>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, qc, s_top, st, overflow, shadow_rays);
     }
     flush_trace_counters<false>(P, pb, overflow, 3000 + bounce, closest_rays, shadow_rays, st, max_vis);
 }
@@ -861,7 +909,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
     const uint n = bc[BC_SHADOW];
-    TraceStats st = {0, 0, 0, 0};
+    TraceStats st = {};
     uint rays = 0;
     int overflow = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < ((n + 63u) & ~63u); qi += gridDim.x * KB) {
@@ -992,6 +1040,11 @@ void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/dis
 }
 
 constexpr int PT_LANES = 4;   // independent slices of a frame that run concurrently (see PtStage::render)
+static uint trace_grid_cap() {   // blocks of a persistent trace launch (TRHIP_GRID_BLOCKS)
+    static const uint cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
+    return cap;
+}
+static size_t qspill_words_per_lane() { return (size_t)trace_grid_cap() * (KB / 64) * 16u * TR_QSPILL; }
 struct TimedSpan { int kind; hipEvent_t a, b; };
 enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_KINDS = 5 };
 
@@ -1023,6 +1076,7 @@ PtStage::~PtStage() {
     free_buffers();
     if (impl->pb.counters) (void)hipFree(impl->pb.counters);
     if (impl->pb.bounce) (void)hipFree(impl->pb.bounce);
+    if (impl->pb.qspill) (void)hipFree(impl->pb.qspill);
     if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
     for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
@@ -1037,8 +1091,9 @@ void PtStage::free_buffers() {
                     pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint *counters = pb.counters, *bounce = pb.bounce;
+    int* qspill = pb.qspill;
     pb = PathBuffers{};
-    pb.counters = counters; pb.bounce = bounce;
+    pb.counters = counters; pb.bounce = bounce; pb.qspill = qspill;
     impl->capacity = 0;
 }
 
@@ -1048,6 +1103,7 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
         HIPCHK(hipMalloc(&pb.counters, PT_LANES * CNT_WORDS * sizeof(uint)));   // one block of counters per lane
         HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
         HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * BC_STRIDE * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
+        HIPCHK(hipMalloc(&pb.qspill, (size_t)PT_LANES * qspill_words_per_lane() * sizeof(int)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
@@ -1113,6 +1169,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     }
     const bool count = count_work != 0;
     const bool timing = detailed_timing != 0;
+    const bool top = TR_BVH4 && sv.treetop != nullptr;   // trace blocks keep the top of the tree in LDS
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
     // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
     // want different resources.  Two ways to fill the gaps, both bit-neutral:
@@ -1139,7 +1196,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
     }
-    static const uint grid_cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
+    const uint grid_cap = trace_grid_cap();
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
@@ -1166,7 +1223,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             LP.rng_sample = shard_sample_base + shard_sample_stride * LP.previous_samples;
             timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
             timed(T_CLOSEST, stream, [&] {
-                auto kc = count ? k_trace_closest<true, false> : k_trace_closest<false, false>;
+                auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
+                                : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>);
                 hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, 0, (const uint*)nullptr, lb.bounce);
             });
             for (int smp = 0; smp < opt.samples_per_pass; ++smp) {
@@ -1216,6 +1274,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         PathBuffers lb = pb;   // the lane's view: shared per-path arrays, its own queues / shadow queue / counters
         lb.counters = pb.counters + lane * CNT_WORDS;
         lb.bounce = pb.bounce + (size_t)lane * P.bounce_words;
+        lb.qspill = pb.qspill + (size_t)lane * qspill_words_per_lane();
         lb.queue[0] = pb.queue[0] + LP.id_offset; lb.queue[1] = pb.queue[1] + LP.id_offset;
         lb.sh_org_tmax = pb.sh_org_tmax + LP.id_offset; lb.sh_dir_id = pb.sh_dir_id + LP.id_offset;
         lb.sh_contrib = pb.sh_contrib + LP.id_offset; lb.sh_lobes = pb.sh_lobes + LP.id_offset;
@@ -1238,10 +1297,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     uint* bc = lb.bounce + BC_STRIDE * bounce;
                     if (fused && bounce > 0) {
                         // closest(b) together with shadow(b - 1): one launch, one tail
-                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
+                        hipLaunchKernelGGL(top ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
-                            auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
+                            auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
+                                            : (timing ? (top ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)
+                                                      : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>));
                             hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
                         });
                     }
@@ -1264,7 +1325,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                             ss = impl->side;
                         }
                         timed(T_SHADOW, ss, [&] {
-                            auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
+                            auto ks = count ? (top ? k_trace_shadow<true, true> : k_trace_shadow<true, false>) : (top ? k_trace_shadow<false, true> : k_trace_shadow<false, false>);
                             hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb, bc);
                         });
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
@@ -1306,6 +1367,10 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
     out->tri_tests = rd(CNT_TRIS); out->alpha_tests = rd(CNT_ALPHA); out->surface_hits = rd(CNT_SURF);
     for (int l = 1; l < PT_LANES; ++l) { h[CNT_OVERFLOW] |= hl[l][CNT_OVERFLOW]; h[CNT_MAXSP] = std::max(h[CNT_MAXSP], hl[l][CNT_MAXSP]); h[CNT_MAXVIS] = std::max(h[CNT_MAXVIS], hl[l][CNT_MAXVIS]); }
     out->stack_overflows = h[CNT_OVERFLOW];
+    if (getenv("TRHIP_DEBUG"))
+        fprintf(stderr, "[trhip] closest-hit loop: %llu node phases (%llu with <= 16 active rays serving %llu visits, %llu with <= 8), %llu triangle phases; quad tail: %llu node phases, %llu triangle phases; %llu node visits\n",
+                (unsigned long long)rd(CNT_PH_NODE), (unsigned long long)rd(CNT_PH_NODE16), (unsigned long long)rd(CNT_LV_NODE16), (unsigned long long)rd(CNT_PH_NODE8),
+                (unsigned long long)rd(CNT_PH_TRI), (unsigned long long)rd(CNT_PH_QNODE), (unsigned long long)rd(CNT_PH_QTRI), (unsigned long long)rd(CNT_NODES));
     if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] overflow %u src %u; max stack depth %u; max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_OVERFLOW], h[CNT_DBG + 12], h[CNT_MAXSP], h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
     return 0;
 }

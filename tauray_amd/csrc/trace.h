@@ -141,7 +141,13 @@ struct LaneStack {
     }
 };
 
-struct TraceStats { uint nodes, tris, alpha, maxsp; };
+struct TraceStats {
+    uint nodes, tris, alpha, maxsp;
+    // divergence statistics of the closest-hit loop (counting builds only), kept by the first active lane of a wave: node / triangle
+    // phases executed, node phases that ran with at most 16 / 8 active rays, and the ray visits those phases served
+    uint ph_node, ph_tri, ph_node16, ph_node8, lv_node16;
+    uint ph_qnode, ph_qtri;   // phases of the quad-cooperative tail (trace_quad.h)
+};
 
 // get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit
 TR_DEV f2 candidate_uv(const SceneView& sv, int inst, int prim, float bu, float bv) {
@@ -319,20 +325,42 @@ struct Hit4 { float t[4]; int c[4]; };
 // one compare.  NaNs (0 * inf: origin on a plane of an axis the ray does not move along) are dropped by min / max, i.e.
 // that axis does not constrain the interval.  Empty slots hold an inverted infinite box: their near distance is +inf (or
 // their far distance -inf) for every ray, so they never pass and need no test of their own.
-TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h) {
-    const char* base = reinterpret_cast<const char*>(nodes);
-    const uint t = (uint)node << 7;
-    uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
-    // opaque to the optimiser: once it splits the known +32 / +64 out of ay / az as immediate offsets, it addresses the far
-    // planes with 64-bit adds instead of the base + 32-bit offset form
-    asm volatile("" : "+v"(ay), "+v"(az));
-    const f4 nxv = *reinterpret_cast<const f4*>(base + (size_t)ax), fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
-    const f4 nyv = *reinterpret_cast<const f4*>(base + (size_t)ay), fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
-    const f4 nzv = *reinterpret_cast<const f4*>(base + (size_t)az), fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
-    const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
+template <bool TOP>
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* top, int node, float tmin, float tmax, Hit4& h) {
+    f4 nxv, fxv, nyv, fyv, nzv, fzv;
+    int c0, c1, c2, c3;
+    if (TOP && (node & TR_TOP_FLAG)) {
+        // a treetop slot: the seven rows come out of LDS (plane-major, 16 bytes per slot: conflict-free for any mix of slots)
+        const char* lb = reinterpret_cast<const char*>(top);
+        const uint s = ((uint)node & 0xFFu) << 4;
+        // opaque copies: the six plane offsets are loop invariants the compiler would otherwise keep in six registers
+        // (and spill, in the fused kernel); a multiply-add per plane and visit is cheaper
+        uint nox = r.nox, noy = r.noy, noz = r.noz;
+        asm volatile("" : "+v"(nox), "+v"(noy), "+v"(noz));
+        uint ax = nox * TR_TOP_SLOTS + s, ay = noy * TR_TOP_SLOTS + s, az = noz * TR_TOP_SLOTS + s;
+        uint bx = (nox ^ 16u) * TR_TOP_SLOTS + s, by = (noy ^ 16u) * TR_TOP_SLOTS + s, bz = (noz ^ 16u) * TR_TOP_SLOTS + s;
+        nxv = *reinterpret_cast<const f4*>(lb + ax); fxv = *reinterpret_cast<const f4*>(lb + bx);
+        nyv = *reinterpret_cast<const f4*>(lb + ay); fyv = *reinterpret_cast<const f4*>(lb + by);
+        nzv = *reinterpret_cast<const f4*>(lb + az); fzv = *reinterpret_cast<const f4*>(lb + bz);
+        const int4 ch = *reinterpret_cast<const int4*>(lb + 96u * TR_TOP_SLOTS + s);
+        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+        // pins the LDS reads: merged with the other branch they would become flat loads through a selected pointer
+        asm volatile("" : "+v"(nxv.x), "+v"(fxv.x), "+v"(nyv.x), "+v"(fyv.x), "+v"(nzv.x), "+v"(fzv.x), "+v"(c0));
+    } else {
+        const char* base = reinterpret_cast<const char*>(nodes);
+        const uint t = (uint)node << 7;
+        uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
+        // opaque to the optimiser: once it splits the known +32 / +64 out of ay / az as immediate offsets, it addresses the far
+        // planes with 64-bit adds instead of the base + 32-bit offset form
+        asm volatile("" : "+v"(ay), "+v"(az));
+        nxv = *reinterpret_cast<const f4*>(base + (size_t)ax); fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
+        nyv = *reinterpret_cast<const f4*>(base + (size_t)ay); fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
+        nzv = *reinterpret_cast<const f4*>(base + (size_t)az); fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
+        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
+        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+    }
     const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
     const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
-    int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float tx0 = (nx[k] - r.org.x) * r.inv_dir.x, tx1 = (fx[k] - r.org.x) * r.inv_dir.x;
@@ -351,9 +379,10 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, flo
 #define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
                        h.t[a] = sw ? tb : ta; h.t[b] = sw ? ta : tb; h.c[a] = sw ? cb : ca; h.c[b] = sw ? ca : cb; }
 
-template <int ALPHA_MODE, bool COUNT>
+// `top`: the block's LDS copy of the treetop (TOP = true; the traversal then starts at treetop slot 0) or unused.
+template <int ALPHA_MODE, bool COUNT, bool TOP = false>
 TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                           int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
+                           int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow, const float* top = nullptr) {
     hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
     float best_t = tmax;
     bool found = false;
@@ -364,7 +393,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
         LaneStack stk;
         int spill[TR_SPILL_STACK];
         stk.init(lds_stack);
-        int node = sv.node_count > 0 ? 0 : -1;
+        int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
         while (true) {
 #if TR_VOTE > 0
             const bool at_leaf = node < 0;
@@ -372,9 +401,16 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
             if (at_leaf != leaf_phase) continue;
 #endif
+            if (COUNT) {
+                const unsigned long long m = __ballot(true), mn = __ballot(node >= 0);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+                    if (mn) { st.ph_node++; if (__popcll(m) <= 16) { st.ph_node16++; st.lv_node16 += (uint)__popcll(mn); } if (__popcll(m) <= 8) st.ph_node8++; }
+                    else st.ph_tri++;
+                }
+            }
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect(r, sv.nodes4, node, tmin, best_t, h);
+                box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, best_t, h);
                 if (COUNT) st.nodes++;
                 TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                 if (h.t[0] < __builtin_huge_valf()) {
@@ -435,19 +471,20 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     hit.t = found ? best_t : -1.0f;
 }
 
-template <bool COUNT>
-TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
+template <bool COUNT, bool TOP = false>
+TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow,
+                           const float* top = nullptr) {
     float visibility = 1.0f;
     if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
     RayPre r = make_ray(org, dir);
     LaneStack stk;
     int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
-    int node = sv.node_count > 0 ? 0 : -1;
+    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
     while (true) {
         if (node >= 0) {
             Hit4 h;
-            box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
+            box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, tmax, h);
             if (COUNT) st.nodes++;
             int next = 0x7FFFFFFF;
 #pragma unroll
@@ -481,16 +518,25 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
 // LDS words per block for the per-lane stacks
 #define TR_STACK_WORDS (TR_LDS_STACK * TR_BLOCK)
 
-template <int ALPHA_MODE, bool COUNT>
+template <int ALPHA_MODE, bool COUNT, bool TOP = false>
 TR_DEV void trace_closest_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                              int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
-    if (TR_BVH4) trace_closest4<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
+                              int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow, const float* top = nullptr) {
+    if (TR_BVH4) trace_closest4<ALPHA_MODE, COUNT, TOP>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow, top);
     else trace_closest<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
 }
-template <bool COUNT>
-TR_DEV float trace_shadow_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
-    if (TR_BVH4) return trace_shadow4<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
+template <bool COUNT, bool TOP = false>
+TR_DEV float trace_shadow_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow,
+                              const float* top = nullptr) {
+    if (TR_BVH4) return trace_shadow4<COUNT, TOP>(sv, org, dir, tmin, tmax, lds_stack, st, overflow, top);
     return trace_shadow<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
+}
+
+// Copies the scene's treetop into the block's LDS (every thread of the block; ends with a barrier).
+TR_DEV void load_treetop(const SceneView& sv, float* s_top) {
+    const f4* src = sv.treetop;
+    f4* dst = reinterpret_cast<f4*>(s_top);
+    for (uint i = threadIdx.x; i < 7u * TR_TOP_SLOTS; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
 }
 
 }  // namespace tr

@@ -1,0 +1,499 @@
+// Wave-level traversal with a quad-cooperative tail (gfx950, wave64).
+//
+// A wave starts 64 rays together, one per lane (trace.h), and runs as long as its longest ray: on the bench scenes more than
+// half of the node phases of the closest-hit loop execute with at most 16 live rays, 3 of 64 lanes busy on average
+// (tools/phase_probe.py).  When at most TR_QUAD_SWITCH rays are left the wave re-deals them: every surviving ray gets a quad
+// of four lanes, lane q of the quad tests child q of the 4-wide node (one box instead of four, no sorting network: the order
+// of the four entry distances comes from three quad-permute DPP reads), hit leaves are tested by the lanes that found them
+// (siblings in parallel) and the far children are pushed by their lanes in one LDS write.  A node phase of the tail costs
+// about 60 vector instructions instead of 150.  The arithmetic per box and per triangle is the per-lane code's, candidates
+// resolve by the same (t, instance, primitive) order, so hits are bit-identical.
+//
+// The quad keeps using the traversal stack of the lane the ray came from (its LDS column); entries past TR_LDS_STACK live in a
+// per-wave slice of a global buffer (QuadCtx::spill) instead of the owner's private scratch.
+#pragma once
+#include "trace.h"
+
+namespace tr {
+
+#ifndef TR_QUAD_SWITCH
+#define TR_QUAD_SWITCH 16      // live rays at which a wave switches to one ray per quad (0 = never)
+#endif
+#define TR_QSPILL 48           // stack entries per quad beyond the LDS part (deepest stack seen on the bench scenes: 26)
+
+struct QuadCtx {
+    int* wave_stack;   // LDS: stack column of lane 0 of this wave; entry e of lane l at [e * TR_BLOCK + l]
+    int* owner_tab;    // LDS: 16 words of this wave
+    int* spill;        // global: 16 * TR_QSPILL words of this wave
+};
+
+// quad permutes: lane q reads lane (q + k) & 3 of its quad
+template <int CTRL> TR_DEV int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+TR_DEV int qrot1(int v) { return quad_perm<0x39>(v); }
+TR_DEV int qrot2(int v) { return quad_perm<0x4E>(v); }
+TR_DEV int qrot3(int v) { return quad_perm<0x93>(v); }
+TR_DEV float qrot1f(float v) { return __int_as_float(qrot1(__float_as_int(v))); }
+TR_DEV float qrot2f(float v) { return __int_as_float(qrot2(__float_as_int(v))); }
+TR_DEV int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
+TR_DEV float bpermf(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+
+TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its other lanes afterwards (no other wave is involved)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// What the four lanes of a quad share about their ray (same values in all four) plus the lane's own candidate.
+struct QuadRay {
+    f3 org, inv_dir;
+    float Sx, Sy, Sz;
+    int kx, ky, kz;
+    uint nox, noy, noz;
+    float tmin;
+};
+
+// Box of child q of `node` against the quad's ray; returns the child reference, `hit` and the entry distance.
+template <bool TOP>
+TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* top, int node, int q, float tmax, bool& hit, float& t0) {
+    float nx, fx, ny, fy, nz, fz;
+    int c;
+    if (TOP && (node & TR_TOP_FLAG)) {
+        const char* lb = reinterpret_cast<const char*>(top);
+        const uint s = (((uint)node & 0xFFu) << 4) + ((uint)q << 2);
+        nx = *reinterpret_cast<const float*>(lb + r.nox * TR_TOP_SLOTS + s); fx = *reinterpret_cast<const float*>(lb + (r.nox ^ 16u) * TR_TOP_SLOTS + s);
+        ny = *reinterpret_cast<const float*>(lb + r.noy * TR_TOP_SLOTS + s); fy = *reinterpret_cast<const float*>(lb + (r.noy ^ 16u) * TR_TOP_SLOTS + s);
+        nz = *reinterpret_cast<const float*>(lb + r.noz * TR_TOP_SLOTS + s); fz = *reinterpret_cast<const float*>(lb + (r.noz ^ 16u) * TR_TOP_SLOTS + s);
+        c = *reinterpret_cast<const int*>(lb + 96u * TR_TOP_SLOTS + s);
+        asm volatile("" : "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz), "+v"(c));
+    } else {
+        const char* base = reinterpret_cast<const char*>(nodes);
+        const uint t = ((uint)node << 7) | ((uint)q << 2);
+        uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
+        asm volatile("" : "+v"(ay), "+v"(az));
+        nx = *reinterpret_cast<const float*>(base + (size_t)ax); fx = *reinterpret_cast<const float*>(base + (size_t)(ax ^ 16u));
+        ny = *reinterpret_cast<const float*>(base + (size_t)ay); fy = *reinterpret_cast<const float*>(base + (size_t)(ay ^ 16u));
+        nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
+        c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
+    }
+    // the arithmetic of box4_intersect for one child
+    const float tx0 = (nx - r.org.x) * r.inv_dir.x, tx1 = (fx - r.org.x) * r.inv_dir.x;
+    const float ty0 = (ny - r.org.y) * r.inv_dir.y, ty1 = (fy - r.org.y) * r.inv_dir.y;
+    const float tz0 = (nz - r.org.z) * r.inv_dir.z, tz1 = (fz - r.org.z) * r.inv_dir.z;
+    t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, r.tmin));
+    const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
+    hit = t0 <= t1;
+    asm volatile("" : "+v"(c));
+    return c;
+}
+
+// The quad's stack: entries below TR_LDS_STACK in the owner lane's LDS column, the rest in the wave's global slice.
+struct QuadStack {
+    int* lds;        // owner's column
+    int* glob;       // this quad's TR_QSPILL words
+    int sp;
+    int overflow;
+    TR_DEV void store(int pos, int v) {
+        if (pos < TR_LDS_STACK) lds[pos * TR_BLOCK] = v;
+        else {
+            const int k = pos - TR_LDS_STACK;
+            if (k >= TR_QSPILL) overflow++;
+            glob[k < TR_QSPILL ? k : TR_QSPILL - 1] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // read back by the other lanes of the quad
+        }
+    }
+    TR_DEV int load(int pos) {
+        int v = lds[(pos < TR_LDS_STACK ? pos : 0) * TR_BLOCK];
+        asm volatile("" : "+v"(v));
+        if (pos >= TR_LDS_STACK) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int k = pos - TR_LDS_STACK;
+            v = glob[k < TR_QSPILL ? k : TR_QSPILL - 1];
+        }
+        return v;
+    }
+};
+
+// Closest hit for the rays of one wave.  Every lane of the wave calls this (`valid` = the lane has a ray); parameters and
+// result as trace_closest4.
+template <int ALPHA_MODE, bool COUNT, bool TOP>
+TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
+                                int* lds_stack, const QuadCtx& qc, const float* top, HitRecord& hit, TraceStats& st, int& overflow) {
+    hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
+    float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
+    uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;   // none found yet
+    RayPre r = make_ray(org, dir);
+    const bool finite_ray = valid && ray_is_finite(org, dir);
+    bool live = finite_ray && sv.tri_count > 0;
+    LaneStack stk;
+    int spill[TR_SPILL_STACK];
+    stk.init(lds_stack);
+    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+
+    // candidate of a triangle test against the lane's best so far (shader/rt_common.rahit:15-24 for non-opaque geometry)
+    auto consider = [&](const TriRecord& tr, float t, float bu, float bv) {
+        const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+        const bool closer = t < best_t || (t == best_t && best_inst != 0xFFFFFFFFu && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
+        if (closer) {
+            bool accept = true;
+            if (tr.inst_flags & 0x80000000u) {
+                if (COUNT) st.alpha++;
+                const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
+                accept = !(a <= cutoff);
+            }
+            if (accept) { best_t = t; best_inst = inst; best_prim = tr.prim; best_u = bu; best_v = bv; }
+        }
+    };
+
+    // ---- one ray per lane while more than TR_QUAD_SWITCH rays are live
+    while (true) {
+        const unsigned long long act = __ballot(live);
+        if (__popcll(act) <= TR_QUAD_SWITCH) break;
+        if (live) {
+            const bool at_leaf = node < 0;
+#if TR_VOTE > 0
+            const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
+            const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
+#else
+            const bool leaf_phase = at_leaf;
+#endif
+            if (COUNT) {
+                const unsigned long long m = __ballot(true);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+                    if (!leaf_phase) { st.ph_node++; if (__popcll(m) <= 16) { st.ph_node16++; st.lv_node16 += (uint)__popcll(__ballot(!at_leaf)); } if (__popcll(m) <= 8) st.ph_node8++; }
+                    else st.ph_tri++;
+                }
+            }
+            if (at_leaf == leaf_phase) {
+                bool descend = false;
+                if (!at_leaf) {
+                    Hit4 h;
+                    box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, best_t, h);
+                    if (COUNT) st.nodes++;
+                    TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
+                    if (h.t[0] < __builtin_huge_valf()) {
+                        if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
+                        if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
+                        if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
+                        if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
+                        node = h.c[0];
+                        descend = true;
+                    }
+                } else {
+                    const TriRecord tr = sv.tris[~node];
+                    if (COUNT) st.tris++;
+                    float t, bu, bv;
+                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                    if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) consider(tr, t, bu, bv);
+                }
+                if (!descend) {
+                    if (stk.sp == 0) live = false;
+                    else node = stk.pop(spill);
+                }
+            }
+        }
+    }
+
+    // ---- the tail: one ray per quad
+    const unsigned long long act = __ballot(live);
+    const int n_act = __popcll(act);
+    if (n_act > 0) {
+        const int lane = threadIdx.x & 63, q = lane & 3, qd = lane >> 2;
+        const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
+        if (live) {
+            qc.owner_tab[my_rank] = lane;
+            for (int e = TR_LDS_STACK; e < stk.sp; ++e) {   // entries the owner kept in its private spill move to the quad's global slice
+                const int k = e - TR_LDS_STACK;
+                if (k < TR_QSPILL) qc.spill[my_rank * TR_QSPILL + k] = spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1];
+                else overflow++;
+            }
+        }
+        wave_sync_lds();
+        const bool has_ray = qd < n_act;
+        const int owner = has_ray ? qc.owner_tab[qd] : lane;
+        const int src = owner << 2;
+        QuadRay qr;
+        qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
+        qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
+        qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
+        {
+            const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
+            qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
+            qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
+        }
+        qr.tmin = bpermf(src, tmin);
+        const uint qseed = (uint)bperm(src, (int)seed);
+        // every lane of the quad starts from the owner's best candidate; the quad shares the culling bound
+        float lt = bpermf(src, best_t), lu = bpermf(src, best_u), lv = bpermf(src, best_v);
+        uint linst = (uint)bperm(src, (int)best_inst), lprim = (uint)bperm(src, (int)best_prim);
+        float qbest = lt;
+        int qnode = bperm(src, node);
+        QuadStack qs;
+        qs.lds = qc.wave_stack + owner;
+        qs.glob = qc.spill + qd * TR_QSPILL;
+        qs.sp = bperm(src, stk.sp);
+        qs.overflow = 0;
+        bool qlive = has_ray;
+        int pend = -1;      // triangle this lane has to test
+        RayPre tr_ray;      // what tri_intersect reads
+        tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;
+        while (true) {
+            int w = pend >= 0 ? 1 : 0;
+            w |= qrot1(w); w |= qrot2(w);
+            const bool qwait = w != 0;                      // a lane of this quad holds a triangle
+            if (__ballot(qlive || qwait) == 0) break;
+            const bool can_node = qlive && !qwait;
+            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= (TR_VOTE > 0 ? TR_VOTE : 1) || __ballot(can_node) == 0;
+            if (COUNT && lane == 0) { if (tri_phase) st.ph_qtri++; else st.ph_qnode++; }
+            if (tri_phase) {
+                if (pend >= 0) {
+                    const TriRecord tr = sv.tris[pend];
+                    if (COUNT) st.tris++;
+                    float t, bu, bv;
+                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                    if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, __builtin_huge_valf(), t, bu, bv)) {
+                        const uint inst = tr.inst_flags & 0x7FFFFFFFu;
+                        const bool closer = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
+                        if (closer) {
+                            bool accept = true;
+                            if (tr.inst_flags & 0x80000000u) {
+                                if (COUNT) st.alpha++;
+                                const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                                const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(qseed, (int)inst, (int)tr.prim) : 0.0001f;
+                                accept = !(a <= cutoff);
+                            }
+                            if (accept) { lt = t; linst = inst; lprim = tr.prim; lu = bu; lv = bv; }
+                        }
+                    }
+                }
+                pend = -1;
+                float m = lt;
+                m = fminf(m, qrot1f(m)); m = fminf(m, qrot2f(m));
+                qbest = fminf(qbest, m);
+            } else if (can_node && qnode < 0) {
+                // a leaf the ray brought along from the per-lane phase (its current node or an entry of its stack: the per-lane
+                // loop pushes leaves, the quads do not): lane 0 tests it, the quad goes on with the next entry
+                if (q == 0) pend = ~qnode;
+                if (qs.sp == 0) qlive = false;
+                else { qs.sp--; qnode = qs.load(qs.sp); }
+            } else if (can_node) {
+                bool hitb; float t0;
+                const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qbest, hitb, t0);
+                if (COUNT && q == 0) st.nodes++;
+                const bool inner = hitb && c >= 0;
+                if (hitb && c < 0) pend = ~c;
+                // order of the inner children that were hit: entry distance, ties by slot (two low mantissa bits carry the slot)
+                const uint key = inner ? ((__float_as_uint(t0) & ~3u) | (uint)q) : 0xFFFFFFFFu;
+                const uint k1 = (uint)qrot1((int)key), k2 = (uint)qrot2((int)key), k3 = (uint)qrot3((int)key);
+                const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+                int n_inner = inner ? 1 : 0;
+                n_inner += qrot1(n_inner); n_inner += qrot2(n_inner);
+                int nx = (inner && rank == 0) ? c : 0;
+                nx |= qrot1(nx); nx |= qrot2(nx);
+                if (n_inner > 0) {
+                    if (inner && rank >= 1) qs.store(qs.sp + n_inner - 1 - rank, c);   // the second nearest ends up on top
+                    qs.sp += n_inner - 1;
+                    if (COUNT) st.maxsp = max(st.maxsp, (uint)qs.sp);
+                    qnode = nx;
+                } else if (qs.sp == 0) qlive = false;
+                else { qs.sp--; qnode = qs.load(qs.sp); }
+            }
+        }
+        // the quad's result: smallest (t, instance, primitive) of its four lanes
+        {
+            float ot = qrot1f(lt), ou = qrot1f(lu), ov = qrot1f(lv); uint oi = (uint)qrot1((int)linst), op = (uint)qrot1((int)lprim);
+            bool take = ot < lt || (ot == lt && (oi < linst || (oi == linst && op < lprim)));
+            lt = take ? ot : lt; lu = take ? ou : lu; lv = take ? ov : lv; linst = take ? oi : linst; lprim = take ? op : lprim;
+            ot = qrot2f(lt); ou = qrot2f(lu); ov = qrot2f(lv); oi = (uint)qrot2((int)linst); op = (uint)qrot2((int)lprim);
+            take = ot < lt || (ot == lt && (oi < linst || (oi == linst && op < lprim)));
+            lt = take ? ot : lt; lu = take ? ou : lu; lv = take ? ov : lv; linst = take ? oi : linst; lprim = take ? op : lprim;
+        }
+        int qo = qs.overflow;
+        qo += qrot1(qo); qo += qrot2(qo);
+        // back to the lanes the rays came from: the owner of rank k reads lane 4 k
+        const int back = my_rank << 4;
+        const float rt = bpermf(back, lt), ru = bpermf(back, lu), rv = bpermf(back, lv);
+        const uint ri = (uint)bperm(back, (int)linst), rp = (uint)bperm(back, (int)lprim);
+        const int ro = bperm(back, qo);
+        if (live) { best_t = rt; best_u = ru; best_v = rv; best_inst = ri; best_prim = rp; overflow += ro; }
+    }
+    overflow += stk.overflow;
+
+    bool found = best_inst != 0xFFFFFFFFu;
+    if (found) { hit.instance_id = (int)best_inst; hit.primitive_id = (int)best_prim; hit.u = best_u; hit.v = best_v; }
+    if (include_lights && finite_ray) {
+        // rt_common_point_light.rint:11-17 / .rchit:10-15, shader/rt_common.glsl:36-51
+        for (uint i = 0; i < sv.point_light_count; ++i) {
+            const PointLight& pl = sv.point_lights[i];
+            float radius = pl.radius;
+            if (radius == 0.0f) continue;
+            f3 oc = org - pl.pos;
+            float a = dot(dir, dir);
+            float b = 2.0f * dot(oc, dir);
+            float c = dot(oc, oc) - radius * radius;
+            float disc = b * b - 4.0f * a * c;
+            if (disc < 0) continue;
+            float hh = (-b - sqrtf(disc)) / (2.0f * a);
+            if (hh > 0 && hh > tmin && hh < best_t) {
+                best_t = hh; found = true;
+                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = hh; hit.v = 0;
+            }
+        }
+    }
+    hit.t = found ? best_t : -1.0f;
+}
+
+// Any-hit visibility for the shadow rays of one wave (trace_shadow4 with the quad-cooperative tail).  Every lane of the wave
+// calls this; returns the product of (1 - alpha) over the non-opaque hits, 0 after an opaque one.
+template <bool COUNT, bool TOP>
+TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, const QuadCtx& qc,
+                                const float* top, TraceStats& st, int& overflow) {
+    float visibility = 1.0f;
+    bool live = valid && sv.tri_count > 0 && ray_is_finite(org, dir);
+    RayPre r = make_ray(org, dir);
+    LaneStack stk;
+    int spill[TR_SPILL_STACK];
+    stk.init(lds_stack);
+    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+    while (true) {
+        if (__popcll(__ballot(live)) <= TR_QUAD_SWITCH) break;
+        if (live) {
+            bool descend = false;
+            if (node >= 0) {
+                Hit4 h;
+                box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, tmax, h);
+                if (COUNT) st.nodes++;
+                int next = 0x7FFFFFFF;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (h.t[k] < __builtin_huge_valf()) {
+                        if (next == 0x7FFFFFFF) next = h.c[k];
+                        else stk.push(spill, h.c[k]);
+                    }
+                }
+                if (next != 0x7FFFFFFF) { node = next; descend = true; }
+            } else {
+                const TriRecord tr = sv.tris[~node];
+                if (COUNT) st.tris++;
+                float t, bu, bv;
+                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+                    if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
+                    else {
+                        if (COUNT) st.alpha++;
+                        const float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                        visibility *= 1.0f - alpha;
+                        if (visibility == 0.0f) live = false;
+                    }
+                }
+            }
+            if (live && !descend) {
+                if (stk.sp == 0) live = false;
+                else node = stk.pop(spill);
+            }
+        }
+    }
+    const unsigned long long act = __ballot(live);
+    const int n_act = __popcll(act);
+    if (n_act > 0) {
+        const int lane = threadIdx.x & 63, q = lane & 3, qd = lane >> 2;
+        const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
+        if (live) {
+            qc.owner_tab[my_rank] = lane;
+            for (int e = TR_LDS_STACK; e < stk.sp; ++e) {
+                const int k = e - TR_LDS_STACK;
+                if (k < TR_QSPILL) qc.spill[my_rank * TR_QSPILL + k] = spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1];
+                else overflow++;
+            }
+        }
+        wave_sync_lds();
+        const bool has_ray = qd < n_act;
+        const int owner = has_ray ? qc.owner_tab[qd] : lane;
+        const int src = owner << 2;
+        QuadRay qr;
+        qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
+        qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
+        qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
+        {
+            const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
+            qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
+            qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
+        }
+        qr.tmin = bpermf(src, tmin);
+        const float qtmax = bpermf(src, tmax);
+        const float owner_vis = bpermf(src, visibility);
+        float lvis = q == 0 ? owner_vis : 1.0f;     // the owner's product so far rides in lane 0 of the quad
+        int qnode = bperm(src, node);
+        QuadStack qs;
+        qs.lds = qc.wave_stack + owner;
+        qs.glob = qc.spill + qd * TR_QSPILL;
+        qs.sp = bperm(src, stk.sp);
+        qs.overflow = 0;
+        bool qlive = has_ray;
+        int pend = -1;
+        RayPre tr_ray;
+        tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;
+        while (true) {
+            int w = pend >= 0 ? 1 : 0;
+            w |= qrot1(w); w |= qrot2(w);
+            const bool qwait = w != 0;
+            if (__ballot(qlive || qwait) == 0) break;
+            const bool can_node = qlive && !qwait;
+            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= (TR_VOTE > 0 ? TR_VOTE : 1) || __ballot(can_node) == 0;
+            if (tri_phase) {
+                if (pend >= 0) {
+                    const TriRecord tr = sv.tris[pend];
+                    if (COUNT) st.tris++;
+                    float t, bu, bv;
+                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+                    if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, qtmax, t, bu, bv)) {
+                        if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
+                        else {
+                            if (COUNT) st.alpha++;
+                            lvis *= 1.0f - candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                        }
+                    }
+                }
+                pend = -1;
+                int z = lvis == 0.0f ? 1 : 0;
+                z |= qrot1(z); z |= qrot2(z);
+                if (z) qlive = false;      // occluded: nothing left to find
+            } else if (can_node && qnode < 0) {      // a leaf inherited from the per-lane phase
+                if (q == 0) pend = ~qnode;
+                if (qs.sp == 0) qlive = false;
+                else { qs.sp--; qnode = qs.load(qs.sp); }
+            } else if (can_node) {
+                bool hitb; float t0;
+                const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qtmax, hitb, t0);
+                if (COUNT && q == 0) st.nodes++;
+                const bool inner = hitb && c >= 0;
+                if (hitb && c < 0) pend = ~c;
+                const uint key = inner ? (uint)q : 0xFFFFFFFFu;      // slot order, as the per-lane loop descends
+                const uint k1 = (uint)qrot1((int)key), k2 = (uint)qrot2((int)key), k3 = (uint)qrot3((int)key);
+                const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+                int n_inner = inner ? 1 : 0;
+                n_inner += qrot1(n_inner); n_inner += qrot2(n_inner);
+                int nx = (inner && rank == 0) ? c : 0;
+                nx |= qrot1(nx); nx |= qrot2(nx);
+                if (n_inner > 0) {
+                    if (inner && rank >= 1) qs.store(qs.sp + n_inner - 1 - rank, c);
+                    qs.sp += n_inner - 1;
+                    qnode = nx;
+                } else if (qs.sp == 0) qlive = false;
+                else { qs.sp--; qnode = qs.load(qs.sp); }
+            }
+        }
+        float v = lvis;
+        v *= qrot1f(v); v *= qrot2f(v);
+        int qo = qs.overflow;
+        qo += qrot1(qo); qo += qrot2(qo);
+        const int back = my_rank << 4;
+        const float rv = bpermf(back, v);
+        const int ro = bperm(back, qo);
+        if (live) { visibility = rv; overflow += ro; }
+    }
+    overflow += stk.overflow;
+    return visibility;
+}
+
+}  // namespace tr
