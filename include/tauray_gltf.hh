@@ -1,0 +1,800 @@
+// tauray_gltf.hh - GLB (binary glTF 2.0) loader for the C++ host layer: file -> tr::scene_data, the flattened scene
+// trhip_scene_upload takes (SURVEY.md Appendix A arrays).
+//
+// What the reference's loader does for the subset the path tracer needs: create_material (src/gltf.cc:199-280), nodes / lights /
+// cameras (:330-505), meshes (:510-798), mesh::calculate_normals / calculate_tangents (src/mesh.cc:113-185), followed by the
+// instance flattening of scene_stage (src/scene_stage.cc:664-819: one instance per (model, vertex group) in node traversal
+// order) and the host-side packing of src/camera.cc:323-478, src/light.cc and src/scene_stage.cc:17-111,1066-1354.
+// Extensions: KHR_lights_punctual, KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength, TR_data.
+// Not read: animations, morph targets, skins (skinned meshes load in their bind pose), external (non-embedded) images,
+// interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
+// (tests/test_cpp_host.py::test_cpp_glb_loader_matches_python_loader).
+#ifndef TAURAY_GLTF_HH
+#define TAURAY_GLTF_HH
+#include <array>
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <map>
+
+#include "tauray_hip.hh"
+
+namespace tr
+{
+namespace gltf_detail
+{
+
+//---------------------------------------------------------------------------------------------------------------------
+// JSON (the subset glTF uses; numbers as double)
+struct json
+{
+    enum kind_t { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+    bool b = false;
+    double num = 0;
+    std::string str;
+    std::vector<json> arr;
+    std::vector<std::pair<std::string, json>> obj;
+
+    const json* find(const std::string& key) const
+    {
+        if(kind != OBJ) return nullptr;
+        for(const auto& kv: obj) if(kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    bool has(const std::string& key) const { return find(key) != nullptr; }
+    const json& at(const std::string& key) const
+    {
+        const json* j = find(key);
+        if(!j) throw std::runtime_error("glTF: missing key " + key);
+        return *j;
+    }
+    const json& at(size_t i) const
+    {
+        if(kind != ARR || i >= arr.size()) throw std::runtime_error("glTF: index out of range");
+        return arr[i];
+    }
+    double number(const std::string& key, double fallback) const { const json* j = find(key); return j && j->kind == NUM ? j->num : fallback; }
+    int integer(const std::string& key, int fallback) const { const json* j = find(key); return j && j->kind == NUM ? (int)j->num : fallback; }
+    size_t size() const { return kind == ARR ? arr.size() : 0; }
+};
+
+class json_parser
+{
+public:
+    json_parser(const char* p, size_t n): p(p), end(p + n) {}
+    json parse() { json v = value(); ws(); return v; }
+private:
+    const char *p, *end;
+    [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("glTF JSON: ") + what); }
+    void ws() { while(p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
+    json value()
+    {
+        ws();
+        if(p >= end) fail("unexpected end");
+        json v;
+        if(*p == '{')
+        {
+            v.kind = json::OBJ; ++p; ws();
+            if(p < end && *p == '}') { ++p; return v; }
+            while(true)
+            {
+                ws();
+                std::string k = string();
+                ws();
+                if(p >= end || *p != ':') fail("expected ':'");
+                ++p;
+                v.obj.emplace_back(std::move(k), value());
+                ws();
+                if(p < end && *p == ',') { ++p; continue; }
+                if(p < end && *p == '}') { ++p; return v; }
+                fail("expected ',' or '}'");
+            }
+        }
+        if(*p == '[')
+        {
+            v.kind = json::ARR; ++p; ws();
+            if(p < end && *p == ']') { ++p; return v; }
+            while(true)
+            {
+                v.arr.push_back(value());
+                ws();
+                if(p < end && *p == ',') { ++p; continue; }
+                if(p < end && *p == ']') { ++p; return v; }
+                fail("expected ',' or ']'");
+            }
+        }
+        if(*p == '"') { v.kind = json::STR; v.str = string(); return v; }
+        if(end - p >= 4 && !std::strncmp(p, "true", 4)) { p += 4; v.kind = json::BOOL; v.b = true; return v; }
+        if(end - p >= 5 && !std::strncmp(p, "false", 5)) { p += 5; v.kind = json::BOOL; return v; }
+        if(end - p >= 4 && !std::strncmp(p, "null", 4)) { p += 4; return v; }
+        // number: strtod parses what Python's float() parses (correctly rounded decimal -> double)
+        std::string tmp;
+        while(p < end && (std::isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) tmp.push_back(*p++);
+        if(tmp.empty()) fail("unexpected character");
+        v.kind = json::NUM;
+        v.num = std::strtod(tmp.c_str(), nullptr);
+        return v;
+    }
+    std::string string()
+    {
+        if(p >= end || *p != '"') fail("expected string");
+        ++p;
+        std::string s;
+        while(p < end && *p != '"')
+        {
+            if(*p == '\\')
+            {
+                if(++p >= end) fail("bad escape");
+                switch(*p)
+                {
+                case 'n': s.push_back('\n'); break;
+                case 't': s.push_back('\t'); break;
+                case 'r': s.push_back('\r'); break;
+                case 'b': s.push_back('\b'); break;
+                case 'f': s.push_back('\f'); break;
+                case 'u': if(end - p < 5) fail("bad \\u escape"); s.push_back('?'); p += 4; break;   // names only: not needed exactly
+                default: s.push_back(*p);
+                }
+                ++p;
+            }
+            else s.push_back(*p++);
+        }
+        if(p >= end) fail("unterminated string");
+        ++p;
+        return s;
+    }
+};
+
+//---------------------------------------------------------------------------------------------------------------------
+// 4x4 double matrices, mathematical (row, column) indexing; stored to the GPU structs column-major like glm
+struct mat4d
+{
+    double m[4][4];
+    static mat4d identity() { mat4d r{}; for(int i = 0; i < 4; ++i) r.m[i][i] = 1; return r; }
+};
+inline mat4d mul(const mat4d& a, const mat4d& b)
+{
+    mat4d r{};
+    for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j)
+    {
+        double s = 0;
+        for(int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+        r.m[i][j] = s;
+    }
+    return r;
+}
+inline mat4d transpose(const mat4d& a) { mat4d r{}; for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) r.m[i][j] = a.m[j][i]; return r; }
+// LU with partial pivoting, then the inverse column by column (what LAPACK's getrf / getri amount to for a 4x4)
+inline mat4d inverse(const mat4d& a)
+{
+    double lu[4][4];
+    int piv[4] = {0, 1, 2, 3};
+    std::memcpy(lu, a.m, sizeof(lu));
+    for(int k = 0; k < 4; ++k)
+    {
+        int best = k;
+        for(int i = k + 1; i < 4; ++i) if(std::fabs(lu[i][k]) > std::fabs(lu[best][k])) best = i;
+        if(best != k) { for(int j = 0; j < 4; ++j) std::swap(lu[k][j], lu[best][j]); std::swap(piv[k], piv[best]); }
+        for(int i = k + 1; i < 4; ++i)
+        {
+            lu[i][k] /= lu[k][k];
+            for(int j = k + 1; j < 4; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+        }
+    }
+    mat4d r{};
+    for(int c = 0; c < 4; ++c)
+    {
+        double y[4];
+        for(int i = 0; i < 4; ++i)
+        {
+            double s = piv[i] == c ? 1.0 : 0.0;
+            for(int j = 0; j < i; ++j) s -= lu[i][j] * y[j];
+            y[i] = s;
+        }
+        for(int i = 3; i >= 0; --i)
+        {
+            double s = y[i];
+            for(int j = i + 1; j < 4; ++j) s -= lu[i][j] * r.m[j][c];
+            r.m[i][c] = s / lu[i][i];
+        }
+    }
+    return r;
+}
+inline void to_glm(const mat4d& a, float* out16) { for(int c = 0; c < 4; ++c) for(int r = 0; r < 4; ++r) out16[c * 4 + r] = (float)a.m[r][c]; }
+
+// transformable::get_transform (src/transformable.cc:203-212)
+inline mat4d trs_matrix(const double t[3], const double q[4], const double s[3])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double rot[3][3] = {
+        {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+        {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+        {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    mat4d m = mat4d::identity();
+    for(int i = 0; i < 3; ++i) for(int j = 0; j < 3; ++j) m.m[i][j] = rot[i][j] * s[j];
+    for(int i = 0; i < 3; ++i) m.m[i][3] = t[i];
+    return m;
+}
+
+//---------------------------------------------------------------------------------------------------------------------
+// PNG (8 bit, non-interlaced; gray, gray + alpha, RGB, RGBA) -> RGBA8, row 0 = top row of the file
+inline std::vector<uint8_t> decode_png(const uint8_t* data, size_t size, uint32_t& w, uint32_t& h)
+{
+#ifndef TAURAY_HIP_WITH_ZLIB
+    (void)data; (void)size; (void)w; (void)h;
+    throw std::runtime_error("glTF: PNG textures need a build with TAURAY_HIP_WITH_ZLIB");
+#else
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if(size < 8 || std::memcmp(data, sig, 8) != 0) throw std::runtime_error("glTF: image is not a PNG");
+    auto be32 = [&](size_t o) { return (uint32_t(data[o]) << 24) | (uint32_t(data[o + 1]) << 16) | (uint32_t(data[o + 2]) << 8) | uint32_t(data[o + 3]); };
+    size_t pos = 8;
+    std::vector<uint8_t> idat;
+    int depth = 0, ctype = 0, interlace = 0;
+    w = h = 0;
+    while(pos + 12 <= size)
+    {
+        const uint32_t len = be32(pos);
+        const char* tag = reinterpret_cast<const char*>(data + pos + 4);
+        const uint8_t* body = data + pos + 8;
+        if(pos + 12 + len > size) throw std::runtime_error("glTF: truncated PNG");
+        if(!std::strncmp(tag, "IHDR", 4)) { w = be32(pos + 8); h = be32(pos + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        else if(!std::strncmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if(!std::strncmp(tag, "IEND", 4)) break;
+        pos += 12 + size_t(len);
+    }
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if(depth != 8 || interlace != 0 || ch == 0) throw std::runtime_error("glTF: unsupported PNG (8-bit non-interlaced gray / RGB / RGBA only)");
+    const size_t stride = size_t(w) * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf raw_len = (uLongf)raw.size();
+    if(uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) throw std::runtime_error("glTF: PNG inflate failed");
+    std::vector<uint8_t> px(stride * h);
+    std::vector<uint8_t> zero(stride, 0);
+    for(uint32_t y = 0; y < h; ++y)
+    {
+        const uint8_t ft = raw[(stride + 1) * y];
+        const uint8_t* line = raw.data() + (stride + 1) * y + 1;
+        uint8_t* cur = px.data() + stride * y;
+        const uint8_t* prev = y ? px.data() + stride * (y - 1) : zero.data();
+        for(size_t x = 0; x < stride; ++x)
+        {
+            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = prev[x], c = x >= (size_t)ch ? prev[x - ch] : 0;
+            int pred = 0;
+            switch(ft)
+            {
+            case 0: pred = 0; break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+            default: throw std::runtime_error("glTF: bad PNG filter");
+            }
+            cur[x] = (uint8_t)((line[x] + pred) & 255);
+        }
+    }
+    std::vector<uint8_t> rgba(size_t(w) * h * 4);
+    for(size_t i = 0; i < size_t(w) * h; ++i)
+    {
+        const uint8_t* s = px.data() + i * ch;
+        uint8_t* d = rgba.data() + i * 4;
+        if(ch == 1) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
+        else if(ch == 2) { d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; }
+        else if(ch == 3) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
+        else std::memcpy(d, s, 4);
+    }
+    return rgba;
+#endif
+}
+
+//---------------------------------------------------------------------------------------------------------------------
+// GPU-side PODs
+#pragma pack(push, 4)
+struct vertex { float pos[3], normal[3], uv[2], tangent[4]; };
+struct material { float albedo_factor[4], metallic_roughness_factor[4], emission_factor[4], transmittance, ior, normal_factor; uint32_t flags; int32_t albedo_tex, mr_tex, normal_tex, emission_tex; };
+struct instance { int32_t light_base_id, sh_grid_index; uint32_t pad; float shadow_terminator_mul; float model[16], model_normal[16], model_prev[16]; material mat; };
+struct directional_light { float color[3]; int32_t shadow_map_index; float dir[3]; float dir_cutoff; };
+struct point_light { float color[3], dir[3], pos[3], radius, dir_cutoff, dir_falloff, cutoff_radius, spot_radius; int32_t shadow_map_index, padding; };
+struct camera_data { float view[16], view_inverse[16], view_proj[16], proj_inverse[16], origin[4], dof_params[4], projection_info[4], pan[4]; };
+struct mesh_span { uint32_t vertex_offset, vertex_count, index_offset, triangle_count; };
+struct texture_info { uint32_t width, height, texel_offset, pad; };
+#pragma pack(pop)
+static_assert(sizeof(vertex) == 48 && sizeof(material) == 80 && sizeof(instance) == 288 && sizeof(camera_data) == 320, "layout");
+static_assert(sizeof(directional_light) == 32 && sizeof(point_light) == 64, "layout");
+
+struct glb_file
+{
+    json doc;
+    std::vector<uint8_t> bin;
+
+    explicit glb_file(const std::string& path)
+    {
+        std::ifstream f(path, std::ios::binary);
+        if(!f) throw std::runtime_error("Failed to open " + path);
+        std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        if(d.size() < 12 || std::memcmp(d.data(), "glTF", 4) != 0) throw std::runtime_error(path + " is not a GLB file");
+        size_t off = 12;
+        bool have_json = false;
+        while(off + 8 <= d.size())
+        {
+            uint32_t clen, ctype;
+            std::memcpy(&clen, d.data() + off, 4); std::memcpy(&ctype, d.data() + off + 4, 4);
+            if(off + 8 + clen > d.size()) throw std::runtime_error(path + " is truncated");
+            if(ctype == 0x4E4F534A) { doc = json_parser(reinterpret_cast<const char*>(d.data() + off + 8), clen).parse(); have_json = true; }
+            else if(ctype == 0x004E4942) bin.assign(d.begin() + off + 8, d.begin() + off + 8 + clen);
+            off += 8 + size_t(clen);
+        }
+        if(!have_json) throw std::runtime_error(path + " has no JSON chunk");
+    }
+
+    // accessor as rows of doubles (exact for every component type glTF has)
+    std::vector<double> accessor(int index, int& components, size_t& count) const
+    {
+        const json& a = doc.at("accessors").at((size_t)index);
+        const json& bv = doc.at("bufferViews").at((size_t)a.integer("bufferView", 0));
+        const int ct = a.integer("componentType", 0);
+        const std::string& type = a.at("type").str;
+        components = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
+        const int sz = ct == 5120 || ct == 5121 ? 1 : ct == 5122 || ct == 5123 ? 2 : ct == 5125 || ct == 5126 ? 4 : 0;
+        if(!components || !sz) throw std::runtime_error("glTF: unsupported accessor type");
+        count = (size_t)a.number("count", 0);
+        const size_t base = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
+        size_t stride = (size_t)bv.number("byteStride", 0);
+        if(!stride) stride = size_t(sz) * components;
+        if(count && base + stride * (count - 1) + size_t(sz) * components > bin.size()) throw std::runtime_error("glTF: accessor exceeds the buffer");
+        std::vector<double> out(count * components);
+        for(size_t i = 0; i < count; ++i)
+            for(int c = 0; c < components; ++c)
+            {
+                const uint8_t* p = bin.data() + base + i * stride + size_t(c) * sz;
+                double v = 0;
+                switch(ct)
+                {
+                case 5120: v = *reinterpret_cast<const int8_t*>(p); break;
+                case 5121: v = *p; break;
+                case 5122: { int16_t t; std::memcpy(&t, p, 2); v = t; break; }
+                case 5123: { uint16_t t; std::memcpy(&t, p, 2); v = t; break; }
+                case 5125: { uint32_t t; std::memcpy(&t, p, 4); v = t; break; }
+                default: { float t; std::memcpy(&t, p, 4); v = t; break; }
+                }
+                out[i * components + c] = v;
+            }
+        return out;
+    }
+};
+
+// create_material (src/gltf.cc:199-280)
+inline material create_material(const glb_file& g, const json& mat)
+{
+    static const json empty;
+    const json& pbr = mat.has("pbrMetallicRoughness") ? mat.at("pbrMetallicRoughness") : empty;
+    auto tex_source = [&](const json* info) -> int32_t {
+        if(!info || info->integer("index", -1) < 0) return -1;
+        return g.doc.at("textures").at((size_t)info->integer("index", 0)).integer("source", -1);
+    };
+    double albedo[4] = {1, 1, 1, 1}, emission[3] = {0, 0, 0};
+    if(const json* f = pbr.find("baseColorFactor")) for(size_t i = 0; i < 4 && i < f->size(); ++i) albedo[i] = f->at(i).num;
+    if(const json* f = mat.find("emissiveFactor")) for(size_t i = 0; i < 3 && i < f->size(); ++i) emission[i] = f->at(i).num;
+    double transmittance = 0.0, ior = 1.45;
+    const json& ext = mat.has("extensions") ? mat.at("extensions") : empty;
+    bool discard_tr_emission = false;
+    if(const json* es = ext.find("KHR_materials_emissive_strength")) if(es->has("emissiveStrength"))
+    {
+        const double k = es->at("emissiveStrength").num;
+        for(double& e: emission) e = e * k;
+        discard_tr_emission = true;
+    }
+    const json* pbr_ext = pbr.find("extensions");
+    if(const json* tr = pbr_ext ? pbr_ext->find("TR_data") : nullptr)
+    {
+        if(tr->has("transmission")) transmittance = tr->at("transmission").num;
+        if(tr->has("ior")) ior = tr->at("ior").num;
+        if(!discard_tr_emission && tr->has("emission")) for(size_t i = 0; i < 3; ++i) emission[i] = tr->at("emission").at(i).num;
+    }
+    if(const json* t = ext.find("KHR_materials_transmission")) if(t->has("transmissionFactor")) transmittance = t->at("transmissionFactor").num;
+    if(const json* t = ext.find("KHR_materials_ior")) if(t->has("ior")) ior = t->at("ior").num;
+    material m{};
+    for(int i = 0; i < 4; ++i) m.albedo_factor[i] = (float)albedo[i];
+    m.metallic_roughness_factor[0] = (float)pbr.number("metallicFactor", 1.0);
+    m.metallic_roughness_factor[1] = (float)pbr.number("roughnessFactor", 1.0);
+    for(int i = 0; i < 3; ++i) m.emission_factor[i] = (float)emission[i];
+    m.transmittance = (float)transmittance; m.ior = (float)ior; m.normal_factor = 1.0f;
+    const json* ds = mat.find("doubleSided");
+    m.flags = ds && ds->kind == json::BOOL && ds->b ? 1u : 0u;
+    m.albedo_tex = tex_source(pbr.find("baseColorTexture"));
+    m.mr_tex = tex_source(pbr.find("metallicRoughnessTexture"));
+    m.normal_tex = tex_source(mat.find("normalTexture"));
+    m.emission_tex = tex_source(mat.find("emissiveTexture"));
+    return m;
+}
+
+struct vertex_group { material mat; std::vector<vertex> vertices; std::vector<uint32_t> indices; };
+
+// mesh::calculate_normals (src/mesh.cc:113-143)
+inline void calculate_normals(std::vector<vertex>& v, const std::vector<uint32_t>& idx)
+{
+    for(vertex& x: v) x.normal[0] = x.normal[1] = x.normal[2] = 0;
+    for(size_t i = 0; i + 2 < idx.size(); i += 3)
+    {
+        vertex &v0 = v[idx[i]], &v1 = v[idx[i + 1]], &v2 = v[idx[i + 2]];
+        const float d0[3] = {v1.pos[0] - v0.pos[0], v1.pos[1] - v0.pos[1], v1.pos[2] - v0.pos[2]};
+        const float d1[3] = {v2.pos[0] - v0.pos[0], v2.pos[1] - v0.pos[1], v2.pos[2] - v0.pos[2]};
+        float hn[3] = {d0[1] * d1[2] - d1[1] * d0[2], d0[2] * d1[0] - d1[2] * d0[0], d0[0] * d1[1] - d1[0] * d0[1]};
+        const float len = std::sqrt(hn[0] * hn[0] + hn[1] * hn[1] + hn[2] * hn[2]);
+        if(len > 1e-6f) for(float& c: hn) c /= len;
+        for(vertex* p: {&v0, &v1, &v2}) for(int k = 0; k < 3; ++k) p->normal[k] += hn[k];
+    }
+    for(vertex& x: v)
+    {
+        const float len = std::sqrt(x.normal[0] * x.normal[0] + x.normal[1] * x.normal[1] + x.normal[2] * x.normal[2]);
+        if(len > 1e-6f) for(float& c: x.normal) c /= len;
+    }
+}
+
+// mesh::calculate_tangents (src/mesh.cc:145-185); only the first vertex of a triangle accumulates, as in the reference
+inline void calculate_tangents(std::vector<vertex>& v, const std::vector<uint32_t>& idx)
+{
+    auto normalize3 = [](float* a) { const float l = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); a[0] /= l; a[1] /= l; a[2] /= l; };
+    std::vector<std::array<float, 4>> acc(v.size(), std::array<float, 4>{0, 0, 0, 0});
+    for(size_t i = 0; i + 2 < idx.size(); i += 3)
+    {
+        const vertex &v0 = v[idx[i]], &v1 = v[idx[i + 1]], &v2 = v[idx[i + 2]];
+        const float d0[3] = {v1.pos[0] - v0.pos[0], v1.pos[1] - v0.pos[1], v1.pos[2] - v0.pos[2]};
+        const float d1[3] = {v2.pos[0] - v0.pos[0], v2.pos[1] - v0.pos[1], v2.pos[2] - v0.pos[2]};
+        float hn[3] = {d0[1] * d1[2] - d1[1] * d0[2], d0[2] * d1[0] - d1[2] * d0[0], d0[0] * d1[1] - d1[0] * d0[1]};
+        const float len = std::sqrt(hn[0] * hn[0] + hn[1] * hn[1] + hn[2] * hn[2]);
+        if(len > 1e-6f) for(float& c: hn) c /= len;
+        const float uv0[2] = {v1.uv[0] - v0.uv[0], v1.uv[1] - v0.uv[1]}, uv1[2] = {v2.uv[0] - v0.uv[0], v2.uv[1] - v0.uv[1]};
+        float ht[3], hb[3];
+        for(int k = 0; k < 3; ++k) { ht[k] = uv1[1] * d0[k] - uv0[1] * d1[k]; hb[k] = uv1[0] * d1[k] - uv0[0] * d0[k]; }
+        normalize3(ht); normalize3(hb);
+        const float cr[3] = {hn[1] * ht[2] - ht[1] * hn[2], hn[2] * ht[0] - ht[2] * hn[0], hn[0] * ht[1] - ht[0] * hn[1]};
+        const float sign = (cr[0] * hb[0] + cr[1] * hb[1] + cr[2] * hb[2]) < 0 ? -1.0f : 1.0f;
+        std::array<float, 4>& a = acc[idx[i]];
+        a[0] += ht[0]; a[1] += ht[1]; a[2] += ht[2]; a[3] += sign;
+    }
+    for(size_t i = 0; i < v.size(); ++i)
+    {
+        const float* n = v[i].normal;
+        const float d = n[0] * acc[i][0] + n[1] * acc[i][1] + n[2] * acc[i][2];
+        float t[3] = {acc[i][0] - n[0] * d, acc[i][1] - n[1] * d, acc[i][2] - n[2] * d};
+        normalize3(t);
+        v[i].tangent[0] = t[0]; v[i].tangent[1] = t[1]; v[i].tangent[2] = t[2];
+        v[i].tangent[3] = acc[i][3] < 0 ? -1.0f : 1.0f;
+    }
+}
+
+}   // namespace gltf_detail
+
+struct glb_load_options
+{
+    float aspect_ratio = 0;               // 0: width / height (set_camera_params, src/tauray.cc:68-110)
+    bool force_single_sided = false, force_double_sided = false;
+    bool gather_emissive_triangles = true;   // scene_stage::options::gather_emissive_triangles (src/tauray.cc:384)
+};
+
+// load_gltf + scene flattening for a .glb file.
+inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t height, const glb_load_options& lo = {})
+{
+    using namespace gltf_detail;
+    constexpr double PI = 3.14159265358979323846;
+    const glb_file g(path);
+    const json& j = g.doc;
+    static const json empty;
+    auto list = [&](const char* key) -> const json& { return j.has(key) ? j.at(key) : empty; };
+
+    // The reference loads images flipped (stbi flag) and flips them back (src/gltf.cc:525,557): row 0 = top row of the file.
+    struct texture { uint32_t w, h; std::vector<uint8_t> rgba; };
+    std::vector<texture> textures;
+    for(const json& img: list("images").arr)
+    {
+        if(!img.has("bufferView")) throw std::runtime_error("glTF: only embedded images are supported");
+        const json* mime = img.find("mimeType");
+        if(!mime || mime->str != "image/png") throw std::runtime_error("glTF: only PNG images are supported");
+        const json& bv = j.at("bufferViews").at((size_t)img.integer("bufferView", 0));
+        const size_t o = (size_t)bv.number("byteOffset", 0), n = (size_t)bv.number("byteLength", 0);
+        if(o + n > g.bin.size()) throw std::runtime_error("glTF: image exceeds the buffer");
+        texture t;
+        t.rgba = decode_png(g.bin.data() + o, n, t.w, t.h);
+        textures.push_back(std::move(t));
+    }
+
+    // meshes -> vertex groups
+    std::vector<std::vector<vertex_group>> models;
+    for(const json& mesh: list("meshes").arr)
+    {
+        std::vector<vertex_group> groups;
+        for(const json& p: mesh.at("primitives").arr)
+        {
+            vertex_group vg;
+            if(p.integer("material", -1) >= 0)
+            {
+                vg.mat = create_material(g, j.at("materials").at((size_t)p.integer("material", 0)));
+                if(lo.force_single_sided && vg.mat.transmittance == 0) vg.mat.flags &= ~1u;
+                if(lo.force_double_sided) vg.mat.flags |= 1u;
+            }
+            else
+            {
+                vg.mat = material{};
+                for(float& c: vg.mat.albedo_factor) c = 1;
+                vg.mat.metallic_roughness_factor[1] = 1; vg.mat.ior = 1.45f; vg.mat.normal_factor = 1;
+                vg.mat.albedo_tex = vg.mat.mr_tex = vg.mat.normal_tex = vg.mat.emission_tex = -1;
+            }
+            const json& at = p.at("attributes");
+            int nc; size_t count;
+            const std::vector<double> pos = g.accessor(at.integer("POSITION", -1), nc, count);
+            vg.vertices.assign(count, vertex{});
+            for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].pos[k] = (float)pos[i * nc + k];
+            auto fill = [&](const char* name, int want, float vertex::*dummy) { (void)name; (void)want; (void)dummy; };
+            (void)fill;
+            if(at.has("NORMAL")) { int c; size_t n; auto a = g.accessor(at.integer("NORMAL", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].normal[k] = (float)a[i * c + k]; }
+            if(at.has("TEXCOORD_0")) { int c; size_t n; auto a = g.accessor(at.integer("TEXCOORD_0", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 2; ++k) vg.vertices[i].uv[k] = (float)a[i * c + k]; }
+            if(at.has("TANGENT")) { int c; size_t n; auto a = g.accessor(at.integer("TANGENT", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 4; ++k) vg.vertices[i].tangent[k] = (float)a[i * c + k]; }
+            if(p.has("indices")) { int c; size_t n; auto a = g.accessor(p.integer("indices", 0), c, n); vg.indices.resize(n * c); for(size_t i = 0; i < a.size(); ++i) vg.indices[i] = (uint32_t)a[i]; }
+            else { vg.indices.resize(count); for(size_t i = 0; i < count; ++i) vg.indices[i] = (uint32_t)i; }
+            for(uint32_t ix: vg.indices) if(ix >= count) throw std::runtime_error("glTF: index out of range");
+            if(!at.has("NORMAL")) calculate_normals(vg.vertices, vg.indices);
+            if(!at.has("TANGENT")) calculate_tangents(vg.vertices, vg.indices);
+            groups.push_back(std::move(vg));
+        }
+        models.push_back(std::move(groups));
+    }
+
+    scene_data s;
+    std::vector<instance> instances;
+    std::vector<mesh_span> spans;
+    std::vector<vertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<point_light> point_lights, spot_lights;
+    std::vector<directional_light> dir_lights;
+    struct camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; };
+    std::vector<camera> cameras;
+    double light_angle = 0, light_radius = 0;
+
+    auto make_point_light = [&](const double color[3], const double pos[3], double radius) {
+        point_light p{};
+        for(int k = 0; k < 3; ++k) { p.color[k] = (float)color[k]; p.pos[k] = (float)pos[k]; }
+        p.radius = (float)radius;
+        const double cutoff_brightness = 5.0 / 256.0;
+        p.cutoff_radius = (float)std::sqrt(std::max(color[0], std::max(color[1], color[2])) / cutoff_brightness);
+        p.spot_radius = -1.0f;
+        p.shadow_map_index = -1;
+        return p;
+    };
+
+    std::function<void(int, const mat4d&)> visit = [&](int node_index, const mat4d& parent) {
+        const json& node = j.at("nodes").at((size_t)node_index);
+        const json* ext = node.find("extensions");
+        const json* tr = ext ? ext->find("TR_data") : nullptr;
+        if(tr) if(const json* l = tr->find("light"))
+        {
+            if(l->has("angle")) light_angle = l->at("angle").num;
+            if(l->has("radius")) light_radius = l->at("radius").num;
+        }
+        mat4d local;
+        if(const json* m = node.find("matrix"))
+        {   // column-major in the file
+            for(int c = 0; c < 4; ++c) for(int r = 0; r < 4; ++r) local.m[r][c] = m->at(size_t(c * 4 + r)).num;
+        }
+        else
+        {
+            double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, sc[3] = {1, 1, 1};
+            if(const json* a = node.find("translation")) for(int k = 0; k < 3; ++k) t[k] = a->at((size_t)k).num;
+            if(const json* a = node.find("rotation")) for(int k = 0; k < 4; ++k) q[k] = a->at((size_t)k).num;
+            if(const json* a = node.find("scale")) for(int k = 0; k < 3; ++k) sc[k] = a->at((size_t)k).num;
+            local = trs_matrix(t, q, sc);
+        }
+        const mat4d glob = mul(parent, local);
+
+        if(node.has("mesh"))
+        {
+            double sto = 0;
+            if(tr) if(const json* m = tr->find("mesh")) sto = m->number("shadow_terminator_offset", 0.0);
+            for(const vertex_group& vg: models.at((size_t)node.integer("mesh", 0)))
+            {   // one INSTANCE record (src/scene_stage.cc:1085-1114); skinned meshes stay in their bind pose at their node
+                instance in{};
+                in.light_base_id = -1; in.sh_grid_index = -1;
+                in.shadow_terminator_mul = (float)(1.0 / (1.0 - 0.5 * sto));
+                to_glm(glob, in.model);
+                to_glm(transpose(inverse(glob)), in.model_normal);
+                to_glm(glob, in.model_prev);
+                in.mat = vg.mat;
+                instances.push_back(in);
+                spans.push_back(mesh_span{(uint32_t)vertices.size(), (uint32_t)vg.vertices.size(), (uint32_t)indices.size(), (uint32_t)(vg.indices.size() / 3)});
+                vertices.insert(vertices.end(), vg.vertices.begin(), vg.vertices.end());
+                indices.insert(indices.end(), vg.indices.begin(), vg.indices.end());
+            }
+        }
+        if(node.has("camera"))
+        {
+            const json& c = j.at("cameras").at((size_t)node.integer("camera", 0));
+            camera cam{};
+            cam.transform = glob;
+            if(c.at("type").str == "perspective")
+            {
+                const json& pp = c.at("perspective");
+                cam.perspective = true;
+                cam.fov = pp.at("yfov").num * (180.0 / PI);
+                cam.aspect = pp.number("aspectRatio", 1.0);
+                cam.near = pp.at("znear").num;
+                cam.far = pp.has("zfar") ? pp.at("zfar").num : std::numeric_limits<double>::infinity();
+            }
+            else
+            {
+                const json& o = c.at("orthographic");
+                cam.perspective = false;
+                const double xm = o.at("xmag").num, ym = o.at("ymag").num;
+                const double v[6] = {-0.5 * xm, 0.5 * xm, -0.5 * ym, 0.5 * ym, o.at("znear").num, o.at("zfar").num};
+                std::memcpy(cam.ortho, v, sizeof(v));
+            }
+            cameras.push_back(cam);
+        }
+        if(const json* kl = ext ? ext->find("KHR_lights_punctual") : nullptr)
+        {
+            const json& l = j.at("extensions").at("KHR_lights_punctual").at("lights").at((size_t)kl->integer("light", 0));
+            double color[3] = {1, 1, 1};
+            if(const json* c = l.find("color")) for(int k = 0; k < 3; ++k) color[k] = c->at((size_t)k).num;
+            const double intensity = l.number("intensity", 1.0);
+            for(double& c: color) c = c * intensity;
+            // get_global_direction: normalize(global orientation * (0, 0, -1)); orientation = the rotation part, columns normalised
+            double direction[3], position[3];
+            {
+                double coln[3];
+                for(int c = 0; c < 3; ++c) coln[c] = std::sqrt(glob.m[0][c] * glob.m[0][c] + glob.m[1][c] * glob.m[1][c] + glob.m[2][c] * glob.m[2][c]);
+                for(int r = 0; r < 3; ++r)
+                    direction[r] = (glob.m[r][0] / coln[0]) * 0.0 + (glob.m[r][1] / coln[1]) * 0.0 + (glob.m[r][2] / coln[2]) * -1.0;
+                for(int r = 0; r < 3; ++r) position[r] = glob.m[r][3];
+            }
+            auto normalized = [](const double d[3], float out[3]) {
+                const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                for(int k = 0; k < 3; ++k) out[k] = (float)(d[k] / n);
+            };
+            const std::string& type = l.at("type").str;
+            if(type == "directional")
+            {   // directional_light_entry (src/scene_stage.cc:46-62); TR_data.light.angle is in radians in the file
+                directional_light d{};
+                for(int k = 0; k < 3; ++k) d.color[k] = (float)color[k];
+                d.shadow_map_index = -1;
+                normalized(direction, d.dir);
+                const double angle_deg = light_angle * (180.0 / PI);
+                d.dir_cutoff = (float)std::cos(angle_deg * (PI / 180.0));
+                dir_lights.push_back(d);
+            }
+            else if(type == "point" || type == "spot")
+            {   // point_light_entry (src/scene_stage.cc:64-98): radiant intensity = power / 4 pi
+                double c4[3];
+                for(int k = 0; k < 3; ++k) c4[k] = color[k] / (4 * PI);
+                point_light p = make_point_light(c4, position, light_radius);
+                if(type == "spot")
+                {
+                    const json& sp = l.at("spot");
+                    const double outer = sp.number("outerConeAngle", PI / 4) * (180.0 / PI), inner = sp.number("innerConeAngle", 0.0) * (180.0 / PI);
+                    // spotlight::set_inner_angle (src/light.cc:103-112) with ratio 4 / 255
+                    double falloff = 1.0;
+                    if(inner > 0)
+                    {
+                        const double ci = std::cos(inner * (PI / 180.0)), co = std::cos(outer * (PI / 180.0));
+                        falloff = std::log(4 / 255.0) / std::log(std::max(1.0 - ci, 0.0) / (1.0 - co));
+                    }
+                    normalized(direction, p.dir);
+                    p.dir_cutoff = (float)std::cos(outer * (PI / 180.0));
+                    p.dir_falloff = (float)falloff;
+                    p.spot_radius = (float)(double(p.cutoff_radius) * std::tan(outer * (PI / 180.0)));
+                    spot_lights.push_back(p);
+                }
+                else point_lights.push_back(p);
+            }
+        }
+        if(const json* ch = node.find("children")) for(const json& c: ch->arr) visit((int)c.num, glob);
+    };
+    for(const json& sc: list("scenes").arr)
+        if(const json* nodes = sc.find("nodes")) for(const json& n: nodes->arr) visit((int)n.num, mat4d::identity());
+
+    // light_base_id (src/scene_stage.cc:1069-1075)
+    uint32_t tri_light_count = 0;
+    for(size_t i = 0; i < instances.size(); ++i)
+    {
+        const float* e = instances[i].mat.emission_factor;
+        if(lo.gather_emissive_triangles && (e[0] != 0 || e[1] != 0 || e[2] != 0)) { instances[i].light_base_id = (int32_t)tri_light_count; tri_light_count += spans[i].triangle_count; }
+    }
+
+    // cameras: set_camera_params forces the aspect ratio (src/tauray.cc:68-110), camera::write_uniform_buffer packs (src/camera.cc:431-478)
+    const double aspect = lo.aspect_ratio > 0 ? (double)lo.aspect_ratio : double(width) / double(height);
+    std::vector<camera_data> cams;
+    for(camera& c: cameras)
+    {
+        camera_data cd{};
+        mat4d proj{};
+        double info[4];
+        if(c.perspective)
+        {
+            c.aspect = aspect;
+            const double t = std::tan((c.fov * (PI / 180.0)) / 2.0);
+            proj.m[0][0] = 1.0 / (c.aspect * t); proj.m[1][1] = 1.0 / t; proj.m[3][2] = -1.0;
+            const double w = 2 * std::tan((c.fov * (PI / 180.0)) / 2.0), z = w * c.aspect;
+            if(std::isinf(c.far)) { proj.m[2][2] = -1.0; proj.m[2][3] = -2.0 * c.near; info[0] = -c.near; info[1] = -1.0; }
+            else
+            {
+                proj.m[2][2] = -(c.far + c.near) / (c.far - c.near); proj.m[2][3] = -(2.0 * c.far * c.near) / (c.far - c.near);
+                info[0] = c.near * c.far / (c.near - c.far); info[1] = (c.near + c.far) / (c.near - c.far);
+            }
+            info[2] = z; info[3] = w;
+            cd.dof_params[0] = 1.0f;
+        }
+        else
+        {
+            double l = c.ortho[0], r = c.ortho[1], b = c.ortho[2], t = c.ortho[3];
+            const double n = c.ortho[4], f = c.ortho[5];
+            const double yr = (r - l) / aspect, yc = (b + t) * 0.5;      // camera::set_aspect (src/camera.cc:166-186)
+            b = yc - yr * 0.5; t = yc + yr * 0.5;
+            proj = mat4d::identity();
+            proj.m[0][0] = 2 / (r - l); proj.m[1][1] = 2 / (t - b); proj.m[2][2] = -2 / (f - n);
+            proj.m[0][3] = -(r + l) / (r - l); proj.m[1][3] = -(t + b) / (t - b); proj.m[2][3] = -(f + n) / (f - n);
+            info[0] = f - n; info[1] = -f; info[2] = r - l; info[3] = t - b;
+        }
+        const mat4d view = inverse(c.transform);
+        to_glm(view, cd.view);
+        to_glm(c.transform, cd.view_inverse);
+        to_glm(mul(proj, view), cd.view_proj);
+        to_glm(inverse(proj), cd.proj_inverse);
+        for(int k = 0; k < 4; ++k) cd.origin[k] = (float)c.transform.m[k][3];
+        for(int k = 0; k < 4; ++k) cd.projection_info[k] = (float)info[k];
+        cams.push_back(cd);
+        s.projection = c.perspective ? 0u : 1u;
+    }
+    if(!cameras.empty()) s.projection = cameras[0].perspective ? 0u : 1u;
+
+    // point lights first, then spotlights (src/scene_stage.cc:1287-1317)
+    point_lights.insert(point_lights.end(), spot_lights.begin(), spot_lights.end());
+
+    // texture table + material::potentially_transparent (src/material.cc:7-11, check_opaque src/gltf.cc:54-66)
+    std::vector<texture_info> infos;
+    std::vector<bool> opaque;
+    for(const texture& t: textures)
+    {
+        infos.push_back(texture_info{t.w, t.h, (uint32_t)(s.texels.size() / 4), 0});
+        s.texels.insert(s.texels.end(), t.rgba.begin(), t.rgba.end());
+        bool op = true;
+        for(size_t i = 3; i < t.rgba.size(); i += 4) if(t.rgba[i] != 255) { op = false; break; }
+        opaque.push_back(op);
+    }
+    for(const instance& in: instances)
+    {
+        bool tr = in.mat.transmittance > 0 || in.mat.albedo_factor[3] < 1.0f;
+        if(in.mat.albedo_tex >= 0 && (size_t)in.mat.albedo_tex < opaque.size() && !opaque[(size_t)in.mat.albedo_tex]) tr = true;
+        s.non_opaque.push_back(tr ? 1 : 0);
+    }
+
+    auto bytes = [](const auto& v, std::vector<uint8_t>& out) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(v.data());
+        out.assign(p, p + v.size() * sizeof(v[0]));
+    };
+    bytes(instances, s.instances); bytes(spans, s.spans); bytes(vertices, s.vertices); bytes(indices, s.indices);
+    bytes(point_lights, s.point_lights); bytes(dir_lights, s.directional_lights); bytes(infos, s.texture_infos); bytes(cams, s.cameras);
+    s.gather_emissive_triangles = tri_light_count > 0 ? 1u : 0u;
+    return s;
+}
+
+// writes the .trsc dump load_scene_dump reads (the format of tauray_amd/scene_io.py)
+inline void write_scene_dump(const scene_data& s, const std::string& path)
+{
+    std::ofstream f(path, std::ios::binary);
+    if(!f) throw std::runtime_error("Failed to write " + path);
+    const uint32_t version = 1;
+    f.write("TRSC", 4); f.write(reinterpret_cast<const char*>(&version), 4);
+    const std::vector<uint8_t>* sections[] = {&s.instances, &s.spans, &s.vertices, &s.indices, &s.point_lights, &s.directional_lights,
+        &s.texture_infos, &s.texels, &s.envmap, &s.alias_table, &s.cameras, &s.non_opaque};
+    for(const auto* sec: sections)
+    {
+        const uint64_t n = sec->size();
+        f.write(reinterpret_cast<const char*>(&n), 8);
+        f.write(reinterpret_cast<const char*>(sec->data()), (std::streamsize)n);
+    }
+    f.write(reinterpret_cast<const char*>(&s.envmap_width), 4); f.write(reinterpret_cast<const char*>(&s.envmap_height), 4);
+    f.write(reinterpret_cast<const char*>(s.environment_factor), 16);
+    f.write(reinterpret_cast<const char*>(&s.gather_emissive_triangles), 4); f.write(reinterpret_cast<const char*>(&s.projection), 4);
+}
+
+}
+
+#endif

@@ -197,6 +197,9 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     // ---- the tail: one ray per quad
     const unsigned long long act = __ballot(live);
     const int n_act = __popcll(act);
+#ifdef TR_QUAD_DEBUG
+    const float dbg_u = live ? (float)stk.sp : -1.0f, dbg_v = live ? (float)((node < 0 ? 1000 : 0) + n_act) : -1.0f;
+#endif
     if (n_act > 0) {
         const int lane = threadIdx.x & 63, q = lane & 3, qd = lane >> 2;
         const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
@@ -253,17 +256,18 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
                     if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, __builtin_huge_valf(), t, bu, bv)) {
                         const uint inst = tr.inst_flags & 0x7FFFFFFFu;
-                        const bool closer = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
-                        if (closer) {
-                            bool accept = true;
-                            if (tr.inst_flags & 0x80000000u) {
-                                if (COUNT) st.alpha++;
-                                const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                                const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(qseed, (int)inst, (int)tr.prim) : 0.0001f;
-                                accept = !(a <= cutoff);
-                            }
-                            if (accept) { lt = t; linst = inst; lprim = tr.prim; lu = bu; lv = bv; }
+                        bool accept = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
+                        if (accept && (tr.inst_flags & 0x80000000u)) {
+                            if (COUNT) st.alpha++;
+                            const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(qseed, (int)inst, (int)tr.prim) : 0.0001f;
+                            accept = !(a <= cutoff);
                         }
+                        // selects, not a branch: hipcc 7.2 lowered the branchy form (five assignments under `if (accept)`) to code that
+                        // kept the old lt / lv for accepted non-opaque candidates (the pair went through one 64-bit move that the
+                        // alpha branch overwrote) - found as Suzanne hits with t = inf, tools/ab_dump.py
+                        lt = accept ? t : lt; lu = accept ? bu : lu; lv = accept ? bv : lv;
+                        linst = accept ? inst : linst; lprim = accept ? tr.prim : lprim;
                     }
                 }
                 pend = -1;
@@ -341,6 +345,9 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         }
     }
     hit.t = found ? best_t : -1.0f;
+#ifdef TR_QUAD_DEBUG
+    hit.u = dbg_u; hit.v = dbg_v;      // what the ray looked like when the wave switched to quads
+#endif
 }
 
 // Any-hit visibility for the shadow rays of one wave (trace_shadow4 with the quad-cooperative tail).  Every lane of the wave
