@@ -19,6 +19,9 @@ namespace tr {
 #ifndef TR_QUAD_SWITCH
 #define TR_QUAD_SWITCH 16      // live rays at which a wave switches to one ray per quad (0 = never)
 #endif
+#ifndef TR_QUAD_VOTE
+#define TR_QUAD_VOTE 4         // lanes holding a triangle at which the quads of a wave run a triangle phase (2 / 4 / 8 / 16 measured)
+#endif
 #define TR_QSPILL 48           // stack entries per quad beyond the LDS part (deepest stack seen on the bench scenes: 26)
 
 struct QuadCtx {
@@ -246,7 +249,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             const bool qwait = w != 0;                      // a lane of this quad holds a triangle
             if (__ballot(qlive || qwait) == 0) break;
             const bool can_node = qlive && !qwait;
-            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= (TR_VOTE > 0 ? TR_VOTE : 1) || __ballot(can_node) == 0;
+            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= TR_QUAD_VOTE || __ballot(can_node) == 0;
             if (COUNT && lane == 0) { if (tri_phase) st.ph_qtri++; else st.ph_qnode++; }
             if (tri_phase) {
                 if (pend >= 0) {
@@ -446,7 +449,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             const bool qwait = w != 0;
             if (__ballot(qlive || qwait) == 0) break;
             const bool can_node = qlive && !qwait;
-            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= (TR_VOTE > 0 ? TR_VOTE : 1) || __ballot(can_node) == 0;
+            const bool tri_phase = __popcll(__ballot(pend >= 0)) >= TR_QUAD_VOTE || __ballot(can_node) == 0;
             if (tri_phase) {
                 if (pend >= 0) {
                     const TriRecord tr = sv.tris[pend];

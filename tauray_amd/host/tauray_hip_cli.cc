@@ -1,8 +1,10 @@
 // tauray_hip - headless command line front-end of the MI355X path-tracing core, shaped after `tauray --headless`
 // (reference src/main.cc, src/tauray.cc:1017-1132 replay_viewer): load a scene, create an rt_renderer over the
-// selected devices, render N frames, tonemap, save.  Scene input is a .trsc dump (tauray_amd/scene_io.py).
+// selected devices, render N frames, tonemap, save.  Scene input is a .glb file (include/tauray_gltf.hh, the loader of
+// src/gltf.cc for the path tracer's subset) or a .trsc dump (tauray_amd/scene_io.py); --dump-scene=out.trsc writes the loaded
+// scene as a dump and exits without touching a GPU.
 //
-//   tauray_hip scene.trsc --width=512 --height=512 --headless=out/frame [--max-ray-depth=8] [--samples-per-pixel=1]
+//   tauray_hip scene.glb|scene.trsc --width=512 --height=512 --headless=out/frame [--max-ray-depth=8] [--samples-per-pixel=1]
 //              [--frames=1] [--fake-devices=N | --devices=0,1,...] [--distribution-strategy=scanline|shuffled-strips]
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
@@ -13,6 +15,7 @@
 #include <sstream>
 
 #include "tauray_hip.hh"
+#include "tauray_gltf.hh"
 
 using namespace tr;
 
@@ -31,6 +34,7 @@ int main(int argc, char** argv)
         std::string renderer = "path-tracer";
         std::vector<int> devices;
         bool timing = false;
+        std::string dump_scene;
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
@@ -57,6 +61,7 @@ int main(int argc, char** argv)
                 renderer = val("--renderer=");
                 if(renderer != "path-tracer" && renderer != "direct") throw std::runtime_error("unknown renderer " + renderer + " (path-tracer, direct)");
             }
+            else if(starts(a, "--dump-scene=")) dump_scene = val("--dump-scene=");
             else if(starts(a, "--device-workloads="))
             {
                 std::string v = val("--device-workloads=");
@@ -119,10 +124,12 @@ int main(int argc, char** argv)
             else if(starts(a, "--")) throw std::runtime_error("unknown option " + a);
             else scene_path = a;
         }
-        if(scene_path.empty()) throw std::runtime_error("usage: tauray_hip scene.trsc [options]");
+        if(scene_path.empty()) throw std::runtime_error("usage: tauray_hip scene.glb|scene.trsc [options]");
         if(devices.empty()) devices.assign((size_t)std::max(fake_devices, 1), 0);
 
-        scene_data scene = load_scene_dump(scene_path);
+        const bool is_glb = scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0;
+        scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
+        if(!dump_scene.empty()) { write_scene_dump(scene, dump_scene); return 0; }
         // create_renderer (src/tauray.cc:355-421): classes without lights get weight 0, projection follows the camera
         if(scene.point_light_count() == 0) opt.sampling_weights.point_lights = 0;
         if(scene.directional_light_count() == 0) opt.sampling_weights.directional_lights = 0;

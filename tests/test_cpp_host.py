@@ -107,6 +107,48 @@ def test_exr_writer_all_compressions(tmp_path):
     assert sizes[(64, 48, 3, 3)] < sizes[(64, 48, 3, 0)] and sizes[(64, 48, 3, 2)] < sizes[(64, 48, 3, 0)]   # they do compress
 
 
+def test_cpp_glb_loader_matches_python_loader(tmp_path):
+    """tr::load_glb (include/tauray_gltf.hh: the C++ host's reader for src/gltf.cc's path-tracer subset) against the Python
+    mirror's loader on the reference's own test/test.glb: every array of the flattened scene - instances with their model /
+    normal matrices and materials, spans, vertices (including the tangents mesh::calculate_tangents makes up for the teapot,
+    which has no uvs: NaN), indices, lights, the PNG texture, non-opaque flags - byte for byte; the camera block to 1e-12 (the
+    two inverses differ in how they round a zero)."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene_io import write_scene_dump
+    names = ["instances", "spans", "vertices", "indices", "point_lights", "directional_lights", "texture_infos", "texels", "envmap",
+             "alias_table", "cameras", "non_opaque"]
+
+    def sections(path):
+        d = open(path, "rb").read()
+        assert d[:4] == b"TRSC"
+        pos, out = 8, {}
+        for n in names:
+            size = struct.unpack("<Q", d[pos:pos + 8])[0]
+            out[n] = d[pos + 8:pos + 8 + size]
+            pos += 8 + size
+        out["tail"] = d[pos:]
+        return out
+
+    for (w, h) in ((128, 128), (1920, 1080)):
+        cpp, py = str(tmp_path / "cpp.trsc"), str(tmp_path / "py.trsc")
+        subprocess.check_call([CLI, os.path.join(GOLDEN, "test.glb"), f"--width={w}", f"--height={h}", f"--dump-scene={cpp}"])
+        write_scene_dump(load_glb(os.path.join(GOLDEN, "test.glb"), w, h), py)
+        a, b = sections(cpp), sections(py)
+        for n in names + ["tail"]:
+            if n == "cameras":
+                x, y = np.frombuffer(a[n], np.float32), np.frombuffer(b[n], np.float32)
+                assert x.shape == y.shape and np.abs(x.astype(np.float64) - y).max() < 1e-12
+            else:
+                assert a[n] == b[n], f"{n} differs at {w}x{h}"
+        assert len(a["vertices"]) == 48 * 45827 or len(a["vertices"]) > 0
+    # the skinned fixture loads in its bind pose; a file that is not a GLB is refused
+    subprocess.check_call([CLI, os.path.join(GOLDEN, "skinned.glb"), "--width=64", "--height=64", f"--dump-scene={tmp_path / 's.trsc'}"])
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"not a glb file at all")
+    r = subprocess.run([CLI, str(bad), f"--dump-scene={tmp_path / 'x.trsc'}"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a GLB" in r.stderr
+
+
 def test_cli_fails_loudly(scene_dump):
     r = subprocess.run([CLI, "/nonexistent.trsc"], capture_output=True, text=True)
     assert r.returncode == 1 and "Failed to open" in r.stderr
@@ -127,10 +169,11 @@ def test_cpp_renderer_matches_python_mirror_and_fake_devices(tmp_path, scene_dum
     R.TonemapStage(ctx).run(color, disp, W, H)
     ref = disp.download((H, W, 4))
     common = [scene_dump, f"--width={W}", f"--height={H}", "--max-ray-depth=4", "--filetype=raw"]
-    for tag, extra in (("one", []), ("fake3_scanline", ["--fake-devices=3", "--distribution-strategy=scanline"]),
-                       ("fake4_strips", ["--fake-devices=4", "--distribution-strategy=shuffled-strips"])):
+    glb_common = [os.path.join(GOLDEN, "test.glb")] + common[1:]      # the same frame straight from the reference's .glb
+    for tag, extra, args in (("one", [], common), ("fake3_scanline", ["--fake-devices=3", "--distribution-strategy=scanline"], common),
+                             ("fake4_strips", ["--fake-devices=4", "--distribution-strategy=shuffled-strips"], common), ("from_glb", [], glb_common)):
         prefix = str(tmp_path / tag)
-        r = subprocess.run([CLI] + common + [f"--headless={prefix}", "-t"] + extra, capture_output=True, text=True)
+        r = subprocess.run([CLI] + args + [f"--headless={prefix}", "-t"] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert "[path tracing (1 viewports)]" in r.stdout and "HOST:" in r.stdout
         got = np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4)
