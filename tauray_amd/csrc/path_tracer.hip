@@ -55,6 +55,7 @@ struct PathBuffers {
     // per lane and bounce b (BC_STRIDE words apart): live paths entering b, shadow rays of b, work cursors of the closest-hit /
     // shadow kernel of b (BC_*).  Zeroed by k_raygen; nothing has to be rotated between bounces.
     uint* bounce;
+    f4* surf;         // TRHIP_SHADE_SPLIT: 5 f4 per path, what k_surface hands to k_shade (see SurfRecord below); null otherwise
     int* qspill;      // deep stack entries of the quad-cooperative tail of the closest-hit waves (trace_quad.h): 16 * TR_QSPILL words per wave of a launch
     uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
@@ -571,12 +572,58 @@ __global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams
     write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
 }
 
+// The split form of a bounce (TRHIP_SHADE_SPLIT=1): k_surface does the gathers of get_intersection_info for surface hits -
+// indices, three vertices, the instance record, up to four texture taps - at high occupancy and leaves what evaluate_ray
+// needs of the result in five float4 per path; k_shade<.., true> reads that record instead of calling shade_surface.
+//   0: pos.xyz, tri_light_pdf   1: hard_normal.xyz, metallic   2: mapped_normal.xyz, roughness
+//   3: albedo.rgb, transmittance   4: emission.rgb, +-material ior (negative: the ray is inside, ior_in = ior, ior_out = 1)
+TR_DEV void store_surface(f4* surf, size_t n, uint id, const SurfacePoint& v, const SampledMaterial& m) {
+    surf[id] = F4(v.pos, v.tri_light_pdf);
+    surf[n + id] = F4(v.hard_normal, m.metallic);
+    surf[2 * n + id] = F4(v.mapped_normal, m.roughness);
+    surf[3 * n + id] = F4(F3(m.albedo), m.transmittance);
+    surf[4 * n + id] = F4(m.emission, m.ior_in != 1.0f || m.ior_out == 1.0f ? -m.ior_in : m.ior_out);
+}
+TR_DEV void load_surface(const f4* surf, size_t n, uint id, SurfacePoint& v, SampledMaterial& m) {
+    const f4 a = surf[id], b = surf[n + id], c = surf[2 * n + id], d = surf[3 * n + id], e = surf[4 * n + id];
+    v.pos = F3(a); v.tri_light_pdf = a.w;
+    v.hard_normal = F3(b); m.metallic = b.w;
+    v.mapped_normal = F3(c); v.smooth_normal = F3(c); m.roughness = c.w;
+    m.albedo = F4(F3(d), 1.0f); m.transmittance = d.w;
+    m.emission = F3(e);
+    if (__float_as_uint(e.w) >> 31) { m.ior_in = -e.w; m.ior_out = 1.0f; }
+    else { m.ior_in = 1.0f; m.ior_out = e.w; }
+    const float f0 = (m.ior_out - m.ior_in) / (m.ior_out + m.ior_in);      // as shade_surface ends (scene.glsl:150-151)
+    m.f0 = f0 * f0;
+}
+
+#ifndef TR_SURFACE_WAVES
+#define TR_SURFACE_WAVES 5
+#endif
+__global__ __launch_bounds__(KB, TR_SURFACE_WAVES) void k_surface(SceneView sv, PtParams P, PathBuffers pb, const uint* queue, const uint* bc) {
+    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
+    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
+        const uint id = queue ? queue[qi] : qi + P.id_offset;
+        const int4 h = pb.hit[id];
+        if (h.x < 0 || (pb.misc[id].w & 1u)) continue;
+        const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id];
+        SurfacePoint v;
+        SampledMaterial mat;
+        shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), F3(d4), F3(o4), P.nee_tri != 0, P.opt.tri_light_mode,
+                      P.opt.pre_transformed_vertices != 0, v, mat);
+        store_surface(pb.surf, P.n_launch, id, v, mat);
+    }
+}
+
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
 #ifndef TR_SHADE_WAVES
 #define TR_SHADE_WAVES 3
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+#ifndef TR_SHADE2_WAVES
+#define TR_SHADE2_WAVES 4      // waves per SIMD asked for the half of the split bounce that does no gathering
+#endif
+template <bool COUNT, bool SPLIT>
+__global__ __launch_bounds__(KB, SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                               uint* bc, uint* next_queue) {
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     const uint n_round = (n + (uint)KB - 1u) & ~((uint)KB - 1u);   // whole blocks take part in the appends
@@ -617,7 +664,8 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_shade(SceneView sv, PtPa
             if (h.x >= 0) {
                 surface = true;
                 if (COUNT) surf++;
-                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat);
+                if (SPLIT) load_surface(pb.surf, P.n_launch, id, v, mat);
+                else shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat);
                 mat.albedo.w = 1.0f;
                 if (P.nee_tri) {
                     tri_pdf = v.tri_light_pdf;
@@ -1088,7 +1136,7 @@ PtStage::~PtStage() {
 void PtStage::free_buffers() {
     PathBuffers& pb = impl->pb;
     void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
-                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
+                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.surf, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint *counters = pb.counters, *bounce = pb.bounce;
     int* qspill = pb.qspill;
@@ -1170,6 +1218,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     const bool count = count_work != 0;
     const bool timing = detailed_timing != 0;
     const bool top = TR_BVH4 && sv.treetop != nullptr;   // trace blocks keep the top of the tree in LDS
+    static const bool split = getenv("TRHIP_SHADE_SPLIT") && atoi(getenv("TRHIP_SHADE_SPLIT")) != 0;   // k_surface + k_shade<.., true>
+    if (split && !direct && !pb.surf) HIPCHK(hipMalloc(&pb.surf, impl->capacity * 5 * 16));
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
     // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
     // want different resources.  Two ways to fill the gaps, both bit-neutral:
@@ -1312,8 +1362,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         // a shorter tail than 2048 when frames overlap (test.glb -2.5 %, the larger scenes unchanged)
                         static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 1024u;
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
-                        if (count) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        if (split) {
+                            hipLaunchKernelGGL(k_surface, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, q, bc);
+                            if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        }
+                        else if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
