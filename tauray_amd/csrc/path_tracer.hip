@@ -65,7 +65,7 @@ struct PathBuffers {
 // (measured: 0.83 ms instead of 0.56 ms for one k_shade launch of 2 M paths).
 enum { BC_QUEUE = 0, BC_SHADOW = 64, BC_CUR_CLOSEST = 128, BC_CUR_SHADOW = 192, BC_STRIDE = 256 };
 enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
-       CNT_MAXSP = 30, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_WORDS = 48 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
+       CNT_MAXSP = 30, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_PH_HIST = 48, CNT_WORDS = 64 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
 
 struct PtParams {
     trhip_pt_options opt;
@@ -258,6 +258,7 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
             st.ph_node += __shfl_xor(st.ph_node, off); st.ph_tri += __shfl_xor(st.ph_tri, off); st.ph_node16 += __shfl_xor(st.ph_node16, off);
             st.ph_node8 += __shfl_xor(st.ph_node8, off); st.lv_node16 += __shfl_xor(st.lv_node16, off);
             st.ph_qnode += __shfl_xor(st.ph_qnode, off); st.ph_qtri += __shfl_xor(st.ph_qtri, off);
+            for (int b = 0; b < 8; ++b) st.ph_hist[b] += __shfl_xor(st.ph_hist[b], off);
             st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off));
         }
     }
@@ -269,6 +270,7 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
             add64(pb.counters, CNT_PH_NODE, st.ph_node); add64(pb.counters, CNT_PH_TRI, st.ph_tri); add64(pb.counters, CNT_PH_NODE16, st.ph_node16);
             add64(pb.counters, CNT_PH_NODE8, st.ph_node8); add64(pb.counters, CNT_LV_NODE16, st.lv_node16);
             add64(pb.counters, CNT_PH_QNODE, st.ph_qnode); add64(pb.counters, CNT_PH_QTRI, st.ph_qtri);
+            for (int b = 0; b < 8; ++b) add64(pb.counters, CNT_PH_HIST + 2 * b, st.ph_hist[b]);
             atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis);
         }
     }
@@ -1426,6 +1428,11 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
         fprintf(stderr, "[trhip] closest-hit loop: %llu node phases (%llu with <= 16 active rays serving %llu visits, %llu with <= 8), %llu triangle phases; quad tail: %llu node phases, %llu triangle phases; %llu node visits\n",
                 (unsigned long long)rd(CNT_PH_NODE), (unsigned long long)rd(CNT_PH_NODE16), (unsigned long long)rd(CNT_LV_NODE16), (unsigned long long)rd(CNT_PH_NODE8),
                 (unsigned long long)rd(CNT_PH_TRI), (unsigned long long)rd(CNT_PH_QNODE), (unsigned long long)rd(CNT_PH_QTRI), (unsigned long long)rd(CNT_NODES));
+    if (getenv("TRHIP_DEBUG")) {
+        fprintf(stderr, "[trhip] per-lane node phases by live rays (1-8, 9-16, ..., 57-64):");
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", (unsigned long long)rd(CNT_PH_HIST + 2 * b));
+        fprintf(stderr, "\n");
+    }
     if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] overflow %u src %u; max stack depth %u; max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_OVERFLOW], h[CNT_DBG + 12], h[CNT_MAXSP], h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
     return 0;
 }

@@ -147,6 +147,7 @@ struct TraceStats {
     // phases executed, node phases that ran with at most 16 / 8 active rays, and the ray visits those phases served
     uint ph_node, ph_tri, ph_node16, ph_node8, lv_node16;
     uint ph_qnode, ph_qtri;   // phases of the quad-cooperative tail (trace_quad.h)
+    uint ph_hist[8];          // per-lane node phases by live rays: 1-8, 9-16, ..., 57-64
 };
 
 // get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit

@@ -163,7 +163,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             if (COUNT) {
                 const unsigned long long m = __ballot(true);
                 if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
-                    if (!leaf_phase) { st.ph_node++; if (__popcll(m) <= 16) { st.ph_node16++; st.lv_node16 += (uint)__popcll(__ballot(!at_leaf)); } if (__popcll(m) <= 8) st.ph_node8++; }
+                    if (!leaf_phase) { st.ph_node++; st.ph_hist[(__popcll(m) - 1) >> 3]++; if (__popcll(m) <= 16) { st.ph_node16++; st.lv_node16 += (uint)__popcll(__ballot(!at_leaf)); } if (__popcll(m) <= 8) st.ph_node8++; }
                     else st.ph_tri++;
                 }
             }
