@@ -16,7 +16,11 @@ namespace tr {
 #define TR_BLOCK 256
 #endif
 #ifndef TR_VOTE
-#define TR_VOTE 8          // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote)
+#define TR_VOTE 16         // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote); 8 before the
+                           // quad tail took over the thin end of a wave, 12 / 16 / 20 / 24 / 32 measured since: 16
+#endif
+#ifndef TR_VOTE_SHADOW_WAVE
+#define TR_VOTE_SHADOW_WAVE 16   // the same vote in the per-lane loop of trace_shadow_wave4 (0: none); 8 / 16 measured: -1 ... -2 % shadow time
 #endif
 // The slab test compares a box's entry distance with min(exit distance, current closest hit / tmax) * TR_SLAB_PAD.  The pad
 // covers the rounding of both slab distances and, on the tmax side, the error of the distance the triangle test computes

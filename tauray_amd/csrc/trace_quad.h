@@ -22,7 +22,8 @@ namespace tr {
 #ifndef TR_QUAD_VOTE
 #define TR_QUAD_VOTE 4         // lanes holding a triangle at which the quads of a wave run a triangle phase (2 / 4 / 8 / 16 measured)
 #endif
-#define TR_QSPILL 48           // stack entries per quad beyond the LDS part (deepest stack seen on the bench scenes: 26)
+#define TR_QSPILL TR_SPILL_STACK   // stack entries per quad beyond the LDS part: the per-lane loop's depth (deepest stack seen on the bench scenes: 26)
+static_assert(TR_QUAD_SWITCH <= 16, "a wave has sixteen quads");
 
 struct QuadCtx {
     int* wave_stack;   // LDS: stack column of lane 0 of this wave; entry e of lane l at [e * TR_BLOCK + l]
@@ -156,7 +157,8 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             const bool at_leaf = node < 0;
 #if TR_VOTE > 0
             const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
-            const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
+            // a triangle phase when TR_VOTE lanes hold a leaf - or half of the live ones, once the wave has thinned out
+            const bool leaf_phase = n_leaf >= (TR_VOTE < ((n_all + 1) >> 1) ? TR_VOTE : ((n_all + 1) >> 1)) || n_leaf == n_all;
 #else
             const bool leaf_phase = at_leaf;
 #endif
@@ -367,7 +369,18 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
     while (true) {
         if (__popcll(__ballot(live)) <= TR_QUAD_SWITCH) break;
+#if TR_VOTE_SHADOW_WAVE > 0
+        bool go = live;
+        if (live) {     // wave vote as in the closest-hit loop: lanes holding a leaf wait until enough of them do
+            const bool at_leaf = node < 0;
+            const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
+            const bool leaf_phase = n_leaf >= TR_VOTE_SHADOW_WAVE || n_leaf == n_all;
+            go = at_leaf == leaf_phase;
+        }
+        if (go) {
+#else
         if (live) {
+#endif
             bool descend = false;
             if (node >= 0) {
                 Hit4 h;

@@ -12,6 +12,19 @@ from conftest import GOLDEN, ROOT
 CLI = os.path.join(ROOT, "tauray_amd", "tauray_hip")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def fresh_cli(tmp_path_factory):
+    """The tests run the command line built from the sources of this tree, not whatever binary travelled with it: the host layer
+    is plain C++17 over the C ABI, so g++ and libtrhip.so are all it takes (the link line of tauray_amd/csrc/Makefile)."""
+    global CLI
+    out = str(tmp_path_factory.mktemp("cli") / "tauray_hip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-DTAURAY_HIP_WITH_ZLIB", "-I" + os.path.join(ROOT, "include"), "-o", out,
+                           os.path.join(ROOT, "tauray_amd", "host", "tauray_hip_cli.cc"), "-L" + os.path.join(ROOT, "tauray_amd"), "-ltrhip", "-lz",
+                           "-Wl,-rpath," + os.path.join(ROOT, "tauray_amd")])
+    CLI = out
+    yield out
+
+
 def read_simple_exr(path):
     """Independent reader for the scanline EXR files headless::write_exr emits (no compression, ZIPS, ZIP):
     returns ([channel names in file order], {channel: array}, compression code)."""
@@ -78,7 +91,7 @@ def scene_dump(tmp_path_factory, test_glb_128):
 
 
 def test_cli_exists_and_links_only_the_c_abi():
-    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    assert os.path.exists(os.path.join(ROOT, "tauray_amd", "tauray_hip")), "run __graft_entry__.build()"
     needed = subprocess.run(["readelf", "-d", CLI], capture_output=True, text=True).stdout
     assert "libtrhip.so" in needed and "libtorch" not in needed and "libpython" not in needed
 
