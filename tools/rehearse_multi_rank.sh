@@ -1,11 +1,11 @@
-# Rehearsal of the N > 1 bench path on a one-GPU box: all ranks on device 0, gloo instead of RCCL.  usage: bash tools/rehearse_multi_rank.sh [F ...]
+# Rehearsal of the N > 1 bench path on a one-GPU box: all ranks on device 0, gloo instead of RCCL, ranks started by bench.py itself.  usage: bash tools/rehearse_multi_rank.sh [F ...]
 cd $GRAFT_REPO_ROOT
 export TRHIP_BENCH_WATCHDOG=60
 for f in ${@:-1 4}; do
-timeout 120 python bench.py --steps 5 --frames-in-flight $f --no-cpu-baseline --no-roofline --save-display /tmp/disp1.npy > /dev/null
+timeout 180 python bench.py --steps 5 --frames-in-flight $f --no-cpu-baseline --no-roofline --save-display /tmp/disp1.npy > /dev/null
 for n in 2 3; do
 echo "== F=$f N=$n"
-timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus $n --steps 5 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 0 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
+timeout 180 python bench.py --gpus $n --steps 5 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 0 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
 python - <<PY
 import numpy as np
 a=np.load('/tmp/disp1.npy')
@@ -16,7 +16,7 @@ PY
 done; done
 # view and sample shards (smaller frames: gloo moves device memory through the host)
 S="--width 640 --height 360 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline"
-T="python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --dist-backend gloo --one-device --prewarm 0"
+T="python bench.py --gpus 2 --dist-backend gloo --one-device --prewarm 0"      # bench.py starts its own ranks
 timeout 120 python bench.py $S --views 6 --save-display /tmp/v1.npy > /dev/null
 timeout 120 $T $S --views 6 --shard views --save-display /tmp/v2.npy > gpurun_out/rehearse_views.log 2>&1
 timeout 120 python bench.py $S --spp 4 --save-display /tmp/s1.npy > /dev/null
