@@ -624,11 +624,16 @@ __global__ __launch_bounds__(KB, TR_SURFACE_WAVES) void k_surface(SceneView sv, 
 #ifndef TR_SHADE2_WAVES
 #define TR_SHADE2_WAVES 4      // waves per SIMD asked for the half of the split bounce that does no gathering
 #endif
-template <bool COUNT, bool SPLIT>
-__global__ __launch_bounds__(KB, SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+#ifndef TR_SHADE_LAST_WAVES
+#define TR_SHADE_LAST_WAVES 5   // the last bounce only collects emission: no light or BSDF sampling, no queue appends
+#endif
+// LAST: the instance for bounce == max_bounces - 1, where every path is terminal (path_tracer.glsl:445): compiled without the
+// NEE / BSDF half of the loop body and without the block-wide appends (and their barriers).
+template <bool COUNT, bool SPLIT, bool LAST>
+__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES)) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                               uint* bc, uint* next_queue) {
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
-    const uint n_round = (n + (uint)KB - 1u) & ~((uint)KB - 1u);   // whole blocks take part in the appends
+    const uint n_round = LAST ? n : ((n + (uint)KB - 1u) & ~((uint)KB - 1u));   // whole blocks take part in the appends
     uint surf = 0;
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
         bool active = qi < n;
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(KB, SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES) void 
                     env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
                 } else mat.emission += F3(c);
             }
-            const bool terminal = !surface || bounce == P.opt.max_bounces - 1;
+            const bool terminal = LAST || !surface || bounce == P.opt.max_bounces - 1;
 
             // ---- emission with MIS (path_tracer.glsl:413-435)
             float mis_pdf = bsdf_mis_pdf(sv, P, pl_pdf, dl_pdf, tri_pdf, env_pdf, bsdf_pdf);
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(KB, SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES) void 
             }
         }
         // ---- queue compaction (wave ballots)
+        if (LAST) continue;     // nothing survives the last bounce
         uint sslot, nslot;
         block_append2(&bc[BC_SHADOW], want_shadow, sslot, &bc[BC_STRIDE + BC_QUEUE], alive, nslot);
         if (want_shadow) {
@@ -1364,13 +1370,19 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         // a shorter tail than 2048 when frames overlap (test.glb -2.5 %, the larger scenes unchanged)
                         static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 1024u;
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
+                        static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
+                        const bool last = last_variant && bounce == opt.max_bounces - 1 && !split;
                         if (split) {
                             hipLaunchKernelGGL(k_surface, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, q, bc);
-                            if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            if (count) hipLaunchKernelGGL((k_shade<true, true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else hipLaunchKernelGGL((k_shade<false, true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         }
-                        else if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else if (last) {
+                            if (count) hipLaunchKernelGGL((k_shade<true, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        }
+                        else if (count) hipLaunchKernelGGL((k_shade<true, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);

@@ -117,6 +117,78 @@ struct QuadStack {
     }
 };
 
+// Re-deals the live rays of a wave over its quads: ray k (in lane order) goes to quad k.  Every lane of the wave calls this.
+// What both trace loops share of a ray travels here: the slab test's and the triangle test's constants, the current node and
+// the stack (the quad keeps the owner's LDS column; entries the owner had spilled to private scratch move to the quad's slice
+// of the wave's global buffer).
+struct QuadDeal {
+    int q, qd;            // lane in the quad, quad in the wave
+    int my_rank;          // for a live lane: which quad took its ray
+    int src, back;        // ds_bpermute addresses: the lane the quad's ray came from / lane 0 of the quad that took this lane's ray
+    bool has_ray;         // this quad got a ray
+};
+TR_DEV QuadDeal quad_deal(unsigned long long act, bool live, const RayPre& r, float tmin, int node, const LaneStack& stk, const int* spill, const QuadCtx& qc,
+                          int& overflow, QuadRay& qr, RayPre& tr_ray, QuadStack& qs, int& qnode) {
+    QuadDeal d;
+    const int lane = threadIdx.x & 63, n_act = __popcll(act);
+    d.q = lane & 3; d.qd = lane >> 2;
+    d.my_rank = __popcll(act & ((1ull << lane) - 1ull));
+    if (live) {
+        qc.owner_tab[d.my_rank] = lane;
+        for (int e = TR_LDS_STACK; e < stk.sp; ++e) {
+            const int k = e - TR_LDS_STACK;
+            if (k < TR_QSPILL) qc.spill[d.my_rank * TR_QSPILL + k] = spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1];
+            else overflow++;
+        }
+    }
+    wave_sync_lds();
+    d.has_ray = d.qd < n_act;
+    const int owner = d.has_ray ? qc.owner_tab[d.qd] : lane;
+    d.src = owner << 2;
+    d.back = d.my_rank << 4;
+    const int src = d.src;
+    qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
+    qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
+    qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
+    const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
+    qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
+    qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
+    qr.tmin = bpermf(src, tmin);
+    tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;   // what tri_intersect reads
+    qnode = bperm(src, node);
+    qs.lds = qc.wave_stack + owner;
+    qs.glob = qc.spill + d.qd * TR_QSPILL;
+    qs.sp = bperm(src, stk.sp);
+    qs.overflow = 0;
+    return d;
+}
+
+// What a quad does with the children its lanes found: `inner` = this lane's child is an inner node that was hit, `key` orders
+// the hits (smaller first; unique per lane).  The first becomes the quad's node, the others go onto the stack with the second
+// on top; without a hit the quad pops its next node or is done.  Quad-uniform control flow; returns the stack depth reached.
+TR_DEV void quad_descend(bool inner, uint key, int c, QuadStack& qs, int& qnode, bool& qlive) {
+    const uint k1 = (uint)qrot1((int)key), k2 = (uint)qrot2((int)key), k3 = (uint)qrot3((int)key);
+    const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+    int n_inner = inner ? 1 : 0;
+    n_inner += qrot1(n_inner); n_inner += qrot2(n_inner);
+    int nx = (inner && rank == 0) ? c : 0;
+    nx |= qrot1(nx); nx |= qrot2(nx);
+    if (n_inner > 0) {
+        if (inner && rank >= 1) qs.store(qs.sp + n_inner - 1 - rank, c);
+        qs.sp += n_inner - 1;
+        qnode = nx;
+    } else if (qs.sp == 0) qlive = false;
+    else { qs.sp--; qnode = qs.load(qs.sp); }
+}
+
+// A leaf the ray brought along from the per-lane phase (its current node or an entry of its stack: the per-lane loop pushes
+// leaves, the quads do not): lane 0 of the quad takes it as its pending triangle, the quad goes on with the next entry.
+TR_DEV void quad_inherited_leaf(int q, int& pend, QuadStack& qs, int& qnode, bool& qlive) {
+    if (q == 0) pend = ~qnode;
+    if (qs.sp == 0) qlive = false;
+    else { qs.sp--; qnode = qs.load(qs.sp); }
+}
+
 // Closest hit for the rays of one wave.  Every lane of the wave calls this (`valid` = the lane has a ray); parameters and
 // result as trace_closest4.
 template <int ALPHA_MODE, bool COUNT, bool TOP>
@@ -206,45 +278,16 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     const float dbg_u = live ? (float)stk.sp : -1.0f, dbg_v = live ? (float)((node < 0 ? 1000 : 0) + n_act) : -1.0f;
 #endif
     if (n_act > 0) {
-        const int lane = threadIdx.x & 63, q = lane & 3, qd = lane >> 2;
-        const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
-        if (live) {
-            qc.owner_tab[my_rank] = lane;
-            for (int e = TR_LDS_STACK; e < stk.sp; ++e) {   // entries the owner kept in its private spill move to the quad's global slice
-                const int k = e - TR_LDS_STACK;
-                if (k < TR_QSPILL) qc.spill[my_rank * TR_QSPILL + k] = spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1];
-                else overflow++;
-            }
-        }
-        wave_sync_lds();
-        const bool has_ray = qd < n_act;
-        const int owner = has_ray ? qc.owner_tab[qd] : lane;
-        const int src = owner << 2;
-        QuadRay qr;
-        qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
-        qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
-        qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
-        {
-            const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
-            qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
-            qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
-        }
-        qr.tmin = bpermf(src, tmin);
+        QuadRay qr; RayPre tr_ray; QuadStack qs; int qnode;
+        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, tr_ray, qs, qnode);
+        const int q = deal.q, src = deal.src;
         const uint qseed = (uint)bperm(src, (int)seed);
         // every lane of the quad starts from the owner's best candidate; the quad shares the culling bound
         float lt = bpermf(src, best_t), lu = bpermf(src, best_u), lv = bpermf(src, best_v);
         uint linst = (uint)bperm(src, (int)best_inst), lprim = (uint)bperm(src, (int)best_prim);
         float qbest = lt;
-        int qnode = bperm(src, node);
-        QuadStack qs;
-        qs.lds = qc.wave_stack + owner;
-        qs.glob = qc.spill + qd * TR_QSPILL;
-        qs.sp = bperm(src, stk.sp);
-        qs.overflow = 0;
-        bool qlive = has_ray;
+        bool qlive = deal.has_ray;
         int pend = -1;      // triangle this lane has to test
-        RayPre tr_ray;      // what tri_intersect reads
-        tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;
         while (true) {
             int w = pend >= 0 ? 1 : 0;
             w |= qrot1(w); w |= qrot2(w);
@@ -252,7 +295,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             if (__ballot(qlive || qwait) == 0) break;
             const bool can_node = qlive && !qwait;
             const bool tri_phase = __popcll(__ballot(pend >= 0)) >= TR_QUAD_VOTE || __ballot(can_node) == 0;
-            if (COUNT && lane == 0) { if (tri_phase) st.ph_qtri++; else st.ph_qnode++; }
+            if (COUNT && (threadIdx.x & 63) == 0) { if (tri_phase) st.ph_qtri++; else st.ph_qnode++; }
             if (tri_phase) {
                 if (pend >= 0) {
                     const TriRecord tr = sv.tris[pend];
@@ -279,33 +322,16 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 float m = lt;
                 m = fminf(m, qrot1f(m)); m = fminf(m, qrot2f(m));
                 qbest = fminf(qbest, m);
-            } else if (can_node && qnode < 0) {
-                // a leaf the ray brought along from the per-lane phase (its current node or an entry of its stack: the per-lane
-                // loop pushes leaves, the quads do not): lane 0 tests it, the quad goes on with the next entry
-                if (q == 0) pend = ~qnode;
-                if (qs.sp == 0) qlive = false;
-                else { qs.sp--; qnode = qs.load(qs.sp); }
-            } else if (can_node) {
+            } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
+            else if (can_node) {
                 bool hitb; float t0;
                 const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qbest, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
                 // order of the inner children that were hit: entry distance, ties by slot (two low mantissa bits carry the slot)
-                const uint key = inner ? ((__float_as_uint(t0) & ~3u) | (uint)q) : 0xFFFFFFFFu;
-                const uint k1 = (uint)qrot1((int)key), k2 = (uint)qrot2((int)key), k3 = (uint)qrot3((int)key);
-                const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
-                int n_inner = inner ? 1 : 0;
-                n_inner += qrot1(n_inner); n_inner += qrot2(n_inner);
-                int nx = (inner && rank == 0) ? c : 0;
-                nx |= qrot1(nx); nx |= qrot2(nx);
-                if (n_inner > 0) {
-                    if (inner && rank >= 1) qs.store(qs.sp + n_inner - 1 - rank, c);   // the second nearest ends up on top
-                    qs.sp += n_inner - 1;
-                    if (COUNT) st.maxsp = max(st.maxsp, (uint)qs.sp);
-                    qnode = nx;
-                } else if (qs.sp == 0) qlive = false;
-                else { qs.sp--; qnode = qs.load(qs.sp); }
+                quad_descend(inner, inner ? ((__float_as_uint(t0) & ~3u) | (uint)q) : 0xFFFFFFFFu, c, qs, qnode, qlive);
+                if (COUNT) st.maxsp = max(st.maxsp, (uint)qs.sp);
             }
         }
         // the quad's result: smallest (t, instance, primitive) of its four lanes
@@ -320,7 +346,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         int qo = qs.overflow;
         qo += qrot1(qo); qo += qrot2(qo);
         // back to the lanes the rays came from: the owner of rank k reads lane 4 k
-        const int back = my_rank << 4;
+        const int back = deal.back;
         const float rt = bpermf(back, lt), ru = bpermf(back, lu), rv = bpermf(back, lv);
         const uint ri = (uint)bperm(back, (int)linst), rp = (uint)bperm(back, (int)lprim);
         const int ro = bperm(back, qo);
@@ -419,43 +445,14 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     const unsigned long long act = __ballot(live);
     const int n_act = __popcll(act);
     if (n_act > 0) {
-        const int lane = threadIdx.x & 63, q = lane & 3, qd = lane >> 2;
-        const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
-        if (live) {
-            qc.owner_tab[my_rank] = lane;
-            for (int e = TR_LDS_STACK; e < stk.sp; ++e) {
-                const int k = e - TR_LDS_STACK;
-                if (k < TR_QSPILL) qc.spill[my_rank * TR_QSPILL + k] = spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1];
-                else overflow++;
-            }
-        }
-        wave_sync_lds();
-        const bool has_ray = qd < n_act;
-        const int owner = has_ray ? qc.owner_tab[qd] : lane;
-        const int src = owner << 2;
-        QuadRay qr;
-        qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
-        qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
-        qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
-        {
-            const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
-            qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
-            qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
-        }
-        qr.tmin = bpermf(src, tmin);
+        QuadRay qr; RayPre tr_ray; QuadStack qs; int qnode;
+        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, tr_ray, qs, qnode);
+        const int q = deal.q, src = deal.src;
         const float qtmax = bpermf(src, tmax);
         const float owner_vis = bpermf(src, visibility);
         float lvis = q == 0 ? owner_vis : 1.0f;     // the owner's product so far rides in lane 0 of the quad
-        int qnode = bperm(src, node);
-        QuadStack qs;
-        qs.lds = qc.wave_stack + owner;
-        qs.glob = qc.spill + qd * TR_QSPILL;
-        qs.sp = bperm(src, stk.sp);
-        qs.overflow = 0;
-        bool qlive = has_ray;
+        bool qlive = deal.has_ray;
         int pend = -1;
-        RayPre tr_ray;
-        tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;
         while (true) {
             int w = pend >= 0 ? 1 : 0;
             w |= qrot1(w); w |= qrot2(w);
@@ -481,36 +478,21 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 int z = lvis == 0.0f ? 1 : 0;
                 z |= qrot1(z); z |= qrot2(z);
                 if (z) qlive = false;      // occluded: nothing left to find
-            } else if (can_node && qnode < 0) {      // a leaf inherited from the per-lane phase
-                if (q == 0) pend = ~qnode;
-                if (qs.sp == 0) qlive = false;
-                else { qs.sp--; qnode = qs.load(qs.sp); }
-            } else if (can_node) {
+            } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
+            else if (can_node) {
                 bool hitb; float t0;
                 const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qtmax, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
-                const uint key = inner ? (uint)q : 0xFFFFFFFFu;      // slot order, as the per-lane loop descends
-                const uint k1 = (uint)qrot1((int)key), k2 = (uint)qrot2((int)key), k3 = (uint)qrot3((int)key);
-                const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
-                int n_inner = inner ? 1 : 0;
-                n_inner += qrot1(n_inner); n_inner += qrot2(n_inner);
-                int nx = (inner && rank == 0) ? c : 0;
-                nx |= qrot1(nx); nx |= qrot2(nx);
-                if (n_inner > 0) {
-                    if (inner && rank >= 1) qs.store(qs.sp + n_inner - 1 - rank, c);
-                    qs.sp += n_inner - 1;
-                    qnode = nx;
-                } else if (qs.sp == 0) qlive = false;
-                else { qs.sp--; qnode = qs.load(qs.sp); }
+                quad_descend(inner, inner ? (uint)q : 0xFFFFFFFFu, c, qs, qnode, qlive);      // slot order, as the per-lane loop descends
             }
         }
         float v = lvis;
         v *= qrot1f(v); v *= qrot2f(v);
         int qo = qs.overflow;
         qo += qrot1(qo); qo += qrot2(qo);
-        const int back = my_rank << 4;
+        const int back = deal.back;
         const float rv = bpermf(back, v);
         const int ro = bperm(back, qo);
         if (live) { visibility = rv; overflow += ro; }
