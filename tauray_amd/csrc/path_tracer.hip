@@ -1096,7 +1096,7 @@ void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/dis
 }
 
 constexpr int PT_LANES = 4;   // independent slices of a frame that run concurrently (see PtStage::render)
-static uint trace_grid_cap() {   // blocks of a persistent trace launch (TRHIP_GRID_BLOCKS)
+static uint trace_grid_cap() {   // most blocks a persistent trace launch gets (TRHIP_GRID_BLOCKS); sizes the quad-tail spill buffer
     static const uint cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
     return cap;
 }
@@ -1254,7 +1254,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
     }
-    const uint grid_cap = trace_grid_cap();
+    // A stage told to run as one lane shares the chip with the other frames in flight (frame slots): four blocks per CU per
+    // launch instead of eight leave room for their launches (sponza_teapots 4.33 -> 4.18 ms per frame with four slots, sponza_class
+    // 3.59 -> 3.44; a lone frame loses as much, which is what the four lanes of the automatic schedule are for).
+    const uint grid_cap = (lanes == 1 && !timing && !getenv("TRHIP_GRID_BLOCKS")) ? 1024u : trace_grid_cap();
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
@@ -1366,9 +1369,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     }
                     if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
                     timed(T_SHADE, ls, [&] {
-                        // k_shade holds three waves per SIMD (768 resident blocks): a grid of 1024 blocks strides over the queue with
-                        // a shorter tail than 2048 when frames overlap (test.glb -2.5 %, the larger scenes unchanged)
-                        static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 1024u;
+                        // k_shade holds three waves per SIMD (768 resident blocks) and strides over the queue; 2048 blocks since the
+                        // trace launches of a frame slot shrank to 1024 (round 2 sweep: profiles/r2/schedule_sweep.txt)
+                        static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 2048u;
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
                         static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
                         const bool last = last_variant && bounce == opt.max_bounces - 1 && !split;
