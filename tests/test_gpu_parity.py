@@ -1818,3 +1818,90 @@ def test_set_device_workloads_resizes_python_shares(R, ctx):
         assert np.array_equal(got, ref), workloads
     with pytest.raises(ValueError):
         R.RtRenderer(ctx, scene, R.options_for_scene(scene, samples_per_pixel=2), (W, H), rank=0, world_size=2, use_torch=False, shard="samples", accumulate=True)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Every kernel instance and every schedule switch renders the same frame
+
+
+@pytest.mark.gpu
+def test_profiling_instances_render_the_same_frame(R, ctx):
+    """bench.py takes its work counters from the counting instances of the kernels (`k_trace_closest<true, ..>`, `k_shade<true, ..>`)
+    and its kernel times from the serialised single-lane schedule (`k_trace_closest<false, true, ..>`, separate shadow launches):
+    both must render the frame of the production instances bit for bit, and count the same rays."""
+    from tauray_amd import scenes
+    W, H = 640, 360
+    scene = scenes.sponza_class(seed=2, target_tris=60000, width=W, height=H)
+    ss = R.SceneStage(ctx, scene)
+    opt = R.options_for_scene(scene, max_bounces=4)
+    frames, counters = {}, {}
+    for tag, (count, timing) in {"plain": (False, False), "counting": (True, False), "timed": (False, True), "both": (True, True)}.items():
+        pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+        pt.set_profiling(count, timing)
+        buf = ctx.alloc(W * H * 16).zero()
+        for _ in range(2):
+            pt.reset_accumulated_samples()
+            pt.run(buf)
+        frames[tag] = buf.download((H, W, 4))
+        counters[tag] = pt.counters()
+        if timing:
+            t = pt.timings()
+            assert t["trace_closest_launches"] == 8 and t["trace_shadow_launches"] == 6 and t["shade_launches"] == 8 and t["trace_closest_ms"] > 0
+        pt.close()
+    for tag in ("counting", "timed", "both"):
+        assert np.array_equal(frames[tag], frames["plain"]), f"{tag}: {int((frames[tag] != frames['plain']).any(-1).sum())} pixels differ"
+        for k in ("closest_rays", "shadow_rays", "stack_overflows"):
+            assert counters[tag][k] == counters["plain"][k], (tag, k)
+    c = counters["counting"]
+    assert c["node_visits"] > 5 * c["closest_rays"] and c["tri_tests"] > c["closest_rays"] and 0 < c["surface_hits"] <= c["closest_rays"]
+    # a ray's visit count depends a little on when its wave switches to quads (the two loops order equal-distance children and
+    # pending leaves differently), i.e. on which rays share a wave: the four-lane and the single-lane schedule agree to 1e-4
+    for k in ("node_visits", "tri_tests"):
+        assert abs(counters["both"][k] - c[k]) <= 1e-4 * c[k], k
+
+
+_SWITCH_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from tauray_amd import renderer as R, scenes
+from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+W, H = 1920, 1080
+scene = scenes.sponza_class(seed=2, target_tris=60000, width=W, height=H)
+ctx = R.Context(0)
+ss = R.SceneStage(ctx, scene)
+pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=4), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+buf = ctx.alloc(W * H * 16).zero()
+pt.run(buf)
+assert pt.counters()["stack_overflows"] == 0
+np.save(sys.argv[2], buf.download((H, W, 4)))
+"""
+
+
+@pytest.mark.gpu
+def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
+    """The environment switches of DESIGN.md section 5 select schedules (lanes, fused launches, grids) and the experiments kept
+    in the tree (treetop in LDS, split k_shade, the general k_shade for the last bounce): a full-size frame (large enough for
+    the four-lane schedule) is the same bits under every one of them."""
+    import subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "render.py"
+    script.write_text(_SWITCH_SCRIPT)
+    variants = {"default": {}, "one_lane_unfused": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0"}, "no_overlap": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0", "TRHIP_OVERLAP": "0"},
+                "two_lanes": {"TRHIP_LANES": "2"}, "small_grids": {"TRHIP_GRID_BLOCKS": "300", "TRHIP_SHADE_BLOCKS": "100"},
+                "treetop": {"TRHIP_TREETOP": "1"}, "shade_split": {"TRHIP_SHADE_SPLIT": "1"}, "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
+                "lbvh": {"TRHIP_BUILDER": "lbvh"}}
+    frames = {}
+    for tag, env in variants.items():
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ)
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"{tag}: {r.stderr[-1500:]}"
+        frames[tag] = np.load(out)
+    ref = frames["default"]
+    assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
+    for tag, f in frames.items():
+        assert np.array_equal(f, ref), f"{tag}: {int((f != ref).any(-1).sum())} pixels differ from the default schedule"
