@@ -6,8 +6,9 @@
 // instance flattening of scene_stage (src/scene_stage.cc:664-819: one instance per (model, vertex group) in node traversal
 // order) and the host-side packing of src/camera.cc:323-478, src/light.cc and src/scene_stage.cc:17-111,1066-1354.
 // Extensions: KHR_lights_punctual, KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength, TR_data.
-// Not read: animations, morph targets, skins (skinned meshes load in their bind pose), external (non-embedded) images,
-// interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
+// Skins: JOINTS_0 / WEIGHTS_0 (renormalised) + inverse bind matrices; skinned meshes sit at the origin (src/gltf.cc:722-731,
+// 777-784) and scene_data::skinned carries the file's rest pose for scene_stage::set_scene.  Not read: animations, morph targets,
+// external (non-embedded) images, interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
 // (tests/test_cpp_host.py::test_cpp_glb_loader_matches_python_loader).
 #ifndef TAURAY_GLTF_HH
 #define TAURAY_GLTF_HH
@@ -408,7 +409,7 @@ inline material create_material(const glb_file& g, const json& mat)
     return m;
 }
 
-struct vertex_group { material mat; std::vector<vertex> vertices; std::vector<uint32_t> indices; };
+struct vertex_group { material mat; std::vector<vertex> vertices; std::vector<uint32_t> indices; std::vector<trhip_skin> skins; };
 
 // mesh::calculate_normals (src/mesh.cc:113-143)
 inline void calculate_normals(std::vector<vertex>& v, const std::vector<uint32_t>& idx)
@@ -535,6 +536,24 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
             for(uint32_t ix: vg.indices) if(ix >= count) throw std::runtime_error("glTF: index out of range");
             if(!at.has("NORMAL")) calculate_normals(vg.vertices, vg.indices);
             if(!at.has("TANGENT")) calculate_tangents(vg.vertices, vg.indices);
+            if(at.has("JOINTS_0"))
+            {   // mesh::skin_data, weights renormalised (src/gltf.cc:722-731)
+                int c; size_t n;
+                const std::vector<double> jt = g.accessor(at.integer("JOINTS_0", 0), c, n);
+                vg.skins.assign(count, trhip_skin{});
+                for(size_t i = 0; i < count; ++i) for(int k = 0; k < 4; ++k) vg.skins[i].joints[k] = (uint32_t)jt[i * c + k];
+                if(at.has("WEIGHTS_0"))
+                {
+                    int wc; size_t wn;
+                    const std::vector<double> wt = g.accessor(at.integer("WEIGHTS_0", 0), wc, wn);
+                    for(size_t i = 0; i < count; ++i)
+                    {
+                        const float w[4] = {(float)wt[i * wc], (float)wt[i * wc + 1], (float)wt[i * wc + 2], (float)wt[i * wc + 3]};
+                        const float sum = ((w[0] + w[1]) + w[2]) + w[3];
+                        for(int k = 0; k < 4; ++k) vg.skins[i].weights[k] = w[k] / sum;
+                    }
+                }
+            }
             groups.push_back(std::move(vg));
         }
         models.push_back(std::move(groups));
@@ -550,6 +569,9 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     struct camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; };
     std::vector<camera> cameras;
     double light_angle = 0, light_radius = 0;
+    std::map<int, mat4d> node_globals;
+    struct pending_skin { uint32_t instance; int skin; const std::vector<trhip_skin>* skins; };
+    std::vector<pending_skin> skinned_pending;
 
     auto make_point_light = [&](const double color[3], const double pos[3], double radius) {
         point_light p{};
@@ -585,19 +607,24 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
             local = trs_matrix(t, q, sc);
         }
         const mat4d glob = mul(parent, local);
+        node_globals[node_index] = glob;
 
         if(node.has("mesh"))
         {
             double sto = 0;
             if(tr) if(const json* m = tr->find("mesh")) sto = m->number("shadow_terminator_offset", 0.0);
             for(const vertex_group& vg: models.at((size_t)node.integer("mesh", 0)))
-            {   // one INSTANCE record (src/scene_stage.cc:1085-1114); skinned meshes stay in their bind pose at their node
+            {   // one INSTANCE record (src/scene_stage.cc:1085-1114)
                 instance in{};
                 in.light_base_id = -1; in.sh_grid_index = -1;
                 in.shadow_terminator_mul = (float)(1.0 / (1.0 - 0.5 * sto));
-                to_glm(glob, in.model);
-                to_glm(transpose(inverse(glob)), in.model_normal);
-                to_glm(glob, in.model_prev);
+                // glTF places skinned meshes at the origin; the loader enforces it (src/gltf.cc:777-784)
+                const bool skinned = node.has("skin") && !vg.skins.empty();
+                const mat4d model = skinned ? mat4d::identity() : glob;
+                if(skinned) skinned_pending.push_back(pending_skin{(uint32_t)instances.size(), node.integer("skin", 0), &vg.skins});
+                to_glm(model, in.model);
+                to_glm(transpose(inverse(model)), in.model_normal);
+                to_glm(model, in.model_prev);
                 in.mat = vg.mat;
                 instances.push_back(in);
                 spans.push_back(mesh_span{(uint32_t)vertices.size(), (uint32_t)vg.vertices.size(), (uint32_t)indices.size(), (uint32_t)(vg.indices.size() / 3)});
@@ -772,6 +799,28 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     bytes(instances, s.instances); bytes(spans, s.spans); bytes(vertices, s.vertices); bytes(indices, s.indices);
     bytes(point_lights, s.point_lights); bytes(dir_lights, s.directional_lights); bytes(infos, s.texture_infos); bytes(cams, s.cameras);
     s.gather_emissive_triangles = tri_light_count > 0 ? 1u : 0u;
+    // skins: per joint the global transform of its node in the rest pose times the inverse bind matrix (model::update_joints)
+    for(const pending_skin& ps: skinned_pending)
+    {
+        const json& sk = j.at("skins").at((size_t)ps.skin);
+        const json& joints = sk.at("joints");
+        std::vector<double> ibm;
+        if(sk.has("inverseBindMatrices")) { int c; size_t n; ibm = g.accessor(sk.integer("inverseBindMatrices", 0), c, n); }
+        scene_data::skinned_mesh out;
+        out.instance = ps.instance;
+        out.skins = *ps.skins;
+        for(size_t k = 0; k < joints.size(); ++k)
+        {
+            mat4d inv_bind = mat4d::identity();
+            if(ibm.size() >= (k + 1) * 16) for(int c = 0; c < 4; ++c) for(int r = 0; r < 4; ++r) inv_bind.m[r][c] = ibm[k * 16 + size_t(c) * 4 + r];   // column-major in the file
+            const auto it = node_globals.find((int)joints.at(k).num);
+            const mat4d jt = mul(it != node_globals.end() ? it->second : mat4d::identity(), inv_bind);
+            float m[16];
+            to_glm(jt, m);
+            out.joint_transforms.insert(out.joint_transforms.end(), m, m + 16);
+        }
+        s.skinned.push_back(std::move(out));
+    }
     return s;
 }
 

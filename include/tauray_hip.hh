@@ -167,6 +167,12 @@ struct scene_data
     float environment_factor[4] = {0, 0, 0, 0};
     uint32_t gather_emissive_triangles = 0;
     uint32_t projection = 0;
+    // Skinned vertex groups (mesh::get_skin + model::get_joints, src/mesh.hh:32-36, src/model.hh): the instance's vertices above are
+    // the bind pose; `joint_transforms` (column-major mat4 per joint: global transform of the joint node * inverse bind matrix,
+    // model::update_joints src/model.cc:107-118) is the pose scene_stage::set_scene applies - the file's rest pose when a loader
+    // filled it in.  Not part of the .trsc dump.
+    struct skinned_mesh { uint32_t instance = 0; std::vector<trhip_skin> skins; std::vector<float> joint_transforms; };
+    std::vector<skinned_mesh> skinned;
 
     uint32_t instance_count() const { return (uint32_t)(instances.size() / 288); }
     uint32_t camera_count() const { return (uint32_t)(cameras.size() / 320); }
@@ -236,6 +242,13 @@ public:
         d.non_opaque = s.non_opaque.data();
         d.gather_emissive_triangles = s.gather_emissive_triangles;
         check(trhip_scene_upload(dev->h, &d));
+        // skinned meshes: the uploaded vertices are the bind pose; pose them before the build (the reference runs skinning.comp on
+        // the first scene update, src/scene_stage.cc:1543-1567)
+        for(const scene_data::skinned_mesh& sk: s.skinned)
+        {
+            set_skin(sk.instance, sk.skins.data(), (uint32_t)sk.skins.size());
+            skin(sk.instance, sk.joint_transforms.data(), (uint32_t)(sk.joint_transforms.size() / 16));
+        }
         check(trhip_scene_build_accel(dev->h, &accel));
     }
 

@@ -10,6 +10,7 @@
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
 //              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1] [--renderer=path-tracer|direct]
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -129,7 +130,23 @@ int main(int argc, char** argv)
 
         const bool is_glb = scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0;
         scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
-        if(!dump_scene.empty()) { write_scene_dump(scene, dump_scene); return 0; }
+        if(!dump_scene.empty())
+        {   // the flattened scene, and next to it what the loader found of skins: per skinned instance u32 instance, u32 vertices,
+            // u32 joints, the {joints, weights} records, the rest-pose joint matrices
+            write_scene_dump(scene, dump_scene);
+            if(!scene.skinned.empty())
+            {
+                std::ofstream f(dump_scene + ".skins", std::ios::binary);
+                for(const auto& sk: scene.skinned)
+                {
+                    const uint32_t head[3] = {sk.instance, (uint32_t)sk.skins.size(), (uint32_t)(sk.joint_transforms.size() / 16)};
+                    f.write(reinterpret_cast<const char*>(head), 12);
+                    f.write(reinterpret_cast<const char*>(sk.skins.data()), (std::streamsize)(sk.skins.size() * sizeof(trhip_skin)));
+                    f.write(reinterpret_cast<const char*>(sk.joint_transforms.data()), (std::streamsize)(sk.joint_transforms.size() * 4));
+                }
+            }
+            return 0;
+        }
         // create_renderer (src/tauray.cc:355-421): classes without lights get weight 0, projection follows the camera
         if(scene.point_light_count() == 0) opt.sampling_weights.point_lights = 0;
         if(scene.directional_light_count() == 0) opt.sampling_weights.directional_lights = 0;

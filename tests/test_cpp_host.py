@@ -154,8 +154,26 @@ def test_cpp_glb_loader_matches_python_loader(tmp_path):
             else:
                 assert a[n] == b[n], f"{n} differs at {w}x{h}"
         assert len(a["vertices"]) == 48 * 45827 or len(a["vertices"]) > 0
-    # the skinned fixture loads in its bind pose; a file that is not a GLB is refused
-    subprocess.check_call([CLI, os.path.join(GOLDEN, "skinned.glb"), "--width=64", "--height=64", f"--dump-scene={tmp_path / 's.trsc'}"])
+    # the skinned fixture: same bind-pose scene, same {joints, weights} per vertex, same rest-pose joint matrices
+    cpp, py = str(tmp_path / "s.trsc"), str(tmp_path / "s_py.trsc")
+    subprocess.check_call([CLI, os.path.join(GOLDEN, "skinned.glb"), "--width=64", "--height=64", f"--dump-scene={cpp}"])
+    sc = load_glb(os.path.join(GOLDEN, "skinned.glb"), 64, 64)
+    write_scene_dump(sc, py)
+    a, b = sections(cpp), sections(py)
+    for n in names + ["tail"]:
+        if n != "cameras":
+            assert a[n] == b[n], f"skinned.glb: {n} differs"
+    d = open(cpp + ".skins", "rb").read()
+    pos = 0
+    assert len(sc.skinned) >= 1
+    for sk in sc.skinned:
+        inst, nv, nj = struct.unpack("<3I", d[pos:pos + 12]); pos += 12
+        assert inst == sk.instance and nv == len(sk.skins)
+        assert d[pos:pos + 32 * nv] == np.ascontiguousarray(sk.skins).tobytes(); pos += 32 * nv
+        jt = np.frombuffer(d, np.float32, 16 * nj, pos).reshape(nj, 4, 4); pos += 64 * nj
+        want = np.stack([m.T for m in sc.joint_transforms(sk)])      # column-major storage
+        assert np.abs(jt.astype(np.float64) - want).max() < 1e-6
+    assert pos == len(d)
     bad = tmp_path / "bad.glb"
     bad.write_bytes(b"not a glb file at all")
     r = subprocess.run([CLI, str(bad), f"--dump-scene={tmp_path / 'x.trsc'}"], capture_output=True, text=True)
@@ -204,6 +222,40 @@ def test_cpp_renderer_matches_python_mirror_and_fake_devices(tmp_path, scene_dum
         assert np.array_equal(np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4), ref), tag
     r = subprocess.run([CLI] + common + ["--renderer=whitted"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown renderer" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_renders_the_skinned_glb_like_the_python_mirror(tmp_path):
+    """tests/golden/skinned.glb through tr::load_glb + scene_stage::set_scene (bind-pose vertices, skins, rest-pose joint
+    matrices -> trhip_scene_set_skin / trhip_scene_skin before the build) against the Python mirror doing the same: the
+    skinned tube is bent, not straight, and the frames agree (joint matrices may differ in the last bit: tolerance, not bits)."""
+    from tauray_amd import renderer as R
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    W, H = 160, 120
+    glb = os.path.join(GOLDEN, "skinned.glb")
+    scene = load_glb(glb, W, H)
+    ctx = R.Context(0)
+    ss = R.SceneStage(ctx, scene)
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=3), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    color, disp = ctx.alloc(W * H * 16).zero(), ctx.alloc(W * H * 16)
+    pt.run(color)
+    R.TonemapStage(ctx).run(color, disp, W, H)
+    ref = disp.download((H, W, 4))
+    prefix = str(tmp_path / "sk")
+    subprocess.check_call([CLI, glb, f"--width={W}", f"--height={H}", "--max-ray-depth=3", "--filetype=raw", f"--headless={prefix}"])
+    got = np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4)
+    differing = float((np.abs(got - ref).max(-1) > 1e-3).mean())
+    assert differing < 2e-3 and abs(float(got.mean()) - float(ref.mean())) < 1e-4, f"{differing:.4%} of the pixels differ"
+    # and it is the posed mesh that was rendered: without the skins the (straight) bind pose gives another image
+    bind = load_glb(glb, W, H)
+    bind.skinned = []
+    ss2 = R.SceneStage(R.Context(0), bind)
+    pt2 = R.PathTracerStage(ss2.ctx, ss2, R.options_for_scene(bind, max_bounces=3), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    c2, d2 = ss2.ctx.alloc(W * H * 16).zero(), ss2.ctx.alloc(W * H * 16)
+    pt2.run(c2)
+    R.TonemapStage(ss2.ctx).run(c2, d2, W, H)
+    assert float((np.abs(d2.download((H, W, 4)) - ref).max(-1) > 1e-3).mean()) > 0.01
 
 
 @pytest.mark.gpu
