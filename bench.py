@@ -292,6 +292,9 @@ def main():
             "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_range": traffic_range, "traffic_source": traffic_src,
             "valu": valu,
+            # what the PMC traffic says the kernel really pulls from HBM, as a fraction of peak (the tree is served by L2 / MALL, so
+            # this is far below `frac`, which prices the algorithmic bytes): HBM is not what binds this kernel
+            "traffic_frac": [round(t / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for t in traffic_range] if (traffic_range and avg_ms > 0) else None,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             # what a frame cannot avoid moving even with a perfectly cached tree: ray + hit records written and read once, one
