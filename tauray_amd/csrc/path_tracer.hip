@@ -1100,13 +1100,18 @@ static uint trace_grid_cap() {   // most blocks a persistent trace launch gets (
     static const uint cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
     return cap;
 }
-static size_t qspill_words_per_lane() { return (size_t)trace_grid_cap() * (KB / 64) * 16u * TR_QSPILL; }
+// words of the quad-tail spill buffer one lane of a frame needs: a slice per wave of its largest trace launch
+static size_t qspill_words_per_lane(size_t paths) {
+    const size_t blocks = std::min<size_t>(trace_grid_cap(), (paths + KB - 1) / KB);
+    return std::max<size_t>(blocks, 1) * (KB / 64) * 16u * TR_QSPILL;
+}
 struct TimedSpan { int kind; hipEvent_t a, b; };
 enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_KINDS = 5 };
 
 struct PtStage::Impl {
     PathBuffers pb{};
     size_t capacity = 0;
+    size_t qspill_lane_words = 0;
     hipEvent_t ev[2]{};
     bool ev_init = false;
     std::vector<hipEvent_t> pool;      // recycled events for per-launch timing
@@ -1159,7 +1164,12 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
         HIPCHK(hipMalloc(&pb.counters, PT_LANES * CNT_WORDS * sizeof(uint)));   // one block of counters per lane
         HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
         HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * BC_STRIDE * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
-        HIPCHK(hipMalloc(&pb.qspill, (size_t)PT_LANES * qspill_words_per_lane() * sizeof(int)));
+    }
+    if (qspill_words_per_lane(n) > impl->qspill_lane_words) {     // grows with the frame, up to the grid cap (59 MB per lane)
+        if (pb.qspill) HIPCHK(hipFree(pb.qspill));
+        pb.qspill = nullptr;
+        impl->qspill_lane_words = qspill_words_per_lane(n);
+        HIPCHK(hipMalloc(&pb.qspill, (size_t)PT_LANES * impl->qspill_lane_words * sizeof(int)));
     }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
@@ -1335,7 +1345,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         PathBuffers lb = pb;   // the lane's view: shared per-path arrays, its own queues / shadow queue / counters
         lb.counters = pb.counters + lane * CNT_WORDS;
         lb.bounce = pb.bounce + (size_t)lane * P.bounce_words;
-        lb.qspill = pb.qspill + (size_t)lane * qspill_words_per_lane();
+        lb.qspill = pb.qspill + (size_t)lane * impl->qspill_lane_words;
         lb.queue[0] = pb.queue[0] + LP.id_offset; lb.queue[1] = pb.queue[1] + LP.id_offset;
         lb.sh_org_tmax = pb.sh_org_tmax + LP.id_offset; lb.sh_dir_id = pb.sh_dir_id + LP.id_offset;
         lb.sh_contrib = pb.sh_contrib + LP.id_offset; lb.sh_lobes = pb.sh_lobes + LP.id_offset;
