@@ -526,8 +526,6 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
             const std::vector<double> pos = g.accessor(at.integer("POSITION", -1), nc, count);
             vg.vertices.assign(count, vertex{});
             for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].pos[k] = (float)pos[i * nc + k];
-            auto fill = [&](const char* name, int want, float vertex::*dummy) { (void)name; (void)want; (void)dummy; };
-            (void)fill;
             if(at.has("NORMAL")) { int c; size_t n; auto a = g.accessor(at.integer("NORMAL", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].normal[k] = (float)a[i * c + k]; }
             if(at.has("TEXCOORD_0")) { int c; size_t n; auto a = g.accessor(at.integer("TEXCOORD_0", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 2; ++k) vg.vertices[i].uv[k] = (float)a[i * c + k]; }
             if(at.has("TANGENT")) { int c; size_t n; auto a = g.accessor(at.integer("TANGENT", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 4; ++k) vg.vertices[i].tangent[k] = (float)a[i * c + k]; }
@@ -767,7 +765,6 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         for(int k = 0; k < 4; ++k) cd.origin[k] = (float)c.transform.m[k][3];
         for(int k = 0; k < 4; ++k) cd.projection_info[k] = (float)info[k];
         cams.push_back(cd);
-        s.projection = c.perspective ? 0u : 1u;
     }
     if(!cameras.empty()) s.projection = cameras[0].perspective ? 0u : 1u;
 
