@@ -249,6 +249,7 @@ public:
             set_skin(sk.instance, sk.skins.data(), (uint32_t)sk.skins.size());
             skin(sk.instance, sk.joint_transforms.data(), (uint32_t)(sk.joint_transforms.size() / 16));
         }
+        check(trhip_scene_set_build_mode(dev->h, 0));     // first build of a scene: ePreferFastTrace
         check(trhip_scene_build_accel(dev->h, &accel));
     }
 
@@ -265,6 +266,8 @@ public:
     void skin(uint32_t instance, const float* joint_transforms, uint32_t joint_count) { check(trhip_scene_skin(dev->h, instance, joint_transforms, joint_count)); }
     void update_acceleration(bool rebuild = false)
     {
+        // geometry that is rebuilt after its first build is dynamic: ePreferFastBuild (src/acceleration_structure.cc:129-131)
+        if(rebuild) check(trhip_scene_set_build_mode(dev->h, 1));
         check(rebuild ? trhip_scene_build_accel(dev->h, &accel) : trhip_scene_refit_accel(dev->h, &accel));
     }
 

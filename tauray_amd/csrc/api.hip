@@ -478,8 +478,15 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);
     if (const char* b = getenv("TRHIP_BUILDER")) dev->scene.builder = std::string(b) == "lbvh" ? 0 : 1;
     if (const char* r = getenv("TRHIP_PLOC_RADIUS")) dev->scene.ploc_radius = std::max(1, atoi(r));
+    if (const char* o = getenv("TRHIP_BVH_OPT")) dev->scene.optimise_rounds = std::max(0, atoi(o));
+    if (const char* o = getenv("TRHIP_BVH_OPT_MOD")) dev->scene.optimise_modulus = std::max(1, atoi(o));
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
+}
+int trhip_scene_set_build_mode(trhip_device* dev, int prefer_fast_build) {
+    DEVCHK(dev);
+    dev->scene.fast_build = prefer_fast_build != 0;
+    return 0;
 }
 int trhip_scene_refit_accel(trhip_device* dev, trhip_accel_info* out) {
     DEVCHK(dev);

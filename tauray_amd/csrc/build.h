@@ -47,6 +47,9 @@ struct DeviceScene {
     int builder = 1;                     // 0 = Karras LBVH, 1 = PLOC over the Morton order (TRHIP_BUILDER=lbvh|ploc)
     uint build_rounds = 0;
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
+    int optimise_rounds = 8;             // reinsertion rounds after the build (bvh_optimize.h; TRHIP_BVH_OPT)
+    bool fast_build = false;             // trhip_scene_set_build_mode: no optimisation rounds
+    int optimise_modulus = 1;            // a node searches every optimise_modulus-th round (TRHIP_BVH_OPT_MOD)
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
     bool accel_built = false;
     uint accel_capacity = 0xFFFFFFFFu;   // triangle count the output buffers were allocated for

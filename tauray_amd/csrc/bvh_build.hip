@@ -359,6 +359,12 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
 }
 
 
+}  // namespace
+}  // namespace tr
+#include "bvh_optimize.h"
+namespace tr {
+namespace {
+
 // shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
 __global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const uint* tri_prefix, TriLight* out) {
     uint gid = blockIdx.x * BT + threadIdx.x;
@@ -676,6 +682,10 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                  o_arrive = plan(n1 * 4), o_cref0 = plan((size_t)n * 4), o_cref1 = plan((size_t)n * 4), o_cbox0 = plan((size_t)n * 24),
                  o_cbox1 = plan((size_t)n * 24), o_nn = plan((size_t)n * 4), o_valid = plan(((size_t)n + BT) * 4), o_pos = plan(((size_t)n + BT) * 4),
                  o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(TR_BVH4 ? n1 * sizeof(BvhNode) : 0);
+    const bool optimise = ds.optimise_rounds > 0 && !ds.fast_build && n > 2;
+    const size_t n_all = (size_t)n + n1;
+    const size_t o_uparent = plan(optimise ? n_all * 4 : 0), o_moves = plan(optimise ? n_all * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all * 8 : 0),
+                 o_optstat = plan(64);
     if (plan_bytes > ds.scratch_bytes) {
         if (ds.scratch) (void)hipFree(ds.scratch);
         ds.scratch = nullptr; ds.scratch_bytes = 0;
@@ -763,7 +773,42 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 }
                 ds.build_rounds = (uint)rounds;
             }
-            if (ds.builder != 0 || ds.dfs_layout || TR_BVH4) {
+            if (optimise) {
+                // static geometry, "prefer fast trace": reinsertion rounds on the binary tree (bvh_optimize.h)
+                OptTree t{(uint)n1, n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
+                OptMove* moves = reinterpret_cast<OptMove*>(base + o_moves);
+                unsigned long long* lock = reinterpret_cast<unsigned long long*>(base + o_lock);
+                double* cost = reinterpret_cast<double*>(base + o_optstat);
+                uint* applied = reinterpret_cast<uint*>(base + o_optstat + 16);
+                const uint ablocks = (uint)((n_all + BT - 1) / BT);
+                const bool debug = getenv("TRHIP_DEBUG") != nullptr;
+                auto report = [&](int round) -> int {
+                    if (!debug) return 0;
+                    double h[3] = {0, 0, 0};
+                    HIPCHK(hipMemsetAsync(cost, 0, 8, stream));
+                    hipLaunchKernelGGL(k_opt_cost, dim3(iblocks), dim3(BT), 0, stream, t, cost);
+                    HIPCHK(hipMemcpyAsync(h, cost, 24, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    uint moved[2]; memcpy(moved, &h[2], 8);
+                    fprintf(stderr, "[trhip] tree optimisation round %d: inner area sum %.6g, %u of %u moves applied\n", round, h[0], round ? moved[0] : 0u, round ? moved[1] : 0u);
+                    return 0;
+                };
+                hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);
+                if (int rc = report(0)) return rc;
+                for (int round = 0; round < ds.optimise_rounds; ++round) {
+                    HIPCHK(hipMemsetAsync(lock, 0, n_all * 8, stream));
+                    HIPCHK(hipMemsetAsync(applied, 0, 8, stream));
+                    HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
+                    hipLaunchKernelGGL(k_opt_search, dim3(ablocks), dim3(BT), 0, stream, t, moves, (uint)round % (uint)ds.optimise_modulus, (uint)ds.optimise_modulus);
+                    hipLaunchKernelGGL(k_opt_lock, dim3(ablocks), dim3(BT), 0, stream, t, moves, lock, debug ? applied + 1 : nullptr);
+                    hipLaunchKernelGGL(k_opt_verify, dim3(ablocks), dim3(BT), 0, stream, t, moves, lock);
+                    hipLaunchKernelGGL(k_opt_apply, dim3(ablocks), dim3(BT), 0, stream, t, moves, applied);
+                    hipLaunchKernelGGL(k_opt_refit, dim3(blocks), dim3(BT), 0, stream, t, arrive, ranges);
+                    if (int rc = report(round + 1)) return rc;
+                }
+                parent_internal = t.parent;     // the first n - 1 entries are the inner nodes' parents
+            }
+            if (ds.builder != 0 || ds.dfs_layout || TR_BVH4 || optimise) {
                 int* new_id = reinterpret_cast<int*>(base + o_new_id);
                 if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);

@@ -1,0 +1,190 @@
+// Tree optimisation by parallel reinsertion (Meister & Bittner, "Parallel Reinsertion for Bounding Volume Hierarchy
+// Optimization", 2018) on the binary tree the PLOC / LBVH rounds leave behind, before it is relabelled and collapsed: what the
+// reference asks its driver for with ePreferFastTrace on static meshes (src/acceleration_structure.cc:129-133).
+//
+// One round: every node x looks for the place in the tree where hanging it - together with its parent p, which is spliced out
+// and re-used as the new inner node - lowers the sum of the inner nodes' surface areas most (branch-and-bound walk: up from p,
+// and at every pivot on the way down into the subtree on the other side); every candidate move stamps its gain on the nodes it
+// needs untouched (64-bit atomicMax of gain | node id: the result does not depend on thread order), the moves that own all their
+// stamps are applied, and the boxes are refitted bottom-up.  Included by bvh_build.hip only.
+#pragma once
+
+namespace tr {
+namespace {
+
+// Nodes carry one id here: inner node i -> i, leaf l -> n_inner + l.  `children` keeps the builder's references (>= 0 inner
+// node, < 0 leaf ~l); `parent[id]` = inner node or -1 for the root (node 0).
+struct OptTree {
+    uint n_inner, n_leaf;
+    int2* children;
+    float* node_box;          // 6 per inner node
+    const float* leaf_box;    // 6 per leaf
+    int* parent;              // n_inner + n_leaf
+};
+TR_DEV int opt_id(int ref, uint n_inner) { return ref >= 0 ? ref : (int)n_inner + ~ref; }
+TR_DEV int opt_ref(int id, uint n_inner) { return id < (int)n_inner ? id : ~(id - (int)n_inner); }
+TR_DEV const float* opt_box(const OptTree& t, int id) { return id < (int)t.n_inner ? t.node_box + 6 * (size_t)id : t.leaf_box + 6 * (size_t)(id - (int)t.n_inner); }
+TR_DEV float opt_area(const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; }
+TR_DEV int opt_sibling(const OptTree& t, int parent, int child) {
+    const int2 ch = t.children[parent];
+    const int a = opt_id(ch.x, t.n_inner);
+    return a == child ? opt_id(ch.y, t.n_inner) : a;
+}
+
+__global__ __launch_bounds__(BT) void k_opt_parents(OptTree t) {
+    const uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= t.n_inner) return;
+    const int2 ch = t.children[i];
+    t.parent[opt_id(ch.x, t.n_inner)] = (int)i;
+    t.parent[opt_id(ch.y, t.n_inner)] = (int)i;
+    if (i == 0) t.parent[0] = -1;
+}
+
+#define OPT_STACK 96
+#define OPT_MAX_STEPS 8192     // node visits one search may spend
+
+struct OptMove { int target, pivot; float gain; };   // hang x next to `target`; `pivot` = lowest common ancestor of the old and the new place
+
+// The best new place of every node.  `phase` / `modulus`: only nodes with id % modulus == phase search in this round.
+__global__ __launch_bounds__(BT) void k_opt_search(OptTree t, OptMove* moves, uint phase, uint modulus) {
+    const uint x = blockIdx.x * BT + threadIdx.x;
+    const uint n_all = t.n_inner + t.n_leaf;
+    if (x >= n_all) return;
+    OptMove mv = {-1, -1, 0.0f};
+    const int p = t.parent[x];
+    if (p > 0 && x % modulus == phase) {     // the root and its children stay where they are
+        float bx[6];
+        { const float* b = opt_box(t, (int)x); for (int k = 0; k < 6; ++k) bx[k] = b[k]; }
+        const float ax = opt_area(bx);
+        float d_path = opt_area(t.node_box + 6 * (size_t)p);     // what the path below the pivot saves once x and p are gone
+        float bw[6] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+        int stack_node[OPT_STACK]; float stack_ind[OPT_STACK];
+        int steps = 0;
+        int prev = (int)x;
+        for (int pivot = p; pivot >= 0 && steps < OPT_MAX_STEPS; prev = pivot, pivot = t.parent[pivot]) {
+            const int sib = opt_sibling(t, pivot, prev);
+            int sp = 0;
+            stack_node[sp] = sib; stack_ind[sp] = 0.0f; sp++;
+            while (sp > 0 && steps < OPT_MAX_STEPS) {
+                --sp; ++steps;
+                const int y = stack_node[sp]; const float ind = stack_ind[sp];
+                const float* by = opt_box(t, y);
+                float u[6];
+                for (int k = 0; k < 3; ++k) { u[k] = fminf(by[k], bx[k]); u[3 + k] = fmaxf(by[3 + k], bx[3 + k]); }
+                const float direct = opt_area(u);
+                const float gain = d_path - ind - direct;
+                if (gain > mv.gain) { mv.gain = gain; mv.target = y; mv.pivot = pivot; }
+                if (y < (int)t.n_inner) {
+                    const float ind2 = ind + direct - opt_area(by);       // what y's own growth costs every place below it
+                    if (d_path - ind2 - ax > mv.gain && sp + 2 <= OPT_STACK) {
+                        const int2 ch = t.children[y];
+                        stack_node[sp] = opt_id(ch.x, t.n_inner); stack_ind[sp] = ind2; sp++;
+                        stack_node[sp] = opt_id(ch.y, t.n_inner); stack_ind[sp] = ind2; sp++;
+                    }
+                }
+            }
+            const float* bs = opt_box(t, sib);
+            for (int k = 0; k < 3; ++k) { bw[k] = fminf(bw[k], bs[k]); bw[3 + k] = fmaxf(bw[3 + k], bs[3 + k]); }
+            if (pivot != p) d_path += opt_area(t.node_box + 6 * (size_t)pivot) - opt_area(bw);   // the pivot shrinks to what is left below it
+        }
+        // a move must pay for itself beyond rounding noise
+        if (!(mv.gain > 1e-6f * ax)) mv.target = -1;
+    }
+    moves[x] = mv;
+}
+
+TR_DEV unsigned long long opt_key(float gain, uint x) { return ((unsigned long long)__float_as_uint(gain) << 32) | (unsigned long long)x; }
+
+// The nodes a move needs untouched by any other move of the round: x, its sibling and p (rewired), and the target with its
+// ancestors below the pivot.  The last is what keeps the tree a tree: two moves whose targets lie in each other's moved
+// subtrees would close a cycle, and then one's x or p is an ancestor of the other's target below its pivot - a stamp both
+// want.  The old ancestors of p are not protected: a concurrent move there only makes the gain an estimate (the boxes are
+// refitted afterwards anyway).  f(id) is called for each node of the set.
+template <typename F>
+TR_DEV void opt_for_lock_set(const OptTree& t, uint x, const OptMove& mv, F f) {
+    const int p = t.parent[x];
+    f((int)x); f(opt_sibling(t, p, (int)x)); f(p);
+    for (int a = mv.target; a >= 0 && a != mv.pivot; a = t.parent[a]) f(a);
+}
+
+__global__ __launch_bounds__(BT) void k_opt_lock(OptTree t, const OptMove* moves, unsigned long long* lock, uint* candidates) {
+    const uint x = blockIdx.x * BT + threadIdx.x;
+    if (x >= t.n_inner + t.n_leaf) return;
+    const OptMove mv = moves[x];
+    if (mv.target < 0) return;
+    if (candidates) atomicAdd(candidates, 1u);
+    const unsigned long long key = opt_key(mv.gain, x);
+    opt_for_lock_set(t, x, mv, [&](int id) { atomicMax(&lock[id], key); });
+}
+
+// Drops the moves that do not own every stamp of their lock set (the tree is only read here).
+__global__ __launch_bounds__(BT) void k_opt_verify(OptTree t, OptMove* moves, const unsigned long long* lock) {
+    const uint x = blockIdx.x * BT + threadIdx.x;
+    if (x >= t.n_inner + t.n_leaf) return;
+    const OptMove mv = moves[x];
+    if (mv.target < 0) return;
+    const unsigned long long key = opt_key(mv.gain, x);
+    bool mine = true;
+    opt_for_lock_set(t, x, mv, [&](int id) { mine = mine && lock[id] == key; });
+    if (!mine) moves[x].target = -1;
+}
+
+// Applies the surviving moves.  A move reads and writes only nodes it owns, plus two child slots it finds by ids it owns (the
+// one holding p in p's parent, the one holding the target in the target's parent): two moves never touch the same word.
+__global__ __launch_bounds__(BT) void k_opt_apply(OptTree t, const OptMove* moves, uint* applied) {
+    const uint x = blockIdx.x * BT + threadIdx.x;
+    if (x >= t.n_inner + t.n_leaf) return;
+    const OptMove mv = moves[x];
+    if (mv.target < 0) return;
+    const int p = t.parent[x], y = mv.target;
+    const int s = opt_sibling(t, p, (int)x);
+    const int g = t.parent[p], q = t.parent[y];
+    int* ch = reinterpret_cast<int*>(t.children);
+    const int ref_p = opt_ref(p, t.n_inner), ref_s = opt_ref(s, t.n_inner), ref_y = opt_ref(y, t.n_inner), ref_x = opt_ref((int)x, t.n_inner);
+    // s takes p's place
+    if (ch[2 * g] == ref_p) ch[2 * g] = ref_s; else ch[2 * g + 1] = ref_s;
+    t.parent[s] = g;
+    // p takes y's place (q may be g or s by now: read after the write above)
+    if (ch[2 * q] == ref_y) ch[2 * q] = ref_p; else ch[2 * q + 1] = ref_p;
+    t.parent[p] = q;
+    ch[2 * p] = ref_y; ch[2 * p + 1] = ref_x;
+    t.parent[y] = p;
+    atomicAdd(applied, 1u);
+}
+
+// Bottom-up boxes and leaf counts of the whole tree (the second thread to reach a node owns it, as k_refit).
+__global__ __launch_bounds__(BT) void k_opt_refit(OptTree t, uint* arrive, uint* subtree_size) {
+    const uint leaf = blockIdx.x * BT + threadIdx.x;
+    if (leaf >= t.n_leaf) return;
+    int node = t.parent[t.n_inner + leaf];
+    while (node >= 0) {
+        __threadfence();
+        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) return;
+        __threadfence();
+        const int2 ch = t.children[node];
+        const float* b0 = ch.x >= 0 ? t.node_box + 6 * (size_t)ch.x : t.leaf_box + 6 * (size_t)(~ch.x);
+        const float* b1 = ch.y >= 0 ? t.node_box + 6 * (size_t)ch.y : t.leaf_box + 6 * (size_t)(~ch.y);
+        for (int k = 0; k < 3; ++k) {
+            const float l0 = __hip_atomic_load(&b0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h0 = __hip_atomic_load(&b0[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float l1 = __hip_atomic_load(&b1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h1 = __hip_atomic_load(&b1[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&t.node_box[6 * (size_t)node + k], fminf(l0, l1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&t.node_box[6 * (size_t)node + 3 + k], fmaxf(h0, h1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint n0 = ch.x >= 0 ? __hip_atomic_load(&subtree_size[ch.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+        const uint n1 = ch.y >= 0 ? __hip_atomic_load(&subtree_size[ch.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+        __hip_atomic_store(&subtree_size[node], n0 + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        node = t.parent[node];
+    }
+}
+
+// sum of the inner nodes' areas (the part of the SAH cost a reinsertion can change), for TRHIP_DEBUG
+__global__ __launch_bounds__(BT) void k_opt_cost(OptTree t, double* sum) {
+    const uint i = blockIdx.x * BT + threadIdx.x;
+    double a = i < t.n_inner ? (double)opt_area(t.node_box + 6 * (size_t)i) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, a);
+}
+
+}  // namespace
+}  // namespace tr

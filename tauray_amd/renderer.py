@@ -165,10 +165,12 @@ class Context:
 class SceneStage:
     """scene_stage: uploads the flattened scene and builds the acceleration structure on the device."""
 
-    def __init__(self, ctx: Context, scene: Optional[SceneDesc] = None):
+    def __init__(self, ctx: Context, scene: Optional[SceneDesc] = None, fast_trace_rebuilds: bool = False):
         self.ctx = ctx
         self.scene = None
         self.accel = None
+        # the first build of a scene is a static build (tree optimisation on); rebuilds after a change are fast builds unless asked
+        self.fast_trace_rebuilds = fast_trace_rebuilds
         if scene is not None:
             self.set_scene(scene)
 
@@ -211,6 +213,7 @@ class SceneStage:
             self.set_skin(sk.instance, sk.skins)
             self.skin(sk.instance, scene.joint_transforms(sk), refit=None)
         info = AccelInfoC()
+        check(L.trhip_scene_set_build_mode(self.ctx.h, 0))
         check(L.trhip_scene_build_accel(self.ctx.h, C.byref(info)))
         self.accel = dict(triangle_count=info.triangle_count, node_count=info.node_count,
                           tri_light_count=info.tri_light_count, build_ms=info.build_ms,
@@ -247,6 +250,8 @@ class SceneStage:
         if refit:
             check(_lib.lib().trhip_scene_refit_accel(self.ctx.h, C.byref(info)))
         else:
+            # a scene that is rebuilt after its first build is dynamic: ePreferFastBuild (src/acceleration_structure.cc:129-131)
+            check(_lib.lib().trhip_scene_set_build_mode(self.ctx.h, 0 if self.fast_trace_rebuilds else 1))
             check(_lib.lib().trhip_scene_build_accel(self.ctx.h, C.byref(info)))
         self.accel.update(node_count=info.node_count, build_ms=info.build_ms, tri_light_count=info.tri_light_count,
                           bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))

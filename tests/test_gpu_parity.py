@@ -994,6 +994,37 @@ def test_skinned_glb_scene(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_tree_optimisation_changes_the_work_not_the_hits(R, ctx):
+    """trhip_scene_set_build_mode: the static build (reinsertion rounds on the binary tree, csrc/bvh_optimize.h) and the fast
+    build give the same hits - the same frame bit for bit - and the optimised tree needs fewer node visits for them."""
+    from tauray_amd import scenes
+    W, H = 640, 360
+    scene = scenes.sponza_class(seed=5, target_tris=120000, width=W, height=H)
+    opt = R.options_for_scene(scene, max_bounces=3)
+
+    def frame_and_visits(ss):
+        pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+        pt.set_profiling(True, False)
+        buf = ctx.alloc(W * H * 16).zero()
+        pt.run(buf)
+        c = pt.counters()
+        pt.close()
+        assert c["stack_overflows"] == 0
+        return buf.download((H, W, 4)), c["node_visits"], c["closest_rays"] + c["shadow_rays"]
+
+    ss = R.SceneStage(ctx, scene)                       # first build of a scene: prefer fast trace
+    a, visits_opt, rays = frame_and_visits(ss)
+    ss.update_instances(scene.instances)                # a rebuild after a change: prefer fast build
+    b, visits_fast, rays_b = frame_and_visits(ss)
+    assert np.array_equal(a, b) and rays == rays_b, f"{int((a != b).any(-1).sum())} pixels differ between the optimised and the fast build"
+    assert visits_opt < 0.99 * visits_fast, (visits_opt, visits_fast)
+    ss2 = R.SceneStage(ctx, scene, fast_trace_rebuilds=True)
+    ss2.update_instances(scene.instances)
+    c, visits_again, _ = frame_and_visits(ss2)
+    assert np.array_equal(a, c) and abs(visits_again - visits_opt) <= 1e-3 * visits_opt, (visits_again, visits_opt)
+
+
+@pytest.mark.gpu
 def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     """BASELINE config 4 at its full size (sponza_teapots, 1920x1080, 4 bounces), through properties that need no oracle: the
     frame does not depend on the tree (PLOC vs LBVH build, refit vs rebuild), on how it is sharded (8 shuffled-strip shards,
@@ -1890,12 +1921,13 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     variants = {"default": {}, "one_lane_unfused": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0"}, "no_overlap": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0", "TRHIP_OVERLAP": "0"},
                 "two_lanes": {"TRHIP_LANES": "2"}, "small_grids": {"TRHIP_GRID_BLOCKS": "300", "TRHIP_SHADE_BLOCKS": "100"},
                 "treetop": {"TRHIP_TREETOP": "1"}, "shade_split": {"TRHIP_SHADE_SPLIT": "1"}, "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
-                "lbvh": {"TRHIP_BUILDER": "lbvh"}}
+                "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"},
+                "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"}}
     frames = {}
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
