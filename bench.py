@@ -14,8 +14,10 @@ options at the reference's CLI defaults), followed by the multi-GPU gather/stitc
 save are outside the timed region (reference README "Benchmarking", docs/MANUAL.md:405-408).
 
 Prints ONE JSON line (rank 0).  `value` = rays actually traced (closest-hit + shadow, device counters) per second
-over all GPUs.  With N > 1 the frame is sharded by interleaved scanlines (DISTRIBUTION_SCANLINE) and the partial
-frames are gathered on rank 0 over RCCL: total work is fixed, so scaling is "strong".
+over all GPUs.  With N > 1 the pixels of the frame are sharded - shuffled strips (DISTRIBUTION_SHUFFLED_STRIPS, the
+reference's command-line default) whose shares its load balancer settles during the untimed frames, or interleaved
+scanlines with --strategy scanline - and the partial frames are gathered on rank 0 over RCCL: total work is fixed, so
+scaling is "strong".
 
 The K timed frames are K distinct frames (frame index = sample counter), four of them in flight at a time on their own
 streams like the reference's frame slots (--frames-in-flight); the region is closed by a
@@ -55,6 +57,10 @@ def parse():
     ap.add_argument("--views", type=int, default=1, help="camera-grid viewports per frame (45 = the 5x9 light field of config 5)")
     ap.add_argument("--shard", default="pixels", choices=["pixels", "views", "samples"],
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
+    ap.add_argument("--strategy", default="auto", choices=["auto", "scanline", "strips"],
+                    help="how N > 1 GPUs divide the pixels of a frame: interleaved scanlines, or shuffled strips whose shares the load "
+                         "balancer sets (the reference's command-line default, src/tauray.cc:519-521); auto = strips")
+    ap.add_argument("--no-balance", action="store_true", help="shuffled strips with equal shares: no load-balancer updates during the untimed frames")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
@@ -99,7 +105,7 @@ def main():
         faulthandler.dump_traceback_later(watchdog, exit=True)
     from tauray_amd import renderer as R
     from tauray_amd import scenes
-    from tauray_amd.distribution import DISTRIBUTION_SCANLINE
+    from tauray_amd.distribution import DISTRIBUTION_SCANLINE, DISTRIBUTION_SHUFFLED_STRIPS, LoadBalancer
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 4
@@ -138,8 +144,9 @@ def main():
         scene.cameras = generate_camera_grid(scene.cameras[0], gw, args.views // gw, 0.02, 0.02, 5.0)
     ctx = R.Context(local_rank)
     opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
-    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, rank=rank, world_size=world, viewports=args.views,
-                      shard=args.shard, frames_in_flight=args.frames_in_flight)
+    strips = world > 1 and args.shard == "pixels" and args.strategy != "scanline"
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE, rank=rank, world_size=world,
+                      viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight)
 
     def sync_all():
         rr.sync()
@@ -160,7 +167,35 @@ def main():
     rr.set_profiling(False, False)
     # Not part of the W warm-up steps: a fresh box takes a few hundred milliseconds of work to reach its clocks and to fault
     # in every buffer, more than W = 3 frames of 2 ms give it.  A fixed frame count keeps the ranks of a multi-GPU job in step.
-    run_frames(args.prewarm)
+    balance = None
+    if strips and not args.no_balance and args.prewarm >= 16:
+        # load_balancer (src/load_balancer.cc:12-32, updated once per frame by src/tauray.cc:1005-1116) during the untimed frames:
+        # share / time = a device's speed, the shares move towards speed / sum of speeds by the reference's 0.1 EMA step.  The
+        # reference times "path tracing" on every device; with frames in flight that timer spans several overlapping frames and
+        # says little about what a share costs (tools/display_rank_probe.py), so a rank's time is the wall time per frame of its
+        # own work running free - path tracing of its share and, on the display rank, the stitch and the tonemap next to it
+        # (transfer.StandaloneExchange: nothing travels during these frames).  The display rank ends up with less than 1 / N.
+        # Reading the clocks drains the frame slots, which the timed frames should not pay for: the shares then stay.
+        from tauray_amd.transfer import StandaloneExchange
+        lb = LoadBalancer(world)
+        every, rounds = 8, 24
+        rr.exchange = StandaloneExchange()
+        run_frames(max(args.prewarm - every * rounds, 8))
+        for _ in range(rounds):
+            rr.sync()
+            t1 = time.perf_counter()
+            run_frames(every)
+            rr.sync()
+            times = [0.0] * world
+            dist.all_gather_object(times, (time.perf_counter() - t1) / every * 1e3)
+            rr.set_device_workloads(lb.update(times))
+        rr.exchange = None
+        balance = {"updates": rounds, "frames_per_update": every, "workloads": [round(w, 4) for w in lb.workloads],
+                   "ms_per_frame_running_free": [round(t, 4) for t in times]}
+        sync_all()
+        run_frames(args.frames_in_flight * 2)
+    else:
+        run_frames(args.prewarm)
     sync_all()
     rr.reset_accumulation(reset_sample_counter=True)
     run_frames(args.warmup)
@@ -196,11 +231,13 @@ def main():
         "dtype": "f32", "data": "synthetic" if args.workload != "test_glb" else "reference fixture test/test.glb (81 364 triangles)",
         "config": {"workload": args.workload, "triangles": scene.triangle_count, "width": W, "height": H, "bounces": args.bounces,
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
-                   "parallelism": ({"pixels": "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
+                   "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
+                                    else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
                    "views": args.views, "frames_in_flight": args.frames_in_flight, "prewarm_frames": args.prewarm,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
+        **({"load_balance": balance} if balance else {}),
         "rays_per_frame": rays_total // args.steps,
         "msample_per_s": round(W * H * args.views * args.spp * args.steps / elapsed / 1e6, 2),
     }

@@ -651,6 +651,13 @@ class RtRenderer:
                 total[k] = total.get(k, 0) + v
         return total
 
+    def path_tracing_ms(self) -> float:
+        """The "path tracing" timer the load balancer reads (src/load_balancer.cc:17,25): the last frame of every slot, averaged.
+        Waits for the slots."""
+        self.sync()
+        t = [slot.pt.timings()["path_tracing_ms"] for slot in self.slots]
+        return sum(t) / len(t)
+
     def set_device_workloads(self, ratios):
         """rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183): only for shuffled strips."""
         if self.strategy in (DISTRIBUTION_SCANLINE, DISTRIBUTION_DUPLICATE):

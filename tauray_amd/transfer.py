@@ -97,6 +97,32 @@ class LocalExchange:
         return {}
 
 
+class StandaloneExchange:
+    """Calibration only (bench.py's load-balancer phase): nothing travels.  The display rank stitches standing buffers of the
+    shapes it would receive, the other ranks send nothing, so every rank runs its share of a frame - the display rank with its
+    stitch and tonemap - uncoupled from the others, and its wall time per frame says what that share costs it."""
+
+    def __init__(self):
+        self.mailbox = {}
+
+    def attach(self, rank: int, ctx):
+        pass
+
+    def gather_to_display(self, color, dists: List[DistributionParams], rank: int, world_size: int, viewports: int, recv_buffers, ctx):
+        if rank != 0:
+            return {}
+        out = {}
+        for r in range(1, world_size):
+            shape = partial_shape(dists[r], viewports)
+            box = self.mailbox.get(r)
+            if box is None or box[1] != shape:
+                ctx.sync()          # a stitch of the previous shape may still read the old buffer
+                box = (ctx.alloc(max(shape[0] * shape[1] * shape[2] * 16, 16)).zero(), shape)
+                self.mailbox[r] = box
+            out[r] = box[0]
+        return out
+
+
 def shard_viewports(viewports: int, rank: int, world_size: int) -> List[int]:
     """View sharding: viewport v belongs to device v mod N."""
     return list(range(rank, viewports, world_size))

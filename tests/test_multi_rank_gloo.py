@@ -130,3 +130,50 @@ def test_view_and_sample_shards_equal_single_device(tmp_path, world, mode, oracl
     else:                   # same samples, summed in a different order
         ref = osc.render_pt(oracle.options_for_scene(scene, max_bounces=2, samples_per_pixel=SPP), W, H, frame_counter=1)
         assert float(np.abs(got[..., :3] - ref[..., :3]).max()) <= 2e-6 * max(1.0, float(np.abs(ref[..., :3]).max()))
+
+
+def _balance_worker(rank, world, port, out_path):
+    """bench.py's load-balancer rounds with a made-up cost model in place of the GPU: a rank's frame costs a fixed part (larger
+    on the display rank, which also stitches and tonemaps) plus a part proportional to its share of the pixels."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tauray_amd import distribution as D
+    lb = D.LoadBalancer(world)
+    fixed = 0.21 if rank == 0 else 0.12
+    history = []
+    for _ in range(60):
+        mine = fixed + 3.86 * lb.workloads[rank]
+        times = [0.0] * world
+        dist.all_gather_object(times, mine)
+        lb.update(times)
+        history.append(list(lb.workloads))
+    # what every rank would hand to set_device_workloads: the strips of the whole image, each exactly once
+    size = (1920, 1080)
+    cum, strips = 0.0, []
+    for i in range(world):
+        d = D.get_device_distribution_params(size, D.DISTRIBUTION_SHUFFLED_STRIPS, cum, lb.workloads[i], i, world, i == 0)
+        cum += lb.workloads[i]
+        strips.append((d.index, d.count))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, (history[-1], strips, times))
+    if rank == 0:
+        np.save(out_path, np.array([len({repr(e[:2]) for e in everyone})] + list(history[-1]) + list(everyone[0][2]) + [c for s in strips for c in s], dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_load_balancer_rounds_agree_on_every_rank_and_even_out_the_frame_times(tmp_path):
+    world = 4
+    out = str(tmp_path / "balance.npy")
+    port = 29500 + (os.getpid() + 977) % 2000
+    mp.spawn(_balance_worker, args=(world, port, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert r[0] == 1, "the ranks computed different shares from the same gathered times"
+    shares, times, strips = r[1:1 + world], r[1 + world:1 + 2 * world], r[1 + 2 * world:].reshape(world, 2)
+    assert abs(shares.sum() - 1) < 1e-9 and shares[0] < 1 / world < shares[1]
+    assert times.max() / times.min() < 1.01, times          # equal frame times: the display rank's extra work is paid for by a smaller share
+    # consecutive pixel ranges of whole strips that cover the image (src/distribution_strategy.cc:62-126)
+    assert strips[0, 0] == 0 and all(strips[i, 0] + strips[i, 1] == strips[i + 1, 0] for i in range(world - 1))
+    assert strips[-1, 0] + strips[-1, 1] >= 1920 * 1080

@@ -5,7 +5,7 @@ for f in ${@:-1 4}; do
 timeout 180 python bench.py --steps 5 --frames-in-flight $f --no-cpu-baseline --no-roofline --save-display /tmp/disp1.npy > /dev/null
 for n in 2 3; do
 echo "== F=$f N=$n"
-timeout 180 python bench.py --gpus $n --steps 5 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 0 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
+timeout 180 python bench.py --gpus $n --steps 5 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 200 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
 python - <<PY
 import numpy as np
 a=np.load('/tmp/disp1.npy')
@@ -14,6 +14,16 @@ try:
 except Exception as e: print('missing', e)
 PY
 done; done
+# the reference's other pixel strategy (interleaved scanlines, no balancing), and strips with equal shares
+for extra in "--strategy scanline" "--no-balance"; do
+timeout 180 python bench.py --gpus 2 --steps 5 --warmup 2 --dist-backend gloo --one-device --prewarm 0 $extra --save-display /tmp/dispx.npy > gpurun_out/rehearse_extra.log 2>&1
+python - <<PY
+import numpy as np
+try:
+    print("$extra equal:", np.array_equal(np.load('/tmp/disp1.npy'), np.load('/tmp/dispx.npy')))
+except Exception as e: print('$extra missing', e)
+PY
+done
 # view and sample shards (smaller frames: gloo moves device memory through the host)
 S="--width 640 --height 360 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline"
 T="python bench.py --gpus 2 --dist-backend gloo --one-device --prewarm 0"      # bench.py starts its own ranks
