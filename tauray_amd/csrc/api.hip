@@ -480,6 +480,7 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     if (const char* r = getenv("TRHIP_PLOC_RADIUS")) dev->scene.ploc_radius = std::max(1, atoi(r));
     if (const char* o = getenv("TRHIP_BVH_OPT")) dev->scene.optimise_rounds = std::max(0, atoi(o));
     if (const char* o = getenv("TRHIP_BVH_OPT_MOD")) dev->scene.optimise_modulus = std::max(1, atoi(o));
+    if (const char* c = getenv("TRHIP_COLLAPSE")) dev->scene.collapse_by_cost = std::string(c) != "greedy";
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
 }

@@ -48,6 +48,7 @@ struct DeviceScene {
     uint build_rounds = 0;
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int optimise_rounds = 8;             // reinsertion rounds after the build (bvh_optimize.h; TRHIP_BVH_OPT)
+    bool collapse_by_cost = true;        // 4-wide nodes chosen by least area sum (k_collapse_cost) instead of greedily (TRHIP_COLLAPSE=greedy)
     bool fast_build = false;             // trhip_scene_set_build_mode: no optimisation rounds
     int optimise_modulus = 1;            // a node searches every optimise_modulus-th round (TRHIP_BVH_OPT_MOD)
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)

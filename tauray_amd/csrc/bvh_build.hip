@@ -319,17 +319,25 @@ __global__ __launch_bounds__(BT) void k_emit_nodes(uint n_internal, const int2* 
     nodes[new_id[i]] = out;
 }
 
-// BVH2 -> BVH4, in place: every binary node keeps its (depth-first) index and adopts up to four descendants, found by
+}  // namespace
+}  // namespace tr
+#include "bvh_optimize.h"
+namespace tr {
+namespace {
+
+// BVH2 -> BVH4, in place: every binary node keeps its (depth-first) index and adopts up to four descendants: the ones
+// k_collapse_cost chose (`dec`: least sum of 4-wide node areas), or - dec = nullptr, TRHIP_COLLAPSE=greedy - found by
 // repeatedly opening the adopted inner node with the largest box.  Nodes that were adopted away are never referenced
 // again; they stay as dead 128-byte lines, which costs memory but neither bandwidth nor cache (a node is one line).
 __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* children, const float* node_box, const float* leaf_box, const int* new_id,
-                                                  Bvh4Node* nodes4) {
+                                                  const uint8_t* dec, Bvh4Node* nodes4) {
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= n_internal) return;
     int cand[4];
     cand[0] = children[i].x; cand[1] = children[i].y;
     int ncand = 2;
-    while (ncand < 4) {
+    if (dec) ncand = collapse_children(children, dec, (int)i, cand);
+    while (!dec && ncand < 4) {
         int best = -1; float best_area = -1.0f;
         for (int c = 0; c < ncand; ++c) {
             if (cand[c] < 0) continue;
@@ -358,12 +366,6 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
     nodes4[new_id[i]] = out;
 }
 
-
-}  // namespace
-}  // namespace tr
-#include "bvh_optimize.h"
-namespace tr {
-namespace {
 
 // shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
 __global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const uint* tri_prefix, TriLight* out) {
@@ -627,6 +629,9 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         }
         (void)hipFree(counter);
         ds.levels_valid = true;
+        if (getenv("TRHIP_DEBUG"))
+            fprintf(stderr, "[trhip] 4-wide tree: %u live nodes of %u slots in %zu levels, %.3f children per node\n", ds.level_offsets.back(), n1,
+                    ds.level_offsets.size() - 1, (double)(n + ds.level_offsets.back() - 1) / (double)ds.level_offsets.back());
     }
     if (n > 0) hipLaunchKernelGGL(k_retransform, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv, n, ds.tris);
     for (size_t l = ds.level_offsets.size(); l-- > 1;) {
@@ -684,8 +689,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                  o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(TR_BVH4 ? n1 * sizeof(BvhNode) : 0);
     const bool optimise = ds.optimise_rounds > 0 && !ds.fast_build && n > 2;
     const size_t n_all = (size_t)n + n1;
-    const size_t o_uparent = plan(optimise ? n_all * 4 : 0), o_moves = plan(optimise ? n_all * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all * 8 : 0),
-                 o_optstat = plan(64);
+    const bool dp_collapse = TR_BVH4 && ds.collapse_by_cost && !ds.fast_build && n > 2;   // a fast build keeps the greedy choice (the cost pass would double its time)
+    const size_t o_uparent = plan(optimise || dp_collapse ? n_all * 4 : 0), o_moves = plan(optimise ? n_all * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all * 8 : 0),
+                 o_optstat = plan(64), o_ccost = plan(dp_collapse ? n1 * 12 : 0), o_cdec = plan(dp_collapse ? n1 : 0);
     if (plan_bytes > ds.scratch_bytes) {
         if (ds.scratch) (void)hipFree(ds.scratch);
         ds.scratch = nullptr; ds.scratch_bytes = 0;
@@ -813,7 +819,15 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
 #if TR_BVH4
-                hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes4);
+                const uint8_t* dec = nullptr;
+                if (dp_collapse) {
+                    OptTree t{(uint)n1, n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
+                    if (!optimise) hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);
+                    HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
+                    hipLaunchKernelGGL(k_collapse_cost, dim3(blocks), dim3(BT), 0, stream, t, arrive, reinterpret_cast<float*>(base + o_ccost), reinterpret_cast<uint8_t*>(base + o_cdec));
+                    dec = reinterpret_cast<const uint8_t*>(base + o_cdec);
+                }
+                hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, dec, ds.nodes4);
 #else
                 hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
 #endif

@@ -186,5 +186,69 @@ __global__ __launch_bounds__(BT) void k_opt_cost(OptTree t, double* sum) {
     if ((threadIdx.x & 63) == 0) atomicAdd(sum, a);
 }
 
+
+// ---- which binary nodes become 4-wide nodes (after Ylitie, Karras & Laine 2017, section 3.1, for four-wide nodes over
+// single-triangle leaves).  cost(n, i), i = 1..3: the least sum of 4-wide node areas with which the subtree of n can hang in i
+// slots of a node above it: in one slot n is a 4-wide node itself (its area + the best way to deal its four slots to its two
+// children), in more slots it may instead be opened and its slots dealt to the children.  Leaves cost nothing in any number of
+// slots.  Bottom-up like k_opt_refit; `dec[n]` = bits 0-1: slots of the left child when n is a node (1..3), bit 2: in two
+// slots n is opened, bits 3-4: in three slots n is opened with that many slots for the left child (0 = n stays as in two).
+__global__ __launch_bounds__(BT) void k_collapse_cost(OptTree t, uint* arrive, float* cost /*3 per inner node*/, uint8_t* dec) {
+    const uint leaf = blockIdx.x * BT + threadIdx.x;
+    if (leaf >= t.n_leaf) return;
+    int node = t.parent[t.n_inner + leaf];
+    while (node >= 0) {
+        __threadfence();
+        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) return;
+        __threadfence();
+        const int2 ch = t.children[node];
+        float cl[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
+        if (ch.x >= 0) for (int k = 0; k < 3; ++k) cl[k] = __hip_atomic_load(&cost[3 * (size_t)ch.x + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ch.y >= 0) for (int k = 0; k < 3; ++k) cr[k] = __hip_atomic_load(&cost[3 * (size_t)ch.y + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float d4 = cl[0] + cr[2]; uint m4 = 1;
+        if (cl[1] + cr[1] < d4) { d4 = cl[1] + cr[1]; m4 = 2; }
+        if (cl[2] + cr[0] < d4) { d4 = cl[2] + cr[0]; m4 = 3; }
+        const float c1 = opt_area(t.node_box + 6 * (size_t)node) + d4;
+        const float d2 = cl[0] + cr[0];
+        const uint open2 = d2 < c1 ? 1u : 0u;
+        const float c2 = open2 ? d2 : c1;
+        float d3 = cl[0] + cr[1]; uint m3 = 1;
+        if (cl[1] + cr[0] < d3) { d3 = cl[1] + cr[0]; m3 = 2; }
+        const uint open3 = d3 < c2 ? m3 : 0u;
+        const float c3 = open3 ? d3 : c2;
+        __hip_atomic_store(&cost[3 * (size_t)node], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cost[3 * (size_t)node + 1], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cost[3 * (size_t)node + 2], c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dec[node] = (uint8_t)(m4 | (open2 << 2) | (open3 << 3));
+        node = t.parent[node];
+    }
+}
+
+// The references that fill the four slots of binary node n as a 4-wide node, in order; returns how many.
+TR_DEV int collapse_children(const int2* children, const uint8_t* dec, int n, int out[4]) {
+    int stack_node[8], stack_slots[8];
+    int sp = 0, count = 0;
+    const int2 ch = children[n];
+    const int m4 = dec[n] & 3;
+    stack_node[sp] = ch.y; stack_slots[sp] = 4 - m4; sp++;
+    stack_node[sp] = ch.x; stack_slots[sp] = m4; sp++;
+    while (sp > 0) {
+        --sp;
+        const int node = stack_node[sp];
+        int slots = stack_slots[sp];
+        if (node < 0) { out[count++] = node; continue; }
+        const uint d = dec[node];
+        int left = 0;                                   // slots of the left child once the node is opened; 0 = it stays a node
+        if (slots == 3) { left = (int)((d >> 3) & 3u); if (left == 0) slots = 2; }
+        if (slots == 2 && left == 0) left = (int)((d >> 2) & 1u);
+        if (left == 0) { out[count++] = node; continue; }
+        const int2 c = children[node];
+        stack_node[sp] = c.y; stack_slots[sp] = slots - left; sp++;
+        stack_node[sp] = c.x; stack_slots[sp] = left; sp++;
+    }
+    return count;
+}
+
 }  // namespace
 }  // namespace tr
