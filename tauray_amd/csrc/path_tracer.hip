@@ -1264,10 +1264,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
     }
-    // A stage told to run as one lane shares the chip with the other frames in flight (frame slots): four blocks per CU per
-    // launch instead of eight leave room for their launches (sponza_teapots 4.33 -> 4.18 ms per frame with four slots, sponza_class
-    // 3.59 -> 3.44; a lone frame loses as much, which is what the four lanes of the automatic schedule are for).
-    const uint grid_cap = (lanes == 1 && !timing && !getenv("TRHIP_GRID_BLOCKS")) ? 1024u : trace_grid_cap();
+    // Trace launches of frames that share the chip - with the other frames in flight (frame slots, one lane each) or with the
+    // other three lanes of their own frame - get four blocks per CU instead of eight, which leaves room for the launches next
+    // to them (four slots: sponza_teapots 4.33 -> 4.18 ms per frame, sponza_class 3.59 -> 3.44; four lanes of a lone frame:
+    // 4.78 -> 4.52 ms, profiles/r2/schedule_sweep.txt).  Only a kernel that is timed alone wants the whole chip.
+    const uint grid_cap = (!timing && !getenv("TRHIP_GRID_BLOCKS")) ? 1024u : trace_grid_cap();
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
