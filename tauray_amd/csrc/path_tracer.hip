@@ -1123,6 +1123,7 @@ struct PtStage::Impl {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t lane_stream[PT_LANES] = {};   // lanes 2.. (lane 0 = caller's stream, lane 1 = side)
     hipEvent_t lane_join[PT_LANES] = {};
+    hipEvent_t pass_done[PT_LANES] = {};      // sample lanes: k_resolve of the lane's latest pass
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
@@ -1143,6 +1144,7 @@ PtStage::~PtStage() {
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
     if (impl->side) { (void)hipStreamDestroy(impl->side); (void)hipEventDestroy(impl->ev_fork); (void)hipEventDestroy(impl->ev_join); }
     for (int l = 2; l < PT_LANES; ++l) if (impl->lane_stream[l]) { (void)hipStreamDestroy(impl->lane_stream[l]); (void)hipEventDestroy(impl->lane_join[l]); }
+    for (auto& e : impl->pass_done) if (e) (void)hipEventDestroy(e);
     delete impl;
 }
 
@@ -1226,7 +1228,16 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     P.bounce_words = (uint)BC_STRIDE * ((uint)opt.max_bounces + 2u);
     P.fused_resolve = opt.samples_per_pass == 1;
     P.T = targets;
-    if (int rc = ensure_buffers(n, targets.diffuse || targets.reflection)) return rc;
+    const bool timing = detailed_timing != 0;
+    static const bool split = getenv("TRHIP_SHADE_SPLIT") && atoi(getenv("TRHIP_SHADE_SPLIT")) != 0;   // k_surface + k_shade<.., true>
+    // A frame of several one-sample passes can keep whole samples in flight instead of slices of one (see "sample lanes" below):
+    // every lane then needs path state for all n paths.
+    static const bool sample_lanes_enabled = !(getenv("TRHIP_SAMPLE_LANES") && atoi(getenv("TRHIP_SAMPLE_LANES")) == 0);
+    const int passes_total = opt.samples_per_pixel / opt.samples_per_pass;
+    const int sample_lane_count = std::min(passes_total, PT_LANES);
+    const bool sample_lanes = sample_lanes_enabled && !direct && !timing && !split && lanes == 0 && opt.samples_per_pass == 1 && passes_total >= 2 &&
+                              n * (size_t)sample_lane_count * 224u <= ((size_t)8 << 30);
+    if (int rc = ensure_buffers(sample_lanes ? n * (size_t)sample_lane_count : n, targets.diffuse || targets.reflection)) return rc;
     PathBuffers& pb = impl->pb;
     SceneView sv = scene->view();
     if (opt.pre_transformed_vertices) {   // PRE_TRANSFORMED_VERTICES: shade from scene_stage's world-space vertex copy
@@ -1234,9 +1245,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         sv.vertices = scene->world_vertices; sv.spans = scene->world_spans;
     }
     const bool count = count_work != 0;
-    const bool timing = detailed_timing != 0;
     const bool top = TR_BVH4 && sv.treetop != nullptr;   // trace blocks keep the top of the tree in LDS
-    static const bool split = getenv("TRHIP_SHADE_SPLIT") && atoi(getenv("TRHIP_SHADE_SPLIT")) != 0;   // k_surface + k_shade<.., true>
     if (split && !direct && !pb.surf) HIPCHK(hipMalloc(&pb.surf, impl->capacity * 5 * 16));
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
     // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
@@ -1253,7 +1262,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // by throughput; extra hardware queues only add dispatch latency there (measured: 1 M paths 1.68 ms on one lane, 1.94 ms
     // on four; 2 M paths 3.87 ms vs 3.10 ms).
     static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)1500000;
-    const int n_lanes = timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(lanes_env, PT_LANES))));
+    //  * sample lanes (a frame of two or more one-sample passes, the offline case - BASELINE config 3 is 4096 of them): the lanes
+    //    take turns with whole samples instead of sharing one, each with path state of its own, so that up to four samples are
+    //    in flight like the frames of a renderer with frame slots (3.4 instead of 4.0 ms per sample on sponza_class).  A pass
+    //    ends in k_resolve, which blends into the targets and therefore runs in pass order: each one waits for the previous
+    //    pass's, on whatever lane that ran.
+    const int n_lanes = sample_lanes ? sample_lane_count
+                                     : (timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(lanes_env, PT_LANES)))));
     // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
     static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
     const bool first_hit_targets = targets.albedo || targets.material || targets.normal || targets.pos || targets.instance_id || targets.screen_motion;
@@ -1329,33 +1344,55 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
         for (int l = 2; l < n_lanes; ++l) HIPCHK(hipStreamWaitEvent(impl->lane_stream[l], impl->ev_fork, 0));
     }
-    const uint per_lane = (uint)((((n + n_lanes - 1) / n_lanes + 63) / 64) * 64);   // whole 8x8 tiles per lane
+    const uint per_lane = sample_lanes ? (uint)n : (uint)((((n + n_lanes - 1) / n_lanes + 63) / 64) * 64);   // whole 8x8 tiles per lane
     {   // interleave the lanes' tiles when the image is whole tiles and divides evenly (always true for 1080p / 4 lanes)
         const size_t tiles = n / 64;
-        const bool even = viewports == 1 && (lw & 7u) == 0 && (lh & 7u) == 0 && n_lanes > 1 && tiles % (size_t)n_lanes == 0 &&
+        const bool even = !sample_lanes && viewports == 1 && (lw & 7u) == 0 && (lh & 7u) == 0 && n_lanes > 1 && tiles % (size_t)n_lanes == 0 &&
                           (size_t)per_lane * (size_t)n_lanes == n;
         P.L.tile_lanes = even ? (uint)n_lanes : 1u;
         P.L.tiles_per_lane = even ? (uint)(tiles / (size_t)n_lanes) : 0u;
     }
+    if (sample_lanes) for (int l = 0; l < n_lanes; ++l) if (!impl->pass_done[l]) HIPCHK(hipEventCreateWithFlags(&impl->pass_done[l], hipEventDisableTiming));
+    struct LaneCtx { hipStream_t ls; PtParams LP; PathBuffers lb; uint blocks_all, blocks_q; bool shadow_in_flight; };
+    LaneCtx lane_ctx[PT_LANES];
+    int lanes_used = 0;
     for (int lane = 0; lane < n_lanes; ++lane) {
-        const hipStream_t ls = lane == 0 ? stream : (lane == 1 ? impl->side : impl->lane_stream[lane]);
-        PtParams LP = P;
-        LP.id_offset = (uint)lane * per_lane;
-        if (LP.id_offset >= n) break;
-        LP.n_ids = std::min(per_lane, (uint)n - LP.id_offset);
-        PathBuffers lb = pb;   // the lane's view: shared per-path arrays, its own queues / shadow queue / counters
+        LaneCtx& c = lane_ctx[lane];
+        c.ls = lane == 0 ? stream : (lane == 1 ? impl->side : impl->lane_stream[lane]);
+        c.LP = P;
+        c.LP.id_offset = sample_lanes ? 0u : (uint)lane * per_lane;
+        if (c.LP.id_offset >= n) break;
+        c.LP.n_ids = std::min(per_lane, (uint)n - c.LP.id_offset);
+        PathBuffers& lb = c.lb;
+        lb = pb;   // the lane's view: its own queues / shadow queue / counters; the per-path arrays shared (slices of one sample) or its own (sample lanes)
         lb.counters = pb.counters + lane * CNT_WORDS;
         lb.bounce = pb.bounce + (size_t)lane * P.bounce_words;
         lb.qspill = pb.qspill + (size_t)lane * impl->qspill_lane_words;
-        lb.queue[0] = pb.queue[0] + LP.id_offset; lb.queue[1] = pb.queue[1] + LP.id_offset;
-        lb.sh_org_tmax = pb.sh_org_tmax + LP.id_offset; lb.sh_dir_id = pb.sh_dir_id + LP.id_offset;
-        lb.sh_contrib = pb.sh_contrib + LP.id_offset; lb.sh_lobes = pb.sh_lobes + LP.id_offset;
-        const uint blocks_all = (LP.n_ids + KB - 1) / KB;
+        const size_t q0 = sample_lanes ? (size_t)lane * n : (size_t)c.LP.id_offset;
+        lb.queue[0] = pb.queue[0] + q0; lb.queue[1] = pb.queue[1] + q0;
+        lb.sh_org_tmax = pb.sh_org_tmax + q0; lb.sh_dir_id = pb.sh_dir_id + q0;
+        lb.sh_contrib = pb.sh_contrib + q0; lb.sh_lobes = pb.sh_lobes + q0;
+        if (sample_lanes) {
+            const size_t o = (size_t)lane * n;
+            lb.org_pdf += o; lb.dir_reg += o; lb.atten_alpha += o; lb.diffuse += o; lb.reflection += o; lb.plobes += o; lb.first_mat += o; lb.first_emis += o;
+            lb.rng += o; lb.misc += o; lb.hit += o;
+        }
+        c.blocks_all = (c.LP.n_ids + KB - 1) / KB;
         // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
-        const uint blocks_q = blocks_all < grid_cap ? blocks_all : grid_cap;
-        bool shadow_in_flight = false;
-        const int passes = opt.samples_per_pixel / opt.samples_per_pass;
-        for (int pass = 0; pass < passes; ++pass) {
+        c.blocks_q = c.blocks_all < grid_cap ? c.blocks_all : grid_cap;
+        c.shadow_in_flight = false;
+        lanes_used = lane + 1;
+    }
+    const int passes = passes_total;
+    // every launch of one pass of one lane
+    auto enqueue_pass = [&](int lane, int pass) -> int {
+        LaneCtx& c = lane_ctx[lane];
+        const hipStream_t ls = c.ls;
+        PtParams& LP = c.LP;
+        PathBuffers& lb = c.lb;
+        const uint blocks_all = c.blocks_all, blocks_q = c.blocks_q;
+        bool& shadow_in_flight = c.shadow_in_flight;
+        {
             LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
             for (int s = 0; s < opt.samples_per_pass; ++s) {
                 LP.sample_in_pass = (uint)s;
@@ -1417,8 +1454,18 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                 if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
                 if (!LP.fused_resolve) hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, ls, LP, lb);
             }
+            // sample lanes: the targets have seen pass - 1 before this pass blends into them
+            if (sample_lanes && pass > 0) HIPCHK(hipStreamWaitEvent(ls, impl->pass_done[(pass - 1) % n_lanes], 0));
             timed(T_RESOLVE, ls, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, ls, LP, lb); });
+            if (sample_lanes && pass + 1 < passes) HIPCHK(hipEventRecord(impl->pass_done[lane], ls));
         }
+        return 0;
+    };
+    if (sample_lanes) {
+        for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(pass % lanes_used, pass)) return rc;
+    } else {
+        for (int lane = 0; lane < lanes_used; ++lane)
+            for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(lane, pass)) return rc;
     }
     if (n_lanes > 1) {   // join
         HIPCHK(hipEventRecord(impl->ev_join, impl->side));

@@ -1025,6 +1025,38 @@ def test_tree_optimisation_changes_the_work_not_the_hits(R, ctx):
 
 
 @pytest.mark.gpu
+def test_sample_lanes_render_the_frame_of_pixel_lanes(R, ctx, oracle):
+    """A frame of several one-sample passes keeps whole samples in flight on the stage's lanes (each with path state of its own,
+    k_resolve in pass order) instead of slices of one sample: the same bits as four pixel lanes, as one lane, and as the
+    oracle's frame within the usual tolerance; also with the demodulated targets, 3 passes on 4 lanes, and accumulated on top of
+    an earlier frame."""
+    from tauray_amd import scenes
+    W, H = 480, 270
+    scene = scenes.sponza_class(seed=9, target_tris=50000, width=W, height=H)
+    ss = R.SceneStage(ctx, scene)
+    for spp, extra in ((8, {}), (3, {}), (5, dict(film=2, sampler=1))):
+        opt = R.options_for_scene(scene, max_bounces=3, samples_per_pixel=spp, samples_per_pass=1, **extra)
+        frames = {}
+        for lanes in (0, 4, 1):
+            pt = R.PathTracerStage(ctx, ss, opt, _dup((W, H)))
+            pt.set_lanes(lanes)
+            color, diffuse, reflection = (ctx.alloc(W * H * 16).zero() for _ in range(3))
+            targets = {"color": color, "diffuse": diffuse, "reflection": reflection}
+            pt.run_targets(targets)
+            pt.run_targets(targets)          # a second frame accumulates on top (samples_accumulated = spp)
+            assert pt.counters()["stack_overflows"] == 0
+            frames[lanes] = np.concatenate([b.download((H, W, 4)) for b in (color, diffuse, reflection)], axis=-1)
+            pt.close()
+        assert np.isfinite(frames[0]).all() and frames[0][..., :3].mean() > 1e-3
+        for lanes in (4, 1):
+            assert np.array_equal(frames[0], frames[lanes]), f"{spp} spp: sample lanes vs {lanes} pixel lane(s): {int((frames[0] != frames[lanes]).any(-1).sum())} pixels differ"
+    osc = oracle.OracleScene(scene)
+    opt = R.options_for_scene(scene, max_bounces=3, samples_per_pixel=8, samples_per_pass=1)
+    _compare(_render_hip(R, ctx, ss, scene, (W, H), max_bounces=3, samples_per_pixel=8, samples_per_pass=1),
+             osc.render_pt(oracle.options_for_scene(scene, max_bounces=3, samples_per_pixel=8, samples_per_pass=1), W, H), "8 one-sample passes")
+
+
+@pytest.mark.gpu
 def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     """BASELINE config 4 at its full size (sponza_teapots, 1920x1080, 4 bounces), through properties that need no oracle: the
     frame does not depend on the tree (PLOC vs LBVH build, refit vs rebuild), on how it is sharded (8 shuffled-strip shards,

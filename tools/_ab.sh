@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for w in sponza_teapots test_glb sponza_class; do
-python bench.py --steps 40 --warmup 5 --workload $w --no-cpu-baseline --no-roofline --sustained-frames 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'], d['ms_per_step'], d['value'], d['ms_per_frame_sync'], d['value_sync_per_frame'])"
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sample_lanes" 2>&1 | tail -5
