@@ -797,6 +797,14 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                     HIPCHK(hipStreamSynchronize(stream));
                     uint moved[2]; memcpy(moved, &h[2], 8);
                     fprintf(stderr, "[trhip] tree optimisation round %d: inner area sum %.6g, %u of %u moves applied\n", round, h[0], round ? moved[0] : 0u, round ? moved[1] : 0u);
+                    if (round) {   // every box against its children, every leaf count, every parent link
+                        uint bad = 0;
+                        HIPCHK(hipMemsetAsync(applied, 0, 4, stream));
+                        hipLaunchKernelGGL(k_opt_check, dim3(iblocks), dim3(BT), 0, stream, t, ranges, applied);
+                        HIPCHK(hipMemcpyAsync(&bad, applied, 4, hipMemcpyDeviceToHost, stream));
+                        HIPCHK(hipStreamSynchronize(stream));
+                        if (bad) return set_error("tree optimisation: " + std::to_string(bad) + " inconsistent nodes after round " + std::to_string(round));
+                    }
                     return 0;
                 };
                 hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);

@@ -152,16 +152,22 @@ __global__ __launch_bounds__(BT) void k_opt_apply(OptTree t, const OptMove* move
     atomicAdd(applied, 1u);
 }
 
+// What the bottom-up passes hand from thread to thread (boxes, leaf counts, cost tables) is written and read with agent-scope
+// atomic stores and loads, which go past the caches that are not coherent between CUs and XCDs; the arrival counter is a
+// relaxed agent-scope atomic.  Between the two a thread only has to wait until its own stores have completed - no cache
+// write-back or invalidation, which is what made the release / acquire form of this loop (k_refit) cost 7 ms per million
+// triangles instead of 1.  TRHIP_DEBUG checks every box of the finished tree against its children (k_opt_check).
+TR_DEV void opt_publish() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 // Bottom-up boxes and leaf counts of the whole tree (the second thread to reach a node owns it, as k_refit).
 __global__ __launch_bounds__(BT) void k_opt_refit(OptTree t, uint* arrive, uint* subtree_size) {
     const uint leaf = blockIdx.x * BT + threadIdx.x;
     if (leaf >= t.n_leaf) return;
     int node = t.parent[t.n_inner + leaf];
     while (node >= 0) {
-        __threadfence();
-        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        opt_publish();
+        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == 0) return;
-        __threadfence();
         const int2 ch = t.children[node];
         const float* b0 = ch.x >= 0 ? t.node_box + 6 * (size_t)ch.x : t.leaf_box + 6 * (size_t)(~ch.x);
         const float* b1 = ch.y >= 0 ? t.node_box + 6 * (size_t)ch.y : t.leaf_box + 6 * (size_t)(~ch.y);
@@ -176,6 +182,21 @@ __global__ __launch_bounds__(BT) void k_opt_refit(OptTree t, uint* arrive, uint*
         __hip_atomic_store(&subtree_size[node], n0 + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         node = t.parent[node];
     }
+}
+
+
+// Debug: inner nodes whose box is not exactly the union of their children's, or whose leaf count is not the children's sum.
+__global__ __launch_bounds__(BT) void k_opt_check(OptTree t, const uint* subtree_size, uint* bad) {
+    const uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= t.n_inner) return;
+    const int2 ch = t.children[i];
+    const float* b0 = ch.x >= 0 ? t.node_box + 6 * (size_t)ch.x : t.leaf_box + 6 * (size_t)(~ch.x);
+    const float* b1 = ch.y >= 0 ? t.node_box + 6 * (size_t)ch.y : t.leaf_box + 6 * (size_t)(~ch.y);
+    bool ok = t.parent[opt_id(ch.x, t.n_inner)] == (int)i && t.parent[opt_id(ch.y, t.n_inner)] == (int)i;
+    for (int k = 0; k < 3; ++k) ok = ok && t.node_box[6 * (size_t)i + k] == fminf(b0[k], b1[k]) && t.node_box[6 * (size_t)i + 3 + k] == fmaxf(b0[3 + k], b1[3 + k]);
+    ok = ok && subtree_size[i] == (ch.x >= 0 ? subtree_size[ch.x] : 1u) + (ch.y >= 0 ? subtree_size[ch.y] : 1u);
+    if (i == 0) ok = ok && subtree_size[0] == t.n_leaf && t.parent[0] == -1;
+    if (!ok) atomicAdd(bad, 1u);
 }
 
 // sum of the inner nodes' areas (the part of the SAH cost a reinsertion can change), for TRHIP_DEBUG
@@ -198,10 +219,9 @@ __global__ __launch_bounds__(BT) void k_collapse_cost(OptTree t, uint* arrive, f
     if (leaf >= t.n_leaf) return;
     int node = t.parent[t.n_inner + leaf];
     while (node >= 0) {
-        __threadfence();
-        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        opt_publish();
+        const uint prev = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == 0) return;
-        __threadfence();
         const int2 ch = t.children[node];
         float cl[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
         if (ch.x >= 0) for (int k = 0; k < 3; ++k) cl[k] = __hip_atomic_load(&cost[3 * (size_t)ch.x + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

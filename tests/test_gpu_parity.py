@@ -994,7 +994,7 @@ def test_skinned_glb_scene(R, ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_tree_optimisation_changes_the_work_not_the_hits(R, ctx):
+def test_tree_optimisation_changes_the_work_not_the_hits(R, ctx, monkeypatch):
     """trhip_scene_set_build_mode: the static build (reinsertion rounds on the binary tree, csrc/bvh_optimize.h) and the fast
     build give the same hits - the same frame bit for bit - and the optimised tree needs fewer node visits for them."""
     from tauray_amd import scenes
@@ -1019,6 +1019,12 @@ def test_tree_optimisation_changes_the_work_not_the_hits(R, ctx):
     assert np.array_equal(a, b) and rays == rays_b, f"{int((a != b).any(-1).sum())} pixels differ between the optimised and the fast build"
     assert visits_opt < 0.99 * visits_fast, (visits_opt, visits_fast)
     ss2 = R.SceneStage(ctx, scene, fast_trace_rebuilds=True)
+    # with TRHIP_DEBUG a static build checks itself after every reinsertion round: every box against its children's, every leaf
+    # count, every parent link (k_opt_check); an inconsistent tree fails the build
+    monkeypatch.setenv("TRHIP_DEBUG", "1")
+    for _ in range(5):
+        ss2.update_instances(scene.instances)
+    monkeypatch.delenv("TRHIP_DEBUG")
     ss2.update_instances(scene.instances)
     c, visits_again, _ = frame_and_visits(ss2)
     assert np.array_equal(a, c) and abs(visits_again - visits_opt) <= 1e-3 * visits_opt, (visits_again, visits_opt)
