@@ -12,7 +12,7 @@ ctx = R.Context(0)
 sc = scenes.WORKLOADS[wname](W, H)
 opt = R.options_for_scene(sc, max_bounces=4, samples_per_pixel=1)
 for world in (1, 2, 4, 8):
-    for F in (1, 4, 6):
+    for F in (1, 4, 6, 8):
         rr = R.RtRenderer(ctx, sc, opt, (W, H), strategy=strategy, rank=world - 1, world_size=world, use_torch=False, frames_in_flight=F)
         def frames(n):
             for _ in range(n):
