@@ -108,17 +108,27 @@ def test_config3_full_size_accumulation_property(R, ctx):
     ss = R.SceneStage(ctx, scene)
     acc = ctx.alloc(W * H * 16).zero()
     pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=4), _dup((W, H)))
+    import time
     half = None
+    ctx.sync()
+    t0 = time.perf_counter()
     for f in range(N):
         pt.run(acc)
         if f == N // 2 - 1:
             half = acc.download((H, W, 4))
     frames = acc.download((H, W, 4))
+    seconds_frames = time.perf_counter() - t0
     assert pt.counters()["stack_overflows"] == 0
     pt.close()
     one = ctx.alloc(W * H * 16).zero()
     pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=4, samples_per_pixel=N, samples_per_pass=1), _dup((W, H)))
-    pt.run(one)
+    ctx.sync()
+    t0 = time.perf_counter()
+    pt.run(one)              # BASELINE config 3 as the reference renders it: one frame, N one-sample passes (sample lanes)
+    ctx.sync()
+    seconds_passes = time.perf_counter() - t0
+    rays = pt.counters()
+    rays = rays["closest_rays"] + rays["shadow_rays"]
     passes = one.download((H, W, 4))
     pt.close()
     # The integrand itself produces a NaN sample about once in 40 frames of this scene - in the oracle at the same pixel of the
@@ -133,7 +143,9 @@ def test_config3_full_size_accumulation_property(R, ctx):
     second = 2.0 * frames[..., :3][ok].astype(np.float64) - half[..., :3][ok]
     noise = _rms(half[..., :3][ok], second)
     _report("config3_full_size", {"scene": "sponza_class", "size": [W, H], "spp": N, "frames_equal_passes": True, "nan_pixels": int(nan_px.sum()),
-                                  "rms_between_sample_halves": noise, "mean_radiance": float(frames[..., :3][ok].mean())})
+                                  "rms_between_sample_halves": noise, "mean_radiance": float(frames[..., :3][ok].mean()),
+                                  "seconds_one_frame_of_passes": seconds_passes, "ms_per_sample": seconds_passes / N * 1e3,
+                                  "mray_per_s": rays / seconds_passes / 1e6, "seconds_accumulated_one_sample_frames": seconds_frames})
 
 
 def test_l2_against_the_reference_golden_image(R, ctx):
