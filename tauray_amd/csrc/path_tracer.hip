@@ -1284,6 +1284,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // to them (four slots: sponza_teapots 4.33 -> 4.18 ms per frame, sponza_class 3.59 -> 3.44; four lanes of a lone frame:
     // 4.78 -> 4.52 ms, profiles/r2/schedule_sweep.txt).  Only a kernel that is timed alone wants the whole chip.
     const uint grid_cap = (!timing && !getenv("TRHIP_GRID_BLOCKS")) ? 1024u : trace_grid_cap();
+    // A trace kernel that is timed alone gets exactly the blocks that are resident at its register budget (persistent waves: a
+    // block that has to wait for a slot only lengthens the tail): 1536 for the closest-hit kernel, 0.544 -> 0.527 ms per launch
+    // on sponza_teapots against the 2048 both used to get; the shadow kernel's budget is 8 per CU, i.e. 2048.
+    static const uint n_cu = [] { int dev = 0, cu = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return (uint)std::max(cu, 1); }();
+    const uint closest_cap = (timing && !getenv("TRHIP_GRID_BLOCKS")) ? std::min(n_cu * (uint)TR_CLOSEST_WAVES, trace_grid_cap()) : grid_cap;   // the spill buffer of the quad tail is sized by trace_grid_cap()
+    const uint shadow_cap = (timing && !getenv("TRHIP_GRID_BLOCKS")) ? std::min(n_cu * (uint)TR_SHADOW_WAVES, trace_grid_cap()) : grid_cap;
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
@@ -1412,7 +1418,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                             auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
                                             : (timing ? (top ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)
                                                       : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>));
-                            hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
+                            hipLaunchKernelGGL(kc, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
                         });
                     }
                     if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
@@ -1446,7 +1452,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         }
                         timed(T_SHADOW, ss, [&] {
                             auto ks = count ? (top ? k_trace_shadow<true, true> : k_trace_shadow<true, false>) : (top ? k_trace_shadow<false, true> : k_trace_shadow<false, false>);
-                            hipLaunchKernelGGL(ks, dim3(blocks_q), dim3(KB), 0, ss, sv, LP, lb, bc);
+                            hipLaunchKernelGGL(ks, dim3(std::min(blocks_all, shadow_cap)), dim3(KB), 0, ss, sv, LP, lb, bc);
                         });
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                     }
