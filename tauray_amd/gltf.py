@@ -18,6 +18,7 @@ from typing import List
 
 import numpy as np
 
+from . import animation as A
 from . import scene as S
 
 _COMP = {5120: ("i1", 1), 5121: ("u1", 1), 5122: ("<i2", 2), 5123: ("<u2", 2), 5125: ("<u4", 4), 5126: ("<f4", 4)}
@@ -285,8 +286,9 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
     voff = ioff = 0
     light_meta = {"angle": 0.0, "radius": 0.0}
     node_globals, skinned_pending = {}, []
+    nodes, roots = {}, []
 
-    def visit(node_index, parent):
+    def visit(node_index, parent, parent_index=-1):
         nonlocal voff, ioff
         node = j["nodes"][node_index]
         tr = node.get("extensions", {}).get("TR_data")
@@ -297,9 +299,15 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 light_meta["radius"] = float(tr["light"]["radius"])
         if "matrix" in node:
             local = np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T
+            rec = A.Node(parent_index, list(node.get("children", [])), None, local)
         else:
             local = S.trs_matrix(node.get("translation", (0, 0, 0)), node.get("rotation", (0, 0, 0, 1)),
                                  node.get("scale", (1, 1, 1)))
+            rec = A.Node(parent_index, list(node.get("children", [])),
+                         {"translation": np.array(node.get("translation", (0, 0, 0)), dtype=np.float64),
+                          "rotation": np.array(node.get("rotation", (0, 0, 0, 1)), dtype=np.float64),
+                          "scale": np.array(node.get("scale", (1, 1, 1)), dtype=np.float64)}, None)
+        nodes[node_index] = rec      # what SceneAnimator needs to move the node later (tauray_amd/animation.py)
         glob = parent @ local
         node_globals[node_index] = glob
 
@@ -313,6 +321,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                     skinned_pending.append((len(inst_list), node["skin"], skin))
                     inst_list.append(S.make_instance(np.eye(4), mat, sto))
                 else:
+                    rec.instances.append(len(inst_list))
                     inst_list.append(S.make_instance(glob, mat, sto))
                 span_list.append((voff, len(v), ioff, len(idx) // 3))
                 vert_list.append(v)
@@ -334,6 +343,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 o = c["orthographic"]
                 cam.projection = S.PROJ_ORTHOGRAPHIC
                 cam.ortho = (-0.5 * o["xmag"], 0.5 * o["xmag"], -0.5 * o["ymag"], 0.5 * o["ymag"], o["znear"], o["zfar"])
+            rec.cameras.append(len(cameras))
             cameras.append(cam)
 
         kl = node.get("extensions", {}).get("KHR_lights_punctual")
@@ -355,11 +365,29 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 spot_lights.append(S.make_spotlight(color / (4 * math.pi), position, direction,
                                                     light_meta["radius"], outer, fall))
         for ch in node.get("children", []):
-            visit(ch, glob)
+            visit(ch, glob, node_index)
 
     for sc in j.get("scenes", []):
         for n in sc["nodes"]:
+            roots.append(n)
             visit(n, np.eye(4))
+
+    # animation clips per node (src/gltf.cc:580-627): channel -> the target node's pool entry of the clip's name
+    animations = {}
+    for anim in j.get("animations", []):
+        for chan in anim["channels"]:
+            target = chan["target"]
+            if "node" not in target:
+                continue
+            sampler = anim["samplers"][chan["sampler"]]
+            interp = A.INTERPOLATION.get(sampler.get("interpolation", "LINEAR"), A.LINEAR)
+            path_name = target["path"]
+            if path_name not in ("translation", "rotation", "scale"):
+                continue            # morph-target weights
+            clip = animations.setdefault(target["node"], {}).setdefault(anim.get("name", ""), A.Animation())
+            track = A.read_track(g.accessor(sampler["input"]).astype(np.float32).reshape(-1),
+                                 g.accessor(sampler["output"]).astype(np.float32).reshape(-1, 4 if path_name == "rotation" else 3), interp)
+            setattr(clip, {"translation": "position", "rotation": "orientation", "scale": "scaling"}[path_name], track)
 
     aspect = aspect_ratio if aspect_ratio > 0 else width / float(height)
     for cam in cameras:
@@ -377,6 +405,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
         textures=textures, envmap=None, environment_factor=(0, 0, 0, 0), cameras=cameras,
         name=path.split("/")[-1])
     desc.node_globals = node_globals
+    desc.nodes, desc.roots, desc.animations = nodes, roots, animations
     for inst, skin_index, skin in skinned_pending:
         sk = j["skins"][skin_index]
         joints = list(sk["joints"])

@@ -228,6 +228,20 @@ class SceneStage:
             self.skin(sk.instance, self.scene.joint_transforms(sk, node_globals), refit=None)
         return self._accel_after_change(refit)
 
+    def animate(self, animator, dt_ticks: int, refit: bool = True):
+        """One frame of a playing animation (update(scene, dt) of src/scene.cc:226-235 followed by scene_stage::update):
+        `animator` (tauray_amd.animation.SceneAnimator over this stage's scene) advances by dt microseconds; the new instance
+        records, cameras (with last frame's as camera_pair.previous) and joint matrices go to the device, and the acceleration
+        structure is updated once - refitted, or rebuilt with `refit=False`."""
+        instances, cameras, node_globals = animator.update(dt_ticks)
+        inst = np.ascontiguousarray(instances)
+        check(_lib.lib().trhip_scene_update_instances(self.ctx.h, inst.ctypes.data, len(inst)))
+        for sk in self.scene.skinned:
+            self.skin(sk.instance, self.scene.joint_transforms(sk, node_globals), refit=None)
+        self.update_cameras(cameras)
+        self.set_previous_cameras(animator.previous_cameras)
+        return self._accel_after_change(refit)
+
     def update_cameras(self, cameras):
         data = np.concatenate([c.pack() for c in cameras])
         check(_lib.lib().trhip_scene_update_cameras(self.ctx.h, data.ctypes.data, len(data)))

@@ -314,6 +314,9 @@ class SceneDesc:
     name: str = "scene"
     skinned: List["SkinnedMesh"] = field(default_factory=list)     # vertices of these instances are the bind pose
     node_globals: dict = field(default_factory=dict)               # glTF node index -> global transform of the rest pose
+    nodes: dict = field(default_factory=dict)                      # glTF node index -> animation.Node (tree, local transform, instances, cameras)
+    roots: list = field(default_factory=list)                      # root nodes of the file's scenes
+    animations: dict = field(default_factory=dict)                 # glTF node index -> {clip name: animation.Animation}
 
     def joint_transforms(self, sk: "SkinnedMesh", node_globals: Optional[dict] = None) -> np.ndarray:
         """model::update_joints (src/model.cc:107-118): joint node's global transform * inverse bind matrix, (n, 4, 4)."""

@@ -1063,6 +1063,53 @@ def test_sample_lanes_render_the_frame_of_pixel_lanes(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_animated_glb_playback(R, ctx, oracle):
+    """tests/golden/animated.glb played the way `tauray --animation --framerate 24` plays a file (src/tauray.cc:252-253,
+    1052-1092): per frame the animator moves nodes, cameras and joints, SceneStage.animate uploads instance records, joint
+    matrices and cameras and updates the acceleration structure (refit, every third frame a rebuild).  Checked frames equal an
+    oracle scene built from the same transforms: geometry features bit for bit, motion features and path-traced frames within
+    the usual tolerances."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.animation import SceneAnimator
+    W = H = 128
+    scene = load_glb(os.path.join(GOLDEN, "animated.glb"), W, H)
+    ss = R.SceneStage(ctx, scene)
+    an = SceneAnimator(scene)
+    an.play("")
+    dt = round(1000000.0 / 24.0)
+
+    def feature(fid):
+        fs = R.FeatureStage(ctx, ss, fid, _dup((W, H)))
+        buf = ctx.alloc(W * H * 16).zero()
+        fs.run(buf)
+        return buf.download((H, W, 4))
+
+    ids = []
+    frame = 0
+    while True:
+        ss.animate(an, 0 if frame == 0 else dt, refit=(frame % 3 != 2))
+        if not an.is_playing():
+            break
+        if frame in (0, 5, 13, 22, 29):
+            osc = oracle.OracleScene(scene, node_globals=an.node_globals)
+            osc.set_previous_cameras(an.previous_cameras)
+            for fid in (5, 3, 1, 9):      # distance, world position, world normal, instance id
+                assert np.array_equal(feature(fid), osc.render_feature(fid, W, H), equal_nan=True), f"feature {fid}, frame {frame}"
+            if frame > 0:
+                hit = np.isfinite(feature(5)[..., 0])
+                for fid in (6, 8):        # world motion, screen motion: model_prev and the previous camera are last frame's
+                    g, r = feature(fid), osc.render_feature(fid, W, H)
+                    assert float(np.abs(g[hit] - r[hit]).max()) <= 1e-5 * max(1.0, float(np.abs(r[hit]).max())), f"motion feature {fid}, frame {frame}"
+                assert float(np.abs(feature(8)[hit][..., :2]).max()) > 1e-3, "nothing moved on screen"
+            _compare(_render_hip(R, ctx, ss, scene, (W, H), max_bounces=3),
+                     osc.render_pt(oracle.options_for_scene(scene, max_bounces=3), W, H), f"animated frame {frame}")
+            ids.append(feature(9)[..., 0].copy())
+        frame += 1
+    assert frame == 30, frame            # 1.25 s at 24 fps: the clip ends when the timer reaches its last key
+    assert all((ids[k] != ids[k + 1]).sum() > 50 for k in range(len(ids) - 1)), "the picture did not change between checked frames"
+
+
+@pytest.mark.gpu
 def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     """BASELINE config 4 at its full size (sponza_teapots, 1920x1080, 4 bounces), through properties that need no oracle: the
     frame does not depend on the tree (PLOC vs LBVH build, refit vs rebuild), on how it is sharded (8 shuffled-strip shards,

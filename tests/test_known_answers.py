@@ -381,3 +381,97 @@ def test_skinned_glb_loader(oracle):
     osc = oracle.OracleScene(scene)
     ids = osc.render_feature(9, 64, 64)[..., 0]
     assert (ids == 0).sum() > 20 and (ids == 1).sum() > 100
+
+
+# ---------------------------------------------------------------------------------------------------
+# glTF animation clips (tauray_amd/animation.py = src/animation.{hh,cc,tcc} + src/gltf.cc:167-190,580-627)
+def _load_animated():
+    import importlib.util
+    import os
+    from conftest import GOLDEN, ROOT
+    from tauray_amd.gltf import load_glb
+    spec = importlib.util.spec_from_file_location("make_animated_glb", os.path.join(ROOT, "tools", "make_animated_glb.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return load_glb(os.path.join(GOLDEN, "animated.glb"), 64, 64), gen
+
+
+def test_animation_tracks_of_the_animated_fixture():
+    """The loader turns every channel into the track its target path names, with microsecond ticks, and the interpolation rules
+    of animation::interpolate: clamped outside the keys, LINEAR mix, slerp for rotations, STEP, CUBICSPLINE with tangents scaled by
+    the key interval in seconds - against values recomputed here from the generator's tables."""
+    from tauray_amd import animation as A
+    scene, gen = _load_animated()
+    names = {n: sorted(pool) for n, pool in scene.animations.items()}
+    box, child = 8, 9
+    assert names[box] == ["move", "spin"] and names[child] == ["move"] and sorted(names) == [3, 4, 7, 8, 9]
+    move = scene.animations[box]["move"]
+    assert move.position.timestamps == [0, 350000, 800000, 1250000] and move.position.interpolation == A.LINEAR
+    assert move.scaling.interpolation == A.STEP and move.orientation.interpolation == A.CUBICSPLINE
+    assert move.loop_time == 1250000 and scene.animations[box]["spin"].loop_time == 500000
+    # LINEAR: between keys 1 and 2 at t = 0.5 s, ratio (0.5 - 0.35) / 0.45
+    r = np.float32(500000 - 350000) / np.float32(800000 - 350000)
+    want = np.array(gen.BOX_T_VALUES[1], np.float32) * (1 - float(r)) + np.array(gen.BOX_T_VALUES[2], np.float32) * float(r)
+    assert np.allclose(move.position.sample(500000), want, rtol=0, atol=1e-7)
+    assert np.array_equal(move.position.sample(-5), np.array(gen.BOX_T_VALUES[0], np.float32)) and np.array_equal(move.position.sample(9_000_000), np.array(gen.BOX_T_VALUES[-1], np.float32))
+    # STEP holds the earlier key; exactly on a key the later segment starts (upper_bound)
+    assert np.allclose(move.scaling.sample(499999), gen.BOX_S_VALUES[0]) and np.allclose(move.scaling.sample(500000), gen.BOX_S_VALUES[1])
+    # slerp: half way between 0 and 170 degrees about x is 85 degrees
+    q = scene.animations[child]["move"].orientation.sample(625000, quaternion=True)
+    assert np.allclose(q, gen.quat((1, 0, 0), 85.0), atol=1e-6)
+    # CUBICSPLINE: Hermite form with the tangents of the file times the interval; at the keys it returns the keys
+    tr = move.orientation
+    assert np.allclose(tr.sample(600000, quaternion=True), gen.quat((0, 1, 0), 100.0), atol=1e-6)
+    t, dt = 0.25 / 0.6, 0.6
+    p1, p2 = np.array(gen.quat((0, 1, 0), 0.0)), np.array(gen.quat((0, 1, 0), 100.0))
+    m1, m2 = np.array([0.0, 0.45, 0.0, -0.4]) * 0.7 * dt, np.array([0.0, 0.9, 0.0, -0.4]) * dt       # out-tangent of key 0, in-tangent of key 1
+    h = (2 * t**3 - 3 * t**2 + 1) * p1 + (t**3 - 2 * t**2 + t) * m1 + (-2 * t**3 + 3 * t**2) * p2 + (t**3 - t**2) * m2
+    assert np.allclose(tr.sample(250000, quaternion=True), h, atol=1e-6)
+
+
+def test_animation_playback_moves_instances_cameras_and_joints():
+    """SceneAnimator = play() + update() of src/scene.cc: fallback picks the alphabetically first clip per node, a named clip
+    plays only where it exists, a clip that does not loop stops after its last key and leaves the pose of the frame before, a
+    looping one wraps; children inherit their parents' motion; model_prev is last frame's model."""
+    from tauray_amd.animation import SceneAnimator
+    from tauray_amd.scene import from_glm, trs_matrix
+    scene, gen = _load_animated()
+    box_inst, child_inst = scene.nodes[8].instances[0], scene.nodes[9].instances[0]
+    rest = scene.instances.copy()
+    an = SceneAnimator(scene)
+    assert not an.is_playing()
+    an.play("")
+    assert an.is_playing() and all(c.current is scene.animations[n]["move"] for n, c in an.controllers.items())
+    dt = 250000
+    inst, cams, globs = an.update(0)
+    assert np.allclose(from_glm(inst["model"][box_inst])[:3, 3], gen.BOX_T_VALUES[0]) and np.array_equal(inst["model_prev"], rest["model"])
+    before = inst["model"].copy()
+    inst, cams, globs = an.update(dt)
+    assert np.array_equal(inst["model_prev"], before)
+    # the box at 0.25 s: translation by LINEAR, scale by STEP (first key), rotation by the spline; its child rides on it
+    m = scene.animations[8]["move"]
+    want = trs_matrix(m.position.sample(dt), m.orientation.sample(dt, True) / np.linalg.norm(m.orientation.sample(dt, True)), m.scaling.sample(dt))
+    assert np.allclose(from_glm(inst["model"][box_inst]), want, atol=1e-6)
+    child_local = trs_matrix((0.0, 1.8, 0.0), scene.animations[9]["move"].orientation.sample(dt, True), (0.4, 0.4, 0.4))
+    assert np.allclose(from_glm(inst["model"][child_inst]), want @ child_local, atol=1e-6)
+    assert np.allclose(np.asarray(cams[0].transform)[:3, 3], np.array(gen.CAM_VALUES[0]) * 0.8 + np.array(gen.CAM_VALUES[1]) * 0.2, atol=1e-6)
+    assert np.allclose(np.asarray(an.previous_cameras[0].transform)[:3, 3], gen.CAM_VALUES[0])
+    # joints: node 3 turns about z by the LINEAR track, the skin's joint matrices follow through node_globals
+    j1 = scene.animations[3]["move"].orientation.sample(dt, True)
+    assert np.allclose(globs[3], globs[2] @ trs_matrix((0, 1, 0), j1), atol=1e-6)
+    assert not np.allclose(scene.joint_transforms(scene.skinned[0], globs), scene.joint_transforms(scene.skinned[0], {**globs, 3: globs[2]}))
+    # the end: at 1.25 s the timer reaches the loop time, the controllers stop and the pose stays what it was at 1.0 s
+    for _ in range(3):
+        inst, _, _ = an.update(dt)
+    assert an.is_playing()
+    last = inst["model"].copy()
+    inst, _, _ = an.update(dt)
+    assert not an.is_playing() and np.array_equal(inst["model"], last)
+    # a named clip: only the box has "spin"; looping wraps the half-second clip
+    scene2, _ = _load_animated()
+    an = SceneAnimator(scene2)
+    an.play("spin", loop=True)
+    assert [n for n, c in an.controllers.items() if c.playing] == [8]
+    an.update(0)
+    inst, _, _ = an.update(750000)          # 0.75 s into a 0.5 s loop = 0.25 s: 45 degrees about z
+    assert an.is_playing() and np.allclose(from_glm(inst["model"][box_inst])[:3, :3] / 0.5, trs_matrix(rotation=gen.quat((0, 0, 1), 45.0))[:3, :3], atol=1e-6)
