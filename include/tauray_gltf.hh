@@ -7,8 +7,10 @@
 // order) and the host-side packing of src/camera.cc:323-478, src/light.cc and src/scene_stage.cc:17-111,1066-1354.
 // Extensions: KHR_lights_punctual, KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength, TR_data.
 // Skins: JOINTS_0 / WEIGHTS_0 (renormalised) + inverse bind matrices; skinned meshes sit at the origin (src/gltf.cc:722-731,
-// 777-784) and scene_data::skinned carries the file's rest pose for scene_stage::set_scene.  Not read: animations, morph targets,
-// external (non-embedded) images, interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
+// 777-784) and scene_data::skinned carries the file's rest pose for scene_stage::set_scene.  Animation clips (translation / rotation /
+// scale channels, LINEAR / STEP / CUBICSPLINE; src/gltf.cc:167-190,580-627) are kept in scene_data::animation and played by
+// tr::scene_animator below (src/animation.{hh,cc,tcc}, src/scene.cc:213-244).  Not read: morph targets, external (non-embedded)
+// images, interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
 // (tests/test_cpp_host.py::test_cpp_glb_loader_matches_python_loader).
 #ifndef TAURAY_GLTF_HH
 #define TAURAY_GLTF_HH
@@ -297,6 +299,53 @@ struct instance { int32_t light_base_id, sh_grid_index; uint32_t pad; float shad
 struct directional_light { float color[3]; int32_t shadow_map_index; float dir[3]; float dir_cutoff; };
 struct point_light { float color[3], dir[3], pos[3], radius, dir_cutoff, dir_falloff, cutoff_radius, spot_radius; int32_t shadow_map_index, padding; };
 struct camera_data { float view[16], view_inverse[16], view_proj[16], proj_inverse[16], origin[4], dof_params[4], projection_info[4], pan[4]; };
+
+//---------------------------------------------------------------------------------------------------------------------
+// A camera as the file describes it + camera::write_uniform_buffer (src/camera.cc:431-478) with the aspect ratio
+// set_camera_params forces (src/tauray.cc:68-110)
+struct gltf_camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; };
+
+inline camera_data pack_camera(gltf_camera& c, double aspect)
+{
+    camera_data cd{};
+    mat4d proj{};
+    double info[4];
+    if(c.perspective)
+    {
+        c.aspect = aspect;
+        const double t = std::tan((c.fov * (3.14159265358979323846 / 180.0)) / 2.0);
+        proj.m[0][0] = 1.0 / (c.aspect * t); proj.m[1][1] = 1.0 / t; proj.m[3][2] = -1.0;
+        const double w = 2 * std::tan((c.fov * (3.14159265358979323846 / 180.0)) / 2.0), z = w * c.aspect;
+        if(std::isinf(c.far)) { proj.m[2][2] = -1.0; proj.m[2][3] = -2.0 * c.near; info[0] = -c.near; info[1] = -1.0; }
+        else
+        {
+            proj.m[2][2] = -(c.far + c.near) / (c.far - c.near); proj.m[2][3] = -(2.0 * c.far * c.near) / (c.far - c.near);
+            info[0] = c.near * c.far / (c.near - c.far); info[1] = (c.near + c.far) / (c.near - c.far);
+        }
+        info[2] = z; info[3] = w;
+        cd.dof_params[0] = 1.0f;
+    }
+    else
+    {
+        double l = c.ortho[0], r = c.ortho[1], b = c.ortho[2], t = c.ortho[3];
+        const double n = c.ortho[4], f = c.ortho[5];
+        const double yr = (r - l) / aspect, yc = (b + t) * 0.5;      // camera::set_aspect (src/camera.cc:166-186)
+        b = yc - yr * 0.5; t = yc + yr * 0.5;
+        proj = mat4d::identity();
+        proj.m[0][0] = 2 / (r - l); proj.m[1][1] = 2 / (t - b); proj.m[2][2] = -2 / (f - n);
+        proj.m[0][3] = -(r + l) / (r - l); proj.m[1][3] = -(t + b) / (t - b); proj.m[2][3] = -(f + n) / (f - n);
+        info[0] = f - n; info[1] = -f; info[2] = r - l; info[3] = t - b;
+    }
+    const mat4d view = inverse(c.transform);
+    to_glm(view, cd.view);
+    to_glm(c.transform, cd.view_inverse);
+    to_glm(mul(proj, view), cd.view_proj);
+    to_glm(inverse(proj), cd.proj_inverse);
+    for(int k = 0; k < 4; ++k) cd.origin[k] = (float)c.transform.m[k][3];
+    for(int k = 0; k < 4; ++k) cd.projection_info[k] = (float)info[k];
+    return cd;
+}
+
 struct mesh_span { uint32_t vertex_offset, vertex_count, index_offset, triangle_count; };
 struct texture_info { uint32_t width, height, texel_offset, pad; };
 #pragma pack(pop)
@@ -467,6 +516,87 @@ inline void calculate_tangents(std::vector<vertex>& v, const std::vector<uint32_
 
 }   // namespace gltf_detail
 
+//---------------------------------------------------------------------------------------------------------------------
+// Animation clips (src/animation.{hh,cc,tcc}): what load_glb keeps of a file so that tr::scene_animator can play it.
+// Mirrors tauray_amd/animation.py operation by operation (same rounding of timestamps, float ratio, double interpolation).
+struct gltf_animation
+{
+    enum interpolation { LINEAR = 0, STEP, CUBICSPLINE };
+    // std::vector<animation::sample<T>>: microsecond ticks (src/gltf.cc:167-190), three or four components per key
+    struct track
+    {
+        interpolation interp = LINEAR;
+        int width = 0;                                   // 3 (position, scaling) or 4 (orientation); 0 = no such track
+        std::vector<int64_t> timestamps;
+        std::vector<std::array<double, 4>> data, in_tangent, out_tangent;
+
+        // animation::interpolate (src/animation.tcc:39-77)
+        std::array<double, 4> sample(int64_t time, bool quaternion) const
+        {
+            const size_t i = (size_t)(std::upper_bound(timestamps.begin(), timestamps.end(), time) - timestamps.begin());
+            if(i == timestamps.size()) return data.back();
+            if(i == 0) return data.front();
+            const float frame_ticks = (float)(timestamps[i] - timestamps[i - 1]);
+            const double ratio = (double)((float)(time - timestamps[i - 1]) / frame_ticks);
+            std::array<double, 4> r{};
+            if(interp == STEP) return data[i - 1];
+            if(interp == CUBICSPLINE && !in_tangent.empty())
+            {   // cubic_spline (src/math.tcc:24-35): coefficients in float, tangents scaled by the interval in seconds
+                const double scale = (double)(frame_ticks * 0.000001f);
+                const float t = (float)ratio, t2 = t * t, t3 = t2 * t, tmp = 2.0f * t3 - 3.0f * t2;
+                const double c1 = (double)(tmp + 1.0f), c2 = (double)(t3 - 2.0f * t2 + t), c3 = (double)(-tmp), c4 = (double)(t3 - t2);
+                for(int k = 0; k < width; ++k)
+                    r[(size_t)k] = c1 * data[i - 1][(size_t)k] + c2 * (out_tangent[i - 1][(size_t)k] * scale) + c3 * data[i][(size_t)k] + c4 * (in_tangent[i][(size_t)k] * scale);
+                return r;
+            }
+            const std::array<double, 4>& a = data[i - 1];
+            std::array<double, 4> b = data[i];
+            if(quaternion)
+            {   // glm::slerp: the shorter arc, linear when the two nearly coincide
+                double cos_theta = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+                if(cos_theta < 0) { for(double& v: b) v = -v; cos_theta = -cos_theta; }
+                if(!(cos_theta > 1.0 - (double)std::numeric_limits<float>::epsilon()))
+                {
+                    const double angle = std::acos(cos_theta), sa = std::sin((1.0 - ratio) * angle), sb = std::sin(ratio * angle), sn = std::sin(angle);
+                    for(int k = 0; k < 4; ++k) r[(size_t)k] = (sa * a[(size_t)k] + sb * b[(size_t)k]) / sn;
+                    return r;
+                }
+            }
+            for(int k = 0; k < width; ++k) r[(size_t)k] = a[(size_t)k] * (1.0 - ratio) + b[(size_t)k] * ratio;
+            return r;
+        }
+    };
+    // tr::animation: one named clip of one node
+    struct clip
+    {
+        track position, scaling, orientation;
+        int64_t loop_time() const
+        {
+            int64_t t = 0;
+            for(const track* tr: {&position, &scaling, &orientation}) if(tr->width && !tr->timestamps.empty()) t = std::max(t, tr->timestamps.back());
+            return t;
+        }
+    };
+    struct node
+    {
+        int parent = -1;
+        std::vector<int> children;
+        bool has_trs = true;
+        double translation[3] = {0, 0, 0}, rotation[4] = {0, 0, 0, 1}, scale[3] = {1, 1, 1};
+        gltf_detail::mat4d matrix = gltf_detail::mat4d::identity();
+        std::vector<uint32_t> instances, cameras;       // rigid instances / cameras placed by this node's global transform
+        gltf_detail::mat4d local() const { return has_trs ? gltf_detail::trs_matrix(translation, rotation, scale) : matrix; }
+    };
+    struct skin { std::vector<int> joint_nodes; std::vector<gltf_detail::mat4d> inverse_bind; };      // parallel to scene_data::skinned
+
+    std::map<int, node> nodes;
+    std::vector<int> roots;
+    std::map<int, std::map<std::string, clip>> clips;     // node -> animation_pool (std::map: alphabetical)
+    std::vector<gltf_detail::gltf_camera> cameras;
+    std::vector<skin> skins;
+    double aspect = 1.0;
+};
+
 struct glb_load_options
 {
     float aspect_ratio = 0;               // 0: width / height (set_camera_params, src/tauray.cc:68-110)
@@ -564,8 +694,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     std::vector<uint32_t> indices;
     std::vector<point_light> point_lights, spot_lights;
     std::vector<directional_light> dir_lights;
-    struct camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; };
-    std::vector<camera> cameras;
+    std::vector<gltf_camera> cameras;
     double light_angle = 0, light_radius = 0;
     std::map<int, mat4d> node_globals;
     struct pending_skin { uint32_t instance; int skin; const std::vector<trhip_skin>* skins; };
@@ -582,8 +711,13 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         return p;
     };
 
-    std::function<void(int, const mat4d&)> visit = [&](int node_index, const mat4d& parent) {
+    auto anim = std::make_shared<gltf_animation>();
+    std::function<void(int, const mat4d&, int)> visit = [&](int node_index, const mat4d& parent, int parent_index) {
         const json& node = j.at("nodes").at((size_t)node_index);
+        gltf_animation::node& rec = anim->nodes[node_index];
+        rec = gltf_animation::node{};
+        rec.parent = parent_index;
+        if(const json* ch = node.find("children")) for(const json& c: ch->arr) rec.children.push_back((int)c.num);
         const json* ext = node.find("extensions");
         const json* tr = ext ? ext->find("TR_data") : nullptr;
         if(tr) if(const json* l = tr->find("light"))
@@ -595,6 +729,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         if(const json* m = node.find("matrix"))
         {   // column-major in the file
             for(int c = 0; c < 4; ++c) for(int r = 0; r < 4; ++r) local.m[r][c] = m->at(size_t(c * 4 + r)).num;
+            rec.has_trs = false; rec.matrix = local;
         }
         else
         {
@@ -603,6 +738,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
             if(const json* a = node.find("rotation")) for(int k = 0; k < 4; ++k) q[k] = a->at((size_t)k).num;
             if(const json* a = node.find("scale")) for(int k = 0; k < 3; ++k) sc[k] = a->at((size_t)k).num;
             local = trs_matrix(t, q, sc);
+            std::memcpy(rec.translation, t, sizeof(t)); std::memcpy(rec.rotation, q, sizeof(q)); std::memcpy(rec.scale, sc, sizeof(sc));
         }
         const mat4d glob = mul(parent, local);
         node_globals[node_index] = glob;
@@ -620,6 +756,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
                 const bool skinned = node.has("skin") && !vg.skins.empty();
                 const mat4d model = skinned ? mat4d::identity() : glob;
                 if(skinned) skinned_pending.push_back(pending_skin{(uint32_t)instances.size(), node.integer("skin", 0), &vg.skins});
+                else anim->nodes[node_index].instances.push_back((uint32_t)instances.size());
                 to_glm(model, in.model);
                 to_glm(transpose(inverse(model)), in.model_normal);
                 to_glm(model, in.model_prev);
@@ -633,7 +770,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         if(node.has("camera"))
         {
             const json& c = j.at("cameras").at((size_t)node.integer("camera", 0));
-            camera cam{};
+            gltf_camera cam{};
             cam.transform = glob;
             if(c.at("type").str == "perspective")
             {
@@ -652,6 +789,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
                 const double v[6] = {-0.5 * xm, 0.5 * xm, -0.5 * ym, 0.5 * ym, o.at("znear").num, o.at("zfar").num};
                 std::memcpy(cam.ortho, v, sizeof(v));
             }
+            anim->nodes[node_index].cameras.push_back((uint32_t)cameras.size());
             cameras.push_back(cam);
         }
         if(const json* kl = ext ? ext->find("KHR_lights_punctual") : nullptr)
@@ -710,10 +848,41 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
                 else point_lights.push_back(p);
             }
         }
-        if(const json* ch = node.find("children")) for(const json& c: ch->arr) visit((int)c.num, glob);
+        if(const json* ch = node.find("children")) for(const json& c: ch->arr) visit((int)c.num, glob, node_index);
     };
     for(const json& sc: list("scenes").arr)
-        if(const json* nodes = sc.find("nodes")) for(const json& n: nodes->arr) visit((int)n.num, mat4d::identity());
+        if(const json* nodes = sc.find("nodes")) for(const json& n: nodes->arr) { anim->roots.push_back((int)n.num); visit((int)n.num, mat4d::identity(), -1); }
+
+    // animation clips per node (src/gltf.cc:580-627): a channel fills the track its target path names in the target node's pool
+    // entry of the clip's name; timestamps become microsecond ticks (read_animation_accessors, :167-190)
+    for(const json& an: list("animations").arr)
+        for(const json& chan: an.at("channels").arr)
+        {
+            const json& target = chan.at("target");
+            if(!target.has("node")) continue;
+            const std::string& path_name = target.at("path").str;
+            const int width = path_name == "rotation" ? 4 : 3;
+            if(path_name != "translation" && path_name != "rotation" && path_name != "scale") continue;      // morph-target weights
+            const json& sampler = an.at("samplers").at((size_t)chan.integer("sampler", 0));
+            gltf_animation::clip& cl = anim->clips[target.integer("node", 0)][an.has("name") ? an.at("name").str : std::string()];
+            gltf_animation::track& tr = path_name == "translation" ? cl.position : (path_name == "rotation" ? cl.orientation : cl.scaling);
+            tr = gltf_animation::track{};
+            tr.width = width;
+            const std::string interp = sampler.has("interpolation") ? sampler.at("interpolation").str : std::string("LINEAR");
+            tr.interp = interp == "STEP" ? gltf_animation::STEP : (interp == "CUBICSPLINE" ? gltf_animation::CUBICSPLINE : gltf_animation::LINEAR);
+            int comps; size_t count;
+            const std::vector<double> times = g.accessor(sampler.integer("input", 0), comps, count);
+            const size_t n = count;
+            for(size_t k = 0; k < n; ++k) tr.timestamps.push_back((int64_t)std::floor((double)((float)times[k] * 1000000.0f) + 0.5));
+            const std::vector<double> values = g.accessor(sampler.integer("output", 0), comps, count);
+            auto key = [&](size_t index) { std::array<double, 4> v{}; for(int c = 0; c < width; ++c) v[(size_t)c] = (double)(float)values[index * (size_t)width + (size_t)c]; return v; };
+            const bool tangents = count >= 3 * n;
+            for(size_t k = 0; k < n; ++k)
+            {
+                if(tangents) { tr.in_tangent.push_back(key(3 * k)); tr.data.push_back(key(3 * k + 1)); tr.out_tangent.push_back(key(3 * k + 2)); }
+                else tr.data.push_back(key(k));
+            }
+        }
 
     // light_base_id (src/scene_stage.cc:1069-1075)
     uint32_t tri_light_count = 0;
@@ -726,46 +895,8 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     // cameras: set_camera_params forces the aspect ratio (src/tauray.cc:68-110), camera::write_uniform_buffer packs (src/camera.cc:431-478)
     const double aspect = lo.aspect_ratio > 0 ? (double)lo.aspect_ratio : double(width) / double(height);
     std::vector<camera_data> cams;
-    for(camera& c: cameras)
-    {
-        camera_data cd{};
-        mat4d proj{};
-        double info[4];
-        if(c.perspective)
-        {
-            c.aspect = aspect;
-            const double t = std::tan((c.fov * (PI / 180.0)) / 2.0);
-            proj.m[0][0] = 1.0 / (c.aspect * t); proj.m[1][1] = 1.0 / t; proj.m[3][2] = -1.0;
-            const double w = 2 * std::tan((c.fov * (PI / 180.0)) / 2.0), z = w * c.aspect;
-            if(std::isinf(c.far)) { proj.m[2][2] = -1.0; proj.m[2][3] = -2.0 * c.near; info[0] = -c.near; info[1] = -1.0; }
-            else
-            {
-                proj.m[2][2] = -(c.far + c.near) / (c.far - c.near); proj.m[2][3] = -(2.0 * c.far * c.near) / (c.far - c.near);
-                info[0] = c.near * c.far / (c.near - c.far); info[1] = (c.near + c.far) / (c.near - c.far);
-            }
-            info[2] = z; info[3] = w;
-            cd.dof_params[0] = 1.0f;
-        }
-        else
-        {
-            double l = c.ortho[0], r = c.ortho[1], b = c.ortho[2], t = c.ortho[3];
-            const double n = c.ortho[4], f = c.ortho[5];
-            const double yr = (r - l) / aspect, yc = (b + t) * 0.5;      // camera::set_aspect (src/camera.cc:166-186)
-            b = yc - yr * 0.5; t = yc + yr * 0.5;
-            proj = mat4d::identity();
-            proj.m[0][0] = 2 / (r - l); proj.m[1][1] = 2 / (t - b); proj.m[2][2] = -2 / (f - n);
-            proj.m[0][3] = -(r + l) / (r - l); proj.m[1][3] = -(t + b) / (t - b); proj.m[2][3] = -(f + n) / (f - n);
-            info[0] = f - n; info[1] = -f; info[2] = r - l; info[3] = t - b;
-        }
-        const mat4d view = inverse(c.transform);
-        to_glm(view, cd.view);
-        to_glm(c.transform, cd.view_inverse);
-        to_glm(mul(proj, view), cd.view_proj);
-        to_glm(inverse(proj), cd.proj_inverse);
-        for(int k = 0; k < 4; ++k) cd.origin[k] = (float)c.transform.m[k][3];
-        for(int k = 0; k < 4; ++k) cd.projection_info[k] = (float)info[k];
-        cams.push_back(cd);
-    }
+    for(gltf_camera& c: cameras) cams.push_back(pack_camera(c, aspect));
+    anim->cameras = cameras; anim->aspect = aspect;
     if(!cameras.empty()) s.projection = cameras[0].perspective ? 0u : 1u;
 
     // point lights first, then spotlights (src/scene_stage.cc:1287-1317)
@@ -806,10 +937,13 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         scene_data::skinned_mesh out;
         out.instance = ps.instance;
         out.skins = *ps.skins;
+        anim->skins.emplace_back();
         for(size_t k = 0; k < joints.size(); ++k)
         {
             mat4d inv_bind = mat4d::identity();
             if(ibm.size() >= (k + 1) * 16) for(int c = 0; c < 4; ++c) for(int r = 0; r < 4; ++r) inv_bind.m[r][c] = ibm[k * 16 + size_t(c) * 4 + r];   // column-major in the file
+            anim->skins.back().joint_nodes.push_back((int)joints.at(k).num);
+            anim->skins.back().inverse_bind.push_back(inv_bind);
             const auto it = node_globals.find((int)joints.at(k).num);
             const mat4d jt = mul(it != node_globals.end() ? it->second : mat4d::identity(), inv_bind);
             float m[16];
@@ -818,8 +952,104 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         }
         s.skinned.push_back(std::move(out));
     }
+    s.animation = anim;
     return s;
 }
+
+//---------------------------------------------------------------------------------------------------------------------
+// play(scene, name, loop, fallback) / update(scene, dt) / is_playing(scene) of src/scene.cc:213-244 with the controller of
+// src/animation.tcc:79-205 (a queue of one clip), over a scene load_glb produced: `tauray --animation[=name] --framerate F`.
+// update() rewrites scene_data::instances (model, model_normal; model_prev = last frame's model), ::cameras (previous_cameras =
+// last frame's) and the joint matrices of ::skinned; scene_stage::apply / rt_renderer::update_scene send them to the device.
+// Punctual lights on animated nodes keep their loaded place (the C ABI uploads lights with the scene).
+class scene_animator
+{
+public:
+    explicit scene_animator(scene_data& s): scene(&s), anim(s.animation)
+    {
+        if(anim) for(const auto& p: anim->clips) controllers[p.first] = controller{};
+    }
+
+    void play(const std::string& name = "", bool loop = false)
+    {
+        if(!anim) return;
+        for(auto& p: controllers)
+        {
+            controller& c = p.second;
+            const auto& pool = anim->clips.at(p.first);
+            c.timer = 0;
+            auto it = pool.find(name);
+            c.current = it != pool.end() ? &it->second : (name.empty() && !pool.empty() ? &pool.begin()->second : nullptr);   // use_fallback = no name given
+            c.loop_time = c.current ? c.current->loop_time() : 0;
+            c.playing = c.loop_time != 0;
+            c.loop = loop;
+        }
+    }
+
+    bool is_playing() const { for(const auto& p: controllers) if(p.second.playing) return true; return false; }
+
+    // dt in microsecond ticks: 0 for the first frame, round(1e6 / framerate) afterwards (src/tauray.cc:1052,1090)
+    void update(int64_t dt)
+    {
+        using namespace gltf_detail;
+        if(!anim) return;
+        scene->previous_cameras = scene->cameras;
+        for(auto& p: controllers)
+        {
+            controller& c = p.second;
+            gltf_animation::node& node = anim->nodes.at(p.first);
+            if(!c.playing || !node.has_trs) continue;
+            c.timer += dt;
+            if(c.loop) c.timer %= c.loop_time;
+            else if(c.timer >= c.loop_time) { c.playing = false; c.loop_time = 0; c.timer = 0; continue; }   // the node keeps its last pose
+            // animation::apply (src/animation.cc:40-53)
+            if(c.current->position.width) { const auto v = c.current->position.sample(c.timer, false); for(int k = 0; k < 3; ++k) node.translation[k] = v[(size_t)k]; }
+            if(c.current->scaling.width) { const auto v = c.current->scaling.sample(c.timer, false); for(int k = 0; k < 3; ++k) node.scale[k] = v[(size_t)k]; }
+            if(c.current->orientation.width)
+            {
+                auto q = c.current->orientation.sample(c.timer, true);
+                if(c.current->orientation.interp == gltf_animation::CUBICSPLINE)
+                {
+                    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                    for(double& v: q) v = v / n;
+                }
+                for(int k = 0; k < 4; ++k) node.rotation[k] = q[(size_t)k];
+            }
+        }
+        instance* inst = reinterpret_cast<instance*>(scene->instances.data());
+        const uint32_t n_inst = scene->instance_count();
+        for(uint32_t i = 0; i < n_inst; ++i) std::memcpy(inst[i].model_prev, inst[i].model, sizeof(inst[i].model));
+        std::map<int, mat4d> globals;
+        std::function<void(int, const mat4d&)> visit = [&](int n, const mat4d& parent) {
+            const gltf_animation::node& node = anim->nodes.at(n);
+            const mat4d glob = mul(parent, node.local());
+            globals[n] = glob;
+            for(uint32_t i: node.instances) { to_glm(glob, inst[i].model); to_glm(transpose(inverse(glob)), inst[i].model_normal); }
+            for(uint32_t ci: node.cameras) anim->cameras[ci].transform = glob;
+            for(int ch: node.children) visit(ch, glob);
+        };
+        for(int r: anim->roots) visit(r, mat4d::identity());
+        camera_data* cams = reinterpret_cast<camera_data*>(scene->cameras.data());
+        for(size_t ci = 0; ci < anim->cameras.size(); ++ci) cams[ci] = pack_camera(anim->cameras[ci], anim->aspect);
+        for(size_t k = 0; k < anim->skins.size() && k < scene->skinned.size(); ++k)
+        {   // model::update_joints (src/model.cc:107-118)
+            const gltf_animation::skin& sk = anim->skins[k];
+            std::vector<float>& out = scene->skinned[k].joint_transforms;
+            out.resize(sk.joint_nodes.size() * 16);
+            for(size_t jn = 0; jn < sk.joint_nodes.size(); ++jn)
+            {
+                const auto it = globals.find(sk.joint_nodes[jn]);
+                to_glm(mul(it != globals.end() ? it->second : mat4d::identity(), sk.inverse_bind[jn]), out.data() + jn * 16);
+            }
+        }
+    }
+
+private:
+    struct controller { const gltf_animation::clip* current = nullptr; bool loop = false, playing = false; int64_t timer = 0, loop_time = 0; };
+    scene_data* scene;
+    std::shared_ptr<gltf_animation> anim;
+    std::map<int, controller> controllers;
+};
 
 // writes the .trsc dump load_scene_dump reads (the format of tauray_amd/scene_io.py)
 inline void write_scene_dump(const scene_data& s, const std::string& path)

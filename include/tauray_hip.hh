@@ -159,6 +159,8 @@ public:
 //==============================================================================
 // scene: the flattened scene_stage inputs (SURVEY.md Appendix A arrays)
 //==============================================================================
+struct gltf_animation;      // node tree + animation clips of a loaded glTF file (include/tauray_gltf.hh)
+
 struct scene_data
 {
     std::vector<uint8_t> instances, spans, vertices, indices, point_lights, directional_lights, texture_infos, texels,
@@ -173,6 +175,9 @@ struct scene_data
     // filled it in.  Not part of the .trsc dump.
     struct skinned_mesh { uint32_t instance = 0; std::vector<trhip_skin> skins; std::vector<float> joint_transforms; };
     std::vector<skinned_mesh> skinned;
+    // What tr::scene_animator needs to play the file's animation clips (tauray_gltf.hh); null for scenes without a node tree.
+    std::shared_ptr<gltf_animation> animation;
+    std::vector<uint8_t> previous_cameras;       // camera_pair.previous of the current frame (empty = the cameras themselves)
 
     uint32_t instance_count() const { return (uint32_t)(instances.size() / 288); }
     uint32_t camera_count() const { return (uint32_t)(cameras.size() / 320); }
@@ -264,6 +269,18 @@ public:
     }
     // model::update_joints + shader/skinning.comp: column-major mat4 per joint
     void skin(uint32_t instance, const float* joint_transforms, uint32_t joint_count) { check(trhip_scene_skin(dev->h, instance, joint_transforms, joint_count)); }
+    void update_cameras(const void* camera_data_320, uint32_t count) { check(trhip_scene_update_cameras(dev->h, camera_data_320, count)); }
+    // One frame's worth of scene changes (scene_stage::update after update(scene, dt), src/scene.cc:226-235): the instance records,
+    // joint matrices and cameras of `s` - as tr::scene_animator::update left them - go to the device and the acceleration
+    // structure is updated once.
+    void apply(const scene_data& s, bool rebuild = false)
+    {
+        update_instances(s.instances.data(), s.instance_count());
+        for(const scene_data::skinned_mesh& sk: s.skinned) skin(sk.instance, sk.joint_transforms.data(), (uint32_t)(sk.joint_transforms.size() / 16));
+        update_cameras(s.cameras.data(), s.camera_count());
+        if(!s.previous_cameras.empty()) set_previous_cameras(s.previous_cameras.data(), (uint32_t)(s.previous_cameras.size() / 320));
+        update_acceleration(rebuild);
+    }
     void update_acceleration(bool rebuild = false)
     {
         // geometry that is rebuilt after its first build is dynamic: ePreferFastBuild (src/acceleration_structure.cc:129-131)
@@ -549,6 +566,14 @@ public:
     void finish_all()
     {
         for(auto& d: per_device) { for(slot_data& sl: d.slots) d.dev->sync(sl.stream); d.dev->sync(); }
+    }
+
+    // The scene changed (an animation step): every device's copy follows (the scene is replicated, src/gpu_buffer.hh:63-116).
+    // Frames in flight read the old scene: they are finished first.
+    void update_scene(const scene_data& s, bool rebuild = false)
+    {
+        finish_all();
+        for(auto& d: per_device) d.scene_update->apply(s, rebuild);
     }
 
     // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap.  Enqueues only.

@@ -36,7 +36,7 @@ def slerp(a, b, t):
     """glm::slerp for quaternions stored (x, y, z, w): the shorter arc, linear when the two nearly coincide."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    cos_theta = float(np.dot(a, b))
+    cos_theta = float(a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3])
     if cos_theta < 0:
         b, cos_theta = -b, -cos_theta
     if cos_theta > 1.0 - np.finfo(np.float32).eps:
@@ -95,14 +95,14 @@ class Animation:
         if self.orientation is not None:
             q = self.orientation.sample(time, quaternion=True)
             if self.orientation.interpolation == CUBICSPLINE:
-                q = q / np.linalg.norm(q)
+                q = q / math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
             trs["rotation"] = q
 
 
 def read_track(timestamps_s: np.ndarray, values: np.ndarray, interpolation: int) -> Track:
     """read_animation_accessors (src/gltf.cc:167-190): ticks = round(seconds * 1e6); three values per key (in-tangent, value,
     out-tangent) when the output accessor holds that many."""
-    ts = [int(round(float(np.float32(t) * np.float32(1000000)))) for t in timestamps_s]
+    ts = [int(math.floor(float(np.float32(t) * np.float32(1000000)) + 0.5)) for t in timestamps_s]      # C round() of a float product
     n = len(ts)
     if len(values) >= 3 * n:
         v = values[:3 * n].reshape(n, 3, -1)

@@ -36,6 +36,9 @@ int main(int argc, char** argv)
         std::vector<int> devices;
         bool timing = false;
         std::string dump_scene;
+        bool frames_given = false, animation_flag = false;      // --animation[=name] --framerate=F (src/options.hh:110-129)
+        std::string animation_name;
+        double framerate = 60.0;
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
@@ -55,7 +58,10 @@ int main(int argc, char** argv)
             else if(starts(a, "--min-ray-dist=")) opt.min_ray_dist = std::stof(val("--min-ray-dist="));
             else if(starts(a, "--samples-per-pixel=")) opt.samples_per_pixel = std::stoi(val("--samples-per-pixel="));
             else if(starts(a, "--samples-per-pass=")) opt.samples_per_pass = std::stoi(val("--samples-per-pass="));
-            else if(starts(a, "--frames=")) { frames = std::stoi(val("--frames=")); hopt.single_frame = frames == 1; }
+            else if(starts(a, "--frames=")) { frames = std::stoi(val("--frames=")); hopt.single_frame = frames == 1; frames_given = true; }
+            else if(a == "--animation") animation_flag = true;                                  // any clip a node has (src/tauray.cc:252-253)
+            else if(starts(a, "--animation=")) { animation_flag = true; animation_name = val("--animation="); }
+            else if(starts(a, "--framerate=")) framerate = std::stod(val("--framerate="));
             else if(starts(a, "--warmup-frames=")) warmup = std::stoi(val("--warmup-frames="));
             else if(starts(a, "--renderer="))
             {
@@ -130,8 +136,16 @@ int main(int argc, char** argv)
 
         const bool is_glb = scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0;
         scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
+        // play(scene, name, !replay, name == "") (src/tauray.cc:252-253); ticks in microseconds per update (:1052)
+        scene_animator animator(scene);
+        if(animation_flag) animator.play(animation_name, false);
+        const int64_t update_dt = (int64_t)std::floor(1000000.0 / framerate + 0.5);
+        const bool animated = animation_flag && animator.is_playing();
+        if(animated && !frames_given) { frames = std::numeric_limits<int>::max(); hopt.single_frame = false; }      // until the clip ends
         if(!dump_scene.empty())
-        {   // the flattened scene, and next to it what the loader found of skins: per skinned instance u32 instance, u32 vertices,
+        {
+            // with --animation the dump is the scene after --frames updates (the first one by dt = 0)
+            if(animated) for(int f = 0; f < (frames_given ? frames : 1); ++f) animator.update(f == 0 ? 0 : update_dt);   // the flattened scene, and next to it what the loader found of skins: per skinned instance u32 instance, u32 vertices,
             // u32 joints, the {joints, weights} records, the rest-pose joint matrices
             write_scene_dump(scene, dump_scene);
             if(!scene.skinned.empty())
@@ -167,7 +181,7 @@ int main(int argc, char** argv)
             if(workloads.size() != rr.per_device.size()) throw std::runtime_error("--device-workloads needs one ratio per device");
             rr.set_device_workloads(workloads);
         }
-        if(frames_in_flight > 1)
+        if(frames_in_flight > 1 && !animated)
         {   // frame f renders while the frames before it are read back, compressed and written (the reference overlaps
             // its save workers with the next frames the same way, src/headless.cc:349-422)
             std::vector<int> in_slot(frames_in_flight, -1);
@@ -190,6 +204,14 @@ int main(int argc, char** argv)
         }
         for(int f = -warmup; f < frames; ++f)
         {
+            if(animated && f >= 0)
+            {   // update(s, dt, true) before the frame, the first one by dt = 0; without --frames the run ends with the clip
+                // (src/tauray.cc:1064-1092)
+                if(!frames_given && !animator.is_playing()) break;
+                animator.update(f == 0 ? 0 : update_dt);
+                if(!frames_given && !animator.is_playing()) break;
+                rr.update_scene(scene, f % 3 == 2);      // an acceleration-structure update, every third frame a fast rebuild
+            }
             auto t0 = std::chrono::high_resolution_clock::now();
             rr.reset_accumulation();                   // offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
             rr.render();

@@ -180,6 +180,45 @@ def test_cpp_glb_loader_matches_python_loader(tmp_path):
     assert r.returncode == 1 and "not a GLB" in r.stderr
 
 
+def test_cpp_animator_matches_python_animator(tmp_path):
+    """tr::scene_animator (include/tauray_gltf.hh) against tauray_amd.animation.SceneAnimator on tests/golden/animated.glb: after
+    the same number of updates at the same frame rate - default clip by fallback, the named clip "spin", a frame rate whose step
+    jumps over keys - the instance records (model and model_prev bit for bit, the normal matrices to 1e-12), the cameras and the
+    skin's joint matrices agree."""
+    from tauray_amd import scene as S
+    from tauray_amd.animation import SceneAnimator
+    from tauray_amd.gltf import load_glb
+    glb = os.path.join(GOLDEN, "animated.glb")
+    dump = str(tmp_path / "an.trsc")
+    for name, frames, fps in (("", 1, 24), ("", 7, 24), ("", 29, 24), ("spin", 5, 60), ("", 2, 3)):
+        subprocess.check_call([CLI, glb, "--width=64", "--height=64", "--animation" + ("=" + name if name else ""), f"--framerate={fps}",
+                               f"--frames={frames}", f"--dump-scene={dump}"])
+        sc = load_glb(glb, 64, 64)
+        an = SceneAnimator(sc)
+        an.play(name)
+        dt = int(np.floor(1000000.0 / fps + 0.5))
+        for f in range(frames):
+            inst, cams, globs = an.update(0 if f == 0 else dt)
+        raw = open(dump, "rb").read()
+        pos, secs = 8, []
+        for _ in range(12):
+            n = struct.unpack_from("<Q", raw, pos)[0]
+            secs.append(raw[pos + 8:pos + 8 + n])
+            pos += 8 + n
+        got = np.frombuffer(secs[0], dtype=S.INSTANCE)
+        what = f"clip {name or '<any>'}, {frames} updates at {fps} fps"
+        assert np.array_equal(got["model"], inst["model"]) and np.array_equal(got["model_prev"], inst["model_prev"]), what
+        assert np.abs(got["model_normal"].astype(np.float64) - inst["model_normal"]).max() < 1e-12, what
+        assert frames == 1 or not np.array_equal(got["model"], got["model_prev"]), what
+        cam = np.frombuffer(secs[10], dtype=np.float32)
+        assert np.abs(cam.astype(np.float64) - np.concatenate([c.pack() for c in cams]).view(np.float32)).max() < 1e-12, what
+        d = open(dump + ".skins", "rb").read()
+        _, nv, nj = struct.unpack_from("<3I", d, 0)
+        joints = np.frombuffer(d[12 + nv * 32:12 + nv * 32 + nj * 64], dtype=np.float32).reshape(nj, 4, 4)
+        want = np.stack([S.to_glm(m) for m in sc.joint_transforms(sc.skinned[0], globs)])
+        assert np.abs(joints.astype(np.float64) - want).max() < 1e-6, what
+
+
 def test_cli_fails_loudly(scene_dump):
     r = subprocess.run([CLI, "/nonexistent.trsc"], capture_output=True, text=True)
     assert r.returncode == 1 and "Failed to open" in r.stderr
@@ -256,6 +295,43 @@ def test_cpp_renders_the_skinned_glb_like_the_python_mirror(tmp_path):
     pt2.run(c2)
     R.TonemapStage(ss2.ctx).run(c2, d2, W, H)
     assert float((np.abs(d2.download((H, W, 4)) - ref).max(-1) > 1e-3).mean()) > 0.01
+
+
+@pytest.mark.gpu
+def test_cpp_plays_the_animated_glb_like_the_python_mirror(tmp_path):
+    """`tauray_hip animated.glb --animation --framerate=24`: frames until the clip ends (30: the timer reaches the last key in
+    the 31st update), each after scene_animator::update + rt_renderer::update_scene (instances, joints, cameras, acceleration
+    structure); checked frames agree with the Python mirror playing the same file (SceneAnimator + SceneStage.animate)."""
+    from tauray_amd import renderer as R
+    from tauray_amd.animation import SceneAnimator
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    W, H = 160, 120
+    glb = os.path.join(GOLDEN, "animated.glb")
+    prefix = str(tmp_path / "an")
+    subprocess.check_call([CLI, glb, f"--width={W}", f"--height={H}", "--max-ray-depth=3", "--filetype=raw", "--animation", "--framerate=24", f"--headless={prefix}"])
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".raw"))
+    assert len(files) == 30, files
+    scene = load_glb(glb, W, H)
+    ctx = R.Context(0)
+    ss = R.SceneStage(ctx, scene)
+    an = SceneAnimator(scene)
+    an.play("")
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=3), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    color, disp = ctx.alloc(W * H * 16).zero(), ctx.alloc(W * H * 16)
+    shown = []
+    for frame in range(30):
+        ss.animate(an, 0 if frame == 0 else round(1000000.0 / 24.0), refit=(frame % 3 != 2))
+        pt.reset_accumulated_samples()
+        pt.run(color)                                        # the stage's frame counter advances like the renderer's
+        if frame in (0, 9, 20, 29):
+            R.TonemapStage(ctx).run(color, disp, W, H)
+            ref = disp.download((H, W, 4))
+            got = np.fromfile(f"{prefix}{frame}.raw", dtype=np.float32).reshape(H, W, 4)
+            differing = float((np.abs(got - ref).max(-1) > 1e-3).mean())
+            assert differing < 2e-3 and abs(float(got.mean()) - float(ref.mean())) < 1e-4, f"frame {frame}: {differing:.4%} of the pixels differ"
+            shown.append(got)
+    assert all(float((np.abs(shown[k] - shown[k + 1]).max(-1) > 1e-3).mean()) > 0.01 for k in range(3)), "the frames do not move"
 
 
 @pytest.mark.gpu
