@@ -585,6 +585,9 @@ struct gltf_animation
         double translation[3] = {0, 0, 0}, rotation[4] = {0, 0, 0, 1}, scale[3] = {1, 1, 1};
         gltf_detail::mat4d matrix = gltf_detail::mat4d::identity();
         std::vector<uint32_t> instances, cameras;       // rigid instances / cameras placed by this node's global transform
+        // punctual lights on this node: kind, index in the scene's point (point lights, then spotlights) / directional array
+        struct light { bool directional; uint32_t index; };
+        std::vector<light> lights;
         gltf_detail::mat4d local() const { return has_trs ? gltf_detail::trs_matrix(translation, rotation, scale) : matrix; }
     };
     struct skin { std::vector<int> joint_nodes; std::vector<gltf_detail::mat4d> inverse_bind; };      // parallel to scene_data::skinned
@@ -821,6 +824,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
                 normalized(direction, d.dir);
                 const double angle_deg = light_angle * (180.0 / PI);
                 d.dir_cutoff = (float)std::cos(angle_deg * (PI / 180.0));
+                anim->nodes[node_index].lights.push_back({true, (uint32_t)dir_lights.size()});
                 dir_lights.push_back(d);
             }
             else if(type == "point" || type == "spot")
@@ -843,9 +847,14 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
                     p.dir_cutoff = (float)std::cos(outer * (PI / 180.0));
                     p.dir_falloff = (float)falloff;
                     p.spot_radius = (float)(double(p.cutoff_radius) * std::tan(outer * (PI / 180.0)));
+                    anim->nodes[node_index].lights.push_back({false, 0x80000000u | (uint32_t)spot_lights.size()});     // index fixed up below
                     spot_lights.push_back(p);
                 }
-                else point_lights.push_back(p);
+                else
+                {
+                    anim->nodes[node_index].lights.push_back({false, (uint32_t)point_lights.size()});
+                    point_lights.push_back(p);
+                }
             }
         }
         if(const json* ch = node.find("children")) for(const json& c: ch->arr) visit((int)c.num, glob, node_index);
@@ -900,6 +909,7 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     if(!cameras.empty()) s.projection = cameras[0].perspective ? 0u : 1u;
 
     // point lights first, then spotlights (src/scene_stage.cc:1287-1317)
+    for(auto& n: anim->nodes) for(auto& l: n.second.lights) if(!l.directional && (l.index & 0x80000000u)) l.index = (l.index & 0x7FFFFFFFu) + (uint32_t)point_lights.size();
     point_lights.insert(point_lights.end(), spot_lights.begin(), spot_lights.end());
 
     // texture table + material::potentially_transparent (src/material.cc:7-11, check_opaque src/gltf.cc:54-66)
@@ -960,8 +970,9 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
 // play(scene, name, loop, fallback) / update(scene, dt) / is_playing(scene) of src/scene.cc:213-244 with the controller of
 // src/animation.tcc:79-205 (a queue of one clip), over a scene load_glb produced: `tauray --animation[=name] --framerate F`.
 // update() rewrites scene_data::instances (model, model_normal; model_prev = last frame's model), ::cameras (previous_cameras =
-// last frame's) and the joint matrices of ::skinned; scene_stage::apply / rt_renderer::update_scene send them to the device.
-// Punctual lights on animated nodes keep their loaded place (the C ABI uploads lights with the scene).
+// last frame's), the joint matrices of ::skinned and the light records; scene_stage::apply / rt_renderer::update_scene send them
+// to the device.
+// Punctual lights on moving nodes get a new position / direction in scene_data::point_lights / directional_lights.
 class scene_animator
 {
 public:
@@ -1026,6 +1037,24 @@ public:
             globals[n] = glob;
             for(uint32_t i: node.instances) { to_glm(glob, inst[i].model); to_glm(transpose(inverse(glob)), inst[i].model_normal); }
             for(uint32_t ci: node.cameras) anim->cameras[ci].transform = glob;
+            for(const gltf_animation::node::light& l: node.lights)
+            {   // get_global_direction / get_global_position as in load_glb; colours, radii and cone angles do not move
+                double coln[3], direction[3];
+                for(int c = 0; c < 3; ++c) coln[c] = std::sqrt(glob.m[0][c] * glob.m[0][c] + glob.m[1][c] * glob.m[1][c] + glob.m[2][c] * glob.m[2][c]);
+                for(int r = 0; r < 3; ++r) direction[r] = (glob.m[r][0] / coln[0]) * 0.0 + (glob.m[r][1] / coln[1]) * 0.0 + (glob.m[r][2] / coln[2]) * -1.0;
+                const double dn = std::sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]);
+                if(l.directional)
+                {
+                    directional_light& d = reinterpret_cast<directional_light*>(scene->directional_lights.data())[l.index];
+                    for(int k = 0; k < 3; ++k) d.dir[k] = (float)(direction[k] / dn);
+                }
+                else
+                {
+                    point_light& pl = reinterpret_cast<point_light*>(scene->point_lights.data())[l.index];
+                    for(int k = 0; k < 3; ++k) pl.pos[k] = (float)glob.m[k][3];
+                    if(pl.spot_radius >= 0) for(int k = 0; k < 3; ++k) pl.dir[k] = (float)(direction[k] / dn);
+                }
+            }
             for(int ch: node.children) visit(ch, glob);
         };
         for(int r: anim->roots) visit(r, mat4d::identity());

@@ -279,6 +279,8 @@ public:
         for(const scene_data::skinned_mesh& sk: s.skinned) skin(sk.instance, sk.joint_transforms.data(), (uint32_t)(sk.joint_transforms.size() / 16));
         update_cameras(s.cameras.data(), s.camera_count());
         if(!s.previous_cameras.empty()) set_previous_cameras(s.previous_cameras.data(), (uint32_t)(s.previous_cameras.size() / 320));
+        if(s.point_light_count() || s.directional_light_count())
+            check(trhip_scene_update_lights(dev->h, s.point_lights.data(), s.point_light_count(), s.directional_lights.data(), s.directional_light_count()));
         update_acceleration(rebuild);
     }
     void update_acceleration(bool rebuild = false)

@@ -88,6 +88,11 @@ typedef struct trhip_accel_info {
 
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
+/* Moving lights: replaces the 64-byte point / spot light records and the 32-byte directional light records of the uploaded
+ * scene, same counts (what scene_stage::update rewrites when a light's transformable changed, src/scene_stage.cc:1287-1354).
+ * Triangle lights follow their instances (trhip_scene_update_instances + the acceleration-structure update). */
+int trhip_scene_update_lights(trhip_device* dev, const void* point_lights, uint32_t point_light_count, const void* directional_lights,
+                              uint32_t directional_light_count);
 /* camera_pair.previous of every viewport (shader/scene.glsl:176-185); the current cameras until set.  Feeds the motion
  * features and the screen-motion target. */
 int trhip_scene_set_previous_cameras(trhip_device* dev, const void* camera_data, uint32_t count);

@@ -5,8 +5,8 @@ A clip holds up to three tracks per node - position, scaling, orientation - samp
 (src/gltf.cc:167-190 rounds the file's seconds).  `SceneAnimator` is what `tauray --animation[=name] --framerate F` does
 to a loaded scene per frame (src/tauray.cc:252-253, 1052-1092): advance every animated node's timer, rebuild the global
 transforms below it, and hand the renderer new instance records, cameras and joint matrices
-(`SceneStage.update_instances / update_cameras / pose`).  Punctual lights on animated nodes keep their loaded place: the
-C ABI uploads lights with the scene, and the reference's test assets animate meshes, cameras and skeletons only.
+(`SceneStage.update_instances / update_cameras / pose`), and the records of the punctual lights that hang on moving nodes
+(`trhip_scene_update_lights`).
 """
 from __future__ import annotations
 
@@ -153,6 +153,7 @@ class Node:
     matrix: Optional[np.ndarray]
     instances: List[int] = field(default_factory=list)     # rigid instances placed by this node's global transform
     cameras: List[int] = field(default_factory=list)
+    lights: List[tuple] = field(default_factory=list)      # (kind, index in its list, make(global transform) -> record)
 
     def local(self) -> np.ndarray:
         if self.trs is None:
@@ -191,6 +192,7 @@ class SceneAnimator:
                 c.update(node.trs, dt_ticks)
         instances = desc.instances.copy()
         instances["model_prev"] = desc.instances["model"]
+        point_lights, directional_lights = desc.point_lights.copy(), desc.directional_lights.copy()
 
         def visit(n, parent):
             node = desc.nodes[n]
@@ -201,11 +203,17 @@ class SceneAnimator:
                 instances["model_normal"][i] = S.to_glm(np.linalg.inv(glob).T)
             for ci in node.cameras:
                 desc.cameras[ci].transform = glob
+            for kind, index, make in node.lights:       # point lights first, then spotlights, in one array (src/scene_stage.cc:1287-1317)
+                if kind == "directional":
+                    directional_lights[index] = make(glob)
+                else:
+                    point_lights[index + (desc.spotlight_base if kind == "spot" else 0)] = make(glob)
             for ch in node.children:
                 visit(ch, glob)
 
         for r in desc.roots:
             visit(r, np.eye(4))
         desc.instances = instances
+        desc.point_lights, desc.directional_lights = point_lights, directional_lights
         desc.node_globals = dict(self.node_globals)
         return instances, desc.cameras, self.node_globals

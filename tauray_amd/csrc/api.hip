@@ -390,6 +390,19 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     return 0;
 }
 
+int trhip_scene_update_lights(trhip_device* dev, const void* point_lights, uint32_t point_light_count, const void* directional_lights,
+                              uint32_t directional_light_count) {
+    DEVCHK(dev);
+    DeviceScene& s = dev->scene;
+    if (point_light_count != s.point_light_count || directional_light_count != s.directional_light_count)
+        return set_error("trhip_scene_update_lights: the light counts are those of the uploaded scene (" + std::to_string(s.point_light_count) + " point, " +
+                         std::to_string(s.directional_light_count) + " directional)");
+    HIPCHK(hipDeviceSynchronize());
+    if (point_light_count) HIPCHK(hipMemcpy(s.point_lights, point_lights, (size_t)point_light_count * sizeof(PointLight), hipMemcpyHostToDevice));
+    if (directional_light_count) HIPCHK(hipMemcpy(s.directional_lights, directional_lights, (size_t)directional_light_count * sizeof(DirectionalLight), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count) {
     DEVCHK(dev);
     DeviceScene& s = dev->scene;

@@ -350,20 +350,28 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
         if kl is not None:
             l = j["extensions"]["KHR_lights_punctual"]["lights"][kl["light"]]
             color = np.array(l.get("color", [1, 1, 1]), dtype=np.float64) * float(l.get("intensity", 1.0))
-            # get_global_direction: normalize(global orientation * (0,0,-1))
-            rot = glob[:3, :3] / np.linalg.norm(glob[:3, :3], axis=0, keepdims=True)
-            direction = rot @ np.array([0, 0, -1.0])
-            position = glob[:3, 3]
+            angle, radius = light_meta["angle"], light_meta["radius"]
+
+            def place(g):
+                # get_global_direction: normalize(global orientation * (0,0,-1))
+                rot = g[:3, :3] / np.linalg.norm(g[:3, :3], axis=0, keepdims=True)
+                return rot @ np.array([0, 0, -1.0]), g[:3, 3]
+
             if l["type"] == "directional":
-                dir_lights.append(S.make_directional_light(color, direction, math.degrees(light_meta["angle"])))
+                make = lambda g: S.make_directional_light(color, place(g)[0], math.degrees(angle))
+                rec.lights.append(("directional", len(dir_lights), make))
+                dir_lights.append(make(glob))
             elif l["type"] == "point":
-                point_lights.append(S.make_point_light(color / (4 * math.pi), position, light_meta["radius"]))
+                make = lambda g: S.make_point_light(color / (4 * math.pi), place(g)[1], radius)
+                rec.lights.append(("point", len(point_lights), make))
+                point_lights.append(make(glob))
             elif l["type"] == "spot":
                 outer = math.degrees(l["spot"].get("outerConeAngle", math.pi / 4))
                 inner = math.degrees(l["spot"].get("innerConeAngle", 0.0))
                 fall = S.spotlight_falloff_from_inner_angle(inner, outer, 4 / 255.0)
-                spot_lights.append(S.make_spotlight(color / (4 * math.pi), position, direction,
-                                                    light_meta["radius"], outer, fall))
+                make = lambda g: S.make_spotlight(color / (4 * math.pi), place(g)[1], place(g)[0], radius, outer, fall)
+                rec.lights.append(("spot", len(spot_lights), make))
+                spot_lights.append(make(glob))
         for ch in node.get("children", []):
             visit(ch, glob, node_index)
 
@@ -406,6 +414,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
         name=path.split("/")[-1])
     desc.node_globals = node_globals
     desc.nodes, desc.roots, desc.animations = nodes, roots, animations
+    desc.spotlight_base = len(point_lights)
     for inst, skin_index, skin in skinned_pending:
         sk = j["skins"][skin_index]
         joints = list(sk["joints"])

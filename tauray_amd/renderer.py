@@ -240,6 +240,9 @@ class SceneStage:
             self.skin(sk.instance, self.scene.joint_transforms(sk, node_globals), refit=None)
         self.update_cameras(cameras)
         self.set_previous_cameras(animator.previous_cameras)
+        pl, dl = np.ascontiguousarray(self.scene.point_lights), np.ascontiguousarray(self.scene.directional_lights)
+        if len(pl) or len(dl):          # lights on moving nodes
+            check(_lib.lib().trhip_scene_update_lights(self.ctx.h, pl.ctypes.data if len(pl) else None, len(pl), dl.ctypes.data if len(dl) else None, len(dl)))
         return self._accel_after_change(refit)
 
     def update_cameras(self, cameras):

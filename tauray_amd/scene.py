@@ -317,6 +317,7 @@ class SceneDesc:
     nodes: dict = field(default_factory=dict)                      # glTF node index -> animation.Node (tree, local transform, instances, cameras)
     roots: list = field(default_factory=list)                      # root nodes of the file's scenes
     animations: dict = field(default_factory=dict)                 # glTF node index -> {clip name: animation.Animation}
+    spotlight_base: int = 0                                        # index of the first spotlight in point_lights (point lights come first)
 
     def joint_transforms(self, sk: "SkinnedMesh", node_globals: Optional[dict] = None) -> np.ndarray:
         """model::update_joints (src/model.cc:107-118): joint node's global transform * inverse bind matrix, (n, 4, 4)."""

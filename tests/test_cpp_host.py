@@ -184,7 +184,7 @@ def test_cpp_animator_matches_python_animator(tmp_path):
     """tr::scene_animator (include/tauray_gltf.hh) against tauray_amd.animation.SceneAnimator on tests/golden/animated.glb: after
     the same number of updates at the same frame rate - default clip by fallback, the named clip "spin", a frame rate whose step
     jumps over keys - the instance records (model and model_prev bit for bit, the normal matrices to 1e-12), the cameras and the
-    skin's joint matrices agree."""
+    skin's joint matrices agree, and so does the record of the point light that rides on an animated node."""
     from tauray_amd import scene as S
     from tauray_amd.animation import SceneAnimator
     from tauray_amd.gltf import load_glb
@@ -212,6 +212,7 @@ def test_cpp_animator_matches_python_animator(tmp_path):
         assert frames == 1 or not np.array_equal(got["model"], got["model_prev"]), what
         cam = np.frombuffer(secs[10], dtype=np.float32)
         assert np.abs(cam.astype(np.float64) - np.concatenate([c.pack() for c in cams]).view(np.float32)).max() < 1e-12, what
+        assert secs[4] == sc.point_lights.tobytes() and secs[5] == sc.directional_lights.tobytes(), what + ": lights"     # the lamp drifts in "move"
         d = open(dump + ".skins", "rb").read()
         _, nv, nj = struct.unpack_from("<3I", d, 0)
         joints = np.frombuffer(d[12 + nv * 32:12 + nv * 32 + nj * 64], dtype=np.float32).reshape(nj, 4, 4)

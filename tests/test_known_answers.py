@@ -404,7 +404,7 @@ def test_animation_tracks_of_the_animated_fixture():
     scene, gen = _load_animated()
     names = {n: sorted(pool) for n, pool in scene.animations.items()}
     box, child = 8, 9
-    assert names[box] == ["move", "spin"] and names[child] == ["move"] and sorted(names) == [3, 4, 7, 8, 9]
+    assert names[box] == ["move", "spin"] and names[child] == ["move"] and sorted(names) == [3, 4, 6, 7, 8, 9]
     move = scene.animations[box]["move"]
     assert move.position.timestamps == [0, 350000, 800000, 1250000] and move.position.interpolation == A.LINEAR
     assert move.scaling.interpolation == A.STEP and move.orientation.interpolation == A.CUBICSPLINE
@@ -438,6 +438,7 @@ def test_animation_playback_moves_instances_cameras_and_joints():
     scene, gen = _load_animated()
     box_inst, child_inst = scene.nodes[8].instances[0], scene.nodes[9].instances[0]
     rest = scene.instances.copy()
+    rest_lights = scene.point_lights.copy()
     an = SceneAnimator(scene)
     assert not an.is_playing()
     an.play("")
@@ -456,6 +457,10 @@ def test_animation_playback_moves_instances_cameras_and_joints():
     assert np.allclose(from_glm(inst["model"][child_inst]), want @ child_local, atol=1e-6)
     assert np.allclose(np.asarray(cams[0].transform)[:3, 3], np.array(gen.CAM_VALUES[0]) * 0.8 + np.array(gen.CAM_VALUES[1]) * 0.2, atol=1e-6)
     assert np.allclose(np.asarray(an.previous_cameras[0].transform)[:3, 3], gen.CAM_VALUES[0])
+    # the lamp: a point light on an animated node, 0.25 s into its first segment (0 .. 0.6 s)
+    r = float(np.float32(250000) / np.float32(600000))
+    assert np.allclose(scene.point_lights["pos"][0], np.array(gen.LAMP_VALUES[0]) * (1 - r) + np.array(gen.LAMP_VALUES[1]) * r, atol=1e-6)
+    assert np.array_equal(scene.point_lights["color"], rest_lights["color"])
     # joints: node 3 turns about z by the LINEAR track, the skin's joint matrices follow through node_globals
     j1 = scene.animations[3]["move"].orientation.sample(dt, True)
     assert np.allclose(globs[3], globs[2] @ trs_matrix((0, 1, 0), j1), atol=1e-6)

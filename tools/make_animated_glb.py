@@ -5,7 +5,7 @@ animation loader / playback tests (the reference ships no animated asset).  Adde
   * a box with a child box, animated by the clip "move": LINEAR translation (4 keys), CUBICSPLINE rotation about y (3 keys with
     tangents), STEP scale (3 keys); the child has a LINEAR rotation of its own, so its world transform is a product of two clips;
   * the skeleton's joints 1 and 2 bend further in "move" (LINEAR rotation), so the tube is re-skinned every frame;
-  * the camera dollies in "move" (LINEAR translation);
+  * the camera dollies and the lamp (a point light) drifts in "move" (LINEAR translations);
   * a second clip "spin" that only turns the box (what `--animation=spin` must pick, and what must NOT play by fallback on
     nodes that have "move", since "move" sorts first).
 
@@ -35,6 +35,8 @@ JOINT1_DEG = [30.0, -20.0, 55.0]                # about z, on top of nothing: th
 JOINT2_DEG = [40.0, 70.0, -10.0]
 CAM_TIMES = [0.0, 1.25]
 CAM_VALUES = [(0.0, 1.2, 5.0), (0.8, 1.6, 4.0)]
+LAMP_TIMES = [0.0, 0.6, 1.25]
+LAMP_VALUES = [(1.5, 3.0, 2.0), (0.2, 2.4, 2.6), (-1.4, 3.2, 1.0)]
 SPIN_TIMES = [0.0, 0.5]
 SPIN_DEG = [0.0, 90.0]                          # about z
 
@@ -100,6 +102,7 @@ def build():
     joint1 = next(i for i, n in enumerate(doc["nodes"]) if n.get("name") == "joint1")
     joint2 = next(i for i, n in enumerate(doc["nodes"]) if n.get("name") == "joint2")
     camera = next(i for i, n in enumerate(doc["nodes"]) if "camera" in n)
+    lamp = next(i for i, n in enumerate(doc["nodes"]) if n.get("name") == "lamp")
 
     samplers, channels = [], []
 
@@ -120,6 +123,7 @@ def build():
     channel(joint1, "rotation", JOINT_TIMES, [quat((0, 0, 1), d) for d in JOINT1_DEG], "VEC4")
     channel(joint2, "rotation", JOINT_TIMES, [quat((0, 0, 1), d) for d in JOINT2_DEG], "VEC4")
     channel(camera, "translation", CAM_TIMES, CAM_VALUES, "VEC3")
+    channel(lamp, "translation", LAMP_TIMES, LAMP_VALUES, "VEC3")
     doc["animations"] = [{"name": "move", "samplers": samplers, "channels": channels}]
     samplers, channels = [], []
     channel(n_box, "rotation", SPIN_TIMES, [quat((0, 0, 1), d) for d in SPIN_DEG], "VEC4")
