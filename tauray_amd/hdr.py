@@ -1,0 +1,106 @@
+"""Radiance .hdr (RGBE) images: the `--envmap=file.hdr` of the reference (src/options.hh:125; texture::load_from_file ->
+stbi_loadf, src/texture.cc:453-461; environment_map, src/environment_map.cc:11-16).
+
+`load_hdr` returns what stbi_loadf hands the reference plus the alpha channel it appends: (H, W, 4) float32, row 0 = the top
+row of the file (no flip), rgb = mantissa * 2^(exponent - 136) without the half-step other decoders add, 0 for exponent 0,
+alpha 1.  Flat and new-style run-length-encoded scanlines; only the -Y +X orientation, like stb_image."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def load_hdr(path: str) -> np.ndarray:
+    raw = open(path, "rb").read()
+    if not (raw.startswith(b"#?RADIANCE") or raw.startswith(b"#?RGBE")):
+        raise ValueError(f"{path}: not a Radiance .hdr file")
+    pos = raw.index(b"\n") + 1
+    fmt_ok = False
+    while True:
+        end = raw.index(b"\n", pos)
+        line = raw[pos:end]
+        pos = end + 1
+        if line == b"":
+            break
+        if line == b"FORMAT=32-bit_rle_rgbe":
+            fmt_ok = True
+    if not fmt_ok:
+        raise ValueError(f"{path}: unsupported .hdr format")
+    end = raw.index(b"\n", pos)
+    tok = raw[pos:end].split()
+    pos = end + 1
+    if len(tok) != 4 or tok[0] != b"-Y" or tok[2] != b"+X":
+        raise ValueError(f"{path}: unsupported .hdr data layout")
+    h, w = int(tok[1]), int(tok[3])
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    data = np.frombuffer(raw, dtype=np.uint8)
+    flat = w < 8 or w >= 32768
+    for y in range(h):
+        if not flat and not (data[pos] == 2 and data[pos + 1] == 2 and not (data[pos + 2] & 0x80)):
+            if y != 0:
+                raise ValueError(f"{path}: corrupt .hdr scanline")
+            flat = True            # stb_image: the first scanline decides; the whole file is flat
+        if flat:
+            rgbe[y] = data[pos:pos + 4 * w].reshape(w, 4)
+            pos += 4 * w
+            continue
+        if (int(data[pos + 2]) << 8 | int(data[pos + 3])) != w:
+            raise ValueError(f"{path}: invalid decoded scanline length")
+        pos += 4
+        for c in range(4):
+            x = 0
+            while x < w:
+                count = int(data[pos]); pos += 1
+                if count > 128:
+                    count -= 128
+                    rgbe[y, x:x + count, c] = data[pos]; pos += 1
+                else:
+                    rgbe[y, x:x + count, c] = data[pos:pos + count]; pos += count
+                x += count
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e != 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0)).astype(np.float32)
+    out = np.ones((h, w, 4), dtype=np.float32)
+    out[..., :3] = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    return out
+
+
+def write_hdr(path: str, rgb: np.ndarray, rle: bool = True):
+    """Writes float rgb (H, W, 3) as RGBE (round-to-nearest mantissas); for fixtures."""
+    rgb = np.asarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    m = rgb.max(axis=-1)
+    e = np.zeros((h, w), dtype=np.int32)
+    nz = m > 1e-32
+    e[nz] = np.floor(np.log2(m[nz])).astype(np.int32) + 1
+    scale = np.where(nz, np.ldexp(np.float32(256.0), -e), np.float32(0))
+    mant = np.clip(np.floor(rgb * scale[..., None]), 0, 255).astype(np.uint8)
+    rgbe = np.concatenate([mant, np.where(nz, e + 128, 0).astype(np.uint8)[..., None]], axis=-1)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+        for y in range(h):
+            if not rle or w < 8 or w >= 32768:
+                f.write(rgbe[y].tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                row = rgbe[y, :, c]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 4:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        n = 1
+                        while x + n < w and n < 128 and not (x + n + 3 < w and row[x + n] == row[x + n + 1] == row[x + n + 2] == row[x + n + 3]):
+                            n += 1
+                        f.write(bytes([n]) + row[x:x + n].tobytes())
+                        x += n
+
+
+def set_envmap(scene, path: str, factor=(1.0, 1.0, 1.0)):
+    """environment_map(dev, path) on a loaded scene (src/tauray.cc:198-201): lat-long projection, factor (1, 1, 1)."""
+    scene.envmap = load_hdr(path)
+    scene.environment_factor = (float(factor[0]), float(factor[1]), float(factor[2]), 1.0)      # vec4(factor, 1), src/scene_stage.cc:1345
+    return scene

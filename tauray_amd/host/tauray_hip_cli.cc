@@ -16,6 +16,7 @@
 #include <sstream>
 
 #include "tauray_hip.hh"
+#include "tauray_envmap.hh"
 #include "tauray_gltf.hh"
 
 using namespace tr;
@@ -36,6 +37,7 @@ int main(int argc, char** argv)
         std::vector<int> devices;
         bool timing = false;
         std::string dump_scene;
+        std::string envmap_path;
         bool frames_given = false, animation_flag = false;      // --animation[=name] --framerate=F (src/options.hh:110-129)
         std::string animation_name;
         double framerate = 60.0;
@@ -62,6 +64,7 @@ int main(int argc, char** argv)
             else if(a == "--animation") animation_flag = true;                                  // any clip a node has (src/tauray.cc:252-253)
             else if(starts(a, "--animation=")) { animation_flag = true; animation_name = val("--animation="); }
             else if(starts(a, "--framerate=")) framerate = std::stod(val("--framerate="));
+            else if(starts(a, "--envmap=")) envmap_path = val("--envmap=");                        // lat-long .hdr (src/options.hh:125)
             else if(starts(a, "--warmup-frames=")) warmup = std::stoi(val("--warmup-frames="));
             else if(starts(a, "--renderer="))
             {
@@ -136,6 +139,7 @@ int main(int argc, char** argv)
 
         const bool is_glb = scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0;
         scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
+        if(!envmap_path.empty()) set_envmap(scene, envmap_path);      // src/tauray.cc:198-201
         // play(scene, name, !replay, name == "") (src/tauray.cc:252-253); ticks in microseconds per update (:1052)
         scene_animator animator(scene);
         if(animation_flag) animator.play(animation_name, false);

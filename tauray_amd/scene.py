@@ -233,10 +233,14 @@ def build_alias_table(envmap: np.ndarray) -> np.ndarray:
     ys = np.arange(h, dtype=np.float32)
     y0 = ys / np.float32(h)
     y1 = (ys + 1) / np.float32(h)
-    solid = (np.float32(2.0 * math.pi) * (np.cos(np.float32(math.pi) * y0) - np.cos(np.float32(math.pi) * y1))
+    # cos / sin below: evaluated in double and rounded to float, so that the C++ host's table (include/tauray_envmap.hh, libm)
+    # is this one bit for bit; the shader the reference runs here uses the GPU's float cos
+    def cos32(x):
+        return np.array([math.cos(float(v)) for v in x], dtype=np.float64).astype(np.float32)
+    solid = (np.float32(2.0 * math.pi) * (cos32(np.float32(math.pi) * y0) - cos32(np.float32(math.pi) * y1))
              / np.float32(w)).astype(np.float32)
     importance = (lum * solid[:, None]).astype(np.float32).reshape(-1)
-    total = float(np.sum(importance.astype(np.float64)))
+    total = float(np.cumsum(importance.astype(np.float64))[-1]) if n else 0.0      # one running double sum, in pixel order
     inv_average = np.float32(1.0 / (total / n)) if total > 0 else np.float32(0)
     importance = (importance * inv_average).astype(np.float32)
 
@@ -277,7 +281,8 @@ def build_alias_table(envmap: np.ndarray) -> np.ndarray:
                 alias[old_j] = j
                 weight = np.float32(np.float32(weight + importance[j]) - np.float32(1.0))
     del imp
-    sin_theta = np.sin((np.arange(h, dtype=np.float32) + np.float32(0.5)) / np.float32(h) * np.float32(math.pi)).astype(np.float32)
+    sin_theta = np.array([math.sin(float(v)) for v in (np.arange(h, dtype=np.float32) + np.float32(0.5)) / np.float32(h) * np.float32(math.pi)],
+                         dtype=np.float64).astype(np.float32)
     rows = np.arange(n) // w
     denom = (np.float32(2.0 * math.pi * math.pi) * sin_theta).astype(np.float32)
     table["pdf"] = importance / denom[rows]

@@ -220,6 +220,29 @@ def test_cpp_animator_matches_python_animator(tmp_path):
         assert np.abs(joints.astype(np.float64) - want).max() < 1e-6, what
 
 
+def test_cpp_envmap_matches_python(tmp_path):
+    """`tauray_hip --envmap=file.hdr` (include/tauray_envmap.hh: Radiance RGBE reader + environment_map::generate_alias_table)
+    against the Python mirror (tauray_amd/hdr.py, scene.build_alias_table): the texels, every entry of the alias table and the
+    environment factor, byte for byte, for the run-length-encoded and the flat fixture; a file that is not an .hdr fails loudly."""
+    from tauray_amd.hdr import load_hdr
+    from tauray_amd.scene import build_alias_table
+    dump = str(tmp_path / "env.trsc")
+    for name in ("sky.hdr", "sky_flat.hdr"):
+        subprocess.check_call([CLI, os.path.join(GOLDEN, "test.glb"), "--width=64", "--height=64", f"--envmap={os.path.join(GOLDEN, name)}", f"--dump-scene={dump}"])
+        raw = open(dump, "rb").read()
+        pos, secs = 8, []
+        for _ in range(12):
+            n = struct.unpack_from("<Q", raw, pos)[0]
+            secs.append(raw[pos + 8:pos + 8 + n])
+            pos += 8 + n
+        env = load_hdr(os.path.join(GOLDEN, name))
+        assert secs[8] == env.tobytes(), name
+        assert secs[9] == build_alias_table(env).tobytes(), name
+        assert struct.unpack("<II4f", raw[pos:pos + 24]) == (96, 48, 1.0, 1.0, 1.0, 1.0)
+    r = subprocess.run([CLI, os.path.join(GOLDEN, "test.glb"), f"--envmap={os.path.join(GOLDEN, 'test.glb')}", f"--dump-scene={dump}"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not a Radiance" in r.stderr
+
+
 def test_cli_fails_loudly(scene_dump):
     r = subprocess.run([CLI, "/nonexistent.trsc"], capture_output=True, text=True)
     assert r.returncode == 1 and "Failed to open" in r.stderr
@@ -333,6 +356,44 @@ def test_cpp_plays_the_animated_glb_like_the_python_mirror(tmp_path):
             assert differing < 2e-3 and abs(float(got.mean()) - float(ref.mean())) < 1e-4, f"frame {frame}: {differing:.4%} of the pixels differ"
             shown.append(got)
     assert all(float((np.abs(shown[k] - shown[k + 1]).max(-1) > 1e-3).mean()) > 0.01 for k in range(3)), "the frames do not move"
+
+
+@pytest.mark.gpu
+def test_cpp_renders_with_an_envmap_like_the_python_mirror_and_the_oracle(tmp_path):
+    """test.glb lit by tests/golden/sky.hdr (a sun 4000 times brighter than the sky: the alias table matters): the C++ host's
+    frame agrees with the Python mirror's, and the mirror's with the oracle's."""
+    from tauray_amd import renderer as R
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.hdr import set_envmap
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    from oracle import binding as oracle
+    W, H = 160, 120
+    glb, hdr = os.path.join(GOLDEN, "test.glb"), os.path.join(GOLDEN, "sky.hdr")
+    scene = set_envmap(load_glb(glb, W, H), hdr)
+    ctx = R.Context(0)
+    ss = R.SceneStage(ctx, scene)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    assert opt.nee_envmap > 0
+    pt = R.PathTracerStage(ctx, ss, opt, DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    color, disp = ctx.alloc(W * H * 16).zero(), ctx.alloc(W * H * 16)
+    pt.run(color)
+    R.TonemapStage(ctx).run(color, disp, W, H)
+    ref = disp.download((H, W, 4))
+    prefix = str(tmp_path / "env")
+    subprocess.check_call([CLI, glb, f"--width={W}", f"--height={H}", "--max-ray-depth=3", "--filetype=raw", f"--envmap={hdr}", f"--headless={prefix}"])
+    got = np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4)
+    differing = float((np.abs(got - ref).max(-1) > 1e-3).mean())
+    assert differing < 2e-3 and abs(float(got.mean()) - float(ref.mean())) < 1e-4, f"{differing:.4%} of the pixels differ"
+    plain = load_glb(glb, W, H)
+    ss2 = R.SceneStage(ctx, plain)
+    pt2 = R.PathTracerStage(ctx, ss2, R.options_for_scene(plain, max_bounces=3), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    c2 = ctx.alloc(W * H * 16).zero()
+    pt2.run(c2)
+    assert abs(float(c2.download((H, W, 4))[..., :3].mean()) - float(color.download((H, W, 4))[..., :3].mean())) > 0.01, "the environment map lit nothing"
+    hip = color.download((1, H, W, 4))
+    want = oracle.OracleScene(scene).render_pt(oracle.options_for_scene(scene, max_bounces=3), W, H)
+    rel = np.abs(hip[..., :3] - want[..., :3]) / (np.abs(want[..., :3]) + 1e-2)
+    assert float((rel.max(-1) > 1e-2).mean()) < 2e-3 and abs(float(hip[..., :3].mean()) - float(want[..., :3].mean())) < 2e-3 * float(want[..., :3].mean())
 
 
 @pytest.mark.gpu

@@ -480,3 +480,36 @@ def test_animation_playback_moves_instances_cameras_and_joints():
     an.update(0)
     inst, _, _ = an.update(750000)          # 0.75 s into a 0.5 s loop = 0.25 s: 45 degrees about z
     assert an.is_playing() and np.allclose(from_glm(inst["model"][box_inst])[:3, :3] / 0.5, trs_matrix(rotation=gen.quat((0, 0, 1), 45.0))[:3, :3], atol=1e-6)
+
+
+def test_hdr_reader_known_pixels(tmp_path):
+    """tauray_amd/hdr.py against hand-made RGBE bytes: value = mantissa * 2^(exponent - 136) (stb_image's conversion, no half
+    step), exponent 0 is black, alpha 1 is appended, row 0 is the first scanline of the file; run-length-encoded and flat
+    scanlines decode to the same pixels."""
+    import os
+    from conftest import GOLDEN
+    from tauray_amd.hdr import load_hdr
+    px = [(128, 64, 32, 129), (255, 0, 1, 136), (1, 2, 3, 0), (200, 100, 50, 120)] * 2 + [(9, 9, 9, 128)]
+    w = len(px)
+    flat = bytes(v for p in px for v in p)
+    rle = bytes([2, 2, 0, w])
+    for c in range(4):
+        col = [p[c] for p in px]
+        rle += bytes([w]) + bytes(col)                      # one literal run per channel
+    head = b"#?RADIANCE\n# made by hand\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X %d\n" % w
+    f = tmp_path / "t.hdr"
+    f.write_bytes(head + rle + bytes([2, 2, 0, w]) + b"".join(bytes([128 + w, v]) for v in (7, 7, 7, 130)))      # second row: four runs of one value
+    img = load_hdr(str(f))
+    assert img.shape == (2, w, 4) and img.dtype == np.float32
+    assert np.array_equal(img[0, 0], [1.0, 0.5, 0.25, 1.0]) and np.array_equal(img[0, 1], [255.0, 0.0, 1.0, 1.0])
+    assert np.array_equal(img[0, 2], [0, 0, 0, 1]) and np.array_equal(img[0, 3, :3], np.array([200, 100, 50], np.float32) * np.float32(2.0 ** -16))
+    assert np.array_equal(img[1], np.tile(np.array([7 / 64, 7 / 64, 7 / 64, 1.0], np.float32), (w, 1)))
+    g = tmp_path / "narrow.hdr"                             # fewer than eight columns: always flat
+    g.write_bytes(b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 4\n" + flat[:16])
+    assert np.array_equal(load_hdr(str(g))[0], img[0, :4])
+    a, b = load_hdr(os.path.join(GOLDEN, "sky.hdr")), load_hdr(os.path.join(GOLDEN, "sky_flat.hdr"))
+    assert a.shape == (48, 96, 4) and np.array_equal(a, b) and a[..., :3].max() > 3000 and (a[43, :, :3] == 0).all()
+    for bad in (b"P6\n", head[:20], head + rle[:10]):
+        (tmp_path / "bad.hdr").write_bytes(bad)
+        with pytest.raises((ValueError, IndexError)):
+            load_hdr(str(tmp_path / "bad.hdr"))
