@@ -180,9 +180,10 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     bool valid = qi < n;
     uint id = 0;
     u4 misc = {0, 0, 0, 1};
-    if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; valid = !(misc.w & 1u); }
     f4 o = F4(0), d = F4(0);
-    if (valid) { o = pb.org_pdf[id]; d = pb.dir_reg[id]; }
+    // the ray is fetched together with the path's flags, not behind them: one round trip less before the traversal starts, and a
+    // queue holds live paths only (the flag matters at bounce 0, where the ids are all launch ids)
+    if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
     HitRecord hit;
     const bool include_lights = !(P.opt.hide_lights && bounce == 0);
     const uint before = st.nodes;
