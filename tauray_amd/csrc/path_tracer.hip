@@ -630,9 +630,29 @@ __global__ __launch_bounds__(KB, TR_SURFACE_WAVES) void k_surface(SceneView sv, 
 #endif
 // LAST: the instance for bounce == max_bounces - 1, where every path is terminal (path_tracer.glsl:445): compiled without the
 // NEE / BSDF half of the loop body and without the block-wide appends (and their barriers).
-template <bool COUNT, bool SPLIT, bool LAST>
-__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES)) void k_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
+// CLI: the instance for the option set of the reference's command line (uniform-random sampler, point film,
+// power MIS, material bounces, solid-angle triangle lights, no roulette / clamping / regularisation / depth of field / hidden
+// lights / white first-bounce albedo / transparent background / pre-transformed vertices) - what every BASELINE config renders
+// with.  The reference compiles its options into the pipeline as #defines (src/path_tracer_stage.cc:30-116); here the options
+// are data, and this instance pins them to constants so that the compiler drops the other samplers, bounce modes, light modes
+// and their registers.  PtStage::render picks it when the stage's options are that set.
+TR_DEV void pin_cli_defaults(PtParams& P) {
+    P.opt.sampler = 0; P.opt.film = 0; P.opt.mis_mode = 2; P.opt.bounce_mode = 2; P.opt.tri_light_mode = 1;
+    P.opt.russian_roulette_delta = 0.0f; P.opt.indirect_clamping = 0.0f; P.opt.regularization_gamma = 0.0f;
+    P.opt.depth_of_field = 0; P.opt.hide_lights = 0; P.opt.use_white_albedo_on_first_bounce = 0; P.opt.transparent_background = 0;
+    P.opt.pre_transformed_vertices = 0;
+}
+static bool is_cli_default_set(const trhip_pt_options& o) {
+    return o.sampler == 0 && o.film == 0 && o.mis_mode == 2 && o.bounce_mode == 2 && o.tri_light_mode == 1 && o.russian_roulette_delta == 0.0f &&
+           o.indirect_clamping == 0.0f && o.regularization_gamma == 0.0f && o.depth_of_field == 0 && o.hide_lights == 0 &&
+           o.use_white_albedo_on_first_bounce == 0 && o.transparent_background == 0 && o.pre_transformed_vertices == 0;
+}
+
+template <bool COUNT, bool SPLIT, bool LAST, bool CLI = false>
+__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES)) void k_shade(SceneView sv, PtParams P_, PathBuffers pb, int bounce, const uint* queue,
                                               uint* bc, uint* next_queue) {
+    PtParams P = P_;
+    if (CLI) pin_cli_defaults(P);
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     const uint n_round = LAST ? n : ((n + (uint)KB - 1u) & ~((uint)KB - 1u));   // whole blocks take part in the appends
     uint surf = 0;
@@ -1246,6 +1266,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         sv.vertices = scene->world_vertices; sv.spans = scene->world_spans;
     }
     const bool count = count_work != 0;
+    static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
+    const bool cli_set = cli_instances && is_cli_default_set(opt);     // k_shade<.., CLI>
     const bool top = TR_BVH4 && sv.treetop != nullptr;   // trace blocks keep the top of the tree in LDS
     if (split && !direct && !pb.surf) HIPCHK(hipMalloc(&pb.surf, impl->capacity * 5 * 16));
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
@@ -1437,9 +1459,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         }
                         else if (last) {
                             if (count) hipLaunchKernelGGL((k_shade<true, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                             else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         }
                         else if (count) hipLaunchKernelGGL((k_shade<true, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)

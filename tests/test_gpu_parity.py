@@ -2006,13 +2006,13 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     variants = {"default": {}, "one_lane_unfused": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0"}, "no_overlap": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0", "TRHIP_OVERLAP": "0"},
                 "two_lanes": {"TRHIP_LANES": "2"}, "small_grids": {"TRHIP_GRID_BLOCKS": "300", "TRHIP_SHADE_BLOCKS": "100"},
                 "treetop": {"TRHIP_TREETOP": "1"}, "shade_split": {"TRHIP_SHADE_SPLIT": "1"}, "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
-                "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"},
+                "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"}, "generic_shade": {"TRHIP_SHADE_CLI": "0"},
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"}}
     frames = {}
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
