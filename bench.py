@@ -61,6 +61,9 @@ def parse():
                     help="how N > 1 GPUs divide the pixels of a frame: interleaved scanlines, or shuffled strips whose shares the load "
                          "balancer sets (the reference's command-line default, src/tauray.cc:519-521); auto = strips")
     ap.add_argument("--no-balance", action="store_true", help="shuffled strips with equal shares: no load-balancer updates during the untimed frames")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="consecutive frames per path-tracing launch (trhip_pt_set_frame_batch); 0 = 1 on one GPU, and for N > 1 pixel "
+                         "shards - whose launches are too small to fill a GPU - the largest of 5, 4, 3, 2 that divides --steps")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
@@ -145,8 +148,16 @@ def main():
     ctx = R.Context(local_rank)
     opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
     strips = world > 1 and args.shard == "pixels" and args.strategy != "scanline"
+    # A rank of a pixel-sharded job traces 1 / N of a frame per launch: at N = 8 a launch no longer fills the GPU, and several
+    # frames per launch cost 12 % less per frame (tools/shard_share_probe.py).  The frames are the same
+    # frames (tests/test_gpu_parity.py::test_frame_batches_render_the_frames_of_separate_calls).
+    B = args.frames_per_launch
+    if B <= 0:
+        B = next((b for b in (5, 4, 3, 2) if args.steps % b == 0), 1) if (world > 1 and args.shard == "pixels" and args.views == 1) else 1
+    if args.steps % B:
+        raise SystemExit(f"--steps {args.steps} is not a whole number of launches of {B} frames")
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE, rank=rank, world_size=world,
-                      viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight)
+                      viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight, frames_per_launch=B)
 
     def sync_all():
         rr.sync()
@@ -157,7 +168,7 @@ def main():
             torch.cuda.synchronize()
 
     def run_frames(n, one_at_a_time=False):
-        for _ in range(n):
+        for _ in range((n + B - 1) // B):      # B frames per render(); untimed regions round up
             rr.reset_accumulation()     # offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
             rr.render()
             if one_at_a_time:           # per-kernel timing wants kernels that own the chip: no second frame next to them
@@ -187,7 +198,7 @@ def main():
             run_frames(every)
             rr.sync()
             times = [0.0] * world
-            dist.all_gather_object(times, (time.perf_counter() - t1) / every * 1e3)
+            dist.all_gather_object(times, (time.perf_counter() - t1) / (((every + B - 1) // B) * B) * 1e3)
             rr.set_device_workloads(lb.update(times))
         rr.exchange = None
         balance = {"updates": rounds, "frames_per_update": every, "workloads": [round(w, 4) for w in lb.workloads],
@@ -234,7 +245,7 @@ def main():
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
-                   "views": args.views, "frames_in_flight": args.frames_in_flight, "prewarm_frames": args.prewarm,
+                   "views": args.views, "frames_in_flight": args.frames_in_flight, "frames_per_launch": B, "prewarm_frames": args.prewarm,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         **({"load_balance": balance} if balance else {}),
@@ -370,7 +381,7 @@ def main():
         rr.render()
         sync_all()
         if rank == 0:
-            np.save(args.save_display, rr.download("display"))
+            np.save(args.save_display, rr.download("display")[:args.views])        # frame 0 of the launch
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

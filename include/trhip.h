@@ -191,6 +191,13 @@ int trhip_pt_reset_accumulation(trhip_pt* pt, int reset_sample_counter);      /*
 /* rt_stage::frame_counter (src/rt_stage.cc:81-86) of the next frame: with one stage per frame slot, slot k of F renders
  * frames k, k + F, ... and sets the counter before each of them (sample_counter = frame_counter * samples_per_pixel). */
 int trhip_pt_set_frame_counter(trhip_pt* pt, uint32_t frame_counter);
+/* Several consecutive frames in one launch.  After trhip_pt_set_frame_batch(pt, B) a render call takes B * V layers (V = the
+ * viewports of one frame) and renders frames f .. f + B - 1 of the stage's frame counter into them, frame-major: layer l is
+ * viewport l % V of frame f + l / V, with exactly the samples a separate render call for that frame would have drawn; the frame
+ * counter advances by B.  For frames that do not accumulate (offline frames: the caller resets the accumulation between them,
+ * src/tauray.cc:1101).  What it is for: a rank of a pixel-sharded multi-GPU job traces an eighth of a frame per call, launches
+ * that are too small to fill the chip; four frames per launch cost 12 % less per frame. */
+int trhip_pt_set_frame_batch(trhip_pt* pt, uint32_t frames);
 /* How many slices of a frame the stage runs concurrently on its own streams: 0 = automatic
  * (four for frames of >= 1.5 M paths), 1 = everything on the caller's stream - the right choice with several frames in
  * flight, which fill the chip between them. */

@@ -93,6 +93,7 @@ SYMBOLS = {
     "trhip_scene_update_instances": (_i, [_vp, _vp, _u32]),
     "trhip_scene_build_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
     "trhip_scene_refit_accel": (_i, [_vp, C.POINTER(AccelInfoC)]),
+    "trhip_pt_set_frame_batch": (_i, [_vp, C.c_uint32]),
     "trhip_scene_update_lights": (_i, [_vp, _vp, C.c_uint32, _vp, C.c_uint32]),
     "trhip_scene_set_build_mode": (_i, [_vp, _i]),
     "trhip_stitch_batch": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, C.c_float, _vp]),

@@ -578,6 +578,12 @@ int trhip_pt_set_frame_counter(trhip_pt* pt, uint32_t frame_counter) {
     pt->stage->frame_counter = frame_counter;
     return 0;
 }
+int trhip_pt_set_frame_batch(trhip_pt* pt, uint32_t frames) {
+    if (!pt) return set_error("null trhip_pt");
+    if (frames == 0) return set_error("trhip_pt_set_frame_batch: at least one frame per launch");
+    pt->stage->frame_batch = frames;
+    return 0;
+}
 int trhip_pt_set_lanes(trhip_pt* pt, int lanes) {
     if (!pt) return set_error("null trhip_pt");
     if (lanes < 0) return set_error("trhip_pt_set_lanes: lanes must be >= 0");

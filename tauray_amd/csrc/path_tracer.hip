@@ -79,6 +79,8 @@ struct PtParams {
     uint sample_in_pass;
     uint rng_sample;              // index of this sample in the pixel's sequence: sample_base + sample_stride * (previous_samples + sample_in_pass)
     uint vp_base, vp_stride;      // local layer l renders viewport vp_base + l * vp_stride (trhip_pt_set_shard)
+    uint frame_views;             // trhip_pt_set_frame_batch: layers per frame; layer l belongs to frame l / frame_views of the launch
+    uint frame_counter_step;      // ... whose sample counter is sample_counter + that * frame_counter_step
     uint samples_accumulated;
     uint target_w, target_h;
     float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
@@ -130,7 +132,9 @@ TR_DEV void block_append2(uint* counter_a, bool pred_a, uint& slot_a, uint* coun
     __syncthreads();   // s_cnt / s_base are reused by the next iteration
 }
 
-TR_DEV uint global_viewport(const PtParams& P, uint lz) { return P.vp_base + lz * P.vp_stride; }
+// A launch can hold several consecutive frames (trhip_pt_set_frame_batch): its layers are frame-major, frame_views per frame.
+TR_DEV uint global_viewport(const PtParams& P, uint lz) { return P.vp_base + (lz % P.frame_views) * P.vp_stride; }
+TR_DEV uint sample_counter_of(const PtParams& P, uint lz) { return P.sample_counter + (lz / P.frame_views) * P.frame_counter_step; }
 
 // ---------------------------------------------------------------------------------------------------
 // path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
         if (pb.sum_diffuse) { pb.sum_diffuse[i] = F4(0); pb.sum_reflection[i] = F4(0); }
     }
     if (!valid) { pb.misc[i] = misc; return; }
-    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, P.sample_counter,
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, sample_counter_of(P, lz),
                                          P.rng_seed, P.opt.sampler);
     f2 cam_offset = F2(0.0f);
     if (P.opt.film != 0) {   // control.antialiasing == 1
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams
     launch_coord(P.L, misc.z, lx, ly, lz);
     int px, py;
     if (!get_pixel_pos(P.L, lx, ly, px, py)) return;
-    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, P.sample_counter, P.rng_seed, P.opt.sampler);
+    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, sample_counter_of(P, lz), P.rng_seed, P.opt.sampler);
     f2 cam_offset = F2(0.0f);
     if (P.opt.film != 0) {
         f4 r = u4_to_unit(pcg4d(ls.rs));
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
                     launch_coord(P.L, misc.z, lx, ly, lz);
                     int px = 0, py = 0;
                     get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + P.sample_counter};
+                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + sample_counter_of(P, lz)};
                 }
                 // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
                 const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
                     launch_coord(P.L, misc.z, lx, ly, lz);
                     int px = 0, py = 0;
                     if (P.opt.sampler == SAMPLER_SOBOL_OWEN) get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + P.sample_counter};
+                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + sample_counter_of(P, lz)};
                 }
                 const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
                                      (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
@@ -1211,8 +1215,11 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
 
 int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
     if (!scene->accel_built) return set_error("trhip_pt_render: call trhip_scene_build_accel first");
-    if (viewports == 0 || (uint64_t)shard_vp_base + (uint64_t)(viewports - 1) * shard_vp_stride >= scene->camera_count)
+    if (viewports == 0 || viewports % frame_batch != 0) return set_error("trhip_pt_render: the layers of a launch are a whole number of frames (trhip_pt_set_frame_batch)");
+    const uint frame_views = viewports / frame_batch;
+    if ((uint64_t)shard_vp_base + (uint64_t)(frame_views - 1) * shard_vp_stride >= scene->camera_count)
         return set_error("trhip_pt_render: viewport count exceeds uploaded cameras");
+    if (frame_batch > 1 && (accumulated_samples != 0 || direct)) return set_error("trhip_pt_render: a frame batch renders independent frames of the path tracer (reset the accumulation first)");
     if (opt.samples_per_pass <= 0 || opt.samples_per_pixel % opt.samples_per_pass != 0)
         return set_error("trhip_pt_render: samples_per_pixel must be a multiple of samples_per_pass");
     if (dist.size_x == 0 || dist.size_y == 0) return set_error("trhip_pt_render: distribution not set");
@@ -1232,6 +1239,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // src/rt_stage.cc:81; a sample shard renders every shard_sample_stride-th sample of samples_per_pixel * stride per frame
     P.sample_counter = frame_counter * (uint)opt.samples_per_pixel * shard_sample_stride;
     P.vp_base = shard_vp_base; P.vp_stride = shard_vp_stride;
+    P.frame_views = frame_views; P.frame_counter_step = (uint)opt.samples_per_pixel * shard_sample_stride;
     { uint s = opt.rng_seed; P.rng_seed = s != 0 ? pcg(s) : 0; }                  // src/rt_stage.cc:82
     P.samples_accumulated = accumulated_samples;
     P.target_w = target_w; P.target_h = target_h;
@@ -1511,7 +1519,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     timing_pending = true;
     impl->frames++;
     // rt_stage::update: frame_counter++ ; rt_camera_stage::update: accumulated_samples += samples_per_pixel
-    frame_counter++;
+    frame_counter += frame_batch;
     accumulated_samples += (uint)opt.samples_per_pixel;
     return 0;
 }

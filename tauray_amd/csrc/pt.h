@@ -25,6 +25,7 @@ public:
     // trhip_pt_set_shard: which viewports / samples of the whole job this stage renders (view and sample sharding)
     uint shard_vp_base = 0, shard_vp_stride = 1, shard_sample_base = 0, shard_sample_stride = 1;
     int lanes = 0;                   // trhip_pt_set_lanes: 0 = automatic
+    uint frame_batch = 1;            // trhip_pt_set_frame_batch: consecutive frames per render() call
     bool direct = false;             // direct_stage instead of path_tracer_stage (trhip_direct_create)
     hipStream_t last_stream = nullptr;
 

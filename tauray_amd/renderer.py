@@ -370,6 +370,10 @@ class PathTracerStage:
     def set_frame_counter(self, frame_counter: int):
         check(_lib.lib().trhip_pt_set_frame_counter(self.h, frame_counter))
 
+    def set_frame_batch(self, frames: int):
+        """trhip_pt_set_frame_batch: `frames` consecutive frames per run(), as frame-major layer groups of the target."""
+        check(_lib.lib().trhip_pt_set_frame_batch(self.h, int(frames)))
+
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 
@@ -523,18 +527,23 @@ class RtRenderer:
 
     def __init__(self, ctx: Context, scene: SceneDesc, options: PtOptionsC, size, strategy=DISTRIBUTION_SCANLINE,
                  rank=0, world_size=1, viewports=1, tonemap: Optional[dict] = None, accumulate=False, use_torch=None,
-                 shard="pixels", frames_in_flight=1, stage_cls=None, exchange=None):
+                 shard="pixels", frames_in_flight=1, stage_cls=None, exchange=None, frames_per_launch=1):
         """`shard`: what the ranks divide among themselves - "pixels" (the reference's distribution strategies, partial frames
         stitched on rank 0), "views" (viewport v on rank v mod N; nothing is exchanged before output) or "samples" (every
         rank renders samples_per_pixel / N samples of every pixel; one reduce to rank 0).  SURVEY.md section 8(e).
         `exchange`: what carries the partial frames of a pixel-sharded job to rank 0 - None = torch.distributed (RCCL), or a
-        transfer.LocalExchange shared by the ranks of one process (device-to-device copies on the default stream)."""
+        transfer.LocalExchange shared by the ranks of one process (device-to-device copies on the default stream).
+        `frames_per_launch`: B > 1 makes every render() call B consecutive frames (trhip_pt_set_frame_batch): the images grow B
+        layer groups, frame-major, and everything after the path tracing - exchange, stitch, tonemap - handles the B frames in
+        one go.  For frames that do not accumulate; what the ranks of a pixel-sharded job use, whose launches are small."""
         if shard not in ("pixels", "views", "samples"):
             raise ValueError("shard must be pixels, views or samples")
         if frames_in_flight < 1:
             raise ValueError("frames_in_flight must be >= 1")
         if frames_in_flight > 1 and accumulate:
             raise ValueError("accumulating frames depend on each other: frames_in_flight must be 1")
+        if frames_per_launch < 1 or (frames_per_launch > 1 and (accumulate or shard != "pixels")):
+            raise ValueError("frames_per_launch > 1 batches independent frames of a pixel-sharded (or single-device) renderer")
         if shard == "samples" and accumulate and world_size > 1:
             # the reduce sums the ranks' running means into rank 0's target in place: a second accumulated frame would blend
             # new samples into an already reduced mean
@@ -552,6 +561,9 @@ class RtRenderer:
         if self.shard == "views":
             from .transfer import shard_viewports
             viewports = len(shard_viewports(viewports, rank, world_size))
+        self.frames_per_launch = frames_per_launch
+        self.frame_viewports = viewports                    # layers of one frame
+        viewports = viewports * frames_per_launch           # layers of one launch: every buffer, transfer, stitch and tonemap below
         self.viewports = viewports
         self.strategy = DISTRIBUTION_DUPLICATE if (world_size == 1 or self.shard != "pixels") else strategy   # src/tauray.cc:519-521
         self.accumulate = accumulate
@@ -583,6 +595,8 @@ class RtRenderer:
                 slot.pt.set_shard(viewport_base=rank, viewport_stride=world_size)
             elif self.shard == "samples":
                 slot.pt.set_shard(sample_base=rank, sample_stride=world_size)
+            if frames_per_launch > 1:
+                slot.pt.set_frame_batch(frames_per_launch)
             if frames_in_flight > 1:
                 slot.pt.set_lanes(1)             # the frames in flight fill the chip between them
                 slot.stream = ctx.create_stream()
@@ -700,13 +714,13 @@ class RtRenderer:
 
     def render_partial(self, stream=None):
         """The path-tracing part of the next frame on its slot (`stream` overrides the slot's stream)."""
-        slot = self.slots[self.frame_index % self.frames_in_flight]
+        slot = self.slots[(self.frame_index // self.frames_per_launch) % self.frames_in_flight]
         self.current = slot
         if not self.accumulate:
             slot.pt.reset_accumulated_samples()
-        if self.frames_in_flight > 1:
-            slot.pt.set_frame_counter(self.frame_index)      # one stage per slot: slot k renders frames k, k + F, ...
-        self.frame_index += 1
+        if self.frames_in_flight > 1 or self.frames_per_launch > 1:
+            slot.pt.set_frame_counter(self.frame_index)      # one stage per slot: slot k renders frames k, k + F, ... (B at a time)
+        self.frame_index += self.frames_per_launch
         if self.viewports > 0:      # a view shard can be empty (more devices than views)
             slot.pt.run(slot.color, self.viewports, stream if stream is not None else slot.stream)
 

@@ -1110,6 +1110,61 @@ def test_animated_glb_playback(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_frame_batches_render_the_frames_of_separate_calls(R, ctx):
+    """trhip_pt_set_frame_batch / RtRenderer(frames_per_launch=B): B consecutive frames in one launch - frame-major layer groups of
+    one image - are the frames separate render calls produce, bit for bit: one viewport and a 3-view camera grid, whole frames and
+    a strip shard, and through the renderer with frames in flight (tonemapped layers)."""
+    from tauray_amd import scenes
+    from tauray_amd import distribution as D
+    from tauray_amd.scene import generate_camera_grid
+    W, H = 320, 180
+    scene = scenes.sponza_class(seed=3, target_tris=30000, width=W, height=H)
+    scene.cameras = generate_camera_grid(scene.cameras[0], 3, 1, 0.2, 0.2, 5.0)
+    ss = R.SceneStage(ctx, scene)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    for views, dist in ((1, _dup((W, H))), (3, _dup((W, H))), (1, D.get_device_distribution_params((W, H), D.DISTRIBUTION_SHUFFLED_STRIPS, 0.3, 0.45, 1, 3, False))):
+        tw, th = D.get_distribution_target_size(dist)
+        single = []
+        pt = R.PathTracerStage(ctx, ss, opt, dist)
+        for f in range(6):
+            buf = ctx.alloc(views * tw * th * 16).zero()
+            pt.reset_accumulated_samples()
+            pt.run(buf, views)
+            single.append(buf.download((views, th, tw, 4)))
+        pt.close()
+        assert not np.array_equal(single[0], single[1])
+        for B in (2, 3):
+            pt = R.PathTracerStage(ctx, ss, opt, dist)
+            pt.set_frame_batch(B)
+            for call in range(6 // B):
+                buf = ctx.alloc(B * views * tw * th * 16).zero()
+                pt.reset_accumulated_samples()
+                pt.run(buf, B * views)
+                got = buf.download((B, views, th, tw, 4))
+                for k in range(B):
+                    assert np.array_equal(got[k], single[call * B + k]), f"{views} view(s), batch of {B}: frame {call * B + k} differs in {int((got[k] != single[call * B + k]).any(-1).sum())} pixels"
+            assert pt.counters()["stack_overflows"] == 0
+            with pytest.raises(R.TrhipError):
+                pt.run(buf, B * views + 1)           # not a whole number of frames
+            pt.close()
+    # the renderer: six frames as two launches of three, two launches in flight
+    one = R.RtRenderer(ctx, scene, opt, (W, H), viewports=3)
+    ref = []
+    for f in range(6):
+        one.reset_accumulation()
+        one.render()
+        ref.append(one.download("display"))
+    one.close()
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), viewports=3, frames_in_flight=2, frames_per_launch=3)
+    for call in range(2):
+        rr.render()
+        got = rr.download("display").reshape(3, 3, H, W, 4)
+        for k in range(3):
+            assert np.array_equal(got[k], ref[call * 3 + k]), f"renderer, frame {call * 3 + k}"
+    rr.close()
+
+
+@pytest.mark.gpu
 def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     """BASELINE config 4 at its full size (sponza_teapots, 1920x1080, 4 bounces), through properties that need no oracle: the
     frame does not depend on the tree (PLOC vs LBVH build, refit vs rebuild), on how it is sharded (8 shuffled-strip shards,

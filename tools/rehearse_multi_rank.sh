@@ -5,7 +5,7 @@ for f in ${@:-1 4}; do
 timeout 180 python bench.py --steps 5 --frames-in-flight $f --no-cpu-baseline --no-roofline --save-display /tmp/disp1.npy > /dev/null
 for n in 2 3; do
 echo "== F=$f N=$n"
-timeout 180 python bench.py --gpus $n --steps 5 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 200 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
+timeout 180 python bench.py --gpus $n --steps 6 --warmup 2 --frames-in-flight $f --dist-backend gloo --one-device --prewarm 200 --save-display /tmp/disp$n.npy > gpurun_out/rehearse_f${f}_n$n.log 2>&1; grep -n "File \"/root/repo\|File \".*repo\|Error\|error" gpurun_out/rehearse_f${f}_n$n.log | head -30
 python - <<PY
 import numpy as np
 a=np.load('/tmp/disp1.npy')
