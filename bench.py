@@ -62,8 +62,8 @@ def parse():
                          "balancer sets (the reference's command-line default, src/tauray.cc:519-521); auto = strips")
     ap.add_argument("--no-balance", action="store_true", help="shuffled strips with equal shares: no load-balancer updates during the untimed frames")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="consecutive frames per path-tracing launch (trhip_pt_set_frame_batch); 0 = 1 on one GPU, and for N > 1 pixel "
-                         "shards - whose launches are too small to fill a GPU - the largest of 5, 4, 3, 2 that divides --steps")
+                    help="consecutive frames per path-tracing launch (trhip_pt_set_frame_batch); 0 = 2 on one GPU (1 if --steps is odd), "
+                         "and for N > 1 pixel shards - whose launches are too small to fill a GPU - the largest of 5, 4, 3, 2 that divides --steps")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
@@ -153,7 +153,10 @@ def main():
     # frames (tests/test_gpu_parity.py::test_frame_batches_render_the_frames_of_separate_calls).
     B = args.frames_per_launch
     if B <= 0:
-        B = next((b for b in (5, 4, 3, 2) if args.steps % b == 0), 1) if (world > 1 and args.shard == "pixels" and args.views == 1) else 1
+        if world > 1 and args.shard == "pixels" and args.views == 1:
+            B = next((b for b in (5, 4, 3, 2) if args.steps % b == 0), 1)
+        else:       # whole frames: two per launch are worth 2 % on sponza_teapots and 5 % on test.glb, more are not
+            B = 2 if (world == 1 and args.views == 1 and args.spp == 1 and args.steps % 2 == 0) else 1
     if args.steps % B:
         raise SystemExit(f"--steps {args.steps} is not a whole number of launches of {B} frames")
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE, rank=rank, world_size=world,
