@@ -14,7 +14,7 @@ for W in $WORKLOADS; do
       python $R/bench.py --steps 20 --warmup 3 --workload $W --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log || echo "stats pass failed ($W)"
   # counter passes: one lane and unfused launches, so that a k_trace_closest launch is a whole queue of one bounce like
   # the launch the roofline refers to (the profiler serialises kernels under --pmc anyway)
-  B="env TRHIP_LANES=1 TRHIP_FUSED=0 python $R/bench.py --steps 5 --warmup 1 --workload $W --no-cpu-baseline --no-roofline"
+  B="env TRHIP_LANES=1 TRHIP_FUSED=0 python $R/bench.py --steps 6 --warmup 2 --workload $W --no-cpu-baseline --no-roofline"      # an even number of steps: two frames per launch, like the default bench line
   run() { name=$1; shift; timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o t -- $B > $O/$name.log 2>&1 || echo "pass $name failed ($W)"; }
   run fetch FETCH_SIZE
   run write WRITE_SIZE
