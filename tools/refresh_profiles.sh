@@ -4,7 +4,7 @@
 # and runs the plain bench lines right after.  Everything lands in gpurun_out/<round>_summary/: copy it into profiles/<round>/.
 R=$GRAFT_REPO_ROOT; TAG=${1:-r2}
 cd $R
-bash tools/profile_round.sh $TAG sponza_teapots test_glb > gpurun_out/profile_round.log 2>&1
+bash tools/profile_round.sh $TAG sponza_teapots test_glb sponza_class > gpurun_out/profile_round.log 2>&1
 python tools/profile_summary.py gpurun_out/prof_$TAG gpurun_out/${TAG}_summary
 rm -rf gpurun_out/prof_$TAG
 for w in sponza_teapots test_glb sponza_class; do
