@@ -1900,7 +1900,7 @@ def test_random_materials(R, ctx, oracle):
 # Several ranks of one process exchanging partial frames with nothing but stream order between them
 
 
-def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=None, break_waits=False):
+def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=None, break_waits=False, B=1):
     """`world` RtRenderer ranks on fake devices (one Context each on HIP device 0) joined by a transfer.LocalExchange: sends
     are device-to-device copies on the default stream, there is no host synchronisation between or inside frames, and
     every frame's display image is copied to a history buffer in stream order.  Returns [frames, H, W, 4]."""
@@ -1909,7 +1909,7 @@ def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=N
     W, H = size
     ex = LocalExchange(world)
     ctxs = [R.Context(0) for _ in range(world)]
-    rrs = [R.RtRenderer(ctxs[r], scene, opt, size, strategy=strategy, rank=r, world_size=world, exchange=ex, frames_in_flight=F)
+    rrs = [R.RtRenderer(ctxs[r], scene, opt, size, strategy=strategy, rank=r, world_size=world, exchange=ex, frames_in_flight=F, frames_per_launch=B)
            for r in range(world)]
     if workloads is not None:
         for rr in rrs:
@@ -1919,10 +1919,10 @@ def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=N
             c.stream_wait = lambda stream, on: None
     hist = ctxs[0].alloc(frames * W * H * 16).zero()
     ctxs[0].sync()
-    for f in range(frames):
+    for f in range(0, frames, B):      # B frames per render(): B layers of the display image
         for r in list(range(1, world)) + [0]:
             rrs[r].render()
-        rc = _lib.lib().trhip_copy_peer(ctxs[0].h, hist.data_ptr() + f * W * H * 16, ctxs[0].h, rrs[0].display.data_ptr(), W * H * 16, None)
+        rc = _lib.lib().trhip_copy_peer(ctxs[0].h, hist.data_ptr() + f * W * H * 16, ctxs[0].h, rrs[0].display.data_ptr(), B * W * H * 16, None)
         assert rc == 0
     for rr in rrs:
         rr.sync()
@@ -1944,8 +1944,8 @@ def _single_rank_frames(R, ctx, scene, opt, size, frames):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,strategy,F", [(3, 1, 4), (4, 2, 4), (2, 1, 1), (8, 1, 3)])
-def test_in_process_ranks_exchange_is_stream_ordered(R, ctx, world, strategy, F):
+@pytest.mark.parametrize("world,strategy,F,B", [(3, 1, 4, 1), (4, 2, 4, 1), (2, 1, 1, 1), (8, 1, 3, 1), (4, 2, 3, 5), (8, 1, 2, 2)])
+def test_in_process_ranks_exchange_is_stream_ordered(R, ctx, world, strategy, F, B):
     """The bracket of stream dependencies around the exchange in RtRenderer.render (path tracing on the slot stream ->
     default stream: send / stitch / tonemap -> slot stream) is all that orders 50 consecutive frames with four in flight:
     every stitched, tonemapped frame equals the single-rank frame of the same index bit for bit.  The reference's
@@ -1956,7 +1956,7 @@ def test_in_process_ranks_exchange_is_stream_ordered(R, ctx, world, strategy, F)
     opt = R.options_for_scene(scene, max_bounces=3)
     ref = _single_rank_frames(R, ctx, scene, opt, (W, H), frames)
     assert not np.array_equal(ref[0], ref[1])      # the sample counter advances: frames are distinguishable
-    got = _in_process_job(R, scene, opt, (W, H), world, strategy, F, frames)
+    got = _in_process_job(R, scene, opt, (W, H), world, strategy, F, frames, B=B)      # B > 1: frame batches (frames_per_launch)
     wrong = [f for f in range(frames) if not np.array_equal(got[f], ref[f])]
     assert not wrong, f"frames {wrong[:10]} differ from the single-rank frames"
 
