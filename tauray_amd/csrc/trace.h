@@ -16,8 +16,10 @@ namespace tr {
 #define TR_BLOCK 256
 #endif
 #ifndef TR_VOTE
-#define TR_VOTE 16         // closest-hit traversal: lanes holding a leaf wait until this many do (0 disables the vote); 8 before the
-                           // quad tail took over the thin end of a wave, 12 / 16 / 20 / 24 / 32 measured since: 16
+#define TR_VOTE 32         // closest-hit traversal: lanes holding a leaf wait until this many do - or half of the live lanes, which
+                           // with 32 is always the smaller number (0 disables the vote).  8 before the quad tail took over the
+                           // thin end of a wave, 16 after it; re-measured on the static-build tree: 12 / 16 / 24 / 32 = 3.89 / 3.85 /
+                           // 3.81 / 3.79 ms per frame, and 3 / 5 / 6 eighths of the live lanes instead of half: 3.84 / 3.84 / 3.88
 #endif
 #ifndef TR_VOTE_SHADOW_WAVE
 #define TR_VOTE_SHADOW_WAVE 16   // the same vote in the per-lane loop of trace_shadow_wave4 (0: none); 8 / 16 measured: -1 ... -2 % shadow time
