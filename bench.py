@@ -13,18 +13,24 @@ options at the reference's CLI defaults), followed by the multi-GPU gather/stitc
 `render()` sequence of rt_renderer (reference src/rt_renderer.cc:84-133).  Scene upload, BVH build and image
 save are outside the timed region (reference README "Benchmarking", docs/MANUAL.md:405-408).
 
-Prints ONE JSON line (rank 0).  `value` = rays actually traced (closest-hit + shadow, device counters) per second
-over all GPUs.  With N > 1 the pixels of the frame are sharded - shuffled strips (DISTRIBUTION_SHUFFLED_STRIPS, the
-reference's command-line default) whose shares its load balancer settles during the untimed frames, or interleaved
-scanlines with --strategy scanline - and the partial frames are gathered on rank 0 over RCCL: total work is fixed, so
-scaling is "strong".
+Prints ONE JSON line (rank 0).
 
-The K timed frames are K distinct frames (frame index = sample counter), four of them in flight at a time on their own
-streams like the reference's frame slots (--frames-in-flight); the region is closed by a
-synchronisation of every stream (+ barrier), so `ms_per_step` is elapsed / K and `frame_latency_ms` is what one frame
-takes with a host sync after each.  Before the W warm-up steps --prewarm untimed frames bring a cold box to its clocks.
-The `roofline` object is measured in a separate serialised re-run (one frame at a time, per-kernel HIP events), the
-`cpu_baseline` by the CPU oracle on the host cores.
+`value` follows SURVEY.md section 8(d) to the letter: Mray/s = rays actually traced (closest-hit + shadow, device counters) over
+all GPUs / host wall time, where every frame is timed from before render() to after the stream sync - ONE FRAME AT A TIME, no
+frames in flight, one frame per launch.  The timed region holds max(K, 50) such frames (`steps_effective`: K = 20 frames would
+be 0.1 s) between barriers; `ms_per_step` = elapsed / steps_effective, `frame_ms` holds mean and p50 of the per-frame times.
+`value_pipelined` is the same workload the way a renderer that does not wait runs it: four frames in flight on their own
+streams like the reference's frame slots (src/context.hh:26), two frames per launch on one GPU (`pipelined` holds the details).
+With N > 1 the pixels of the frame are sharded - shuffled strips (DISTRIBUTION_SHUFFLED_STRIPS, the reference's command-line
+default) whose shares its load balancer settles during the untimed frames, or interleaved scanlines with --strategy scanline -
+and the partial frames are gathered on rank 0 over RCCL: total work is fixed, so scaling is "strong".
+
+`roofline` (rank 0): the dominant kernel, k_trace_closest, timed alone with HIP events on its launch stream, against every level
+that could bound it - vector-instruction issue (peak = a v_fma_f32 loop measured in this run), L1 -> L2 request bytes, L2-miss
+(fabric: Infinity Cache + HBM) bytes - from rocprofv3 counter passes this script runs itself (children of this process, each
+pass its own run with the kernel trace only; byte-per-request factors from profiles/r3/calibration.json).  `bound` is the level
+with the highest fraction, `frac` that fraction.  `algorithmic_GBps` is SURVEY.md 8(d)'s counted-work figure (cache served).
+`cpu_baseline`: the CPU oracle on the host cores.
 """
 import argparse
 import json
@@ -40,7 +46,18 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); 6.3-6.9 TB/s measured with a float4 stream
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth (MI355X_MICROARCH.md section L2)
+MIN_TIMED_FRAMES = 50   # mean and p50 over >= 50 frames with distinct frame indices
+
+# rocprofv3 counter passes of the roofline (each its own run; SQ has 8 slots, TCC 4 - MI355X_MICROARCH.md section PMC slots)
+PMC_PASSES = {
+    "sq": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY",
+           "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+    "tcc": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"],
+    "l2": ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"],
+}
+HOT_KERNELS = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_shade": "shade"}
 
 
 def parse():
@@ -62,10 +79,10 @@ def parse():
                          "balancer sets (the reference's command-line default, src/tauray.cc:519-521); auto = strips")
     ap.add_argument("--no-balance", action="store_true", help="shuffled strips with equal shares: no load-balancer updates during the untimed frames")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="consecutive frames per path-tracing launch (trhip_pt_set_frame_batch); 0 = 2 on one GPU (1 if --steps is odd), "
-                         "and for N > 1 pixel shards - whose launches are too small to fill a GPU - the largest of 5, 4, 3, 2 that divides --steps")
+                    help="pipelined region: consecutive frames per path-tracing launch (trhip_pt_set_frame_batch); 0 = 2 on one GPU, and for "
+                         "N > 1 pixel shards - whose launches are too small to fill a GPU - 5")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); 1 = one frame at a time; "
+                    help="pipelined region: frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
@@ -74,11 +91,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="roofline without the rocprofv3 counter passes (issue rate and traffic stay null)")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0, help="seconds one counter pass may take")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: render a few serialised frames and exit (what the counter passes profile)")
+    ap.add_argument("--pmc-dump", default=None, help="directory that keeps the per-kernel counter summary of the passes (profiles/)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, meet in one all-reduce, print the world size and stop (checks the launcher path without a GPU)")
     ap.add_argument("--sustained-frames", type=int, default=400,
-                    help="N = 1: a second, longer timed region of this many frames reported as `sustained` (K = 20 frames are 0.1 s; "
-                         "0 switches it off)")
+                    help="N = 1: a longer pipelined region of this many frames reported as `sustained` (0 switches it off)")
     return ap.parse_args()
 
 
@@ -96,8 +116,121 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def pmc_child(args):
+    """What a counter pass profiles: the launches the roofline times - one lane, unfused, every kernel owning the chip
+    (trhip_pt_set_profiling detailed timing: k_trace_closest<false, true, ..>), two frames per launch like the timed-alone run."""
+    from tauray_amd import renderer as R
+    from tauray_amd import scenes
+    from tauray_amd.distribution import DISTRIBUTION_SCANLINE
+    W, H = args.width, args.height
+    scene = scenes.WORKLOADS[args.workload](W, H)
+    ctx = R.Context(0)
+    opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
+    B = max(args.frames_per_launch, 1)
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, frames_in_flight=1, frames_per_launch=B)
+    rr.set_profiling(False, True)
+    for _ in range(max(args.steps // B, 1) + 1):     # the first launch is a warm-up like any other: whole frames either way
+        rr.reset_accumulation()
+        rr.render()
+        rr.sync()
+    rr.close()
+
+
+def run_pmc_passes(args, B, dump_dir=None):
+    """Runs this script as --pmc-child under `rocprofv3 --pmc <set> --kernel-trace`, one run per counter set, and returns
+    ({kernel: {counter: average per launch, 'launches': n, 'avg_us_<pass>': duration under that pass}}, error or None)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {}, "rocprofv3 not found"
+    out = collections.defaultdict(dict)
+    errors = []
+    tmp = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height),
+             "--bounces", str(args.bounces), "--spp", str(args.spp), "--sampler", str(args.sampler), "--steps", "4", "--frames-per-launch", str(B)]
+    for name, counters in PMC_PASSES.items():
+        d = os.path.join(tmp, name)
+        cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            errors.append(f"{name}: timed out after {args.pmc_timeout:.0f} s")
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            errors.append(f"{name}: rc {p.returncode}: " + p.stdout.decode("utf-8", "replace")[-300:].replace("\n", " | "))
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        seen = collections.defaultdict(set)
+        dur = collections.defaultdict(float)
+        for r in csv.DictReader(open(files[0])):
+            kn = r["Kernel_Name"]
+            m = re.search(r"(k_[a-z_0-9]+)<", kn)
+            key = m.group(1) if m and m.group(1) in HOT_KERNELS else None
+            if key is None:
+                continue
+            if key == "k_trace_closest" and "<false, true" not in kn:      # the timed-alone instance only
+                continue
+            agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in seen[key]:
+                seen[key].add(r["Dispatch_Id"])
+                dur[key] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for k in agg:
+            n = len(seen[k])
+            out[k]["launches"] = n
+            out[k]["avg_us_" + name] = round(dur[k] / n / 1e3, 1)
+            for c, v in agg[k].items():
+                out[k][c] = v / n
+    if dump_dir:
+        os.makedirs(dump_dir, exist_ok=True)
+        json.dump({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in d.items()} for k, d in out.items()},
+                  open(os.path.join(dump_dir, f"{args.workload}_pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return dict(out), ("; ".join(errors) if errors else None)
+
+
+def level_fractions(pmc_k, avg_ms, valu_peak_ginst):
+    """Per-level rates of one kernel from its per-launch counters and its un-profiled launch time.  Factors: profiles/r3/calibration.json
+    (one TCP_TCC_READ_REQ = one 128-byte line; one TCC_EA0_RDREQ = 128 bytes unless counted as _32B; write requests 64 / 32 bytes)."""
+    s = avg_ms * 1e-3
+    lv = {}
+    if not pmc_k or s <= 0:
+        return lv
+    if "SQ_INSTS_VALU" in pmc_k and valu_peak_ginst:
+        g = pmc_k["SQ_INSTS_VALU"] / s / 1e9
+        lv["valu"] = {"achieved": round(g, 1), "peak": round(valu_peak_ginst, 1), "unit": "Ginst/s", "frac": round(g / valu_peak_ginst, 4),
+                      "insts_per_launch": int(pmc_k["SQ_INSTS_VALU"]),
+                      "wait_fraction": round(pmc_k["SQ_WAIT_ANY"] / pmc_k["SQ_WAVE_CYCLES"], 3) if pmc_k.get("SQ_WAVE_CYCLES") else None,
+                      "hw_lanes_per_inst": round(pmc_k["SQ_THREAD_CYCLES_VALU"] / pmc_k["SQ_INSTS_VALU"], 1) if pmc_k.get("SQ_THREAD_CYCLES_VALU") else None}
+    if "TCP_TCC_READ_REQ_sum" in pmc_k:
+        b = pmc_k["TCP_TCC_READ_REQ_sum"] * 128.0 + pmc_k.get("TCP_TCC_WRITE_REQ_sum", 0.0) * 64.0
+        lv["l2"] = {"achieved": round(b / s / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(b / s / 1e9 / L2_PEAK_GBS, 4), "bytes_per_launch": int(b),
+                    "hit_rate": round(pmc_k["TCC_HIT_sum"] / (pmc_k["TCC_HIT_sum"] + pmc_k["TCC_MISS_sum"]), 3) if (pmc_k.get("TCC_HIT_sum", 0) + pmc_k.get("TCC_MISS_sum", 0)) > 0 else None}
+    if "TCC_EA0_RDREQ_sum" in pmc_k:
+        rd32 = pmc_k.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        rd = (pmc_k["TCC_EA0_RDREQ_sum"] - rd32) * 128.0 + rd32 * 32.0
+        wr64 = pmc_k.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        wr = wr64 * 64.0 + (pmc_k.get("TCC_EA0_WRREQ_sum", 0.0) - wr64) * 32.0
+        b = rd + wr
+        lv["fabric"] = {"achieved": round(b / s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / s / 1e9 / HBM_PEAK_GBS, 4),
+                        "bytes_per_launch": int(b), "read_bytes": int(rd), "write_bytes": int(wr),
+                        # what rocprofv3's derived FETCH_SIZE / WRITE_SIZE would print for the same counters (KiB; FETCH_SIZE tallies
+                        # 128-byte requests at 64: the x2 of MI355X_MICROARCH.md section HBM, confirmed by the calibration streams)
+                        "FETCH_SIZE_KiB_equiv": round(((pmc_k["TCC_EA0_RDREQ_sum"] - rd32) * 64.0 + rd32 * 32.0) / 1024.0, 1), "WRITE_SIZE_KiB_equiv": round(wr / 1024.0, 1),
+                        "note": "L2 misses: served by the Infinity Cache or HBM (the TCC_EA0 counters cannot tell them apart, calibration.json); an upper bound of the HBM bytes"}
+    return lv
+
+
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
     # A multi-rank run that stops making progress (a peer died, an exchange deadlocked) dumps every thread's stack and exits
@@ -148,37 +281,62 @@ def main():
     ctx = R.Context(local_rank)
     opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
     strips = world > 1 and args.shard == "pixels" and args.strategy != "scanline"
-    # A rank of a pixel-sharded job traces 1 / N of a frame per launch: at N = 8 a launch no longer fills the GPU, and several
-    # frames per launch cost 12 % less per frame (tools/shard_share_probe.py).  The frames are the same
-    # frames (tests/test_gpu_parity.py::test_frame_batches_render_the_frames_of_separate_calls).
+    strategy = DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE
+    steps = max(args.steps, MIN_TIMED_FRAMES)           # frames of every timed region
+    # Pipelined region.  A rank of a pixel-sharded job traces 1 / N of a frame per launch: at N = 8 a launch no longer fills the GPU,
+    # and several frames per launch cost 12 % less per frame (tools/shard_share_probe.py).  The frames are the
+    # same frames (tests/test_gpu_parity.py::test_frame_batches_render_the_frames_of_separate_calls).
     B = args.frames_per_launch
     if B <= 0:
         if world > 1 and args.shard == "pixels" and args.views == 1:
-            B = next((b for b in (5, 4, 3, 2) if args.steps % b == 0), 1)
+            B = 5
         else:       # whole frames: two per launch are worth 2 % on sponza_teapots and 5 % on test.glb, more are not
-            B = 2 if (world == 1 and args.views == 1 and args.spp == 1 and args.steps % 2 == 0) else 1
-    if args.steps % B:
-        raise SystemExit(f"--steps {args.steps} is not a whole number of launches of {B} frames")
-    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE, rank=rank, world_size=world,
+            B = 2 if (world == 1 and args.views == 1 and args.spp == 1) else 1
+    steps_pipelined = ((steps + B - 1) // B) * B
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world,
                       viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight, frames_per_launch=B)
+    # The renderer of a caller that waits for every frame: no frame slots, one frame per launch; each frame runs as four concurrent
+    # lanes (the stage's automatic schedule for frames of >= 1.5 M paths).
+    lone = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world, viewports=args.views, shard=args.shard,
+                        frames_in_flight=1, frames_per_launch=1)
 
-    def sync_all():
-        rr.sync()
+    def sync_all(r):
+        r.sync()
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_frames(n, one_at_a_time=False):
-        for _ in range((n + B - 1) // B):      # B frames per render(); untimed regions round up
-            rr.reset_accumulation()     # offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
-            rr.render()
-            if one_at_a_time:           # per-kernel timing wants kernels that own the chip: no second frame next to them
-                rr.sync()
+    def run_frames(r, n, one_at_a_time=False, times=None):
+        per = r.frames_per_launch
+        for _ in range((n + per - 1) // per):      # `per` frames per render(); untimed regions round up
+            t1 = time.perf_counter() if times is not None else 0.0
+            r.reset_accumulation()     # offline frames: accumulation reset, sample counter kept (src/tauray.cc:1101)
+            r.render()
+            if one_at_a_time:
+                r.sync()
+                if times is not None:
+                    times.append((time.perf_counter() - t1) * 1e3)
 
-    # ---- timed region: W warm-up frames, then exactly K frames between barriers
+    def total_rays(r, elapsed):
+        c = r.counters()
+        if c["stack_overflows"]:
+            raise RuntimeError("BVH traversal stack overflow: results invalid")
+        rays = c["closest_rays"] + c["shadow_rays"]
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            q = torch.tensor([rays], dtype=torch.int64, device=f"cuda:{local_rank}")
+            dist.all_reduce(q, op=dist.ReduceOp.SUM)
+            rays = int(q.item())
+        return rays, elapsed, c
+
+    # ---- untimed frames: clocks, page faults and (N > 1) the load balancer
     rr.set_profiling(False, False)
+    lone.set_profiling(False, False)
     # Not part of the W warm-up steps: a fresh box takes a few hundred milliseconds of work to reach its clocks and to fault
     # in every buffer, more than W = 3 frames of 2 ms give it.  A fixed frame count keeps the ranks of a multi-GPU job in step.
     balance = None
@@ -194,124 +352,109 @@ def main():
         lb = LoadBalancer(world)
         every, rounds = 8, 24
         rr.exchange = StandaloneExchange()
-        run_frames(max(args.prewarm - every * rounds, 8))
+        run_frames(rr, max(args.prewarm - every * rounds, 8))
         for _ in range(rounds):
             rr.sync()
             t1 = time.perf_counter()
-            run_frames(every)
+            run_frames(rr, every)
             rr.sync()
             times = [0.0] * world
             dist.all_gather_object(times, (time.perf_counter() - t1) / (((every + B - 1) // B) * B) * 1e3)
             rr.set_device_workloads(lb.update(times))
         rr.exchange = None
+        lone.set_device_workloads(list(lb.workloads))
         balance = {"updates": rounds, "frames_per_update": every, "workloads": [round(w, 4) for w in lb.workloads],
                    "ms_per_frame_running_free": [round(t, 4) for t in times]}
-        sync_all()
-        run_frames(args.frames_in_flight * 2)
+        sync_all(rr)
+        run_frames(rr, args.frames_in_flight * 2)
     else:
-        run_frames(args.prewarm)
-    sync_all()
+        run_frames(rr, args.prewarm)
+    sync_all(rr)
+
+    # ---- timed region (`value`): W warm-up frames, then max(K, 50) frames, one at a time, host sync after each, between barriers
+    lone.reset_accumulation(reset_sample_counter=True)
+    run_frames(lone, args.warmup, True)
+    sync_all(lone)
+    lone.reset_counters()
+    frame_times = []
+    t0 = time.perf_counter()
+    run_frames(lone, steps, True, frame_times)
+    sync_all(lone)
+    elapsed = time.perf_counter() - t0
+    rays_total, elapsed, _ = total_rays(lone, elapsed)
+    ms_per_step = elapsed / steps * 1e3
+    frame_times.sort()
+
+    # ---- the same frames pipelined (`value_pipelined`): frame slots, B frames per launch, one synchronisation at the end
     rr.reset_accumulation(reset_sample_counter=True)
-    run_frames(args.warmup)
-    sync_all()
+    run_frames(rr, max(args.warmup, B))
+    sync_all(rr)
     rr.reset_counters()
     t0 = time.perf_counter()
-    run_frames(args.steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    counters = rr.counters()
-    rays_local = counters["closest_rays"] + counters["shadow_rays"]
+    run_frames(rr, steps_pipelined)
+    sync_all(rr)
+    elapsed_p = time.perf_counter() - t0
+    rays_p, elapsed_p, _ = total_rays(rr, elapsed_p)
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays_local], dtype=torch.int64, device=f"cuda:{local_rank}")
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_total = int(r.item())
-    else:
-        rays_total = rays_local
-
-    if counters["stack_overflows"]:
-        raise RuntimeError("BVH traversal stack overflow: results invalid")
-
-    ms_per_step = elapsed / args.steps * 1e3
-    mrays = rays_total / elapsed / 1e6
     result = {
         "metric": "Mray/s (closest-hit + shadow rays traced) @%dx%d, %d bounces, %d spp" % (W, H, args.bounces, args.spp),
-        "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.workload != "test_glb" else "reference fixture test/test.glb (81 364 triangles)",
+        "steps_effective": steps,
+        "value_definition": "SURVEY.md 8(d): one frame at a time, host wall time from before render() to after the stream sync, "
+                            f"{steps} frames between barriers (--steps {args.steps}, at least {MIN_TIMED_FRAMES}); frames in flight: see value_pipelined",
+        "frame_ms": {"mean": round(sum(frame_times) / len(frame_times), 4), "p50": round(frame_times[len(frame_times) // 2], 4),
+                     "min": round(frame_times[0], 4), "max": round(frame_times[-1], 4), "frames": len(frame_times)},
+        "value_pipelined": round(rays_p / elapsed_p / 1e6, 2),
+        "pipelined": {"ms_per_frame": round(elapsed_p / steps_pipelined * 1e3, 4), "frames": steps_pipelined, "frames_in_flight": args.frames_in_flight,
+                      "frames_per_launch": B, "unit": "Mray/s"},
         "config": {"workload": args.workload, "triangles": scene.triangle_count, "width": W, "height": H, "bounces": args.bounces,
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
-                   "views": args.views, "frames_in_flight": args.frames_in_flight, "frames_per_launch": B, "prewarm_frames": args.prewarm,
+                   "views": args.views, "frames_in_flight": 1, "frames_per_launch": 1, "prewarm_frames": args.prewarm,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         **({"load_balance": balance} if balance else {}),
-        "rays_per_frame": rays_total // args.steps,
-        "msample_per_s": round(W * H * args.views * args.spp * args.steps / elapsed / 1e6, 2),
+        "rays_per_frame": rays_total // steps,
+        "msample_per_s": round(W * H * args.views * args.spp * steps / elapsed / 1e6, 2),
     }
 
-    # ---- frame latency distribution (mean and p50): the same frames again with a host sync after each one,
-    # so unlike `ms_per_step` (back-to-back frames, the metric) this includes the enqueue latency of every frame
-    if world == 1:
-        # A caller that waits for every frame has no use for frame slots: the renderer of this loop has none, so each frame runs
-        # as four concurrent lanes (the stage's automatic schedule) instead of one lane per slot.
-        lone = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, viewports=args.views, frames_in_flight=1) if args.frames_in_flight > 1 else rr
-        lone.set_profiling(False, False)
-        for _ in range(10):
-            lone.reset_accumulation(); lone.render()
-        lone.sync()
-        lat = []
-        for _ in range(min(args.steps, 50)):
-            t1 = time.perf_counter()
-            lone.reset_accumulation()
-            lone.render()
-            lone.sync()
-            lat.append((time.perf_counter() - t1) * 1e3)
-        if lone is not rr:
-            lone.close()
-        lat.sort()
-        result["frame_latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "mean": round(sum(lat) / len(lat), 4), "min": round(lat[0], 4),
-                                      "frames": len(lat), "note": "host sync after every frame; renderer without frame slots (four lanes per frame)"}
-        # SURVEY.md 8(d) / BASELINE.md define ms/frame as host wall time around one render() including the stream sync: the same
-        # metric by that definition (one frame at a time, no frames in flight), beside the pipelined `value`
-        p50 = lat[len(lat) // 2]
-        result["ms_per_frame_sync"] = round(p50, 4)
-        result["value_sync_per_frame"] = round(result["rays_per_frame"] / (p50 * 1e-3) / 1e6, 2)
-        if args.sustained_frames > 0:      # a timed region long enough for a 1 Hz utilisation sampler to see
-            sync_all()
-            t1 = time.perf_counter()
-            run_frames(args.sustained_frames)
-            sync_all()
-            dt = time.perf_counter() - t1
-            result["sustained"] = {"frames": args.sustained_frames, "ms_per_frame": round(dt / args.sustained_frames * 1e3, 4),
-                                   "value": round(result["rays_per_frame"] * args.sustained_frames / dt / 1e6, 2), "unit": "Mray/s"}
+    if world == 1 and args.sustained_frames > 0:      # a timed region long enough for a 1 Hz utilisation sampler to see
+        sync_all(rr)
+        t1 = time.perf_counter()
+        run_frames(rr, args.sustained_frames)
+        sync_all(rr)
+        dt = time.perf_counter() - t1
+        n_s = ((args.sustained_frames + B - 1) // B) * B
+        result["sustained"] = {"frames": n_s, "ms_per_frame": round(dt / n_s * 1e3, 4), "value": round(result["rays_per_frame"] * n_s / dt / 1e6, 2),
+                               "unit": "Mray/s", "mode": "pipelined"}
 
     # ---- roofline of the dominant kernel (k_trace_closest), rank 0
     if not args.no_roofline:
         # every rank takes part (a frame of a multi-GPU job ends in an exchange between the ranks); rank 0's kernels are reported.
         # re-run of the identical frames (same frame indices) with per-kernel HIP events; detailed timing serialises the
-        # frame (no shadow/closest overlap), so every kernel is measured owning the chip (instance k_trace_closest<false, true>)
+        # frame (one lane, no shadow/closest overlap), so every kernel is measured owning the chip (instance k_trace_closest<false, true>)
+        n_r = ((min(steps, 20) + B - 1) // B) * B
         rr.set_profiling(False, True)
         rr.reset_accumulation(reset_sample_counter=True)
-        run_frames(args.warmup, True)
+        run_frames(rr, max(args.warmup, B), True)
         rr.reset_counters()
-        run_frames(args.steps, True)
+        run_frames(rr, n_r, True)
         timings = rr.timings()
         launches = max(timings["trace_closest_launches"], 1)
         avg_ms = timings["trace_closest_ms"] / launches
-        # counted re-run for the algorithmic byte model
+        # counted re-run for the algorithmic byte model and the rays per wave-level instruction
         rr.set_profiling(True, False)
         rr.reset_accumulation(reset_sample_counter=True)
-        run_frames(args.warmup)
+        run_frames(rr, max(args.warmup, B))
         rr.reset_counters()
-        run_frames(args.steps)
+        run_frames(rr, n_r)
         c = rr.counters()
+        ph = rr.phase_counters()
+        rr.set_profiling(False, False)
         # bytes per SURVEY.md section 8(d), restricted to what trace kernels touch; the closest-hit kernel's share of
         # node/triangle work is apportioned by ray count (both trace kernels walk the same structure)
         closest_share = c["closest_rays"] / max(c["closest_rays"] + c["shadow_rays"], 1)
@@ -319,49 +462,66 @@ def main():
         trace_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52) * closest_share \
             + c["closest_rays"] * (16 + 16 + 16 + 16)   # ray origin + direction + misc read, hit record write
         bytes_per_launch = trace_bytes / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        algorithmic = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = (c["node_visits"] * node_bytes + c["tri_tests"] * 48 + c["alpha_tests"] * 52 + c["surface_hits"] * 268
-                       + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * args.steps) / args.steps
-        # HBM traffic of the same kernel from the committed PMC passes (tools/profile_round.sh; FETCH_SIZE + WRITE_SIZE in
-        # separate runs).  Lower bound as reported; FETCH_SIZE may under-report by up to 2x on gfx950 (upper bound given too).
-        traffic, traffic_range, traffic_src, valu = None, None, None, None
-        try:
-            import glob, json as _json
-            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_summary.json")), reverse=True):
-                k = _json.load(open(f)).get(args.workload, {}).get("k_trace_closest", {})
-                if "hbm_traffic_bytes_per_launch_range" in k:
-                    traffic_range = k["hbm_traffic_bytes_per_launch_range"]
-                    traffic, traffic_src = traffic_range[0], os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))
-                    # HBM is not what binds this kernel (the tree is served by L2 / Infinity Cache): the VALU counters of the
-                    # same committed passes say what does
-                    valu = {"issue_busy": k.get("valu_issue_busy"), "lane_utilisation": k.get("valu_lane_utilisation"),
-                            "wait_fraction": k.get("wait_fraction"), "source": traffic_src}
-                    break
-        except Exception:
-            pass
-        result["roofline"] = {
-            "bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_range": traffic_range, "traffic_source": traffic_src,
-            "valu": valu,
-            # what the PMC traffic says the kernel really pulls from HBM, as a fraction of peak (the tree is served by L2 / MALL, so
-            # this is far below `frac`, which prices the algorithmic bytes): HBM is not what binds this kernel
-            "traffic_frac": [round(t / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for t in traffic_range] if (traffic_range and avg_ms > 0) else None,
-            "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                       + (c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * n_r) / n_r
+        kernel_avg_ms = {k: (timings[v + "_ms"] / max(timings[v + "_launches"], 1)) for k, v in HOT_KERNELS.items()}
+        roof = {
+            "kernel": "k_trace_closest", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "frames_per_launch": B,
+            "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "levels": {},
+            "algorithmic_GBps": round(algorithmic, 1), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "algorithmic_note": "SURVEY.md 8(d) counted-work bytes / launch time: node visits x 112 B etc.; served by L1 / L2 / Infinity Cache, "
+                                "so it may exceed the HBM peak and is not a roofline fraction",
             "frame_algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             # what a frame cannot avoid moving even with a perfectly cached tree: ray + hit records written and read once, one
             # framebuffer write
-            "frame_compulsory_GBps": round(((c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * args.steps)
-                                           / args.steps / (ms_per_step * 1e-3) / 1e9, 1),
-            "kernel_ms_per_frame": {k: round(timings[k + "_ms"] / args.steps, 4) for k in ("trace_closest", "trace_shadow", "shade", "raygen", "resolve")},
+            "frame_compulsory_GBps": round(((c["closest_rays"] + c["shadow_rays"]) * (2 * 48 + 2 * 20) + W * H * args.views * args.spp * 16 * n_r)
+                                           / n_r / (ms_per_step * 1e-3) / 1e9, 1),
+            "kernel_ms_per_frame": {k: round(timings[k + "_ms"] / n_r, 4) for k in ("trace_closest", "trace_shadow", "shade", "raygen", "resolve")},
             "node_visits_per_ray": round(c["node_visits"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
             "tri_tests_per_ray": round(c["tri_tests"] / max(c["closest_rays"] + c["shadow_rays"], 1), 2),
         }
+        if rank == 0:
+            try:
+                valu_peak = ctx.calibrate_valu()
+            except Exception as e:      # an older libtrhip.so
+                valu_peak = None
+                roof["valu_calibration_error"] = str(e)
+            roof["valu_peak_measured_ginst_per_s"] = round(valu_peak, 1) if valu_peak else None
+            pmc, pmc_err = ({}, "switched off (--no-pmc)") if args.no_pmc else run_pmc_passes(args, B, args.pmc_dump)
+            if pmc_err:
+                roof["pmc_error"] = pmc_err
+            lv = level_fractions(pmc.get("k_trace_closest"), avg_ms, valu_peak)
+            # rays per wave-level instruction of the traversal: node visits of the closest-hit rays / node phases (a phase = one pass of
+            # a wave over the node code, one ray per lane or one ray per quad); the hardware lane count (hw_lanes_per_inst) counts a
+            # quad's four lanes as four
+            phases = ph["lane_node_phases"] + ph["quad_node_phases"]
+            if "valu" in lv and phases > 0:
+                rpi = ph["closest_node_visits"] / phases
+                lv["valu"]["rays_per_node_phase"] = round(rpi, 2)
+                lv["valu"]["useful_frac"] = round(lv["valu"]["frac"] * rpi / 64.0, 4)
+                lv["valu"]["node_phases"] = {"one_ray_per_lane": ph["lane_node_phases"], "one_ray_per_quad": ph["quad_node_phases"],
+                                             "per_lane_by_live_rays_1_8_to_57_64": ph["lane_node_phase_hist"]}
+            roof["levels"] = lv
+            if lv:
+                b = max(lv, key=lambda k: lv[k]["frac"])
+                roof.update({"bound": b, "achieved": lv[b]["achieved"], "peak": lv[b]["peak"], "unit": lv[b]["unit"], "frac": lv[b]["frac"]})
+                if "fabric" in lv:
+                    roof["traffic"] = lv["fabric"]["bytes_per_launch"]
+                    roof["traffic_note"] = "L2-miss bytes per launch (read requests x 128 B + write requests x 64 / 32 B; counters under rocprofv3 in this run)"
+                roof["bound_note"] = ("no level is near its peak: the kernel waits on dependent node fetches (wait_fraction) at %d waves per SIMD"
+                                      % 6) if lv[b]["frac"] < 0.6 else None
+            roof["other_kernels"] = {k: {"avg_launch_ms": round(kernel_avg_ms[k], 4), "levels": {n: {"frac": d["frac"], "achieved": d["achieved"], "unit": d["unit"]}
+                                                                                                  for n, d in level_fractions(pmc.get(k), kernel_avg_ms[k], valu_peak).items()}}
+                                     for k in ("k_trace_shadow", "k_shade")}
+            roof["pmc_source"] = "rocprofv3 --pmc passes run by this process (bench.py --pmc-child); factors: profiles/r3/calibration.json"
+        result["roofline"] = roof
 
     # ---- CPU baseline: the oracle (a port; the reference has no CPU path) on the host cores, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import binding as B
-        osc = B.OracleScene(scene)
-        oopt = B.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, sampler=args.sampler)
+        from oracle import binding as OB
+        osc = OB.OracleScene(scene)
+        oopt = OB.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, sampler=args.sampler)
         cores = os.cpu_count() or 1
         frames = 0
         t0 = time.perf_counter()
@@ -372,19 +532,26 @@ def main():
                 break
         dt = time.perf_counter() - t0
         oc = osc.counters()
+        import shutil
+        vk_icd = any(os.path.isdir(d) and os.listdir(d) for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d"))
+        tauray_bin = shutil.which("tauray")
         result["cpu_baseline"] = {
             "value": round((oc["closest_rays"] + oc["shadow_rays"]) / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": f"{frames} full {W}x{H} frame(s) of the same workload, {dt:.1f} s of wall time, OpenMP over rows",
             "ms_per_frame": round(dt / frames * 1e3, 1),
+            # north_star asks for Tauray's raster fallback on the host cores beside the number: it needs a Vulkan software ICD and a
+            # compiled Tauray; neither can be installed here
+            "raster_fallback": ("available but not timed by this script" if (vk_icd and tauray_bin)
+                                else "unavailable: no %s on this box" % " and no ".join(([] if vk_icd else ["Vulkan ICD"]) + ([] if tauray_bin else ["Tauray binary"]))),
         }
 
     if args.save_display:       # frame 0 again on every rank, outside all timing
-        rr.set_profiling(False, False)
-        rr.reset_accumulation(reset_sample_counter=True)
-        rr.render()
-        sync_all()
+        lone.set_profiling(False, False)
+        lone.reset_accumulation(reset_sample_counter=True)
+        lone.render()
+        sync_all(lone)
         if rank == 0:
-            np.save(args.save_display, rr.download("display")[:args.views])        # frame 0 of the launch
+            np.save(args.save_display, lone.download("display")[:args.views])
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

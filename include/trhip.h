@@ -84,6 +84,8 @@ typedef struct trhip_accel_info {
     float build_ms;                   /* device time of the whole build */
     float bounds_min[3], bounds_max[3];
     uint32_t node_bytes;              /* bytes one node visit reads (112: six box planes + child refs of a 4-wide node) */
+    uint32_t leaf_count;              /* leaves of the tree: triangle_count, or more when a static build split large triangles into
+                                         several references (csrc/bvh_presplit.h); node_count = leaf_count - 1 */
 } trhip_accel_info;
 
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
@@ -236,6 +238,22 @@ int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */
 int trhip_pt_reset_counters(trhip_pt* pt);
 int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out);       /* synchronises the stream */
+/* Wave-level statistics of the closest-hit loop, cumulative like trhip_counters and only collected while work counting is on
+ * (trhip_pt_set_profiling): how many node / triangle phases the waves executed one ray per lane and one ray per quad
+ * (csrc/trace_quad.h), and the per-lane node phases by the number of live rays (1-8, 9-16, ..., 57-64).  node_visits divided by
+ * the node phases is the number of rays one vector instruction of the traversal serves - what the VALU roofline of bench.py
+ * multiplies the issue rate with (a hardware lane count cannot tell a quad's four lanes from four rays). */
+typedef struct trhip_phase_counters {
+    uint64_t lane_node_phases, lane_tri_phases, quad_node_phases, quad_tri_phases;
+    uint64_t lane_node_phases_le16, lane_node_visits_le16;
+    uint64_t lane_node_phase_hist[8];
+    uint64_t closest_node_visits;     /* node visits of the closest-hit rays alone (trhip_counters::node_visits includes shadow rays) */
+} trhip_phase_counters;
+int trhip_pt_get_phase_counters(trhip_pt* pt, trhip_phase_counters* out);   /* synchronises the stream */
+/* Peak vector-instruction issue rate of the device as it runs now: a loop of independent v_fma_f32 at eight waves per SIMD,
+ * in 10^9 wave-level instructions per second (MI355X_MICROARCH.md: 2 cycles per wave64 instruction on a SIMD-32; the clock is
+ * what the box sustains).  The peak of the VALU roofline in bench.py; about 2 ms of device time. */
+int trhip_calibrate_valu(trhip_device* dev, float* ginst_per_s);
 
 /* ---- feature_stage (src/feature_stage.cc:22-104): 0 albedo, 1 world normal, 2 view normal, 3 world pos,
  *      4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */
@@ -246,6 +264,8 @@ int trhip_feature_render(trhip_device* dev, int feature, const trhip_distributio
 /* ---- ray-level queries (parity hooks for traceRayEXT, shader/path_tracer.glsl:38-50,387-403).
  * rays: 8 floats each {ox, oy, oz, tmin, dx, dy, dz, tmax}; hits: {i32 instance, i32 primitive, f32 u, f32 v, f32 t}.
  * seeds == NULL selects the feature renderer's fixed alpha cutoff (shader/rt_feature.rahit:17). */
+/* Two queries on one device must not run at the same time (the closest-hit query keeps one spill buffer for the deep stack
+ * entries of its quad tails per device): enqueue them on one stream, or order the streams with trhip_stream_wait. */
 int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, const void* seeds_dev,
                         int include_lights, void* hits_dev, void* stream);
 int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void* visibility_dev, void* stream);

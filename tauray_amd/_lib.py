@@ -34,7 +34,7 @@ class SceneDescC(C.Structure):
 class AccelInfoC(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_light_count", C.c_uint32),
                 ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
-                ("node_bytes", C.c_uint32)]
+                ("node_bytes", C.c_uint32), ("leaf_count", C.c_uint32)]
 
 
 class PtOptionsC(C.Structure):
@@ -63,6 +63,12 @@ class CountersC(C.Structure):
 class TimingsC(C.Structure):
     _fields_ = ([(n, C.c_float) for n in ("path_tracing_ms", "trace_closest_ms", "trace_shadow_ms", "shade_ms", "raygen_ms", "resolve_ms")]
                 + [(n, C.c_uint32) for n in ("trace_closest_launches", "trace_shadow_launches", "shade_launches", "frames")])
+
+
+class PhaseCountersC(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("lane_node_phases", "lane_tri_phases", "quad_node_phases", "quad_tri_phases",
+                                           "lane_node_phases_le16", "lane_node_visits_le16")] + [("lane_node_phase_hist", C.c_uint64 * 8),
+                                                                                                 ("closest_node_visits", C.c_uint64)])
 
 
 class PtTargetsC(C.Structure):
@@ -119,6 +125,8 @@ SYMBOLS = {
     "trhip_pt_get_counters": (_i, [_vp, C.POINTER(CountersC)]),
     "trhip_pt_reset_counters": (_i, [_vp]),
     "trhip_pt_get_timings": (_i, [_vp, C.POINTER(TimingsC)]),
+    "trhip_pt_get_phase_counters": (_i, [_vp, C.POINTER(PhaseCountersC)]),
+    "trhip_calibrate_valu": (_i, [_vp, C.POINTER(C.c_float)]),
     "trhip_feature_render": (_i, [_vp, _i, C.POINTER(DistributionC), _i, _u32, _f, C.POINTER(_f), _vp, _u32, _u32, _vp]),
     "trhip_trace_closest": (_i, [_vp, _u32, _vp, _vp, _i, _vp, _vp]),
     "trhip_trace_shadow": (_i, [_vp, _u32, _vp, _vp, _vp]),

@@ -67,6 +67,24 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     target[(size_t)wy * target_w + (uint)wx] = data;
 }
 
+// trhip_calibrate_valu: 4096 x 64 independent v_fma_f32 per wave
+__global__ __launch_bounds__(KB) void k_calibrate_fma(float* out, int iters, float a, float b) {
+    float r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = (float)threadIdx.x + (float)k;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[k]) : "v"(a), "v"(b));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += r[k];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 // ray-level hooks
 // TOP: through the treetop in LDS, like the frame's trace kernels (so that the ray-level parity tests cover that path).
 // Whole waves walk the ray list together and use the wave-level traversal with its quad-cooperative tail (trace_quad.h),
@@ -493,6 +511,7 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     if (const char* r = getenv("TRHIP_PLOC_RADIUS")) dev->scene.ploc_radius = std::max(1, atoi(r));
     if (const char* o = getenv("TRHIP_BVH_OPT")) dev->scene.optimise_rounds = std::max(0, atoi(o));
     if (const char* o = getenv("TRHIP_BVH_OPT_MOD")) dev->scene.optimise_modulus = std::max(1, atoi(o));
+    if (const char* o = getenv("TRHIP_PRESPLIT")) dev->scene.presplit_percent = std::min(200, std::max(0, atoi(o)));
     if (const char* c = getenv("TRHIP_COLLAPSE")) dev->scene.collapse_by_cost = std::string(c) != "greedy";
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
@@ -598,6 +617,31 @@ int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_counters(out, pt->stage->last_stream); }
 int trhip_pt_reset_counters(trhip_pt* pt) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); HIPCHK(hipStreamSynchronize(pt->stage->last_stream)); return pt->stage->reset_counters(); }
 int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_timings(out); }
+int trhip_pt_get_phase_counters(trhip_pt* pt, trhip_phase_counters* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_phase_counters(out, pt->stage->last_stream); }
+
+int trhip_calibrate_valu(trhip_device* dev, float* ginst_per_s) {
+    DEVCHK(dev);
+    if (!ginst_per_s) return set_error("trhip_calibrate_valu: null out");
+    int cus = 256;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev->hip_device));
+    const int blocks = cus * 8, iters = 4096;      // eight waves per SIMD
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    float best = 0.0f;
+    for (int rep = 0; rep < 4; ++rep) {            // the first launch warms up; the fastest of the rest counts
+        HIPCHK(hipEventRecord(a, nullptr));
+        hipLaunchKernelGGL(k_calibrate_fma, dim3(blocks), dim3(KB), 0, nullptr, reinterpret_cast<float*>(dev->overflow_flag), iters, 1.0001f, 0.5f);
+        HIPCHK(hipEventRecord(b, nullptr));
+        HIPCHK(hipEventSynchronize(b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        const float g = (float)((double)blocks * (KB / 64) * (double)iters * 64.0 / ((double)ms * 1e6));
+        if (rep > 0 && g > best) best = g;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ginst_per_s = best;
+    return 0;
+}
 
 static LaunchCtx make_launch(const trhip_distribution& d) {
     LaunchCtx L{};

@@ -40,7 +40,7 @@ struct DeviceScene {
     BvhNode* nodes = nullptr;
     Bvh4Node* nodes4 = nullptr;
     f4* treetop = nullptr;               // top four levels of nodes4 for the LDS of the trace kernels (TR_TOP_SLOTS)
-    bool use_treetop = true;             // TRHIP_TREETOP=0: trace kernels fetch every node from nodes4
+    bool use_treetop = false;            // set by every build / refit: true only with TRHIP_TREETOP=1 (measured slower)
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
     uint node_count = 0, tri_light_count = 0;
@@ -48,12 +48,15 @@ struct DeviceScene {
     uint build_rounds = 0;
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int optimise_rounds = 8;             // reinsertion rounds after the build (bvh_optimize.h; TRHIP_BVH_OPT)
+    int presplit_percent = 30;           // static builds: extra triangle references the pre-split may spend, in percent of the triangle count (bvh_presplit.h; TRHIP_PRESPLIT, 0 = none)
+    uint leaf_count = 0;                 // leaves of the tree = records in `tris`: the triangles, or their references after a pre-split
+    uint accel_tri_count = 0;            // triangle count of the scene the structure was built for
     bool collapse_by_cost = true;        // 4-wide nodes chosen by least area sum (k_collapse_cost) instead of greedily (TRHIP_COLLAPSE=greedy)
     bool fast_build = false;             // trhip_scene_set_build_mode: no optimisation rounds
     int optimise_modulus = 1;            // a node searches every optimise_modulus-th round (TRHIP_BVH_OPT_MOD)
     int dfs_layout = 1;                  // depth-first node order (TRHIP_NODE_LAYOUT=dfs|build)
     bool accel_built = false;
-    uint accel_capacity = 0xFFFFFFFFu;   // triangle count the output buffers were allocated for
+    uint accel_capacity = 0xFFFFFFFFu;   // leaf count the output buffers were allocated for
     void* scratch = nullptr;             // build temporaries, kept between builds
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};   // centroid bounds of the last build
     // refit support (built on the first trhip_scene_refit_accel after a build): live 4-wide nodes in breadth-first order

@@ -42,10 +42,12 @@ TR_DEV void locate_triangle(const uint* tri_prefix, uint instance_count, uint gi
 // world-space triangle = (model * vec4(pos, 1)).xyz in the GLSL evaluation order; also accumulates the
 // centroid bounds used to quantise Morton codes.
 __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* tri_prefix, const uint8_t* non_opaque,
-                                                     TriRecord* tris_unsorted, uint* cbounds /*6 flipped uints*/) {
+                                                     TriRecord* tris_unsorted, uint* cbounds /*6 flipped uints of the centroid bounds; [16..21] the same for the triangles' bounds*/) {
     uint gid = blockIdx.x * BT + threadIdx.x;
     float cmin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
     float cmax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    float smin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float smax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
     if (gid < sv.tri_count) {
         uint inst, prim;
         locate_triangle(tri_prefix, sv.instance_count, gid, inst, prim);
@@ -67,17 +69,22 @@ __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* t
         f3 lo = min3(min3(p0, p1), p2), hi = max3(max3(p0, p1), p2);
         f3 c = (lo + hi) * 0.5f;
         cmin[0] = cmax[0] = c.x; cmin[1] = cmax[1] = c.y; cmin[2] = cmax[2] = c.z;
+        smin[0] = lo.x; smin[1] = lo.y; smin[2] = lo.z; smax[0] = hi.x; smax[1] = hi.y; smax[2] = hi.z;
     }
     // wave reduce, then one atomic per wave
     for (int k = 0; k < 3; ++k) {
-        float mn = cmin[k], mx = cmax[k];
+        float mn = cmin[k], mx = cmax[k], sn = smin[k], sx = smax[k];
         for (int off = 32; off > 0; off >>= 1) {
             mn = fminf(mn, __shfl_xor(mn, off));
             mx = fmaxf(mx, __shfl_xor(mx, off));
+            sn = fminf(sn, __shfl_xor(sn, off));
+            sx = fmaxf(sx, __shfl_xor(sx, off));
         }
         if ((threadIdx.x & 63) == 0 && mn <= mx) {
             atomicMin(&cbounds[k], float_flip(mn));
             atomicMax(&cbounds[3 + k], float_flip(mx));
+            atomicMin(&cbounds[16 + k], float_flip(sn));     // bounds of the triangles themselves: the grid of the pre-split
+            atomicMax(&cbounds[19 + k], float_flip(sx));
         }
     }
 }
@@ -322,6 +329,7 @@ __global__ __launch_bounds__(BT) void k_emit_nodes(uint n_internal, const int2* 
 }  // namespace
 }  // namespace tr
 #include "bvh_optimize.h"
+#include "bvh_presplit.h"
 namespace tr {
 namespace {
 
@@ -587,7 +595,7 @@ static int build_treetop(DeviceScene& ds, hipStream_t stream) {
     // off unless TRHIP_TREETOP=1: measured slower (profiles/r2/treetop_ab.json)
     static const bool enabled = getenv("TRHIP_TREETOP") && atoi(getenv("TRHIP_TREETOP")) != 0;
     ds.use_treetop = enabled;
-    if (!ds.nodes4 || ds.node_count == 0) return 0;
+    if (!enabled || !ds.nodes4 || ds.node_count == 0) return 0;     // no kernel, no allocation while the feature is off
     if (!ds.treetop) HIPCHK(hipMalloc(&ds.treetop, TR_TOP_WORDS * sizeof(float)));
     hipLaunchKernelGGL(k_build_treetop, dim3(1), dim3(128), 0, stream, ds.nodes4, ds.node_count, ds.treetop);
     HIPCHK(hipGetLastError());
@@ -599,8 +607,9 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 #if !TR_BVH4
     return set_error("trhip_scene_refit_accel: this build traverses the binary tree; rebuild instead");
 #else
-    const uint n = ds.tri_count;
-    if (ds.accel_capacity != n || (n > 0 && !ds.tris) || (n > 1 && !ds.nodes4)) return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
+    const uint n = ds.leaf_count;      // records in ds.tris: triangles, or the references of a pre-split build (their leaf boxes grow to the whole triangle here)
+    if (ds.accel_tri_count != ds.tri_count || ds.accel_capacity == 0xFFFFFFFFu || (n > 0 && !ds.tris) || (n > 1 && !ds.nodes4))
+        return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));
@@ -644,7 +653,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0 && ds.tri_lights) {
         HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
         SceneView sv2 = ds.view();
-        hipLaunchKernelGGL(k_extract_tri_lights, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
+        hipLaunchKernelGGL(k_extract_tri_lights, dim3((ds.tri_count + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
     }
     HIPCHK(hipEventRecord(e1, stream));
     HIPCHK(hipEventSynchronize(e1));
@@ -653,7 +662,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (info) {
         memset(info, 0, sizeof(*info));
-        info->triangle_count = n; info->node_count = ds.node_count; info->node_bytes = 112u; info->tri_light_count = ds.tri_light_count;
+        info->triangle_count = ds.tri_count; info->leaf_count = n; info->node_count = ds.node_count; info->node_bytes = 112u; info->tri_light_count = ds.tri_light_count;
         info->build_ms = ms;
         for (int k = 0; k < 3; ++k) { info->bounds_min[k] = ds.bounds_lo[k]; info->bounds_max[k] = ds.bounds_hi[k]; }
     }
@@ -662,36 +671,45 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 }
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
-    const uint n = ds.tri_count;
+    const uint n_scene = ds.tri_count;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));
     ds.accel_built = false;
     ds.levels_valid = false;   // a new tree: the refit level lists are rebuilt on demand
     SceneView sv = ds.view();
-    sv.tri_count = n;
+    sv.tri_count = n_scene;
     // Temporaries come out of one scratch arena that survives the call, and the outputs keep their allocation while the
     // triangle count does not change: a rebuild (dynamic scenes) performs no allocation at all.
     size_t plan_bytes = 0;
     auto plan = [&](size_t bytes) { size_t o = plan_bytes; plan_bytes += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t n1 = n > 1 ? n - 1 : 0;
+    // Static builds split large triangles into several references first (bvh_presplit.h): the tree then has more leaves than the
+    // scene has triangles.  n_tri = triangles, n = leaves (known once the splits are counted), n_cap = what everything is sized for.
+    const uint n_tri = n_scene;
+    const bool presplit = TR_BVH4 && ds.presplit_percent > 0 && !ds.fast_build && n_tri > 64;
+    const uint split_budget = presplit ? (uint)std::min<uint64_t>((uint64_t)n_tri * (uint)ds.presplit_percent / 100u, 0x7FFFFFFFull - n_tri) : 0u;
+    const uint n_cap = n_tri + split_budget;
+    uint n = n_tri;
+    const size_t n1 = n_cap > 1 ? n_cap - 1 : 0;     // inner nodes the buffers hold
     size_t sort_bytes = 0, scan_bytes = 0;
-    if (n > 0) {
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint*)nullptr, (uint*)nullptr, n, 0, 64, stream));
-        HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, (uint*)nullptr, (uint*)nullptr, 0u, n, rocprim::plus<uint>(), stream));
+    if (n_cap > 0) {
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint*)nullptr, (uint*)nullptr, n_cap, 0, 64, stream));
+        HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, (uint*)nullptr, (uint*)nullptr, 0u, n_cap + BT, rocprim::plus<uint>(), stream));
     }
-    const size_t o_cbounds = plan(16 * sizeof(uint)), o_unsorted = plan((size_t)n * sizeof(TriRecord)), o_keys = plan((size_t)n * 8),
-                 o_keys_sorted = plan((size_t)n * 8), o_vals = plan((size_t)n * 4), o_vals_sorted = plan((size_t)n * 4),
-                 o_leaf_box = plan((size_t)n * 24), o_sort = plan(sort_bytes + 16), o_children = plan(n1 * sizeof(int2)),
-                 o_sizes = plan(n1 * 4), o_parent = plan(n1 * 4), o_parent_leaf = plan((size_t)n * 4), o_node_box = plan(n1 * 24),
-                 o_arrive = plan(n1 * 4), o_cref0 = plan((size_t)n * 4), o_cref1 = plan((size_t)n * 4), o_cbox0 = plan((size_t)n * 24),
-                 o_cbox1 = plan((size_t)n * 24), o_nn = plan((size_t)n * 4), o_valid = plan(((size_t)n + BT) * 4), o_pos = plan(((size_t)n + BT) * 4),
+    const size_t o_cbounds = plan(32 * sizeof(uint)), o_unsorted = plan((size_t)n_cap * sizeof(TriRecord)), o_keys = plan((size_t)n_cap * 8),
+                 o_keys_sorted = plan((size_t)n_cap * 8), o_vals = plan((size_t)n_cap * 4), o_vals_sorted = plan((size_t)n_cap * 4),
+                 o_leaf_box = plan((size_t)n_cap * 24), o_sort = plan(sort_bytes + 16), o_children = plan(n1 * sizeof(int2)),
+                 o_sizes = plan(n1 * 4), o_parent = plan(n1 * 4), o_parent_leaf = plan((size_t)n_cap * 4), o_node_box = plan(n1 * 24),
+                 o_arrive = plan(n1 * 4), o_cref0 = plan((size_t)n_cap * 4), o_cref1 = plan((size_t)n_cap * 4), o_cbox0 = plan((size_t)n_cap * 24),
+                 o_cbox1 = plan((size_t)n_cap * 24), o_nn = plan((size_t)n_cap * 4), o_valid = plan(((size_t)n_cap + BT) * 4), o_pos = plan(((size_t)n_cap + BT) * 4),
                  o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(TR_BVH4 ? n1 * sizeof(BvhNode) : 0);
-    const bool optimise = ds.optimise_rounds > 0 && !ds.fast_build && n > 2;
-    const size_t n_all = (size_t)n + n1;
-    const bool dp_collapse = TR_BVH4 && ds.collapse_by_cost && !ds.fast_build && n > 2;   // a fast build keeps the greedy choice (the cost pass would double its time)
-    const size_t o_uparent = plan(optimise || dp_collapse ? n_all * 4 : 0), o_moves = plan(optimise ? n_all * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all * 8 : 0),
+    const bool optimise = ds.optimise_rounds > 0 && !ds.fast_build && n_tri > 2;
+    const size_t n_all_cap = (size_t)n_cap + n1;
+    const bool dp_collapse = TR_BVH4 && ds.collapse_by_cost && !ds.fast_build && n_tri > 2;   // a fast build keeps the greedy choice (the cost pass would double its time)
+    const size_t o_uparent = plan(optimise || dp_collapse ? n_all_cap * 4 : 0), o_moves = plan(optimise ? n_all_cap * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all_cap * 8 : 0),
                  o_optstat = plan(64), o_ccost = plan(dp_collapse ? n1 * 12 : 0), o_cdec = plan(dp_collapse ? n1 : 0);
+    const size_t o_prio = plan(presplit ? (size_t)n_tri * 4 : 0), o_count = plan(presplit ? ((size_t)n_tri + BT) * 4 : 0), o_offset = plan(presplit ? ((size_t)n_tri + BT) * 4 : 0),
+                 o_refs = plan(presplit ? (size_t)n_cap * sizeof(TriRecord) : 0), o_ref_box = plan(presplit ? (size_t)n_cap * 24 : 0), o_totals = plan(PRESPLIT_CANDIDATES * 8);
     if (plan_bytes > ds.scratch_bytes) {
         if (ds.scratch) (void)hipFree(ds.scratch);
         ds.scratch = nullptr; ds.scratch_bytes = 0;
@@ -701,12 +719,12 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     char* base = static_cast<char*>(ds.scratch);
     uint* cbounds = reinterpret_cast<uint*>(base + o_cbounds);   // 6 flipped centroid bounds, [6] PLOC node allocator, [8..9] cluster counts
     {
-        const uint init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uint init[32] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(cbounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
     }
-    if (ds.accel_capacity != n) {   // outputs
+    if (ds.accel_capacity != n_cap) {   // outputs
         ds.free_accel();
-        if (n > 0) HIPCHK(hipMalloc(&ds.tris, (size_t)n * sizeof(TriRecord)));
+        if (n_cap > 0) HIPCHK(hipMalloc(&ds.tris, (size_t)n_cap * sizeof(TriRecord)));
         if (n1 > 0) {
 #if TR_BVH4
             // traversal addresses a node's planes with 32-bit byte offsets (node << 7 | plane)
@@ -716,10 +734,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
             HIPCHK(hipMalloc(&ds.nodes, n1 * sizeof(BvhNode)));
 #endif
         }
-        ds.accel_capacity = n;
+        ds.accel_capacity = n_cap;
     }
-    ds.node_count = (uint)n1;
-    if (n > 0) {
+    if (n_tri > 0) {
         TriRecord* unsorted = reinterpret_cast<TriRecord*>(base + o_unsorted);
         unsigned long long *keys = reinterpret_cast<unsigned long long*>(base + o_keys), *keys_sorted = reinterpret_cast<unsigned long long*>(base + o_keys_sorted);
         uint *vals = reinterpret_cast<uint*>(base + o_vals), *vals_sorted = reinterpret_cast<uint*>(base + o_vals_sorted);
@@ -733,16 +750,86 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 #else
         BvhNode* nodes2 = ds.nodes;
 #endif
+        const uint tblocks = (n_tri + BT - 1) / BT;
+        hipLaunchKernelGGL(k_pretransform, dim3(tblocks), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
+        bool split_done = false;
+        if (presplit) {
+            // the Morton grid the split planes come from: the bounds of the triangles
+            uint hb[6];
+            HIPCHK(hipMemcpyAsync(hb, cbounds + 16, sizeof(hb), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            SplitGrid g;
+            for (int k = 0; k < 3; ++k) {
+                g.lo[k] = float_unflip(hb[k]);
+                g.ext[k] = float_unflip(hb[3 + k]) - g.lo[k];
+                g.inv[k] = g.ext[k] > 0.0f ? 2097152.0f / g.ext[k] : 0.0f;
+            }
+            float* prio = reinterpret_cast<float*>(base + o_prio);
+            uint *count = reinterpret_cast<uint*>(base + o_count), *offset = reinterpret_cast<uint*>(base + o_offset);
+            unsigned long long* totals = reinterpret_cast<unsigned long long*>(base + o_totals);
+            uint* max_bits = cbounds + 24;
+            hipLaunchKernelGGL(k_split_priority, dim3(tblocks), dim3(BT), 0, stream, n_tri, unsorted, g, prio, max_bits);
+            uint mb = 0;
+            HIPCHK(hipMemcpyAsync(&mb, max_bits, 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            float pmax;
+            memcpy(&pmax, &mb, 4);
+            if (pmax > 0.0f && split_budget > 0) {
+                // the largest scale whose split counts fit the budget: two passes over PRESPLIT_CANDIDATES scales each (geometric
+                // from "the largest priority gets one split" upwards, then linear inside the bracket found)
+                float lo_scale = 0.0f, hi_scale = 0.0f;
+                SplitScales sc;
+                unsigned long long h_tot[PRESPLIT_CANDIDATES];
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int c = 0; c < PRESPLIT_CANDIDATES; ++c)
+                        sc.s[c] = pass == 0 ? (1.0f / pmax) * exp2f(0.75f * (float)c) : lo_scale + (hi_scale - lo_scale) * (float)(c + 1) / (float)(PRESPLIT_CANDIDATES + 1);
+                    HIPCHK(hipMemsetAsync(totals, 0, sizeof(h_tot), stream));
+                    hipLaunchKernelGGL(k_split_totals, dim3(tblocks), dim3(BT), 0, stream, n_tri, prio, sc, totals);
+                    HIPCHK(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    int best = -1;
+                    for (int c = 0; c < PRESPLIT_CANDIDATES; ++c) if (h_tot[c] <= split_budget) best = c;
+                    const float lo_new = best >= 0 ? sc.s[best] : lo_scale;
+                    const float hi_new = best + 1 < PRESPLIT_CANDIDATES ? sc.s[best + 1] : (pass == 0 ? sc.s[PRESPLIT_CANDIDATES - 1] : hi_scale);
+                    if (pass == 0 && best < 0) { lo_scale = 0.0f; hi_scale = sc.s[0]; }
+                    else { lo_scale = lo_new; hi_scale = hi_new; }
+                }
+                if (lo_scale > 0.0f) {
+                    hipLaunchKernelGGL(k_split_counts, dim3(tblocks), dim3(BT), 0, stream, n_tri, prio, lo_scale, count);
+                    HIPCHK(rocprim::exclusive_scan(base + o_scan, scan_bytes, count, offset, 0u, tblocks * BT, rocprim::plus<uint>(), stream));
+                    uint last[2] = {0, 0};
+                    HIPCHK(hipMemcpyAsync(&last[0], offset + (n_tri - 1), 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipMemcpyAsync(&last[1], count + (n_tri - 1), 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    const uint n_refs = last[0] + last[1];
+                    if (n_refs > n_cap) return set_error("pre-split: reference count exceeds its budget");
+                    if (n_refs > n_tri) {
+                        TriRecord* refs = reinterpret_cast<TriRecord*>(base + o_refs);
+                        float* ref_box = reinterpret_cast<float*>(base + o_ref_box);
+                        hipLaunchKernelGGL(k_split_emit, dim3(tblocks), dim3(BT), 0, stream, n_tri, unsorted, offset, count, g, refs, ref_box);
+                        n = n_refs;
+                        const uint rblocks = (n + BT - 1) / BT;
+                        hipLaunchKernelGGL(k_morton_refs, dim3(rblocks), dim3(BT), 0, stream, n, ref_box, g, keys, vals);
+                        HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+                        hipLaunchKernelGGL(k_gather_refs, dim3(rblocks), dim3(BT), 0, stream, n, refs, ref_box, vals_sorted, ds.tris, leaf_box);
+                        split_done = true;
+                        if (getenv("TRHIP_DEBUG")) fprintf(stderr, "[trhip] pre-split: %u triangles -> %u references (budget %u, scale %g)\n", n_tri, n, split_budget, lo_scale);
+                    }
+                }
+            }
+        }
         const uint blocks = (n + BT - 1) / BT;
-        hipLaunchKernelGGL(k_pretransform, dim3(blocks), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
-        hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
-        HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
-        hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
+        if (!split_done) {
+            hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
+            HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+            hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
+        }
+        const size_t n_all = (size_t)n + (n > 1 ? n - 1 : 0);
         if (n > 1) {
             const uint iblocks = (n - 1 + BT - 1) / BT;
             if (ds.builder == 0) {
                 // Karras 2012 LBVH + atomic bottom-up refit
-                HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
+                HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
                 hipLaunchKernelGGL(k_hierarchy, dim3(iblocks), dim3(BT), 0, stream, (int)n, keys_sorted, children, ranges, parent_internal, parent_leaf);
                 hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BT), 0, stream, (int)n, children, parent_internal, parent_leaf, leaf_box,
                                    node_box, arrive, nodes2);
@@ -752,7 +839,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 float* cbox[2] = {reinterpret_cast<float*>(base + o_cbox0), reinterpret_cast<float*>(base + o_cbox1)};
                 uint *nn = reinterpret_cast<uint*>(base + o_nn), *valid = reinterpret_cast<uint*>(base + o_valid), *pos = reinterpret_cast<uint*>(base + o_pos);
                 uint *alloc = cbounds + 6, *c_dev = cbounds + 8;   // count of round r in c_dev[r & 1]; k_ploc_compact writes the other one
-                HIPCHK(hipMemsetAsync(parent_internal, 0xFF, n1 * 4, stream));   // root keeps -1
+                HIPCHK(hipMemsetAsync(parent_internal, 0xFF, (size_t)(n - 1) * 4, stream));   // root keeps -1
                 hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(BT), 0, stream, n, cref[0]);
                 HIPCHK(hipMemcpyAsync(cbox[0], leaf_box, (size_t)n * 24, hipMemcpyDeviceToDevice, stream));
                 HIPCHK(hipMemcpyAsync(c_dev, &n, 4, hipMemcpyHostToDevice, stream));
@@ -781,7 +868,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
             }
             if (optimise) {
                 // static geometry, "prefer fast trace": reinsertion rounds on the binary tree (bvh_optimize.h)
-                OptTree t{(uint)n1, n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
+                OptTree t{(uint)(n - 1), n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
                 OptMove* moves = reinterpret_cast<OptMove*>(base + o_moves);
                 unsigned long long* lock = reinterpret_cast<unsigned long long*>(base + o_lock);
                 double* cost = reinterpret_cast<double*>(base + o_optstat);
@@ -812,7 +899,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 for (int round = 0; round < ds.optimise_rounds; ++round) {
                     HIPCHK(hipMemsetAsync(lock, 0, n_all * 8, stream));
                     HIPCHK(hipMemsetAsync(applied, 0, 8, stream));
-                    HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
+                    HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
                     hipLaunchKernelGGL(k_opt_search, dim3(ablocks), dim3(BT), 0, stream, t, moves, (uint)round % (uint)ds.optimise_modulus, (uint)ds.optimise_modulus);
                     hipLaunchKernelGGL(k_opt_lock, dim3(ablocks), dim3(BT), 0, stream, t, moves, lock, debug ? applied + 1 : nullptr);
                     hipLaunchKernelGGL(k_opt_verify, dim3(ablocks), dim3(BT), 0, stream, t, moves, lock);
@@ -829,9 +916,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 #if TR_BVH4
                 const uint8_t* dec = nullptr;
                 if (dp_collapse) {
-                    OptTree t{(uint)n1, n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
+                    OptTree t{(uint)(n - 1), n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
                     if (!optimise) hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);
-                    HIPCHK(hipMemsetAsync(arrive, 0, n1 * 4, stream));
+                    HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
                     hipLaunchKernelGGL(k_collapse_cost, dim3(blocks), dim3(BT), 0, stream, t, arrive, reinterpret_cast<float*>(base + o_ccost), reinterpret_cast<uint8_t*>(base + o_cdec));
                     dec = reinterpret_cast<const uint8_t*>(base + o_cdec);
                 }
@@ -843,6 +930,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         }
         HIPCHK(hipGetLastError());
     }
+    ds.leaf_count = n;
+    ds.node_count = n > 1 ? n - 1 : 0;
+    ds.accel_tri_count = n_tri;
     if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
     // tri lights
@@ -852,7 +942,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
         ds.tri_light_count = ds.host_tri_light_count;
         SceneView sv2 = ds.view();
-        hipLaunchKernelGGL(k_extract_tri_lights, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
+        hipLaunchKernelGGL(k_extract_tri_lights, dim3((n_tri + BT - 1) / BT), dim3(BT), 0, stream, sv2, ds.tri_prefix, ds.tri_lights);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(e1, stream));
@@ -864,7 +954,8 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     HIPCHK(hipMemcpy(hb, cbounds, sizeof(hb), hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) { ds.bounds_lo[k] = float_unflip(hb[k]); ds.bounds_hi[k] = float_unflip(hb[3 + k]); }
     if (info) {
-        info->triangle_count = n;
+        info->triangle_count = n_tri;
+        info->leaf_count = n;
         info->node_count = ds.node_count;
         info->node_bytes = TR_BVH4 ? 112u : 64u;
         info->tri_light_count = ds.tri_light_count;

@@ -65,7 +65,7 @@ struct PathBuffers {
 // (measured: 0.83 ms instead of 0.56 ms for one k_shade launch of 2 M paths).
 enum { BC_QUEUE = 0, BC_SHADOW = 64, BC_CUR_CLOSEST = 128, BC_CUR_SHADOW = 192, BC_STRIDE = 256 };
 enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
-       CNT_MAXSP = 30, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_PH_HIST = 48, CNT_WORDS = 64 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
+       CNT_MAXSP = 30, CNT_CNODES = 32, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_PH_HIST = 48, CNT_WORDS = 64 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
 
 struct PtParams {
     trhip_pt_options opt;
@@ -198,6 +198,7 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     if (valid) trace_closest_any<0, COUNT, TOP>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
                                                 misc.x, lds_stack, hit, st, overflow, top);
 #endif
+    if (COUNT) st.cnodes += st.nodes - before;      // every lane: in the quad tail lane 0 of a quad counts for the quad's ray
     if (!valid) return;
     if (COUNT) {
         const uint vis = st.nodes - before;
@@ -262,7 +263,7 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
             st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off);
             st.ph_node += __shfl_xor(st.ph_node, off); st.ph_tri += __shfl_xor(st.ph_tri, off); st.ph_node16 += __shfl_xor(st.ph_node16, off);
             st.ph_node8 += __shfl_xor(st.ph_node8, off); st.lv_node16 += __shfl_xor(st.lv_node16, off);
-            st.ph_qnode += __shfl_xor(st.ph_qnode, off); st.ph_qtri += __shfl_xor(st.ph_qtri, off);
+            st.ph_qnode += __shfl_xor(st.ph_qnode, off); st.ph_qtri += __shfl_xor(st.ph_qtri, off); st.cnodes += __shfl_xor(st.cnodes, off);
             for (int b = 0; b < 8; ++b) st.ph_hist[b] += __shfl_xor(st.ph_hist[b], off);
             st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off));
         }
@@ -274,7 +275,7 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
             add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha);
             add64(pb.counters, CNT_PH_NODE, st.ph_node); add64(pb.counters, CNT_PH_TRI, st.ph_tri); add64(pb.counters, CNT_PH_NODE16, st.ph_node16);
             add64(pb.counters, CNT_PH_NODE8, st.ph_node8); add64(pb.counters, CNT_LV_NODE16, st.lv_node16);
-            add64(pb.counters, CNT_PH_QNODE, st.ph_qnode); add64(pb.counters, CNT_PH_QTRI, st.ph_qtri);
+            add64(pb.counters, CNT_PH_QNODE, st.ph_qnode); add64(pb.counters, CNT_PH_QTRI, st.ph_qtri); add64(pb.counters, CNT_CNODES, st.cnodes);
             for (int b = 0; b < 8; ++b) add64(pb.counters, CNT_PH_HIST + 2 * b, st.ph_hist[b]);
             atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis);
         }
@@ -1125,18 +1126,16 @@ static uint trace_grid_cap() {   // most blocks a persistent trace launch gets (
     static const uint cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
     return cap;
 }
-// words of the quad-tail spill buffer one lane of a frame needs: a slice per wave of its largest trace launch
-static size_t qspill_words_per_lane(size_t paths) {
-    const size_t blocks = std::min<size_t>(trace_grid_cap(), (paths + KB - 1) / KB);
-    return std::max<size_t>(blocks, 1) * (KB / 64) * 16u * TR_QSPILL;
-}
+// words of the quad-tail spill buffer one trace launch of `blocks` blocks needs: a slice per wave
+static size_t qspill_words(size_t blocks) { return std::max<size_t>(blocks, 1) * (KB / 64) * 16u * TR_QSPILL; }
 struct TimedSpan { int kind; hipEvent_t a, b; };
 enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_KINDS = 5 };
 
 struct PtStage::Impl {
     PathBuffers pb{};
     size_t capacity = 0;
-    size_t qspill_lane_words = 0;
+    size_t qspill_lane_words = 0;      // one region of PathBuffers::qspill: the largest trace launch of a lane
+    size_t qspill_regions = 0;         // regions allocated: one per lane in use, two for a single lane whose shadow launches run on the side stream
     hipEvent_t ev[2]{};
     bool ev_init = false;
     std::vector<hipEvent_t> pool;      // recycled events for per-launch timing
@@ -1192,12 +1191,6 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
         HIPCHK(hipMemset(pb.counters, 0, PT_LANES * CNT_WORDS * sizeof(uint)));
         HIPCHK(hipMalloc(&pb.bounce, (size_t)PT_LANES * BC_STRIDE * ((size_t)opt.max_bounces + 2u) * sizeof(uint)));
     }
-    if (qspill_words_per_lane(n) > impl->qspill_lane_words) {     // grows with the frame, up to the grid cap (59 MB per lane)
-        if (pb.qspill) HIPCHK(hipFree(pb.qspill));
-        pb.qspill = nullptr;
-        impl->qspill_lane_words = qspill_words_per_lane(n);
-        HIPCHK(hipMalloc(&pb.qspill, (size_t)PT_LANES * impl->qspill_lane_words * sizeof(int)));
-    }
     if (!impl->ev_init) { for (auto& e : impl->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); impl->ev_init = true; }
     if (n <= impl->capacity && (!lobe_sums || pb.sum_diffuse)) return 0;
     free_buffers();
@@ -1210,6 +1203,20 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     if (lobe_sums) { HIPCHK(hipMalloc(&pb.sum_diffuse, n * 16)); HIPCHK(hipMalloc(&pb.sum_reflection, n * 16)); }
     HIPCHK(hipMalloc(&pb.queue[0], n * 4)); HIPCHK(hipMalloc(&pb.queue[1], n * 4));
     impl->capacity = n;
+    return 0;
+}
+
+// The quad-tail spill buffer: `regions` slices of `blocks` blocks' worth each (grows only).  Sized by the lanes a frame really
+// uses and by the grid its trace launches really get - a frame slot running one lane of 1024-block launches holds 30 MB, a lone
+// frame on four lanes 118 MB (it was PT_LANES x the 2048-block cap = 236 MB for every stage).
+static int ensure_qspill(PathBuffers& pb, size_t& lane_words, size_t& regions_have, size_t regions, size_t blocks) {
+    const size_t words = qspill_words(blocks);
+    if (words <= lane_words && regions <= regions_have) return 0;
+    if (pb.qspill) HIPCHK(hipFree(pb.qspill));
+    pb.qspill = nullptr;
+    lane_words = std::max(lane_words, words);
+    regions_have = std::max(regions_have, regions);
+    HIPCHK(hipMalloc(&pb.qspill, regions_have * lane_words * sizeof(int)));
     return 0;
 }
 
@@ -1321,6 +1328,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     static const uint n_cu = [] { int dev = 0, cu = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return (uint)std::max(cu, 1); }();
     const uint closest_cap = (timing && !getenv("TRHIP_GRID_BLOCKS")) ? std::min(n_cu * (uint)TR_CLOSEST_WAVES, trace_grid_cap()) : grid_cap;   // the spill buffer of the quad tail is sized by trace_grid_cap()
     const uint shadow_cap = (timing && !getenv("TRHIP_GRID_BLOCKS")) ? std::min(n_cu * (uint)TR_SHADOW_WAVES, trace_grid_cap()) : grid_cap;
+    {   // spill regions: one per lane; a single lane whose shadow launches overlap the next closest-hit launch on the side stream
+        // needs a second one (both kernels index their slices by block and wave)
+        const size_t lane_paths = sample_lanes ? n : (n + (size_t)n_lanes - 1) / (size_t)n_lanes;
+        const size_t lane_blocks = std::min<size_t>(std::max(std::max(closest_cap, shadow_cap), grid_cap), (lane_paths + KB - 1) / KB + 1);
+        if (int rc = ensure_qspill(impl->pb, impl->qspill_lane_words, impl->qspill_regions, (size_t)std::max(n_lanes, overlap ? 2 : 1), lane_blocks)) return rc;
+    }
     auto& ev = impl->ev;
     // per-launch event pair, recorded on the launch stream, resolved lazily in get_timings()
     auto timed = [&](int kind, hipStream_t on, auto&& launch) {
@@ -1485,7 +1498,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         }
                         timed(T_SHADOW, ss, [&] {
                             auto ks = count ? (top ? k_trace_shadow<true, true> : k_trace_shadow<true, false>) : (top ? k_trace_shadow<false, true> : k_trace_shadow<false, false>);
-                            hipLaunchKernelGGL(ks, dim3(std::min(blocks_all, shadow_cap)), dim3(KB), 0, ss, sv, LP, lb, bc);
+                            // on the side stream the launch runs next to closest(b + 1) of the same lane: its quad tails spill into
+                            // the second region, not into the slices the closest-hit waves are using
+                            PathBuffers sb = lb;
+                            if (overlap) sb.qspill = pb.qspill + impl->qspill_lane_words;
+                            hipLaunchKernelGGL(ks, dim3(std::min(blocks_all, shadow_cap)), dim3(KB), 0, ss, sv, LP, sb, bc);
                         });
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                     }
@@ -1546,6 +1563,22 @@ int PtStage::get_counters(trhip_counters* out, hipStream_t stream) {
         fprintf(stderr, "\n");
     }
     if (getenv("TRHIP_DEBUG")) { float* f = (float*)(h + CNT_DBG); fprintf(stderr, "[trhip] overflow %u src %u; max stack depth %u; max node visits per ray %u; worst ray o=(%g %g %g) d=(%g %g %g) bounce %g id %g pdf %g reg %g\n", h[CNT_OVERFLOW], h[CNT_DBG + 12], h[CNT_MAXSP], h[CNT_MAXVIS], f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]); }
+    return 0;
+}
+
+// Wave-level phase statistics of the counting trace kernels (the denominators of "rays per vector instruction")
+int PtStage::get_phase_counters(trhip_phase_counters* out, hipStream_t stream) {
+    memset(out, 0, sizeof(*out));
+    if (!impl->pb.counters) return 0;
+    HIPCHK(hipStreamSynchronize(stream));
+    uint hl[PT_LANES][CNT_WORDS];
+    HIPCHK(hipMemcpy(hl, impl->pb.counters, sizeof(hl), hipMemcpyDeviceToHost));
+    auto rd = [&](int i) { uint64_t v = 0; for (int l = 0; l < PT_LANES; ++l) v += (uint64_t)hl[l][i] | ((uint64_t)hl[l][i + 1] << 32); return v; };
+    out->lane_node_phases = rd(CNT_PH_NODE); out->lane_tri_phases = rd(CNT_PH_TRI);
+    out->quad_node_phases = rd(CNT_PH_QNODE); out->quad_tri_phases = rd(CNT_PH_QTRI);
+    out->lane_node_phases_le16 = rd(CNT_PH_NODE16); out->lane_node_visits_le16 = rd(CNT_LV_NODE16);
+    out->closest_node_visits = rd(CNT_CNODES);
+    for (int b = 0; b < 8; ++b) out->lane_node_phase_hist[b] = rd(CNT_PH_HIST + 2 * b);
     return 0;
 }
 

@@ -15,6 +15,7 @@ public:
     int get_counters(trhip_counters* out, hipStream_t stream);
     int reset_counters();
     int get_timings(trhip_timings* out);
+    int get_phase_counters(trhip_phase_counters* out, hipStream_t stream);
 
     DeviceScene* scene;
     trhip_pt_options opt;

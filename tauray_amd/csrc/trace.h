@@ -154,6 +154,7 @@ struct TraceStats {
     uint ph_node, ph_tri, ph_node16, ph_node8, lv_node16;
     uint ph_qnode, ph_qtri;   // phases of the quad-cooperative tail (trace_quad.h)
     uint ph_hist[8];          // per-lane node phases by live rays: 1-8, 9-16, ..., 57-64
+    uint cnodes;              // node visits of closest-hit rays alone (`nodes` also counts the shadow rays of a fused launch)
 };
 
 // get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit

@@ -150,6 +150,12 @@ class Context:
         """Work enqueued on `stream` from now on waits for what is on `on` now (None = the default stream)."""
         check(_lib.lib().trhip_stream_wait(self.h, stream, on))
 
+    def calibrate_valu(self) -> float:
+        """Peak vector-instruction issue rate of the device as it runs now, in 10^9 wave-level instructions per second."""
+        g = C.c_float()
+        check(_lib.lib().trhip_calibrate_valu(self.h, C.byref(g)))
+        return float(g.value)
+
     def close(self):
         if self.h:
             _lib.lib().trhip_device_destroy(self.h)
@@ -421,6 +427,15 @@ class PathTracerStage:
         check(_lib.lib().trhip_pt_get_timings(self.h, C.byref(t)))
         return {n: float(getattr(t, n)) for n, _ in TimingsC._fields_}
 
+    def phase_counters(self) -> dict:
+        """Wave-level phase statistics of the counting trace kernels (trhip_pt_get_phase_counters)."""
+        from ._lib import PhaseCountersC
+        p = PhaseCountersC()
+        check(_lib.lib().trhip_pt_get_phase_counters(self.h, C.byref(p)))
+        out = {n: int(getattr(p, n)) for n, _ in PhaseCountersC._fields_ if n != "lane_node_phase_hist"}
+        out["lane_node_phase_hist"] = [int(x) for x in p.lane_node_phase_hist]
+        return out
+
     def close(self):
         if self.h:
             _lib.lib().trhip_pt_destroy(self.h)
@@ -680,6 +695,14 @@ class RtRenderer:
         for slot in self.slots:
             for k, v in slot.pt.timings().items():
                 total[k] = total.get(k, 0) + v
+        return total
+
+    def phase_counters(self) -> dict:
+        self.sync()
+        total = {}
+        for slot in self.slots:
+            for k, v in slot.pt.phase_counters().items():
+                total[k] = [a + b for a, b in zip(total[k], v)] if (k in total and isinstance(v, list)) else (total.get(k, 0) + v if not isinstance(v, list) else v)
         return total
 
     def path_tracing_ms(self) -> float:

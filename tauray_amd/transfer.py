@@ -59,12 +59,13 @@ def gather_to_display(color, dists: List[DistributionParams], rank: int, world_s
 
 class LocalExchange:
     """The same exchange for several ranks that live in ONE process on one or more devices (the reference's own
-    arrangement, and `--fake-devices`): a "send" is a device-to-device copy enqueued on the default stream into the display
-    rank's receive buffer for that peer (trhip_copy_peer, which is what an RCCL send/recv pair amounts to over xGMI), a
-    "receive" is nothing at all - the default stream already orders the copy before the stitch.  No host synchronisation
-    anywhere: a frame is correct only if the renderer's stream dependencies around the exchange are
-    (tests/test_gpu_parity.py::test_in_process_ranks_exchange_is_stream_ordered).  Call order per frame: every non-display
-    rank's render(), then rank 0's."""
+    arrangement, and `--fake-devices`): a "send" is a device-to-device copy enqueued on the sending device's default stream
+    into the display rank's receive buffer for that peer (trhip_copy_peer, which is what an RCCL send/recv pair amounts to over
+    xGMI), followed by trhip_stream_wait_peer: the display device's default stream - where the stitch runs - waits for that copy.
+    With every rank on one device (the fake-device tests) both are the same stream and the wait is a no-op.  A "receive" is
+    nothing at all.  No host synchronisation anywhere: a frame is correct only if the renderer's stream dependencies around
+    the exchange are (tests/test_gpu_parity.py::test_in_process_ranks_exchange_is_stream_ordered).  Call order per frame:
+    every non-display rank's render(), then rank 0's."""
 
     def __init__(self, world_size: int):
         self.world_size = world_size
@@ -92,6 +93,10 @@ class LocalExchange:
             self.mailbox[rank] = box
         if nbytes:
             rc = _lib.lib().trhip_copy_peer(self.display_ctx.h, box[0].data_ptr(), ctx.h, color.data_ptr(), nbytes, None)
+            if rc:
+                raise RuntimeError(_lib.lib().trhip_last_error().decode())
+            # ranks on different devices: the copy sits on the source device's default stream, the stitch on the display device's
+            rc = _lib.lib().trhip_stream_wait_peer(self.display_ctx.h, None, ctx.h, None)
             if rc:
                 raise RuntimeError(_lib.lib().trhip_last_error().decode())
         return {}
