@@ -94,12 +94,12 @@ __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, cons
                                                       HitRecord* out, uint* overflow_flag, int* qspill) {
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
-    __shared__ int s_owner[(KB / 64) * 16];
+    __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     if (TOP) load_treetop(sv, s_top);
     int* my_stack = s_stack + threadIdx.x;
     QuadCtx qc;
     qc.wave_stack = s_stack + (threadIdx.x & ~63u);
-    qc.owner_tab = s_owner + (threadIdx.x >> 6) * 16u;
+    qc.owner_tab = s_owner + (threadIdx.x >> 6) * TR_OWNER_WORDS;
     qc.spill = qspill + ((size_t)blockIdx.x * (KB / 64) + (threadIdx.x >> 6)) * (16u * TR_QSPILL);
     int overflow = 0;
     TraceStats st = {};

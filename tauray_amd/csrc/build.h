@@ -48,7 +48,8 @@ struct DeviceScene {
     uint build_rounds = 0;
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int optimise_rounds = 8;             // reinsertion rounds after the build (bvh_optimize.h; TRHIP_BVH_OPT)
-    int presplit_percent = 30;           // static builds: extra triangle references the pre-split may spend, in percent of the triangle count (bvh_presplit.h; TRHIP_PRESPLIT, 0 = none)
+    int presplit_percent = 0;            // static builds: extra triangle references a pre-split may spend, in percent of the triangle count (bvh_presplit.h;
+                                         // TRHIP_PRESPLIT).  Off: measured +2 ... +8 % node visits for -5 ... -15 % triangle tests, frames 0-3 % slower (profiles/r3/presplit_sweep.txt)
     uint leaf_count = 0;                 // leaves of the tree = records in `tris`: the triangles, or their references after a pre-split
     uint accel_tri_count = 0;            // triangle count of the scene the structure was built for
     bool collapse_by_cost = true;        // 4-wide nodes chosen by least area sum (k_collapse_cost) instead of greedily (TRHIP_COLLAPSE=greedy)

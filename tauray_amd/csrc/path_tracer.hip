@@ -218,7 +218,7 @@ TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb) 
     QuadCtx qc;
     const uint wave = threadIdx.x >> 6;
     qc.wave_stack = s_stack + (threadIdx.x & ~63u);
-    qc.owner_tab = s_owner + wave * 16u;
+    qc.owner_tab = s_owner + wave * TR_OWNER_WORDS;
     qc.spill = pb.qspill + ((size_t)blockIdx.x * (KB / 64) + wave) * (16u * TR_QSPILL);
     return qc;
 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
                                                       uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
-    __shared__ int s_owner[(KB / 64) * 16];
+    __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
@@ -321,7 +321,7 @@ template <bool COUNT, bool TOP>
 __global__ __launch_bounds__(KB, TOP ? (TR_SHADOW_WAVES < 6 ? TR_SHADOW_WAVES : 6) : TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
-    __shared__ int s_owner[(KB / 64) * 16];
+    __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = bc[BC_SHADOW];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView 
                                                                       uint* bc, uint* bc_prev) {
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
-    __shared__ int s_owner[(KB / 64) * 16];
+    __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint nc = bc[BC_QUEUE], ns = bc_prev[BC_SHADOW];

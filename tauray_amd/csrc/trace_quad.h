@@ -25,6 +25,15 @@ namespace tr {
 #define TR_QSPILL TR_SPILL_STACK   // stack entries per quad beyond the LDS part: the per-lane loop's depth (deepest stack seen on the bench scenes: 26)
 static_assert(TR_QUAD_SWITCH <= 16, "a wave has sixteen quads");
 
+// Stack-top prefetch (experiment, TR_PREFETCH > 0): when a node phase pushes children, the one that ends up on top of the stack -
+// the next node this ray pops - is requested right away with a fire-and-forget load (global_load_lds into a per-wave dump area:
+// no destination register, nothing waits for it; one dump area per block), so that the pop finds its line in L1 / L2 instead of paying the trip to the
+// Infinity Cache behind the current node's.  1: closest-hit per-lane loop, 2: + shadow per-lane loop.
+#ifndef TR_PREFETCH
+#define TR_PREFETCH 0
+#endif
+#define TR_OWNER_WORDS 16     // LDS words per wave behind QuadCtx::owner_tab
+
 struct QuadCtx {
     int* wave_stack;   // LDS: stack column of lane 0 of this wave; entry e of lane l at [e * TR_BLOCK + l]
     int* owner_tab;    // LDS: 16 words of this wave
@@ -40,6 +49,15 @@ TR_DEV float qrot1f(float v) { return __int_as_float(qrot1(__float_as_int(v))); 
 TR_DEV float qrot2f(float v) { return __int_as_float(qrot2(__float_as_int(v))); }
 TR_DEV int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 TR_DEV float bpermf(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+
+TR_DEV void prefetch_ref(const SceneView& sv, int c) {
+#if TR_PREFETCH
+    __shared__ int s_dump[64];      // one dump area per block at a link-time address: M0 is a constant, no register is involved
+    const char* p = c >= 0 ? reinterpret_cast<const char*>(sv.nodes4) + ((size_t)(uint)c << 7) : reinterpret_cast<const char*>(sv.tris) + (size_t)(uint)(~c) * 48u;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(p)),
+                                     reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_dump[0]))), 4, 0, 0);
+#endif
+}
 
 TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its other lanes afterwards (no other wave is involved)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -251,7 +269,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     if (h.t[0] < __builtin_huge_valf()) {
                         if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
                         if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
-                        if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
+                        if (h.t[1] < __builtin_huge_valf()) { stk.push(spill, h.c[1]); if (TR_PREFETCH >= 1) prefetch_ref(sv, h.c[1]); }
                         if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                         node = h.c[0];
                         descend = true;
@@ -412,14 +430,15 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 Hit4 h;
                 box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, tmax, h);
                 if (COUNT) st.nodes++;
-                int next = 0x7FFFFFFF;
+                int next = 0x7FFFFFFF, last = 0x7FFFFFFF;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (h.t[k] < __builtin_huge_valf()) {
                         if (next == 0x7FFFFFFF) next = h.c[k];
-                        else stk.push(spill, h.c[k]);
+                        else { stk.push(spill, h.c[k]); last = h.c[k]; }
                     }
                 }
+                if (TR_PREFETCH >= 2 && last != 0x7FFFFFFF) prefetch_ref(sv, last);
                 if (next != 0x7FFFFFFF) { node = next; descend = true; }
             } else {
                 const TriRecord tr = sv.tris[~node];

@@ -224,7 +224,7 @@ class SceneStage:
         self.accel = dict(triangle_count=info.triangle_count, node_count=info.node_count,
                           tri_light_count=info.tri_light_count, build_ms=info.build_ms,
                           bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max),
-                          node_bytes=info.node_bytes)
+                          node_bytes=info.node_bytes, leaf_count=info.leaf_count)
         return self.accel
 
     def pose(self, node_globals: dict, refit: bool = True):
@@ -277,7 +277,7 @@ class SceneStage:
             check(_lib.lib().trhip_scene_set_build_mode(self.ctx.h, 0 if self.fast_trace_rebuilds else 1))
             check(_lib.lib().trhip_scene_build_accel(self.ctx.h, C.byref(info)))
         self.accel.update(node_count=info.node_count, build_ms=info.build_ms, tri_light_count=info.tri_light_count,
-                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max))
+                          bounds_min=tuple(info.bounds_min), bounds_max=tuple(info.bounds_max), leaf_count=info.leaf_count)
         return self.accel
 
     def set_skin(self, instance: int, skins: np.ndarray, source: Optional[np.ndarray] = None):

@@ -430,7 +430,7 @@ def test_bench_scene_one_million_triangles(R, ctx, oracle):
     scene = scenes.sponza_teapots(width=W, height=H)
     assert scene.triangle_count > 900_000
     ss = R.SceneStage(ctx, scene)
-    assert ss.accel["node_count"] == scene.triangle_count - 1
+    assert ss.accel["node_count"] == ss.accel["leaf_count"] - 1 and ss.accel["leaf_count"] == scene.triangle_count
     osc = oracle.OracleScene(scene)
     for fid in (5, 9):   # hit distance, (instance, primitive)
         fs = R.FeatureStage(ctx, ss, fid, _dup((W, H)))
@@ -1173,19 +1173,25 @@ def test_full_size_properties_one_million_triangles(R, ctx, monkeypatch):
     from tauray_amd import distribution as D
     W, H = 1920, 1080
     scene = scenes.sponza_teapots(W, H)
+    # the static build of this test also splits large triangles into several references (csrc/bvh_presplit.h, off by default):
+    # clipped leaf boxes, duplicated triangle records - and the same hits
+    monkeypatch.setenv("TRHIP_PRESPLIT", "30")
     ss = R.SceneStage(ctx, scene)
+    monkeypatch.delenv("TRHIP_PRESPLIT")
     assert ss.accel["triangle_count"] > 900_000
     a = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
     assert np.isfinite(a).all() and (a[..., 3] == 1).all() and a[..., :3].min() >= 0 and a[..., :3].mean() > 1e-3
-    ploc_nodes = ss.accel["node_count"]
-    # another tree over the same triangles: every hit is the same hit, so the frame is bit-identical
+    assert ss.accel["triangle_count"] * 1.2 < ss.accel["leaf_count"] <= ss.accel["triangle_count"] * 1.3 and ss.accel["node_count"] == ss.accel["leaf_count"] - 1
+    # another tree over the same triangles (a rebuild is a fast build: no references, no optimisation rounds): every hit is the
+    # same hit, so the frame is bit-identical
     monkeypatch.setenv("TRHIP_BUILDER", "lbvh")
     ss.update_instances(scene.instances)
+    assert ss.accel["leaf_count"] == ss.accel["triangle_count"]
     b = _render_hip(R, ctx, ss, scene, (W, H), max_bounces=4)
-    assert np.array_equal(b, a), f"LBVH tree vs PLOC tree: {int((b != a).any(-1).sum())} pixels differ"
+    assert np.array_equal(b, a), f"LBVH tree vs PLOC tree with split triangles: {int((b != a).any(-1).sum())} pixels differ"
     monkeypatch.setenv("TRHIP_BUILDER", "ploc")
     ss.update_instances(scene.instances)
-    assert ss.accel["node_count"] == ploc_nodes
+    assert ss.accel["node_count"] == ss.accel["triangle_count"] - 1
     ss.update_instances(scene.instances, refit=True)
     assert np.array_equal(_render_hip(R, ctx, ss, scene, (W, H), max_bounces=4), a), "refitted tree"
     # 8 shuffled-strip shards, all partials stitched by one launch
@@ -1656,8 +1662,8 @@ def test_random_option_combinations(R, ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_triangle_soups(R, ctx, oracle, seed):
+@pytest.mark.parametrize("seed", [1, 2, 3, 12])
+def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
     """Hit parity on geometry no modeller would export: 20 000 random triangles of wildly different sizes (1e-3 .. 1e2), needles,
     zero-area triangles, exact duplicates, coplanar overlapping sheets, a few non-opaque instances; closest-hit and shadow
     queries from inside and outside the cloud, with and without stochastic alpha."""
@@ -1694,7 +1700,11 @@ def test_random_triangle_soups(R, ctx, oracle, seed):
     cam.transform = S.trs_matrix((0, 0, 100))
     sc = S.SceneDesc(instances=np.concatenate(insts), spans=np.array(spans, dtype=S.MESH_SPAN), vertices=verts,
                      indices=np.tile(np.arange(3 * per, dtype=np.uint32), parts), cameras=[cam]).finalize(True)
+    if seed in (2, 12):     # the soup is the worst case for triangle pre-splitting too (csrc/bvh_presplit.h): needles, giants, duplicates
+        monkeypatch.setenv("TRHIP_PRESPLIT", "100" if seed == 2 else "25")
     ss = R.SceneStage(ctx, sc)
+    monkeypatch.delenv("TRHIP_PRESPLIT", raising=False)
+    assert ss.accel["leaf_count"] > n if seed in (2, 12) else ss.accel["leaf_count"] == n
     osc = oracle.OracleScene(sc)
     m = 60_000
     org = np.concatenate([rng.normal(size=(m // 2, 3)) * 2.0, rng.normal(size=(m // 2, 3)) * 60.0]).astype(np.float32)
@@ -2062,12 +2072,13 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "two_lanes": {"TRHIP_LANES": "2"}, "small_grids": {"TRHIP_GRID_BLOCKS": "300", "TRHIP_SHADE_BLOCKS": "100"},
                 "treetop": {"TRHIP_TREETOP": "1"}, "shade_split": {"TRHIP_SHADE_SPLIT": "1"}, "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
                 "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"}, "generic_shade": {"TRHIP_SHADE_CLI": "0"},
-                "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"}}
+                "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
+                "presplit": {"TRHIP_PRESPLIT": "40"}, "presplit_lbvh": {"TRHIP_PRESPLIT": "100", "TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "0"}}
     frames = {}
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
