@@ -234,6 +234,14 @@ typedef struct trhip_pt_targets {
     void* screen_motion;/* RG32F: get_camera_projection(previous camera, previous position).xy (shader/camera.glsl:61-67) */
 } trhip_pt_targets;
 int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
+/* Arithmetic of the shading kernel.  The reference's GLSL runs at the accuracy Vulkan asks of an implementation (SPIR-V
+ * precision requirements: `/` 2.5 ULP, inversesqrt 2 ULP, sin / cos 2^-11 absolute, pow through exp2 and log2), and so does the
+ * shading kernel of the reference's command-line option set here by default (csrc/shade_fast.hip: v_rcp / v_rsq / v_sqrt /
+ * v_sin / v_cos / v_exp / v_log).  ieee != 0: every shading kernel of this stage computes in IEEE fp32 with the C library's
+ * sin / cos / pow, expression by expression like the CPU oracle - slower (1.22 instead of 0.97 ms per 1080p frame of the
+ * million-triangle bench scene), for comparisons that want the last bit.  Ray traversal and the ray-triangle test are IEEE
+ * fp32 in either mode: hits do not depend on it.  The environment variable TRHIP_SHADE_FAST=0 makes ieee the default. */
+int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee);
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */
 int trhip_pt_reset_counters(trhip_pt* pt);

@@ -109,6 +109,7 @@ SYMBOLS = {
     "trhip_stream_wait_peer": (_i, [_vp, _vp, _vp, _vp]),
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
+    "trhip_pt_set_shading_arithmetic": (_i, [_vp, C.c_int]),
     "trhip_pt_set_shard": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "trhip_scene_set_skin": (_i, [_vp, _u32, _vp, _vp, _u32]),
     "trhip_scene_skin": (_i, [_vp, _u32, _vp, _u32]),

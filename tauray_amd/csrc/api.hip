@@ -609,6 +609,11 @@ int trhip_pt_set_lanes(trhip_pt* pt, int lanes) {
     pt->stage->lanes = lanes;
     return 0;
 }
+int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee) {
+    if (!pt) return set_error("null trhip_pt");
+    pt->stage->ieee_shading = ieee ? 1 : 0;
+    return 0;
+}
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
     if (!pt) return set_error("null trhip_pt");
     pt->stage->count_work = count_work; pt->stage->detailed_timing = detailed_timing;

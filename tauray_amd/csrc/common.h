@@ -83,6 +83,20 @@ TR_HD f3 max3(f3 a, f3 b) { return {fmax2(a.x, b.x), fmax2(a.y, b.y), fmax2(a.z,
 TR_HD f3 min3(f3 a, f3 b) { return {fmin2(a.x, b.x), fmin2(a.y, b.y), fmin2(a.z, b.z)}; }
 TR_HD bool any_nan(f3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 
+// sin / cos / pow of the shading code.  GLSL leaves their accuracy to the Vulkan implementation (SPIR-V precision table: sin and
+// cos 2^-11 absolute on [-pi, pi], pow inherited from exp2(y * log2(x)) at a few ulp each); the IEEE build calls the C library's
+// functions like the oracle, the shading translation unit built for speed (TR_SHADE_NATIVE_MATH: shade_fast.hip) the hardware's
+// v_sin_f32 / v_cos_f32 / v_exp_f32 / v_log_f32.  Traversal and the triangle test use neither.
+#if defined(TR_SHADE_NATIVE_MATH) && defined(__HIP_DEVICE_COMPILE__)
+TR_DEV float tsin(float x) { return __sinf(x); }
+TR_DEV float tcos(float x) { return __cosf(x); }
+TR_DEV float tpow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
+TR_HD float tsin(float x) { return sinf(x); }
+TR_HD float tcos(float x) { return cosf(x); }
+TR_HD float tpow(float x, float y) { return powf(x, y); }
+#endif
+
 // column-major matrices, as glm / GLSL
 struct m3 { f3 c[3]; };
 struct m4 { f4 c[4]; };

@@ -1,0 +1,32 @@
+// k_shade for the option set of the reference's command line, compiled a second time with the arithmetic a Vulkan implementation
+// is allowed to use for the reference's GLSL - what the reference itself runs on:
+//   * `/` at 2.5 ulp and sqrt / inversesqrt through the hardware's v_sqrt_f32 / v_rsq_f32 (SPIR-V precision requirements of the
+//     Vulkan specification: division 2.5 ULP, inversesqrt 2 ULP, sqrt inherited from 1 / inversesqrt) instead of the correctly
+//     rounded sequences of the default build (-fno-hip-fp32-correctly-rounded-divide-sqrt);
+//   * sin, cos, pow through v_sin_f32 / v_cos_f32 / v_exp_f32 / v_log_f32 (common.h: TR_SHADE_NATIVE_MATH).
+// Multiply-adds do not contract here either (measured worth nothing; it keeps the instances of the kernel bit-identical).
+// Traversal, the triangle test and every other kernel stay in path_tracer.hip at IEEE fp32: hits are bit-exact against the
+// oracle, radiance is compared within the tolerance DESIGN.md section 3 states.  The IEEE k_shade of the same option set has
+// 11 640 instructions, this one 5 900: the C library's sin / cos / pow and the correctly rounded division and square-root
+// sequences are code the reference never executed.  sponza_teapots: 1.22 -> 0.97 ms per frame (profiles/r3/shade_arithmetic_ab.txt:
+// native sin / cos / pow alone 1.04, division / sqrt alone 1.15, contraction alone 1.21).
+// trhip_pt_set_shading_arithmetic(pt, 1) or TRHIP_SHADE_FAST=0 select the IEEE instances (path_tracer.hip).
+#ifndef TR_SHADE_LIBM_MATH     // A/B builds: only the division / sqrt / contraction flags, sin / cos / pow from the C library
+#define TR_SHADE_NATIVE_MATH 1
+#endif
+#include "pt_kernels.h"
+
+namespace tr {
+
+void launch_shade_fast(bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
+                       const uint* queue, uint* bc, uint* next_queue) {
+    if (last) {
+        if (count) hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        else hipLaunchKernelGGL((k_shade<false, false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+    } else {
+        if (count) hipLaunchKernelGGL((k_shade<true, false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        else hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+    }
+}
+
+}  // namespace tr

@@ -40,13 +40,13 @@ TR_DEV f2 sample_concentric_disk(f2 u) {     // math.glsl:205-218
     f2 a = {fabsf(uo.x), fabsf(uo.y)};
     if (a.x < 0.0001f && a.y < 0.0001f) return F2(0);
     f2 rt = (a.x > a.y) ? F2(uo.x, TR_PI / 4 * (uo.y / uo.x)) : F2(uo.y, TR_PI / 2 - TR_PI / 4 * (uo.x / uo.y));
-    return rt.x * F2(cosf(rt.y), sinf(rt.y));
+    return rt.x * F2(tcos(rt.y), tsin(rt.y));
 }
 TR_DEV float sample_blackman_harris(float u) {   // math.glsl:220-228
     bool flip = u > 0.5f;
     u = flip ? 1 - u : u;
-    float vx = -0.33518669f * powf(u, 0.5f), vy = -0.51620529f * powf(u, 0.3333333333f);
-    float vz = 1.87406934f * powf(u, 0.25f), vw = -0.66315464f * powf(u, 0.2f);
+    float vx = -0.33518669f * tpow(u, 0.5f), vy = -0.51620529f * tpow(u, 0.3333333333f);
+    float vz = 1.87406934f * tpow(u, 0.25f), vw = -0.66315464f * tpow(u, 0.2f);
     float s = 0.29627329f * u + vx + vy + vz + vw;
     return flip ? 1 - s : s;
 }
@@ -55,7 +55,7 @@ TR_DEV f2 sample_blackman_harris_concentric_disk(f2 u) {   // math.glsl:230-241
     f2 a = {fabsf(uo.x), fabsf(uo.y)};
     if (a.x < 0.0001f && a.y < 0.0001f) return F2(0);
     f2 rt = (a.x > a.y) ? F2(u.x, TR_PI / 4 * (uo.y / uo.x)) : F2(u.y, TR_PI / 2 - TR_PI / 4 * (uo.x / uo.y));
-    return (2.0f * sample_blackman_harris(rt.x) - 1.0f) * F2(cosf(rt.y), sinf(rt.y));
+    return (2.0f * sample_blackman_harris(rt.x) - 1.0f) * F2(tcos(rt.y), tsin(rt.y));
 }
 TR_DEV f2 sample_regular_polygon(f2 u, float angle, uint sides) {   // math.glsl:281-292
     float side = floorf(u.x * sides);
@@ -64,8 +64,8 @@ TR_DEV f2 sample_regular_polygon(f2 u, float angle, uint sides) {   // math.glsl
     float side_radians = (2.0f * TR_PI) / sides;
     float a1 = side_radians * side + angle;
     float a2 = side_radians * (side + 1) + angle;
-    f2 b = F2(sinf(a1), cosf(a1));
-    f2 c = F2(sinf(a2), cosf(a2));
+    f2 b = F2(tsin(a1), tcos(a1));
+    f2 c = F2(tsin(a2), tcos(a2));
     u = u.x + u.y > 1 ? 1 - u : u;
     return b * u.x + c * u.y;
 }
@@ -78,19 +78,19 @@ TR_DEV f3 sample_sphere(f2 u) {              // math.glsl:305-315
     float cos_theta = 2 * u.x - 1;
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
     float phi = u.y * 2 * TR_PI;
-    return F3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta);
+    return F3(tcos(phi) * sin_theta, tsin(phi) * sin_theta, cos_theta);
 }
 TR_DEV f3 sample_hemisphere(f2 u) {          // math.glsl:317-327
     float cos_theta = u.x;
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
     float phi = u.y * 2 * TR_PI;
-    return F3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta);
+    return F3(tcos(phi) * sin_theta, tsin(phi) * sin_theta, cos_theta);
 }
 TR_DEV f3 sample_cone(f2 u, f3 dir, float cos_theta_min) {   // math.glsl:342-358
     float cos_theta = mixf(1.0f, cos_theta_min, u.x);
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
     float phi = u.y * 2 * TR_PI;
-    f3 o = mul(create_tangent_space(dir), F3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta));
+    f3 o = mul(create_tangent_space(dir), F3(tcos(phi) * sin_theta, tsin(phi) * sin_theta, cos_theta));
     return dot(o, dir) <= cos_theta_min ? dir : o;
 }
 TR_DEV f3 sample_triangle_area(f2 u, f3 A, f3 B, f3 C) {     // math.glsl:360-371
@@ -121,7 +121,7 @@ TR_DEV f3 sample_spherical_triangle(f2 xi, f3 A, f3 B, f3 C, float& pdf) {   // 
     float solid_angle = 2.0f * atan2f(G0, G1 + G2);
     pdf = 1.0f / solid_angle;
     float chosen_split = xi.x * solid_angle * 0.5f;
-    f3 r = (G0 * cosf(chosen_split) - G1 * sinf(chosen_split)) * nA + G2 * sinf(chosen_split) * nC;
+    f3 r = (G0 * tcos(chosen_split) - G1 * tsin(chosen_split)) * nA + G2 * tsin(chosen_split) * nC;
     f3 Ch = 2.0f * dot(nA, r) * r / dot(r, r) - nA;
     float d = dot(Ch, nB);
     float z = 1 - xi.y + d * xi.y;
@@ -155,8 +155,8 @@ TR_DEV f3 get_barycentric_coords(f3 p, f3 A, f3 B, f3 C) {           // math.gls
 // ------------------------------------------------------------------ color.glsl
 TR_DEV f3 inverse_srgb_correction(f3 col) {   // color.glsl:7-12
     f3 low = col * 0.07739938f;
-    f3 high = F3(powf(fmaf(col.x, 0.94786729f, 0.05213270f), 2.4f), powf(fmaf(col.y, 0.94786729f, 0.05213270f), 2.4f),
-                 powf(fmaf(col.z, 0.94786729f, 0.05213270f), 2.4f));
+    f3 high = F3(tpow(fmaf(col.x, 0.94786729f, 0.05213270f), 2.4f), tpow(fmaf(col.y, 0.94786729f, 0.05213270f), 2.4f),
+                 tpow(fmaf(col.z, 0.94786729f, 0.05213270f), 2.4f));
     return F3(0.04045f < col.x ? high.x : low.x, 0.04045f < col.y ? high.y : low.y, 0.04045f < col.z ? high.z : low.z);
 }
 TR_DEV float rgb_to_luminance(f3 col) { return dot(col, F3(0.2126f, 0.7152f, 0.0722f)); }
@@ -189,14 +189,14 @@ TR_DEV int latlong_direction_to_pixel_id(f3 dir, int sx, int sy) {   // alias_ta
 }
 TR_DEV f3 uv_to_latlong_direction(f2 uv) {     // alias_table.glsl:29-35
     uv = (uv - 0.5f) * TR_PI;
-    f3 dir = F3(cosf(2.0f * uv.x), -sinf(uv.y), sinf(2.0f * uv.x));
+    f3 dir = F3(tcos(2.0f * uv.x), -tsin(uv.y), tsin(2.0f * uv.x));
     float s = sqrtf(1 - dir.y * dir.y);
     dir.x *= s; dir.z *= s;
     return dir;
 }
 
 // ------------------------------------------------------------------ ggx.glsl
-TR_DEV float ggx_fresnel_schlick(float cos_d, float f0) { return f0 + (1.0f - f0) * powf(fmax2(1.0f - cos_d, 0.0f), 5.0f); }
+TR_DEV float ggx_fresnel_schlick(float cos_d, float f0) { return f0 + (1.0f - f0) * tpow(fmax2(1.0f - cos_d, 0.0f), 5.0f); }
 TR_DEV float ggx_fresnel(float cos_d, const SampledMaterial& mat) {         // ggx.glsl:36-49
     if (mat.ior_in > mat.ior_out) {
         float inv_eta = mat.ior_in / mat.ior_out;
@@ -213,7 +213,7 @@ TR_DEV float fresnel_importance(float cos_d, const SampledMaterial& mat) {  // g
         if (sin_theta2 >= 1.0f) return 1.0f;
         cos_d = sqrtf(1.0f - sin_theta2);
     } else if (mat.ior_in == mat.ior_out) return 0.0f;
-    return mat.f0 + (fmax2(1.0f - mat.roughness, mat.f0) - mat.f0) * powf(1.0f - cos_d, 5.0f);
+    return mat.f0 + (fmax2(1.0f - mat.roughness, mat.f0) - mat.f0) * tpow(1.0f - cos_d, 5.0f);
 }
 TR_DEV float ggx_masking(float v_dot_n, float v_dot_h, float a) {           // ggx.glsl:82-87
     float a2 = a * a;
@@ -254,8 +254,8 @@ TR_DEV f3 ggx_vndf_sample(f3 view, float roughness, float u1, float u2) {  // gg
     float a = 1.0f / inv_a;
     float r = sqrtf(u1);
     float phi = u2 < a ? u2 * inv_a * TR_PI : TR_PI + (u2 - a) / (1.0f - a) * TR_PI;
-    float p1 = r * cosf(phi);
-    float p2 = r * sinf(phi) * (u2 < a ? 1.0f : v.z);
+    float p1 = r * tcos(phi);
+    float p2 = r * tsin(phi) * (u2 < a ? 1.0f : v.z);
     float p3 = sqrtf(fmax2(0.0f, 1.0f - p1 * p1 - p2 * p2));
     f3 n = p1 * t1 + p2 * t2 + p3 * v;
     return normalize(F3(roughness * n.x, roughness * n.y, fmax2(0.0f, n.z)));
@@ -409,7 +409,7 @@ TR_DEV f3 modulate_bsdf(const SampledMaterial& mat, const Lobes& b) {      // ma
 TR_DEV float get_spotlight_intensity(const PointLight& l, f3 dir) {        // light.glsl:45-58
     if (l.dir_falloff > 0) {
         float cutoff = dot(dir, -l.dir);
-        cutoff = cutoff > l.dir_cutoff ? 1.0f - powf(fmax2(1.0f - cutoff, 0.0f) / (1.0f - l.dir_cutoff), l.dir_falloff) : 0.0f;
+        cutoff = cutoff > l.dir_cutoff ? 1.0f - tpow(fmax2(1.0f - cutoff, 0.0f) / (1.0f - l.dir_cutoff), l.dir_falloff) : 0.0f;
         return cutoff;
     }
     return 1.0f;
@@ -463,7 +463,7 @@ TR_DEV void get_camera_ray(const CameraData& cam, int projection, bool dof, f2 p
         const float* raw = reinterpret_cast<const float*>(&cam);
         f2 fov = F2(raw[36], raw[37]);
         uv = (uv * 2.0f - 1.0f) * fov;
-        f2 c = F2(cosf(uv.x), cosf(uv.y)), s = F2(sinf(uv.x), sinf(uv.y));
+        f2 c = F2(tcos(uv.x), tcos(uv.y)), s = F2(tsin(uv.x), tsin(uv.y));
         f3 t = F3(s.x * c.y, s.y, -c.x * c.y);
         dir = normalize(F3(mul(cam.view_inverse, F4(t, 0))));
         origin = F3(raw[32], raw[33], raw[34]);

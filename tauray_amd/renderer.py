@@ -380,6 +380,11 @@ class PathTracerStage:
         """trhip_pt_set_frame_batch: `frames` consecutive frames per run(), as frame-major layer groups of the target."""
         check(_lib.lib().trhip_pt_set_frame_batch(self.h, int(frames)))
 
+    def set_shading_arithmetic(self, ieee: bool):
+        """k_shade at IEEE fp32 with the C library's sin / cos / pow (True), or at the accuracy Vulkan asks of the reference's GLSL
+        for the command-line option set (False, the default unless TRHIP_SHADE_FAST=0): include/trhip.h."""
+        check(_lib.lib().trhip_pt_set_shading_arithmetic(self.h, int(bool(ieee))))
+
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 

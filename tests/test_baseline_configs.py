@@ -71,30 +71,37 @@ def test_config3_sponza_class_accumulated_radiance_l2_vs_oracle(R, ctx, oracle):
     assert scene.triangle_count > 250_000
     ss = R.SceneStage(ctx, scene)
     kw = dict(max_bounces=4, samples_per_pixel=N, samples_per_pass=1)
-    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, **kw), _dup((W, H)))
-    color = ctx.alloc(W * H * 16).zero()
-    pt.run(color)
-    img = color.download((H, W, 4))
-    assert pt.counters()["stack_overflows"] == 0
-    pt.close()
     ref = oracle.OracleScene(scene).render_pt(oracle.options_for_scene(scene, **kw), W, H)[0]
-    # the integrand has a NaN sample about once in 8e7 and a running mean keeps it: such pixels must be
-    # the same in both images, and few; the L2 figures are over the others
-    nan_px = np.isnan(ref[..., :3]).any(-1)
-    assert np.array_equal(np.isnan(img[..., :3]).any(-1), nan_px) and nan_px.sum() <= 8 and not np.isinf(img).any() and not np.isinf(ref).any()
-    ok = ~nan_px
-    rgb, rrgb = img[..., :3][ok], ref[..., :3][ok]
-    rms = _rms(rgb, rrgb)
-    per_pixel = np.sqrt(((rgb.astype(np.float64) - rrgb) ** 2).sum(-1))        # L2 norm of the pixel's rgb difference
-    _report("config3_hip_vs_oracle" + ("" if N == 1024 else f"_{N}spp"), {
-        "scene": "sponza_class", "triangles": int(scene.triangle_count), "size": [W, H], "spp": N, "bounces": 4, "nan_pixels": int(nan_px.sum()),
-        "rms_radiance": rms, "mse_radiance": rms * rms, "max_pixel_l2": float(per_pixel.max()), "p999_pixel_l2": float(np.quantile(per_pixel, 0.999)),
-        "bit_equal_pixels": float((rgb == rrgb).all(-1).mean()), "mean_radiance": float(rrgb.mean()), "max_radiance": float(rrgb.max()),
-        "mean_rel_err": abs(float(rgb.mean()) - float(rrgb.mean())) / float(rrgb.mean())})
-    assert rms < L2_BOUND, f"RMS radiance error {rms:.3e} vs the oracle"
-    assert float(np.quantile(per_pixel, 0.999)) < 10 * L2_BOUND
-    assert abs(float(rgb.mean()) - float(rrgb.mean())) / float(rrgb.mean()) < 1e-4
-    assert np.array_equal(img[..., 3], ref[..., 3])
+    # Both arithmetic modes of the shading kernel (include/trhip.h, trhip_pt_set_shading_arithmetic): IEEE fp32 like the oracle, and
+    # the default - what Vulkan asks of the reference's GLSL (csrc/shade_fast.hip).  The BASELINE bound holds for either.
+    for mode, ieee in (("ieee", True), ("default", False)):
+        pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, **kw), _dup((W, H)))
+        pt.set_shading_arithmetic(ieee)
+        color = ctx.alloc(W * H * 16).zero()
+        pt.run(color)
+        img = color.download((H, W, 4))
+        assert pt.counters()["stack_overflows"] == 0
+        pt.close()
+        # the integrand has a NaN sample about once in 8e7 and a running mean keeps it: few such pixels, and
+        # at IEEE fp32 the same ones in both images (inf / inf needs the same overflow); the L2 figures are over the others
+        nan_ref, nan_img = np.isnan(ref[..., :3]).any(-1), np.isnan(img[..., :3]).any(-1)
+        assert nan_ref.sum() <= 8 and nan_img.sum() <= 8 and not np.isinf(img).any() and not np.isinf(ref).any()
+        if ieee:
+            assert np.array_equal(nan_img, nan_ref)
+        ok = ~(nan_ref | nan_img)
+        rgb, rrgb = img[..., :3][ok], ref[..., :3][ok]
+        rms = _rms(rgb, rrgb)
+        per_pixel = np.sqrt(((rgb.astype(np.float64) - rrgb) ** 2).sum(-1))        # L2 norm of the pixel's rgb difference
+        _report("config3_hip_vs_oracle" + ("" if ieee else "_default_shading_arithmetic") + ("" if N == 1024 else f"_{N}spp"), {
+            "scene": "sponza_class", "triangles": int(scene.triangle_count), "size": [W, H], "spp": N, "bounces": 4, "shading_arithmetic": mode,
+            "nan_pixels": [int(nan_img.sum()), int(nan_ref.sum())],
+            "rms_radiance": rms, "mse_radiance": rms * rms, "max_pixel_l2": float(per_pixel.max()), "p999_pixel_l2": float(np.quantile(per_pixel, 0.999)),
+            "bit_equal_pixels": float((rgb == rrgb).all(-1).mean()), "mean_radiance": float(rrgb.mean()), "max_radiance": float(rrgb.max()),
+            "mean_rel_err": abs(float(rgb.mean()) - float(rrgb.mean())) / float(rrgb.mean())})
+        assert rms < L2_BOUND, f"{mode}: RMS radiance error {rms:.3e} vs the oracle"
+        assert float(np.quantile(per_pixel, 0.999)) < 10 * L2_BOUND
+        assert abs(float(rgb.mean()) - float(rrgb.mean())) / float(rrgb.mean()) < (1e-4 if ieee else 1e-3)
+        assert np.array_equal(img[..., 3], ref[..., 3])
 
 
 def test_config3_full_size_accumulation_property(R, ctx):

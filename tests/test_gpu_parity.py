@@ -34,11 +34,14 @@ def _dup(size):
     return DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True)
 
 
-def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, **kw):
+def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, ieee=None, **kw):
+    """`ieee`: True = the shading kernel at IEEE fp32 (trhip_pt_set_shading_arithmetic), None = the stage's default."""
     from tauray_amd.distribution import get_distribution_target_size
     d = dist or _dup(size)
     opt = R.options_for_scene(scene, **kw)
     pt = R.PathTracerStage(ctx, ss, opt, d)
+    if ieee is not None:
+        pt.set_shading_arithmetic(ieee)
     tw, th = get_distribution_target_size(d)
     color = ctx.alloc(viewports * tw * th * 16).zero()
     for _ in range(frames):
@@ -50,12 +53,12 @@ def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, **kw)
     return img
 
 
-def _compare(img, ref, what):
+def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION):
     assert np.isfinite(img).all(), f"{what}: non-finite output"
     rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
     bad = float((rel.max(-1) > REL_TOL).mean())
     mean_err = abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / max(float(ref[..., :3].mean()), 1e-6)
-    assert bad <= MAX_BAD_FRACTION, f"{what}: {bad:.4%} pixels differ by more than {REL_TOL}"
+    assert bad <= max_bad, f"{what}: {bad:.4%} pixels differ by more than {REL_TOL}"
     assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
     assert np.array_equal(img[..., 3], ref[..., 3]), f"{what}: alpha differs"
 
@@ -1427,10 +1430,17 @@ def test_texture_edge_cases(R, ctx, oracle):
     # the feature renderer's any-hit uses a fixed cutoff of 1e-4 (shader/rt_feature.rahit:17): only where the filtered alpha is
     # exactly zero does the back quad show
     assert (ids == 0).sum() > 500 and (ids == 1).sum() > 100, "the alpha-tested texture should show both quads"
-    img, ref = _render_hip(R, ctx, ss, sc, (192, 192), max_bounces=3), osc.render_pt(oracle.options_for_scene(sc, max_bounces=3), 192, 192)
+    # A random normal map puts the view direction within 1e-5 of the mapped normal's horizon for a percent of the paths
+    # (view_to_tangent_space clamps z at 1e-5, shader/math.glsl:472-478): there dot(view, normal) is all cancellation, one ulp of its
+    # inputs moves the BSDF by a percent, and the two arithmetic modes of k_shade (IEEE fp32 like the oracle / what Vulkan asks of
+    # the reference's GLSL, csrc/shade_fast.hip) part on those pixels - as two Vulkan drivers would.  IEEE: the usual bound;
+    # default arithmetic: the same image up to 3 % of such pixels, mean radiance equal.
+    ref = osc.render_pt(oracle.options_for_scene(sc, max_bounces=3), 192, 192)
+    img = _render_hip(R, ctx, ss, sc, (192, 192), max_bounces=3, ieee=True)
     rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
     print("textured quad: pixels outside tolerance", float((rel.max(-1) > REL_TOL).mean()), "bit-equal", float((img == ref).all(-1).mean()))
-    _compare(img, ref, "textured quad")
+    _compare(img, ref, "textured quad, IEEE shading")
+    _compare(_render_hip(R, ctx, ss, sc, (192, 192), max_bounces=3), ref, "textured quad, default shading arithmetic", max_bad=0.03)
     got = _render_targets_hip(R, ctx, ss, sc, (96, 96), ["albedo", "material", "normal"], max_bounces=2)
     ref = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 96, 96, ["albedo", "material", "normal"])
     for n in ("albedo", "material", "normal"):
@@ -1743,9 +1753,12 @@ def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
         ss = R.SceneStage(ctx, lit)
         osc = oracle.OracleScene(lit)
         kw = dict(max_bounces=4, samples_per_pixel=2)
-        img, ref = _render_hip(R, ctx, ss, lit, (128, 128), **kw), osc.render_pt(oracle.options_for_scene(lit, **kw), 128, 128)
+        ref = osc.render_pt(oracle.options_for_scene(lit, **kw), 128, 128)
         assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
-        _compare(img, ref, "paths through the soup")
+        # needles and edge-on giants make shading ill-conditioned for half a percent of the paths (normals from nearly collinear
+        # edges): the usual bound at IEEE fp32, 1.5 % of such pixels with the default shading arithmetic (csrc/shade_fast.hip)
+        _compare(_render_hip(R, ctx, ss, lit, (128, 128), ieee=True, **kw), ref, "paths through the soup, IEEE shading")
+        _compare(_render_hip(R, ctx, ss, lit, (128, 128), **kw), ref, "paths through the soup, default shading arithmetic", max_bad=0.015)
 
 
 @pytest.mark.gpu
@@ -2073,12 +2086,15 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "treetop": {"TRHIP_TREETOP": "1"}, "shade_split": {"TRHIP_SHADE_SPLIT": "1"}, "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
                 "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"}, "generic_shade": {"TRHIP_SHADE_CLI": "0"},
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
-                "presplit": {"TRHIP_PRESPLIT": "40"}, "presplit_lbvh": {"TRHIP_PRESPLIT": "100", "TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "0"}}
+                "presplit": {"TRHIP_PRESPLIT": "40"}, "presplit_lbvh": {"TRHIP_PRESPLIT": "100", "TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "0"},
+                # the shading kernels of the command-line option set exist at IEEE fp32 too (TRHIP_SHADE_FAST=0; csrc/shade_fast.hip)
+                "ieee_shade": {"TRHIP_SHADE_FAST": "0"}, "ieee_generic_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0"},
+                "ieee_general_last_bounce": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_LAST": "0"}}
     frames = {}
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT", "TRHIP_SHADE_FAST"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
@@ -2086,5 +2102,10 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
         frames[tag] = np.load(out)
     ref = frames["default"]
     assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
+    # two arithmetic modes of k_shade: the default (what Vulkan asks of the reference's GLSL) and IEEE fp32; within a mode every
+    # schedule, tree and kernel instance renders the same bits (the general k_shade only exists at IEEE fp32)
+    ieee = frames["ieee_shade"]
     for tag, f in frames.items():
-        assert np.array_equal(f, ref), f"{tag}: {int((f != ref).any(-1).sum())} pixels differ from the default schedule"
+        base = ieee if tag in ("ieee_shade", "ieee_generic_shade", "ieee_general_last_bounce", "generic_shade", "shade_split") else ref
+        assert np.array_equal(f, base), f"{tag}: {int((f != base).any(-1).sum())} pixels differ from the {'IEEE' if base is ieee else 'default'} frame"
+    _compare(ref[None], ieee[None], "default shading arithmetic vs IEEE fp32")

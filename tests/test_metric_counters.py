@@ -16,12 +16,13 @@ def _dup(size):
     return DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True)
 
 
-def _hip_counters(R, ctx, ss, scene, size, frames, **kw):
+def _hip_counters(R, ctx, ss, scene, size, frames, ieee=False, **kw):
     W, H = size
     opt = R.options_for_scene(scene, **kw)
     out = {}
     for counting in (False, True):        # the production kernels count rays; the counting instances also count the work
         pt = R.PathTracerStage(ctx, ss, opt, _dup(size))
+        pt.set_shading_arithmetic(ieee)
         pt.set_profiling(counting, False)
         buf = ctx.alloc(W * H * 16).zero()
         for _ in range(frames):
@@ -44,13 +45,13 @@ def _oracle_counters(oracle, osc, scene, size, frames, **kw):
     return osc.counters()
 
 
-def _check(hip, ora, pixels, frames, what):
+def _check(hip, ora, pixels, frames, what, tol=1e-4):
     # the first closest-hit ray of every pixel is traced unconditionally by both
     assert hip["closest_rays"] >= pixels * frames and ora["closest_rays"] >= pixels * frames
     for k in ("closest_rays", "shadow_rays", "surface_hits"):
         assert ora[k] > 0, (what, k)
         rel = abs(hip[k] - ora[k]) / ora[k]
-        assert rel <= 1e-4, f"{what}: {k} {hip[k]} (HIP) vs {ora[k]} (oracle): {rel:.2e} relative"
+        assert rel <= tol, f"{what}: {k} {hip[k]} (HIP) vs {ora[k]} (oracle): {rel:.2e} relative"
 
 
 @pytest.mark.gpu
@@ -66,9 +67,11 @@ def test_ray_counters_match_the_oracle_on_test_glb(oracle):
     hip1 = _hip_counters(R, ctx, ss, scene, (W, H), 1, max_bounces=1)
     ora1 = _oracle_counters(oracle, osc, scene, (W, H), 1, max_bounces=1)
     assert hip1["closest_rays"] == ora1["closest_rays"] == W * H
-    hip = _hip_counters(R, ctx, ss, scene, (W, H), 4, max_bounces=4)
     ora = _oracle_counters(oracle, osc, scene, (W, H), 4, max_bounces=4)
-    _check(hip, ora, W * H, 4, "test.glb 128x128, 4 bounces, 4 frames")
+    # shading at IEEE fp32 like the oracle: 1e-4; with the default shading arithmetic (csrc/shade_fast.hip) a few more paths flip
+    # a discrete decision (a shadow ray cast or not, a path continued or not): 5e-4
+    _check(_hip_counters(R, ctx, ss, scene, (W, H), 4, ieee=True, max_bounces=4), ora, W * H, 4, "test.glb 128x128, 4 bounces, 4 frames, IEEE shading")
+    _check(_hip_counters(R, ctx, ss, scene, (W, H), 4, max_bounces=4), ora, W * H, 4, "test.glb 128x128, 4 bounces, 4 frames", tol=5e-4)
 
 
 @pytest.mark.gpu
@@ -85,8 +88,9 @@ def test_ray_counters_match_the_oracle_on_the_bench_scene(oracle):
     ora1 = _oracle_counters(oracle, osc, scene, (W, H), 1, max_bounces=1)
     assert hip1["closest_rays"] == ora1["closest_rays"] == W * H
     frames = 8
-    hip = _hip_counters(R, ctx, ss, scene, (W, H), frames, max_bounces=4)
     ora = _oracle_counters(oracle, osc, scene, (W, H), frames, max_bounces=4)
-    _check(hip, ora, W * H, frames, "sponza_teapots 160x90, 4 bounces, 8 frames")
+    _check(_hip_counters(R, ctx, ss, scene, (W, H), frames, ieee=True, max_bounces=4), ora, W * H, frames, "sponza_teapots 160x90, 4 bounces, 8 frames, IEEE shading")
+    hip = _hip_counters(R, ctx, ss, scene, (W, H), frames, max_bounces=4)
+    _check(hip, ora, W * H, frames, "sponza_teapots 160x90, 4 bounces, 8 frames", tol=5e-4)
     # and the metric's numerator per frame at this size is what the bench divides by the frame time
-    assert abs((hip["closest_rays"] + hip["shadow_rays"]) - (ora["closest_rays"] + ora["shadow_rays"])) <= 1e-4 * (ora["closest_rays"] + ora["shadow_rays"])
+    assert abs((hip["closest_rays"] + hip["shadow_rays"]) - (ora["closest_rays"] + ora["shadow_rays"])) <= 5e-4 * (ora["closest_rays"] + ora["shadow_rays"])
