@@ -85,6 +85,9 @@ def parse():
                     help="pipelined region: frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
+                    help="what carries the partial frames of N > 1 pixel shards to rank 0: native = libtrhip_comm.so (include/trhip_comm.h: grouped "
+                         "ncclSend / ncclRecv on RCCL), torch = torch.distributed point-to-point; auto = native with the nccl backend, torch otherwise")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--save-display", default=None, help="rank 0 writes the last tonemapped frame to this .npy file")
     ap.add_argument("--prewarm", type=int, default=120, help="untimed frames before the warm-up steps (clocks, page faults)")
@@ -272,6 +275,30 @@ def main():
     else:
         local_rank = 0
 
+    # The exchange of a pixel-sharded job.  torch.distributed stays what starts the ranks, carries the RCCL id to them and reduces
+    # the timings; the frames themselves go through the C ABI of include/trhip_comm.h when RCCL is the transport.
+    exchange, exchange_name = None, "none"
+    if world > 1 and args.shard == "pixels":
+        exchange_name = "torch.distributed (%s)" % args.dist_backend
+        if args.exchange == "native" or (args.exchange == "auto" and args.dist_backend == "nccl"):
+            try:
+                from tauray_amd import comm as TC
+                box = [TC.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                exchange = TC.NativeExchange(TC.Comm(local_rank, world, rank, box[0]))
+                exchange_name = "libtrhip_comm.so: trhip_gather_partials (grouped ncclSend / ncclRecv, RCCL)"
+            except Exception as e:
+                if args.exchange == "native":
+                    raise
+                print(f"[bench] rank {rank}: native exchange unavailable ({e}); torch.distributed carries the frames", file=sys.stderr)
+                exchange = None
+        ok = [exchange is not None]
+        oks = [None] * world
+        dist.all_gather_object(oks, ok[0])
+        if not all(oks):        # every rank or none
+            exchange = None
+            exchange_name = "torch.distributed (%s)" % args.dist_backend
+
     W, H = args.width, args.height
     scene = scenes.WORKLOADS[args.workload](W, H)
     if args.views > 1:      # light-field grid (src/tauray.cc:680-727): spacing 0.02, recentering distance 5
@@ -294,11 +321,11 @@ def main():
             B = 2 if (world == 1 and args.views == 1 and args.spp == 1) else 1
     steps_pipelined = ((steps + B - 1) // B) * B
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world,
-                      viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight, frames_per_launch=B)
+                      viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight, frames_per_launch=B, exchange=exchange)
     # The renderer of a caller that waits for every frame: no frame slots, one frame per launch; each frame runs as four concurrent
     # lanes (the stage's automatic schedule for frames of >= 1.5 M paths).
     lone = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world, viewports=args.views, shard=args.shard,
-                        frames_in_flight=1, frames_per_launch=1)
+                        frames_in_flight=1, frames_per_launch=1, exchange=exchange)
 
     def sync_all(r):
         r.sync()
@@ -361,7 +388,7 @@ def main():
             times = [0.0] * world
             dist.all_gather_object(times, (time.perf_counter() - t1) / (((every + B - 1) // B) * B) * 1e3)
             rr.set_device_workloads(lb.update(times))
-        rr.exchange = None
+        rr.exchange = exchange
         lone.set_device_workloads(list(lb.workloads))
         balance = {"updates": rounds, "frames_per_update": every, "workloads": [round(w, 4) for w in lb.workloads],
                    "ms_per_frame_running_free": [round(t, 4) for t in times]}
@@ -414,7 +441,7 @@ def main():
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
-                   "views": args.views, "frames_in_flight": 1, "frames_per_launch": 1, "prewarm_frames": args.prewarm,
+                   "views": args.views, "frames_in_flight": 1, "frames_per_launch": 1, "prewarm_frames": args.prewarm, "exchange": exchange_name,
                    "scene_hash": scenes.scene_hash(scene)},
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         **({"load_balance": balance} if balance else {}),

@@ -1,0 +1,225 @@
+// tauray_hip_comm.hh - rt_renderer for one process per GPU: every process owns one device and one share of the frame, the
+// partial frames meet on rank 0 through RCCL (include/trhip_comm.h; link with -ltrhip -ltrhip_comm).
+//
+// The reference drives all devices from one process and moves partial frames with device_transfer: GPU -> pinned host memory
+// -> GPU, paced by timeline semaphores exported between the devices (src/device_transfer.cc:21-347, created per device pair by
+// src/rt_renderer.cc:356-408).  tr::rt_renderer of tauray_hip.hh keeps that arrangement with peer copies; this header is the
+// other arrangement north_star names - one rank per GPU, "per-device partial framebuffers reduced via RCCL over xGMI before
+// tonemap".  The render() sequence is the reference's (src/rt_renderer.cc:84-133): ray tracer -> transfer -> stitch -> tonemap,
+// enqueued on the frame slot's stream without blocking the host; ranks other than 0 stop after the transfer.
+#pragma once
+#include "tauray_hip.hh"
+#include "trhip_comm.h"
+
+#include <chrono>
+#include <fstream>
+#include <thread>
+
+namespace tr
+{
+
+inline void check_comm(int rc)
+{
+    if(rc != 0) throw std::runtime_error(trhip_comm_last_error());
+}
+
+// The 128-byte RCCL id has to reach every rank by the caller's means; for processes that share a file system: rank 0 writes
+// it to `path` (atomically, through a rename), the others wait for the file.
+inline std::vector<char> exchange_comm_id_through_file(const std::string& path, int rank, double timeout_seconds = 120.0)
+{
+    std::vector<char> id(TRHIP_COMM_ID_BYTES);
+    if(rank == 0)
+    {
+        check_comm(trhip_comm_unique_id(id.data()));
+        const std::string tmp = path + ".tmp";
+        { std::ofstream f(tmp, std::ios::binary); f.write(id.data(), (std::streamsize)id.size()); if(!f) throw std::runtime_error("cannot write " + tmp); }
+        if(std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+        return id;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while(true)
+    {
+        std::ifstream f(path, std::ios::binary);
+        if(f && f.read(id.data(), (std::streamsize)id.size())) return id;
+        if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+            throw std::runtime_error("timed out waiting for the communicator id in " + path);
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+}
+
+template<typename Pipeline>
+class basic_process_rt_renderer
+{
+public:
+    using options = typename basic_rt_renderer<Pipeline>::options;
+
+    // `rank` of `nranks` processes, this one on HIP device `hip_device`; `comm_id`: TRHIP_COMM_ID_BYTES bytes every rank holds.
+    basic_process_rt_renderer(int hip_device, int rank, int nranks, const void* comm_id, const scene_data& scene, uvec2 size, options opt)
+    : rank(rank), nranks(nranks), size(size), opt(opt), dev(hip_device), scene_update(dev)
+    {
+        if(nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("process_rt_renderer: rank out of range");
+        if(nranks == 1) this->opt.distribution.strategy = DISTRIBUTION_DUPLICATE;   // src/tauray.cc:519-521
+        const int n_slots = std::max(this->opt.max_frames_in_flight, 1);
+        if(n_slots > 1 && this->opt.accumulate)
+            throw std::runtime_error("process_rt_renderer: accumulating frames depend on each other, frames in flight must be 1");
+        check_comm(trhip_comm_create(hip_device, nranks, rank, comm_id, &comm));
+        scene_update.set_scene(scene);                                // the scene is replicated on every device (src/gpu_buffer.hh:63-116)
+        layers = this->opt.active_viewport_count;
+        set_dists(std::vector<double>((size_t)nranks, 1.0 / nranks));
+        slots.resize((size_t)n_slots);
+        for(slot_data& sl: slots)
+        {
+            sl.stream = dev.create_stream();
+            // targets have the size of the largest share set_device_workloads can hand a rank (src/rt_renderer.cc init_resources)
+            const uvec2 ms = get_distribution_target_max_size(dists[(size_t)rank]);
+            sl.color = dev.alloc(size_t(ms.x) * ms.y * 16 * layers);
+            check(trhip_memset(dev.h, sl.color, 0, size_t(ms.x) * ms.y * 16 * layers, nullptr));
+            path_tracer_stage::options po = this->opt;
+            po.distribution = dists[(size_t)rank];
+            sl.ray_tracer = std::make_unique<Pipeline>(dev, scene_update, sl.color, po);
+            if(n_slots > 1) sl.ray_tracer->set_lanes(1);
+            if(rank == 0)
+            {
+                sl.display = dev.alloc(size_t(size.x) * size.y * 16 * layers);
+                sl.partials.assign((size_t)nranks, nullptr);
+                for(int r = 1; r < nranks; ++r)
+                {
+                    const uvec2 rs = get_distribution_target_max_size(dists[(size_t)r]);
+                    sl.partials[(size_t)r] = dev.alloc(size_t(rs.x) * rs.y * 16 * layers);
+                }
+            }
+        }
+        dev.sync();
+        if(rank == 0) tonemap = std::make_unique<tonemap_stage>(dev, this->opt.tonemap);
+    }
+
+    ~basic_process_rt_renderer()
+    {
+        finish_all();
+        for(slot_data& sl: slots)
+        {
+            sl.ray_tracer.reset();
+            for(void* p: sl.partials) if(p) dev.free(p);
+            if(sl.display) dev.free(sl.display);
+            dev.free(sl.color);
+            dev.destroy_stream(sl.stream);
+        }
+        trhip_comm_destroy(comm);
+    }
+
+    void reset_accumulation(bool reset_sample_counter = false)
+    {
+        for(slot_data& sl: slots)
+        {
+            sl.ray_tracer->reset_accumulated_samples();
+            if(reset_sample_counter) sl.ray_tracer->reset_sample_counter();
+        }
+        if(reset_sample_counter) frame_index = 0;
+        accumulated_frames = 0;
+    }
+
+    void finish_frame() { if(current_slot >= 0) dev.sync(slots[(size_t)current_slot].stream); }
+    void finish_slot(int k) { dev.sync(slots[(size_t)k].stream); }
+    void finish_all() { for(slot_data& sl: slots) dev.sync(sl.stream); dev.sync(); }
+
+    // rt_renderer::render (src/rt_renderer.cc:84-133) for this rank.  Every rank calls it once per frame, in the same order.
+    void render()
+    {
+        const size_t k = frame_index % slots.size();
+        current_slot = (int)k;
+        slot_data& sl = slots[k];
+        if(!opt.accumulate) sl.ray_tracer->reset_accumulated_samples();
+        if(slots.size() > 1) sl.ray_tracer->set_frame_counter(frame_index);
+        sl.ray_tracer->run(sl.stream);
+        if(nranks > 1)
+        {
+            // device_transfer: one grouped exchange on the slot's stream, behind the path tracing it ships and - on rank 0 - in
+            // front of the stitch that reads it
+            std::vector<size_t> bytes((size_t)nranks, 0);
+            for(int r = 0; r < nranks; ++r) bytes[(size_t)r] = target_bytes(dists[(size_t)r]);
+            check_comm(trhip_gather_partials(comm, 0, sl.color, bytes[(size_t)rank], rank == 0 ? sl.partials.data() : nullptr,
+                                             rank == 0 ? bytes.data() : nullptr, sl.stream));
+            if(rank == 0)
+            {
+                std::vector<trhip_distribution> ds;
+                std::vector<const void*> ps;
+                std::vector<uint32_t> ws, hs;
+                for(int r = 1; r < nranks; ++r)
+                {
+                    const uvec2 ts = get_distribution_target_size(dists[(size_t)r]);
+                    if(ts.x == 0 || ts.y == 0) continue;
+                    ds.push_back(to_abi(dists[(size_t)r])); ps.push_back(sl.partials[(size_t)r]); ws.push_back(ts.x); hs.push_back(ts.y);
+                }
+                if(!ds.empty())
+                    check(trhip_stitch_batch(dev.h, (uint32_t)ds.size(), ds.data(), ps.data(), ws.data(), hs.data(), sl.color, (uint32_t)layers,
+                                             stitch_blend_ratio, sl.stream));
+                stitch_blend_ratio = 1.0f;      // src/rt_renderer.cc:122
+            }
+        }
+        if(rank == 0)
+        {
+            display = sl.display;
+            tonemap->run(sl.color, display, size, (uint32_t)layers, sl.stream);
+        }
+        frame_index++;
+        accumulated_frames++;
+    }
+
+    // rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183); every rank calls it with the same ratios
+    void set_device_workloads(const std::vector<double>& ratios)
+    {
+        if(opt.distribution.strategy != DISTRIBUTION_SHUFFLED_STRIPS) return;
+        finish_all();
+        set_dists(ratios);
+        for(slot_data& sl: slots)
+        {
+            sl.ray_tracer->reset_distribution_params(dists[(size_t)rank]);
+            if(rank != 0) sl.ray_tracer->reset_accumulated_samples();
+        }
+        if(opt.accumulate && nranks > 1) stitch_blend_ratio = 1.0f / float(accumulated_frames + 1);
+    }
+
+    double get_path_tracing_time() { return slots[current_slot < 0 ? 0 : (size_t)current_slot].ray_tracer->get_duration_ms(); }
+
+    struct slot_data
+    {
+        void* stream = nullptr;
+        std::unique_ptr<Pipeline> ray_tracer;
+        void* color = nullptr;
+        void* display = nullptr;                 // rank 0
+        std::vector<void*> partials;             // rank 0: where rank r's partial frame lands
+    };
+    int rank, nranks;
+    uvec2 size;
+    options opt;
+    device dev;
+    scene_stage scene_update;
+    trhip_comm* comm = nullptr;
+    std::vector<distribution_params> dists;      // every rank's share (all ranks compute all of them)
+    std::vector<slot_data> slots;
+    std::unique_ptr<tonemap_stage> tonemap;
+    size_t layers = 1;
+    int current_slot = -1;
+    uint32_t frame_index = 0;
+    unsigned accumulated_frames = 0;
+    float stitch_blend_ratio = 1.0f;
+    void* display = nullptr;
+
+private:
+    size_t target_bytes(const distribution_params& d) const { const uvec2 ts = get_distribution_target_size(d); return size_t(ts.x) * ts.y * 16 * layers; }
+    void set_dists(const std::vector<double>& ratios)
+    {
+        if((int)ratios.size() != nranks) throw std::runtime_error("set_device_workloads needs one ratio per rank");
+        dists.resize((size_t)nranks);
+        double cumulative = 0;
+        for(int r = 0; r < nranks; ++r)
+        {
+            const double ratio = std::min(std::max(ratios[(size_t)r], 0.0), 1.0 - cumulative);
+            dists[(size_t)r] = get_device_distribution_params(size, opt.distribution.strategy, cumulative, ratio, (unsigned)r, (unsigned)nranks, r == 0);
+            cumulative += ratio;
+        }
+    }
+};
+using process_rt_renderer = basic_process_rt_renderer<path_tracer_stage>;
+
+}  // namespace tr

@@ -9,6 +9,10 @@
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
 //              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1] [--renderer=path-tracer|direct]
+//
+// One process per GPU (include/tauray_hip_comm.hh): start N copies with --process-count=N --process-rank=0..N-1 --device=<HIP index>
+// --comm-id=<file on a shared file system> (rank 0 writes the RCCL id there, the others wait for it); every rank renders its share
+// of each frame, the partial frames meet on rank 0 through trhip_gather_partials, rank 0 stitches, tonemaps and saves.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -16,6 +20,7 @@
 #include <sstream>
 
 #include "tauray_hip.hh"
+#include "tauray_hip_comm.hh"
 #include "tauray_envmap.hh"
 #include "tauray_gltf.hh"
 
@@ -41,6 +46,8 @@ int main(int argc, char** argv)
         bool frames_given = false, animation_flag = false;      // --animation[=name] --framerate=F (src/options.hh:110-129)
         std::string animation_name;
         double framerate = 60.0;
+        int process_rank = -1, process_count = 0, process_device = 0;      // one process per GPU (see above)
+        std::string comm_id_path;
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
@@ -84,6 +91,10 @@ int main(int argc, char** argv)
                 }
             }
             else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
+            else if(starts(a, "--process-rank=")) process_rank = std::stoi(val("--process-rank="));
+            else if(starts(a, "--process-count=")) process_count = std::stoi(val("--process-count="));
+            else if(starts(a, "--device=")) process_device = std::stoi(val("--device="));
+            else if(starts(a, "--comm-id=")) comm_id_path = val("--comm-id=");
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
             else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
             else if(starts(a, "--exposure=")) opt.tonemap.exposure = std::stof(val("--exposure="));
@@ -177,6 +188,29 @@ int main(int argc, char** argv)
         opt.max_frames_in_flight = frames_in_flight;
         hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = 1;
         headless out(hopt);
+        if(process_count > 0)
+        {   // one process per GPU: this process is rank process_rank of process_count
+            if(process_rank < 0 || process_rank >= process_count) throw std::runtime_error("--process-rank must be in [0, --process-count)");
+            if(comm_id_path.empty()) throw std::runtime_error("--process-count needs --comm-id=<file every rank can read>");
+            if(renderer != "path-tracer" || animated) throw std::runtime_error("--process-count renders still frames with the path tracer");
+            const std::vector<char> id = exchange_comm_id_through_file(comm_id_path, process_rank);
+            process_rt_renderer rr(process_device, process_rank, process_count, id.data(), scene, size, opt);
+            if(!workloads.empty()) rr.set_device_workloads(workloads);
+            for(int f = -warmup; f < frames; ++f)
+            {
+                auto t0 = std::chrono::high_resolution_clock::now();
+                rr.reset_accumulation();
+                rr.render();
+                rr.finish_frame();
+                auto t1 = std::chrono::high_resolution_clock::now();
+                if(f < 0) continue;
+                if(timing)
+                    std::cout << "FRAME " << f << ":\n\tRANK " << process_rank << ":\n\t\t[path tracing (" << opt.active_viewport_count << " viewports)] "
+                              << rr.get_path_tracing_time() << " ms\n\tHOST: " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms\n";
+                if(process_rank == 0) out.save(rr.dev, rr.display, (unsigned)f);
+            }
+            return 0;
+        }
         // --renderer picks the pipeline rt_renderer<Pipeline> is instantiated with (src/tauray.cc:355-421: path-tracer, direct)
         auto run = [&](auto& rr) -> int
         {

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.CountersC) == 7 * 8
     assert C.sizeof(_lib.TimingsC) == 10 * 4
     assert C.sizeof(_lib.TonemapInfoC) == 16
-    assert C.sizeof(_lib.AccelInfoC) == 44
+    assert C.sizeof(_lib.AccelInfoC) == 48
     assert C.sizeof(_lib.PtTargetsC) == 9 * 8
     from oracle import binding as B
     assert C.sizeof(B.PtOptionsC) == C.sizeof(_lib.PtOptionsC)

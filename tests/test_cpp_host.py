@@ -19,8 +19,8 @@ def fresh_cli(tmp_path_factory):
     global CLI
     out = str(tmp_path_factory.mktemp("cli") / "tauray_hip")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-DTAURAY_HIP_WITH_ZLIB", "-I" + os.path.join(ROOT, "include"), "-o", out,
-                           os.path.join(ROOT, "tauray_amd", "host", "tauray_hip_cli.cc"), "-L" + os.path.join(ROOT, "tauray_amd"), "-ltrhip", "-lz",
-                           "-Wl,-rpath," + os.path.join(ROOT, "tauray_amd")])
+                           os.path.join(ROOT, "tauray_amd", "host", "tauray_hip_cli.cc"), "-L" + os.path.join(ROOT, "tauray_amd"), "-ltrhip", "-ltrhip_comm", "-lz",
+                           "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "tauray_amd"), "-Wl,-rpath-link,/opt/rocm/lib"])
     CLI = out
     yield out
 
@@ -285,6 +285,27 @@ def test_cpp_renderer_matches_python_mirror_and_fake_devices(tmp_path, scene_dum
         assert np.array_equal(np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4), ref), tag
     r = subprocess.run([CLI] + common + ["--renderer=whitted"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown renderer" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_one_process_per_gpu_mode_with_one_rank(tmp_path, scene_dump):
+    """tr::process_rt_renderer (include/tauray_hip_comm.hh) behind `--process-count=N --process-rank=R --comm-id=file`: the RCCL
+    communicator is created from the id rank 0 leaves in the file, the frame goes through trhip_gather_partials; with one rank -
+    what a one-GPU box can run - the files equal the single-process renderer's, frame slots included."""
+    W = H = 96
+    common = [scene_dump, f"--width={W}", f"--height={H}", "--max-ray-depth=4", "--filetype=raw", "--frames=3"]
+    ref_prefix = str(tmp_path / "ref")
+    subprocess.check_call([CLI] + common + [f"--headless={ref_prefix}"])
+    for tag, extra in (("proc", []), ("proc_strips", ["--distribution-strategy=shuffled-strips", "--device-workloads=1"])):
+        prefix, idf = str(tmp_path / tag), str(tmp_path / (tag + ".id"))
+        r = subprocess.run([CLI] + common + [f"--headless={prefix}", "--process-count=1", "--process-rank=0", "--device=0", f"--comm-id={idf}", "-t"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert os.path.getsize(idf) == 128 and "RANK 0" in r.stdout
+        for f in range(3):
+            assert np.array_equal(np.fromfile(f"{prefix}{f}.raw", dtype=np.float32), np.fromfile(f"{ref_prefix}{f}.raw", dtype=np.float32)), (tag, f)
+    r = subprocess.run([CLI] + common + ["--process-count=2", "--process-rank=2", f"--comm-id={tmp_path / 'x.id'}"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--process-rank" in r.stderr
 
 
 @pytest.mark.gpu
