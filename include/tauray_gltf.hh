@@ -9,8 +9,10 @@
 // Skins: JOINTS_0 / WEIGHTS_0 (renormalised) + inverse bind matrices; skinned meshes sit at the origin (src/gltf.cc:722-731,
 // 777-784) and scene_data::skinned carries the file's rest pose for scene_stage::set_scene.  Animation clips (translation / rotation /
 // scale channels, LINEAR / STEP / CUBICSPLINE; src/gltf.cc:167-190,580-627) are kept in scene_data::animation and played by
-// tr::scene_animator below (src/animation.{hh,cc,tcc}, src/scene.cc:213-244).  Not read: morph targets, external (non-embedded)
-// images, interlaced or 16-bit PNGs.  Same scope and same results as the Python mirror tauray_amd/gltf.py
+// tr::scene_animator below (src/animation.{hh,cc,tcc}, src/scene.cc:213-244).  Textures: PNG of any colour type, bit depth and
+// interlacing and baseline JPEG (include/tauray_image.hh), embedded or behind a relative / data: uri (src/gltf.cc:532-576); besides
+// .glb containers - the only form the reference opens - .gltf text files with their buffers.  Not read: morph targets,
+// progressive JPEG.  Same scope and same results as the Python mirror tauray_amd/gltf.py
 // (tests/test_cpp_host.py::test_cpp_glb_loader_matches_python_loader).
 #ifndef TAURAY_GLTF_HH
 #define TAURAY_GLTF_HH
@@ -22,6 +24,7 @@
 #include <map>
 
 #include "tauray_hip.hh"
+#include "tauray_image.hh"
 
 namespace tr
 {
@@ -221,76 +224,6 @@ inline mat4d trs_matrix(const double t[3], const double q[4], const double s[3])
 }
 
 //---------------------------------------------------------------------------------------------------------------------
-// PNG (8 bit, non-interlaced; gray, gray + alpha, RGB, RGBA) -> RGBA8, row 0 = top row of the file
-inline std::vector<uint8_t> decode_png(const uint8_t* data, size_t size, uint32_t& w, uint32_t& h)
-{
-#ifndef TAURAY_HIP_WITH_ZLIB
-    (void)data; (void)size; (void)w; (void)h;
-    throw std::runtime_error("glTF: PNG textures need a build with TAURAY_HIP_WITH_ZLIB");
-#else
-    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
-    if(size < 8 || std::memcmp(data, sig, 8) != 0) throw std::runtime_error("glTF: image is not a PNG");
-    auto be32 = [&](size_t o) { return (uint32_t(data[o]) << 24) | (uint32_t(data[o + 1]) << 16) | (uint32_t(data[o + 2]) << 8) | uint32_t(data[o + 3]); };
-    size_t pos = 8;
-    std::vector<uint8_t> idat;
-    int depth = 0, ctype = 0, interlace = 0;
-    w = h = 0;
-    while(pos + 12 <= size)
-    {
-        const uint32_t len = be32(pos);
-        const char* tag = reinterpret_cast<const char*>(data + pos + 4);
-        const uint8_t* body = data + pos + 8;
-        if(pos + 12 + len > size) throw std::runtime_error("glTF: truncated PNG");
-        if(!std::strncmp(tag, "IHDR", 4)) { w = be32(pos + 8); h = be32(pos + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
-        else if(!std::strncmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
-        else if(!std::strncmp(tag, "IEND", 4)) break;
-        pos += 12 + size_t(len);
-    }
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if(depth != 8 || interlace != 0 || ch == 0) throw std::runtime_error("glTF: unsupported PNG (8-bit non-interlaced gray / RGB / RGBA only)");
-    const size_t stride = size_t(w) * ch;
-    std::vector<uint8_t> raw((stride + 1) * h);
-    uLongf raw_len = (uLongf)raw.size();
-    if(uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) throw std::runtime_error("glTF: PNG inflate failed");
-    std::vector<uint8_t> px(stride * h);
-    std::vector<uint8_t> zero(stride, 0);
-    for(uint32_t y = 0; y < h; ++y)
-    {
-        const uint8_t ft = raw[(stride + 1) * y];
-        const uint8_t* line = raw.data() + (stride + 1) * y + 1;
-        uint8_t* cur = px.data() + stride * y;
-        const uint8_t* prev = y ? px.data() + stride * (y - 1) : zero.data();
-        for(size_t x = 0; x < stride; ++x)
-        {
-            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = prev[x], c = x >= (size_t)ch ? prev[x - ch] : 0;
-            int pred = 0;
-            switch(ft)
-            {
-            case 0: pred = 0; break;
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) >> 1; break;
-            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-            default: throw std::runtime_error("glTF: bad PNG filter");
-            }
-            cur[x] = (uint8_t)((line[x] + pred) & 255);
-        }
-    }
-    std::vector<uint8_t> rgba(size_t(w) * h * 4);
-    for(size_t i = 0; i < size_t(w) * h; ++i)
-    {
-        const uint8_t* s = px.data() + i * ch;
-        uint8_t* d = rgba.data() + i * 4;
-        if(ch == 1) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
-        else if(ch == 2) { d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; }
-        else if(ch == 3) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
-        else std::memcpy(d, s, 4);
-    }
-    return rgba;
-#endif
-}
-
-//---------------------------------------------------------------------------------------------------------------------
 // GPU-side PODs
 #pragma pack(push, 4)
 struct vertex { float pos[3], normal[3], uv[2], tangent[4]; };
@@ -352,29 +285,115 @@ struct texture_info { uint32_t width, height, texel_offset, pad; };
 static_assert(sizeof(vertex) == 48 && sizeof(material) == 80 && sizeof(instance) == 288 && sizeof(camera_data) == 320, "layout");
 static_assert(sizeof(directional_light) == 32 && sizeof(point_light) == 64, "layout");
 
+// a glTF `uri`: a data: URI (base64) or a file next to the scene file (percent-encoded relative path)
+inline std::vector<uint8_t> read_uri(const std::string& uri, const std::string& base_dir)
+{
+    auto unquote = [](const std::string& u) {
+        std::string out;
+        for(size_t i = 0; i < u.size(); ++i)
+        {
+            if(u[i] == '%' && i + 2 < u.size() && std::isxdigit((unsigned char)u[i + 1]) && std::isxdigit((unsigned char)u[i + 2]))
+            { out.push_back((char)std::stoi(u.substr(i + 1, 2), nullptr, 16)); i += 2; }
+            else out.push_back(u[i]);
+        }
+        return out;
+    };
+    if(uri.compare(0, 5, "data:") == 0)
+    {
+        const size_t comma = uri.find(',');
+        if(comma == std::string::npos) throw std::runtime_error("glTF: malformed data: uri");
+        const std::string head = uri.substr(0, comma);
+        if(head.size() < 7 || head.compare(head.size() - 7, 7, ";base64") != 0) { const std::string t = unquote(uri.substr(comma + 1)); return std::vector<uint8_t>(t.begin(), t.end()); }
+        std::vector<uint8_t> out;
+        uint32_t acc = 0; int bits = 0;
+        for(size_t i = comma + 1; i < uri.size(); ++i)
+        {
+            const char c = uri[i];
+            int v;
+            if(c >= 'A' && c <= 'Z') v = c - 'A'; else if(c >= 'a' && c <= 'z') v = c - 'a' + 26; else if(c >= '0' && c <= '9') v = c - '0' + 52;
+            else if(c == '+' || c == '-') v = 62; else if(c == '/' || c == '_') v = 63; else continue;      // '=' padding and whitespace
+            acc = (acc << 6) | (uint32_t)v; bits += 6;
+            if(bits >= 8) { bits -= 8; out.push_back((uint8_t)((acc >> bits) & 0xFF)); }
+        }
+        return out;
+    }
+    const std::string path = (base_dir.empty() ? std::string() : base_dir + "/") + unquote(uri);
+    std::ifstream f(path, std::ios::binary);
+    if(!f) throw std::runtime_error("Failed to open " + path);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// The JSON document and the buffers of a .glb container (what the reference opens: LoadBinaryFromFile, src/gltf.cc:527) or of a
+// .gltf text file with its external / data: buffers.
 struct glb_file
 {
     json doc;
-    std::vector<uint8_t> bin;
+    std::vector<std::vector<uint8_t>> buffers;
+    std::string dir;
 
     explicit glb_file(const std::string& path)
     {
         std::ifstream f(path, std::ios::binary);
         if(!f) throw std::runtime_error("Failed to open " + path);
         std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-        if(d.size() < 12 || std::memcmp(d.data(), "glTF", 4) != 0) throw std::runtime_error(path + " is not a GLB file");
-        size_t off = 12;
-        bool have_json = false;
-        while(off + 8 <= d.size())
+        const size_t slash = path.find_last_of('/');
+        dir = slash == std::string::npos ? std::string() : path.substr(0, slash);
+        std::vector<uint8_t> glb_bin;
+        bool have_bin = false;
+        if(d.size() >= 12 && std::memcmp(d.data(), "glTF", 4) == 0)
         {
-            uint32_t clen, ctype;
-            std::memcpy(&clen, d.data() + off, 4); std::memcpy(&ctype, d.data() + off + 4, 4);
-            if(off + 8 + clen > d.size()) throw std::runtime_error(path + " is truncated");
-            if(ctype == 0x4E4F534A) { doc = json_parser(reinterpret_cast<const char*>(d.data() + off + 8), clen).parse(); have_json = true; }
-            else if(ctype == 0x004E4942) bin.assign(d.begin() + off + 8, d.begin() + off + 8 + clen);
-            off += 8 + size_t(clen);
+            size_t off = 12;
+            bool have_json = false;
+            while(off + 8 <= d.size())
+            {
+                uint32_t clen, ctype;
+                std::memcpy(&clen, d.data() + off, 4); std::memcpy(&ctype, d.data() + off + 4, 4);
+                if(off + 8 + clen > d.size()) throw std::runtime_error(path + " is truncated");
+                if(ctype == 0x4E4F534A) { doc = json_parser(reinterpret_cast<const char*>(d.data() + off + 8), clen).parse(); have_json = true; }
+                else if(ctype == 0x004E4942) { glb_bin.assign(d.begin() + off + 8, d.begin() + off + 8 + clen); have_bin = true; }
+                off += 8 + size_t(clen);
+            }
+            if(!have_json) throw std::runtime_error(path + " has no JSON chunk");
         }
-        if(!have_json) throw std::runtime_error(path + " has no JSON chunk");
+        else
+        {
+            size_t i = 0;
+            while(i < d.size() && std::isspace(d[i])) ++i;
+            if(i >= d.size() || d[i] != '{') throw std::runtime_error(path + " is not a GLB file");
+            doc = json_parser(reinterpret_cast<const char*>(d.data()), d.size()).parse();
+        }
+        if(doc.has("buffers"))
+        {
+            size_t i = 0;
+            for(const json& b: doc.at("buffers").arr)
+            {
+                if(b.has("uri")) buffers.push_back(read_uri(b.at("uri").str, dir));
+                else if(i == 0 && have_bin) buffers.push_back(std::move(glb_bin));
+                else throw std::runtime_error("glTF: buffer " + std::to_string(i) + " has neither a uri nor a GLB chunk");
+                ++i;
+            }
+        }
+    }
+
+    const std::vector<uint8_t>& buffer_of(const json& buffer_view) const
+    {
+        const size_t b = (size_t)buffer_view.number("buffer", 0);
+        if(b >= buffers.size()) throw std::runtime_error("glTF: bufferView names a missing buffer");
+        return buffers[b];
+    }
+    // the file behind an `images` entry: embedded (bufferView) or a uri (src/gltf.cc:532-576)
+    std::vector<uint8_t> image(const json& img) const
+    {
+        if(img.has("bufferView"))
+        {
+            const json& bv = doc.at("bufferViews").at((size_t)img.integer("bufferView", 0));
+            const std::vector<uint8_t>& bin = buffer_of(bv);
+            const size_t o = (size_t)bv.number("byteOffset", 0), n = (size_t)bv.number("byteLength", 0);
+            if(o + n > bin.size()) throw std::runtime_error("glTF: image exceeds the buffer");
+            return std::vector<uint8_t>(bin.begin() + (long)o, bin.begin() + (long)(o + n));
+        }
+        if(img.has("uri")) return read_uri(img.at("uri").str, dir);
+        throw std::runtime_error("glTF: image without bufferView or uri");
     }
 
     // accessor as rows of doubles (exact for every component type glTF has)
@@ -382,6 +401,7 @@ struct glb_file
     {
         const json& a = doc.at("accessors").at((size_t)index);
         const json& bv = doc.at("bufferViews").at((size_t)a.integer("bufferView", 0));
+        const std::vector<uint8_t>& bin = buffer_of(bv);
         const int ct = a.integer("componentType", 0);
         const std::string& type = a.at("type").str;
         components = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
@@ -622,14 +642,10 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     std::vector<texture> textures;
     for(const json& img: list("images").arr)
     {
-        if(!img.has("bufferView")) throw std::runtime_error("glTF: only embedded images are supported");
-        const json* mime = img.find("mimeType");
-        if(!mime || mime->str != "image/png") throw std::runtime_error("glTF: only PNG images are supported");
-        const json& bv = j.at("bufferViews").at((size_t)img.integer("bufferView", 0));
-        const size_t o = (size_t)bv.number("byteOffset", 0), n = (size_t)bv.number("byteLength", 0);
-        if(o + n > g.bin.size()) throw std::runtime_error("glTF: image exceeds the buffer");
+        const std::vector<uint8_t> file = g.image(img);      // PNG or JPEG by signature
+        image::decoded d = image::decode(file.data(), file.size());
         texture t;
-        t.rgba = decode_png(g.bin.data() + o, n, t.w, t.h);
+        t.w = d.w; t.h = d.h; t.rgba = std::move(d.rgba);
         textures.push_back(std::move(t));
     }
 

@@ -83,6 +83,8 @@ class TonemapInfoC(C.Structure):
 # every symbol include/trhip.h declares: (name, restype, argtypes)
 _vp, _u32, _i, _f = C.c_void_p, C.c_uint32, C.c_int, C.c_float
 SYMBOLS = {
+    "trhip_image_decode": (_i, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.POINTER(C.c_uint8))]),
+    "trhip_image_free": (None, [C.POINTER(C.c_uint8)]),
     "trhip_device_create": (_i, [_i, C.POINTER(_vp)]),
     "trhip_device_destroy": (None, [_vp]),
     "trhip_last_error": (C.c_char_p, []),

@@ -9,6 +9,7 @@
 #include "pt.h"
 #include "trace.h"
 #include "trace_quad.h"
+#include "../../include/tauray_image.hh"
 
 namespace tr {
 
@@ -253,6 +254,20 @@ struct trhip_pt {
 extern "C" {
 
 const char* trhip_last_error(void) { return g_error.c_str(); }
+
+int trhip_image_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels_in_file, uint8_t** rgba_out) {
+    if (!data || !width || !height || !rgba_out) return set_error("trhip_image_decode: null argument");
+    try {
+        tr::image::decoded d = tr::image::decode(static_cast<const uint8_t*>(data), bytes);
+        uint8_t* p = static_cast<uint8_t*>(malloc(d.rgba.size() ? d.rgba.size() : 1));
+        if (!p) return set_error("trhip_image_decode: out of memory");
+        memcpy(p, d.rgba.data(), d.rgba.size());
+        *width = d.w; *height = d.h; *rgba_out = p;
+        if (channels_in_file) *channels_in_file = (uint32_t)d.channels_in_file;
+    } catch (const std::exception& e) { return set_error(e.what()); }
+    return 0;
+}
+void trhip_image_free(uint8_t* rgba) { free(rgba); }
 
 int trhip_device_create(int hip_device, trhip_device** out) {
     if (!out) return set_error("trhip_device_create: null out");

@@ -1,4 +1,4 @@
-"""Minimal GLB (binary glTF 2.0) reader -> SceneDesc.
+"""glTF 2.0 reader (.glb containers, and .gltf text files with their buffers) -> SceneDesc.
 
 Host mirror of the reference's loader for the subset the path tracer needs
 (src/gltf.cc:199-280 materials, :330-505 nodes/lights/cameras, :510-798
@@ -6,7 +6,8 @@ meshes), followed by the instance flattening of scene_stage
 (src/scene_stage.cc:664-819: one instance per (model, vertex group), in node
 traversal order).  Supports KHR_lights_punctual, KHR_materials_transmission,
 KHR_materials_ior, KHR_materials_emissive_strength, Tauray's TR_data and skins
-(JOINTS_0 / WEIGHTS_0 + inverse bind matrices; animation clips are not played).
+(JOINTS_0 / WEIGHTS_0 + inverse bind matrices).  Textures: PNG of any colour type / bit depth / interlacing and baseline JPEG
+(include/tauray_image.hh), embedded or behind a relative / data: uri.
 """
 from __future__ import annotations
 
@@ -25,102 +26,84 @@ _COMP = {5120: ("i1", 1), 5121: ("u1", 1), 5122: ("<i2", 2), 5123: ("<u2", 2), 5
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 
 
-def decode_png(data: bytes) -> np.ndarray:
-    """PNG -> HxWx4 uint8.  Uses Pillow when importable, otherwise a tiny pure
-    zlib+numpy decoder (8-bit, non-interlaced; gray/gray+alpha/RGB/RGBA)."""
-    try:
-        import io
-        from PIL import Image
-        return np.array(Image.open(io.BytesIO(data)).convert("RGBA"), dtype=np.uint8)
-    except ImportError:
-        return _decode_png_pure(data)
+def decode_image(data: bytes) -> np.ndarray:
+    """A texture file (PNG of any colour type / bit depth / interlacing, baseline or extended-sequential JPEG) -> HxWx4 uint8,
+    row 0 = top row: what stb_image hands the reference's loader (src/gltf.cc:520-576).  One decoder for both hosts:
+    include/tauray_image.hh through trhip_image_decode, so the C++ loader flattens the same scene to the same bytes."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    w, h, ch, p = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    _lib.check(L.trhip_image_decode(bytes(data), len(data), C.byref(w), C.byref(h), C.byref(ch), C.byref(p)))
+    out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+    L.trhip_image_free(p)
+    return out
 
 
-def _decode_png_pure(data: bytes) -> np.ndarray:
-    assert data[:8] == b"\x89PNG\r\n\x1a\n", "not a PNG"
-    pos = 8
-    idat = []
-    w = h = depth = ctype = interlace = None
-    while pos < len(data):
-        (length,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
-        body = data[pos + 8:pos + 8 + length]
-        pos += 12 + length
-        if tag == b"IHDR":
-            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
-        elif tag == b"IDAT":
-            idat.append(body)
-        elif tag == b"IEND":
-            break
-    if depth != 8 or interlace != 0 or ctype not in (0, 2, 4, 6):
-        raise ValueError(f"unsupported PNG (depth={depth}, color type={ctype}, interlace={interlace})")
-    ch = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8)
-    stride = w * ch
-    raw = raw.reshape(h, stride + 1)
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        ft = int(raw[y, 0])
-        line = raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft == 1:
-            cur = line.reshape(w, ch).copy()
-            np.cumsum(cur, axis=0, out=cur)
-            cur = cur.reshape(-1) & 255
-        else:
-            cur = np.zeros(stride, dtype=np.int32)
-            for x in range(stride):
-                a = cur[x - ch] if x >= ch else 0
-                b = prev[x]
-                c = prev[x - ch] if x >= ch else 0
-                if ft == 3:
-                    pred = (a + b) >> 1
-                else:
-                    p = a + b - c
-                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[x] = (line[x] + pred) & 255
-        out[y] = cur
-        prev = cur
-    img = out.reshape(h, w, ch)
-    rgba = np.full((h, w, 4), 255, dtype=np.uint8)
-    if ch == 1:
-        rgba[..., :3] = img
-    elif ch == 2:
-        rgba[..., :3] = img[..., :1]
-        rgba[..., 3] = img[..., 1]
-    elif ch == 3:
-        rgba[..., :3] = img
-    else:
-        rgba = img.copy()
-    return rgba
+decode_png = decode_image      # earlier name
+
+
+def _read_uri(uri: str, base_dir: str) -> bytes:
+    """A glTF `uri`: a data: URI (base64) or a file next to the scene file (percent-encoded relative path)."""
+    import base64
+    import os
+    from urllib.parse import unquote
+    if uri.startswith("data:"):
+        head, _, payload = uri.partition(",")
+        return base64.b64decode(payload) if head.endswith(";base64") else unquote(payload).encode("latin-1")
+    with open(os.path.join(base_dir, unquote(uri)), "rb") as f:
+        return f.read()
 
 
 class _Glb:
+    """The JSON document and the buffers of a .glb container (the only form the reference opens: LoadBinaryFromFile,
+    src/gltf.cc:527) or of a .gltf text file with its external / data: buffers."""
+
     def __init__(self, path):
+        import os
+        self.dir = os.path.dirname(os.path.abspath(path))
         d = open(path, "rb").read()
-        magic, version, _ = struct.unpack("<4sII", d[:12])
-        if magic != b"glTF":
-            raise ValueError("not a GLB file")
-        off = 12
         self.json = None
-        self.bin = b""
-        while off < len(d):
-            clen, ctype = struct.unpack("<II", d[off:off + 8])
-            body = d[off + 8:off + 8 + clen]
-            if ctype == 0x4E4F534A:
-                self.json = json.loads(body)
-            elif ctype == 0x004E4942:
-                self.bin = body
-            off += 8 + clen
+        glb_bin = None
+        if d[:4] == b"glTF":
+            off = 12
+            while off < len(d):
+                clen, ctype = struct.unpack("<II", d[off:off + 8])
+                body = d[off + 8:off + 8 + clen]
+                if ctype == 0x4E4F534A:
+                    self.json = json.loads(body)
+                elif ctype == 0x004E4942:
+                    glb_bin = body
+                off += 8 + clen
+            if self.json is None:
+                raise ValueError("not a GLB file")
+        else:
+            try:
+                self.json = json.loads(d)
+            except Exception:
+                raise ValueError("not a GLB file") from None
+        self.buffers = []
+        for i, b in enumerate(self.json.get("buffers", [])):
+            if "uri" in b:
+                self.buffers.append(_read_uri(b["uri"], self.dir))
+            elif i == 0 and glb_bin is not None:
+                self.buffers.append(glb_bin)
+            else:
+                raise ValueError(f"glTF: buffer {i} has neither a uri nor a GLB chunk")
+        self.bin = self.buffers[0] if self.buffers else b""
 
     def view(self, idx) -> bytes:
         bv = self.json["bufferViews"][idx]
         o = bv.get("byteOffset", 0)
-        return self.bin[o:o + bv["byteLength"]]
+        return self.buffers[bv.get("buffer", 0)][o:o + bv["byteLength"]]
+
+    def image(self, img: dict) -> bytes:
+        """The file behind an `images` entry: embedded (bufferView) or a uri (src/gltf.cc:532-576)."""
+        if "bufferView" in img:
+            return self.view(img["bufferView"])
+        if "uri" in img:
+            return _read_uri(img["uri"], self.dir)
+        raise ValueError("glTF: image without bufferView or uri")
 
     def accessor(self, idx) -> np.ndarray:
         a = self.json["accessors"][idx]
@@ -130,10 +113,11 @@ class _Glb:
         base = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
         stride = bv.get("byteStride", 0) or sz * nc
         count = a["count"]
+        buf = self.buffers[bv.get("buffer", 0)]
         if stride == sz * nc:
-            arr = np.frombuffer(self.bin, dtype=dt, count=count * nc, offset=base).reshape(count, nc)
+            arr = np.frombuffer(buf, dtype=dt, count=count * nc, offset=base).reshape(count, nc)
         else:
-            arr = np.stack([np.frombuffer(self.bin, dtype=dt, count=nc, offset=base + i * stride) for i in range(count)])
+            arr = np.stack([np.frombuffer(buf, dtype=dt, count=nc, offset=base + i * stride) for i in range(count)])
         return arr
 
 
@@ -232,11 +216,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
     # (src/gltf.cc:525,557): net effect is row 0 = top row of the file.
     textures: List[np.ndarray] = []
     for img in j.get("images", []):
-        if "bufferView" not in img:
-            raise ValueError("only embedded images are supported")
-        if img.get("mimeType") != "image/png":
-            raise ValueError("only PNG images are supported")
-        textures.append(decode_png(g.view(img["bufferView"])))
+        textures.append(decode_image(g.image(img)))      # PNG or JPEG by signature, embedded or behind a uri
 
     # meshes -> list of vertex groups (material, vertices, indices)
     models = []

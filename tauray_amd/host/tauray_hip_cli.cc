@@ -1,6 +1,6 @@
 // tauray_hip - headless command line front-end of the MI355X path-tracing core, shaped after `tauray --headless`
 // (reference src/main.cc, src/tauray.cc:1017-1132 replay_viewer): load a scene, create an rt_renderer over the
-// selected devices, render N frames, tonemap, save.  Scene input is a .glb file (include/tauray_gltf.hh, the loader of
+// selected devices, render N frames, tonemap, save.  Scene input is a .glb / .gltf file (include/tauray_gltf.hh, the loader of
 // src/gltf.cc for the path tracer's subset) or a .trsc dump (tauray_amd/scene_io.py); --dump-scene=out.trsc writes the loaded
 // scene as a dump and exits without touching a GPU.
 //
@@ -148,7 +148,8 @@ int main(int argc, char** argv)
         if(scene_path.empty()) throw std::runtime_error("usage: tauray_hip scene.glb|scene.trsc [options]");
         if(devices.empty()) devices.assign((size_t)std::max(fake_devices, 1), 0);
 
-        const bool is_glb = scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0;
+        const bool is_glb = (scene_path.size() > 4 && scene_path.compare(scene_path.size() - 4, 4, ".glb") == 0) ||
+                            (scene_path.size() > 5 && scene_path.compare(scene_path.size() - 5, 5, ".gltf") == 0);
         scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
         if(!envmap_path.empty()) set_envmap(scene, envmap_path);      // src/tauray.cc:198-201
         // play(scene, name, !replay, name == "") (src/tauray.cc:252-253); ticks in microseconds per update (:1052)

@@ -155,12 +155,30 @@ def test_config3_full_size_accumulation_property(R, ctx):
                                   "mray_per_s": rays / seconds_passes / 1e6, "seconds_accumulated_one_sample_frames": seconds_frames})
 
 
+# What the primary ray hits in test/test.glb (instance ids of the feature renderer) and how the HIP image may differ from the golden
+# there: (largest relative offset of the region's mean, largest RMS of its 16x16 block means), each more than twice what
+# tools/golden_residual.py measures at 16 384 spp (profiles/r3/golden_residual.json).  The per-pixel difference is the golden's own
+# Monte-Carlo noise (0.031 RMS; this render's is 0.010); block means average the noise of both images out, and what is left is
+# systematic - and has names:
+#   * torus: the checkout adds the emission of a directly visible emitter twice (shader/path_tracer.glsl:421-435 +
+#     path_tracer.rgen:112); the golden shows it once: +13 %.
+#   * teapot (metal, albedo (0.8, 0.077, 0)): the checkout's material model weighs the metallic lobe with the albedo alone
+#     (modulate_bsdf, shader/material.glsl:52-55; ggx_brdf_inner adds `geometry * distribution * cos_l * metallic` without a Fresnel
+#     term, shader/ggx.glsl:145-146), so a metal with no blue in its albedo reflects no blue at any angle: the blue channel of every
+#     teapot pixel is exactly 0 here and in the oracle.  The golden's teapot has white highlights (blue up to 0.38, above 0.01 in a
+#     tenth of its pixels): it was rendered by an earlier material model whose metals go white at grazing angles.  -6.5 %.
+#   * Suzanne (glass): the same earlier model on the transmission lobe (albedo * transmission today): -4.8 %.
+#   * room faces: +0.2 ... +2.3 %, largest on the darkest wall (mean 0.07), whose light is all indirect off the objects above.
+#   * plane (alpha-blended): -0.2 %.
+GOLDEN_REGIONS = {0: ("room face 0", 0.025, 0.018), 1: ("room face 1", 0.01, 0.009), 2: ("room face 2", 0.05, 0.007), 3: ("room face 3", 0.01, 0.022),
+                  4: ("teapot", 0.14, 0.05), 5: ("suzanne", 0.105, 0.065), 6: ("torus", 0.20, 0.0), 7: ("plane", 0.01, 0.0135)}
+
+
 def test_l2_against_the_reference_golden_image(R, ctx):
     """validate_path-tracer.exr (test/references, 512x512 half, filmic + gamma 2.2) is the one image of the Vulkan path tracer
     that exists here.  HIP render with the CLI defaults it was made with (8 bounces, uniform-random sampler, point film) at
-    SPP_GPU samples per pixel, same tonemap, compared as the reference's own test does (MSE over the image) and as its square
-    root.  The directly visible emissive torus is reported separately: the checkout's shaders count its emission twice
-    (path_tracer.glsl:421-435 + path_tracer.rgen:112), the golden predates that."""
+    SPP_GPU * 4 samples per pixel, same tonemap, compared as the reference's own test does (MSE over the image, test/validate_render.py:
+    26-45), as its square root, and region by region (GOLDEN_REGIONS above: every systematic difference has a bound of its own)."""
     from tauray_amd.gltf import load_glb
     W = H = 512
     N = SPP_GPU * 4
@@ -172,26 +190,47 @@ def test_l2_against_the_reference_golden_image(R, ctx):
     R.TonemapStage(ctx).run(color, disp, W, H)
     ours = disp.download((H, W, 4))[..., :3]
     pt.close()
+    fs = R.FeatureStage(ctx, ss, 9, _dup((W, H)))
+    color.zero()
+    fs.run(color)
+    ids = color.download((H, W, 4))[..., 0]
+    ids = np.where(np.isnan(ids), -1, ids).astype(np.int32)
     gold = load_golden("path-tracer")
     assert np.isfinite(ours).all()
-    torus = (np.abs(gold[..., 0] - 0.8413) < 0.01) & (np.abs(gold[..., 2] - 0.5073) < 0.01)
+    torus = ids == 6
+    assert torus.sum() > 4000 and np.abs(gold[torus][:, 0] - 0.8413).mean() < 0.02      # the visible emitter: where the id image says
     keep = ~torus
     d2 = ((ours.astype(np.float64) - gold) ** 2)
     mse_all, mse_keep = float(d2.mean()), float(d2[keep].mean())
-    # how much of that is the golden's own quantisation (half floats in [0, 1]: 2^-11 relative) and noise cannot be separated
-    # here; 16x16 block means remove the noise of both images
     b = 16
-    bo = np.where(keep[..., None], ours, 0).reshape(H // b, b, W // b, b, 3).sum((1, 3))
-    bg = np.where(keep[..., None], gold, 0).reshape(H // b, b, W // b, b, 3).sum((1, 3))
-    n = keep.reshape(H // b, b, W // b, b).sum((1, 3))[..., None]
-    valid = n[..., 0] > 128
-    block_rms = float(np.sqrt((((bo - bg) / np.maximum(n, 1))[valid] ** 2).mean()))
+
+    def block_rms(mask):      # RMS over the 16x16 blocks (with at least 64 pixels of the region) of the difference of the block means
+        bo = np.where(mask[..., None], ours, 0).reshape(H // b, b, W // b, b, 3).sum((1, 3))
+        bg = np.where(mask[..., None], gold, 0).reshape(H // b, b, W // b, b, 3).sum((1, 3))
+        n = mask.reshape(H // b, b, W // b, b).sum((1, 3))
+        valid = n >= 64
+        return float(np.sqrt((((bo - bg) / np.maximum(n, 1)[..., None])[valid] ** 2).mean()))
+
+    regions = {}
+    for k, (name, max_offset, max_block) in GOLDEN_REGIONS.items():
+        m = ids == k
+        assert m.sum() > 4000, name
+        off = float((ours[m].mean() - gold[m].mean()) / gold[m].mean())
+        regions[name] = {"pixels": int(m.sum()), "rel_mean_offset": off, "block16_rms": block_rms(m)}
+        assert abs(off) < max_offset, f"{name}: mean differs by {off:+.2%} (bound {max_offset:.1%})"
+        if max_block:
+            assert regions[name]["block16_rms"] < max_block, f"{name}: block RMS {regions[name]['block16_rms']:.4f} (bound {max_block})"
+    # the two differences with a known cause have the sign and size that cause gives them
+    assert 0.08 < regions["torus"]["rel_mean_offset"] < 0.20
+    teapot = ids == 4
+    assert float(ours[teapot][:, 2].max()) == 0.0 and float((gold[teapot][:, 2] > 0.01).mean()) > 0.05 and regions["teapot"]["rel_mean_offset"] < -0.03
     _report("hip_vs_reference_golden", {
         "image": "validate_path-tracer.exr", "spp": N, "mse_all_pixels": mse_all, "rms_all_pixels": mse_all ** 0.5,
-        "mse_without_visible_emitter": mse_keep, "rms_without_visible_emitter": mse_keep ** 0.5, "block16_rms": block_rms,
-        "emitter_pixels": int(torus.sum()), "mean_rel_err": abs(float(ours[keep].mean()) - float(gold[keep].mean())) / float(gold[keep].mean())})
-    assert mse_keep < L2_BOUND, f"MSE {mse_keep:.3e} against the reference image"
-    assert block_rms < 0.01
+        "mse_without_visible_emitter": mse_keep, "rms_without_visible_emitter": mse_keep ** 0.5, "block16_rms": block_rms(keep),
+        "emitter_pixels": int(torus.sum()), "mean_rel_err": abs(float(ours[keep].mean()) - float(gold[keep].mean())) / float(gold[keep].mean()),
+        "regions": regions})
+    assert mse_keep < L2_BOUND, f"MSE {mse_keep:.3e} against the reference image"      # north_star's bound; the golden's own noise is 9e-4 of it
+    assert block_rms(keep) < 0.02
     assert mse_all < 0.15       # the reference's own tolerance: 10000 on ImageMagick's Q16 scale (test/CMakeLists.txt)
 
 

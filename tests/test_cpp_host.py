@@ -174,6 +174,23 @@ def test_cpp_glb_loader_matches_python_loader(tmp_path):
         want = np.stack([m.T for m in sc.joint_transforms(sk)])      # column-major storage
         assert np.abs(jt.astype(np.float64) - want).max() < 1e-6
     assert pos == len(d)
+    # the forms real assets come in (tests/golden/textured, tools/make_textured_gltf.py): text glTF with an external buffer and
+    # external images - a baseline 4:2:0 JPEG, an interlaced palette PNG behind a percent-encoded name, a 16-bit PNG -, the same
+    # scene as a .glb with the files embedded and as a .gltf with data: URIs: six loads, one scene, byte for byte
+    dumps = {}
+    for name in ("room.gltf", "room_embedded.glb", "room_datauri.gltf"):
+        cpp, py = str(tmp_path / (name + ".trsc")), str(tmp_path / (name + "_py.trsc"))
+        subprocess.check_call([CLI, os.path.join(GOLDEN, "textured", name), "--width=96", "--height=96", f"--dump-scene={cpp}"])
+        write_scene_dump(load_glb(os.path.join(GOLDEN, "textured", name), 96, 96), py)
+        a, b = sections(cpp), sections(py)
+        for n in names + ["tail"]:
+            if n != "cameras":
+                assert a[n] == b[n], f"{name}: {n} differs"
+        dumps[name] = a
+    for name in ("room_embedded.glb", "room_datauri.gltf"):
+        for n in names:
+            assert dumps[name][n] == dumps["room.gltf"][n], f"{name} vs room.gltf: {n}"
+    assert len(dumps["room.gltf"]["texels"]) == 4 * (64 * 48 + 20 * 12 + 32 * 32)
     bad = tmp_path / "bad.glb"
     bad.write_bytes(b"not a glb file at all")
     r = subprocess.run([CLI, str(bad), f"--dump-scene={tmp_path / 'x.trsc'}"], capture_output=True, text=True)
@@ -285,6 +302,34 @@ def test_cpp_renderer_matches_python_mirror_and_fake_devices(tmp_path, scene_dum
         assert np.array_equal(np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4), ref), tag
     r = subprocess.run([CLI] + common + ["--renderer=whitted"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown renderer" in r.stderr
+
+
+@pytest.mark.gpu
+def test_textured_gltf_renders_the_same_through_both_hosts_and_like_the_oracle(tmp_path):
+    """tests/golden/textured/room.gltf (external buffer, JPEG / interlaced palette PNG / 16-bit PNG textures): the C++ host renders
+    the file the Python mirror renders, bit for bit, and the frame agrees with the CPU oracle on the same flattened scene."""
+    from tauray_amd import renderer as R
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    from tauray_amd.gltf import load_glb
+    from oracle import binding as B
+    W = H = 96
+    path = os.path.join(GOLDEN, "textured", "room.gltf")
+    scene = load_glb(path, W, H)
+    assert len(scene.textures) == 3 and scene.triangle_count == 16
+    ctx = R.Context(0)
+    ss = R.SceneStage(ctx, scene)
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, max_bounces=4), DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    color, disp = ctx.alloc(W * H * 16).zero(), ctx.alloc(W * H * 16)
+    pt.run(color)
+    R.TonemapStage(ctx).run(color, disp, W, H)
+    img, shown = color.download((H, W, 4)), disp.download((H, W, 4))
+    prefix = str(tmp_path / "room")
+    subprocess.check_call([CLI, path, f"--width={W}", f"--height={H}", "--max-ray-depth=4", "--filetype=raw", f"--headless={prefix}"])
+    assert np.array_equal(np.fromfile(prefix + ".raw", dtype=np.float32).reshape(H, W, 4), shown)
+    ref = B.OracleScene(scene).render_pt(B.options_for_scene(scene, max_bounces=4), W, H)[0]
+    rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
+    assert float((rel.max(-1) > 1e-2).mean()) <= 2e-3 and img[..., :3].mean() > 0.01
+    assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / float(ref[..., :3].mean()) < 2e-3
 
 
 @pytest.mark.gpu

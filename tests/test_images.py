@@ -1,0 +1,134 @@
+"""include/tauray_image.hh (texture files -> RGBA8, what stb_image does for the reference's glTF loader, src/gltf.cc:520-576) through
+its C entry point trhip_image_decode - the decoder both hosts use.  Checked against an independent decoder (Pillow: libpng /
+libjpeg-turbo) on files made here: PNG must agree exactly (16-bit samples: the rounded 8-bit value), JPEG - whose inverse DCT and
+chroma upsampling the standard leaves to the decoder - to a few levels.  No GPU involved."""
+import ctypes as C
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def decode(data: bytes):
+    from tauray_amd import _lib
+    L = _lib.lib()
+    w, h, ch, p = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    if L.trhip_image_decode(data, len(data), C.byref(w), C.byref(h), C.byref(ch), C.byref(p)) != 0:
+        raise _lib.TrhipError(L.trhip_last_error().decode())
+    a = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+    L.trhip_image_free(p)
+    return a, ch.value
+
+
+def _picture(w, h, seed=1):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 5.0 + y / 9.0), (x * 3 + y * 2) % 256,
+                  255 * ((x // 3 + y // 2) % 2)], -1) + rng.normal(0, 6, (h, w, 4))
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def _save(arr, mode, fmt, **kw):
+    b = io.BytesIO()
+    PIL.fromarray(arr, mode).save(b, fmt, **kw)
+    return b.getvalue()
+
+
+def _png(w, h, depth, ctype, rows, interlace=0, extra=b""):
+    """A PNG file from raw scanlines (filter type 0 on every row; `rows` = list of passes, each a list of packed row bytes)."""
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body))
+    raw = b"".join(b"\x00" + r for p in rows for r in p)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + extra + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("size", [(64, 48), (33, 17), (1, 1), (5, 3), (200, 131)])
+def test_png_colour_types_match_pillow(size):
+    w, h = size
+    a = _picture(w, h)
+    cases = {"rgba": (_save(a, "RGBA", "PNG"), 4), "rgb": (_save(a[..., :3].copy(), "RGB", "PNG"), 3), "grey": (_save(a[..., 0].copy(), "L", "PNG"), 1),
+             "grey_alpha": (_save(a[..., [0, 3]].copy(), "LA", "PNG"), 2),
+             "palette": (_save(np.asarray(PIL.fromarray(a[..., :3].copy(), "RGB").quantize(37)), "P", "PNG"), None)}
+    pal = PIL.fromarray(a[..., :3].copy(), "RGB").quantize(37)
+    b = io.BytesIO(); pal.save(b, "PNG"); cases["palette"] = (b.getvalue(), 3)
+    b = io.BytesIO(); pal.save(b, "PNG", transparency=5); cases["palette_trns"] = (b.getvalue(), 4)
+    for name, (data, ch) in cases.items():
+        got, n = decode(data)
+        ref = np.array(PIL.open(io.BytesIO(data)).convert("RGBA"))
+        assert got.shape == (h, w, 4) and np.array_equal(got, ref), name
+        assert n == ch, name
+
+
+def test_png_sixteen_bit_sub_byte_and_interlaced():
+    w, h = 37, 23
+    rng = np.random.default_rng(3)
+    # 16 bits per sample, RGBA and grey: the 8-bit value is the rounded one
+    v = rng.integers(0, 65536, size=(h, w, 4), dtype=np.uint16)
+    rows = [[v[y].astype(">u2").tobytes() for y in range(h)]]
+    got, ch = decode(_png(w, h, 16, 6, rows))
+    assert ch == 4 and np.array_equal(got, ((v.astype(np.uint32) * 255 + 32767) // 65535).astype(np.uint8))
+    g16 = v[..., 0]
+    got, ch = decode(_png(w, h, 16, 0, [[g16[y].astype(">u2").tobytes() for y in range(h)]]))
+    want = ((g16.astype(np.uint32) * 255 + 32767) // 65535).astype(np.uint8)
+    assert ch == 1 and np.array_equal(got[..., 0], want) and np.array_equal(got[..., 2], want) and (got[..., 3] == 255).all()
+    # 1, 2 and 4 bits per sample (grey): Pillow reads those too
+    for depth in (1, 2, 4):
+        g = rng.integers(0, 1 << depth, size=(h, w), dtype=np.uint8)
+        packed = []
+        for y in range(h):
+            bits = np.zeros(((w * depth + 7) // 8) * 8, dtype=np.uint8)
+            bits[:w * depth] = np.unpackbits(g[y][:, None], axis=1)[:, 8 - depth:].reshape(-1)
+            packed.append(np.packbits(bits).tobytes())
+        data = _png(w, h, depth, 0, [packed])
+        got, _ = decode(data)
+        assert np.array_equal(got[..., 0], (g.astype(np.uint32) * 255 // ((1 << depth) - 1)).astype(np.uint8)), depth
+        assert np.array_equal(got, np.array(PIL.open(io.BytesIO(data)).convert("RGBA"))) or depth != 1      # Pillow maps 1-bit grey the same way
+    # Adam7: the seven passes of an RGB image, by hand
+    a = _picture(w, h, 9)[..., :3]
+    passes = []
+    for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = a[y0::dy, x0::dx]
+        passes.append([sub[y].tobytes() for y in range(sub.shape[0])] if sub.size else [])
+    data = _png(w, h, 8, 2, passes, interlace=1)
+    got, ch = decode(data)
+    assert ch == 3 and np.array_equal(got[..., :3], a) and (got[..., 3] == 255).all()
+    assert np.array_equal(got, np.array(PIL.open(io.BytesIO(data)).convert("RGBA")))
+    # tRNS on an RGB image: one colour becomes transparent
+    key = a[3, 4]
+    trns = struct.pack(">HHH", *[int(c) for c in key])
+    body = b"tRNS" + trns
+    data = _png(w, h, 8, 2, [[a[y].tobytes() for y in range(h)]], extra=struct.pack(">I", 6) + body + struct.pack(">I", zlib.crc32(body)))
+    got, ch = decode(data)
+    assert ch == 4 and got[3, 4, 3] == 0 and np.array_equal(got[..., 3] == 0, (a == key).all(-1))
+
+
+@pytest.mark.parametrize("size", [(64, 48), (33, 17), (200, 131), (8, 8), (1, 1), (17, 40)])
+def test_jpeg_matches_an_independent_decoder_to_a_few_levels(size):
+    w, h = size
+    a = _picture(w, h)[..., :3].copy()
+    for mode, kw in (("RGB", dict(subsampling=0)), ("RGB", dict(subsampling=1)), ("RGB", dict(subsampling=2)), ("L", {}),
+                     ("RGB", dict(subsampling=2, restart_marker_blocks=3)), ("RGB", dict(subsampling=0, optimize=True)), ("RGB", dict(subsampling=2, quality=35))):
+        data = _save(a if mode == "RGB" else a[..., 0].copy(), mode, "JPEG", **{"quality": 90, **kw})
+        got, ch = decode(data)
+        ref = np.array(PIL.open(io.BytesIO(data)).convert("RGBA")).astype(int)
+        d = np.abs(got.astype(int) - ref)
+        assert got.shape == (h, w, 4) and ch == (3 if mode == "RGB" else 1) and (got[..., 3] == 255).all()
+        assert d.max() <= 6 and d[..., :3].mean() <= 0.4, (mode, kw, int(d.max()), float(d.mean()))
+
+
+def test_unreadable_files_fail_loudly():
+    from tauray_amd import _lib
+    a = _picture(16, 16)[..., :3].copy()
+    with pytest.raises(_lib.TrhipError, match="progressive"):
+        decode(_save(a, "RGB", "JPEG", progressive=True))
+    with pytest.raises(_lib.TrhipError):
+        decode(b"GIF89a" + b"\0" * 64)
+    good = _save(a, "RGB", "PNG")
+    with pytest.raises(_lib.TrhipError):
+        decode(good[:len(good) // 2])
+    with pytest.raises(_lib.TrhipError):
+        decode(_save(a, "RGB", "JPEG")[:200])
