@@ -236,7 +236,7 @@ struct camera_data { float view[16], view_inverse[16], view_proj[16], proj_inver
 //---------------------------------------------------------------------------------------------------------------------
 // A camera as the file describes it + camera::write_uniform_buffer (src/camera.cc:431-478) with the aspect ratio
 // set_camera_params forces (src/tauray.cc:68-110)
-struct gltf_camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; };
+struct gltf_camera { mat4d transform; bool perspective; double fov, aspect, near, far; double ortho[6]; double pan[2] = {0, 0}; };
 
 inline camera_data pack_camera(gltf_camera& c, double aspect)
 {
@@ -257,6 +257,8 @@ inline camera_data pack_camera(gltf_camera& c, double aspect)
         }
         info[2] = z; info[3] = w;
         cd.dof_params[0] = 1.0f;
+        proj.m[0][2] = c.pan[0]; proj.m[1][2] = c.pan[1];      // camera::set_pan (src/camera.cc:375-381): the off-axis shift of a light-field view
+        cd.pan[0] = (float)c.pan[0]; cd.pan[1] = (float)c.pan[1];
     }
     else
     {
@@ -980,6 +982,47 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     }
     s.animation = anim;
     return s;
+}
+
+//---------------------------------------------------------------------------------------------------------------------
+// generate_cameras (src/tauray.cc:680-727): the light-field camera grid of `--camera-grid=w,h,x,y` - grid_w x grid_h copies of
+// the scene's first camera on a plane through it (spacing dx, dy; rolled by roll_deg about the view axis; shifted by `offset`),
+// each panned so that the views coincide at `recentering_distance` (camera::set_pan).  Replaces scene_data::cameras by the grid
+// (row by row from the top, like the reference's camera indices); returns the number of viewports.  For scenes load_glb made.
+inline uint32_t generate_cameras(scene_data& s, int grid_w, int grid_h, double dx, double dy, double recentering_distance = 5.0, double roll_deg = 0.0,
+                                 const double offset[3] = nullptr)
+{
+    using namespace gltf_detail;
+    if(!s.animation || s.animation->cameras.empty()) throw std::runtime_error("generate_cameras: the scene has no camera to build the grid around");
+    if(grid_w < 1 || grid_h < 1) throw std::runtime_error("generate_cameras: empty grid");
+    const gltf_camera parent = s.animation->cameras[0];
+    if(!parent.perspective) throw std::runtime_error("generate_cameras: the grid pans perspective cameras");
+    constexpr double PI = 3.14159265358979323846;
+    const double aspect = s.animation->aspect;
+    const double width = (grid_w - 1) * dx, height = (grid_h - 1) * dy;
+    const double tv = std::tan(parent.fov * (PI / 180.0) * 0.5), th = aspect * tv;      // tan(vfov / 2), tan(hfov / 2)
+    const double c = std::cos(roll_deg * (PI / 180.0)), sn = std::sin(roll_deg * (PI / 180.0));
+    std::vector<gltf_camera> grid;
+    std::vector<camera_data> packed;
+    for(int y = 0; y < grid_h; ++y)
+        for(int x = 0; x < grid_w; ++x)
+        {
+            const double gx = -width * 0.5 + x * dx, gy = height * 0.5 - y * dy;
+            const double gp[3] = {c * gx - sn * gy, sn * gx + c * gy, 0.0};
+            gltf_camera sub = parent;
+            sub.pan[0] = -gp[0] / (th * recentering_distance);
+            sub.pan[1] = -gp[1] / (tv * recentering_distance);
+            mat4d local = mat4d::identity();
+            for(int k = 0; k < 3; ++k) local.m[k][3] = gp[k] + (offset ? offset[k] : 0.0);
+            sub.transform = mul(parent.transform, local);
+            packed.push_back(pack_camera(sub, aspect));
+            grid.push_back(sub);
+        }
+    s.animation->cameras = grid;
+    s.cameras.resize(packed.size() * sizeof(camera_data));
+    std::memcpy(s.cameras.data(), packed.data(), s.cameras.size());
+    s.previous_cameras.clear();
+    return (uint32_t)packed.size();
 }
 
 //---------------------------------------------------------------------------------------------------------------------

@@ -707,6 +707,9 @@ public:
         bool skip_nan_check = false;
         unsigned first_frame_index = 0;
         unsigned display_count = 1;
+        // a view shard (one process per GPU, viewport v on rank v mod N): local layer l is display display_index_base + l *
+        // display_index_stride of display_count_total (0 = display_count) - what the file names are made of
+        unsigned display_index_base = 0, display_index_stride = 1, display_count_total = 0;
     };
 
     explicit headless(const options& opt): opt(opt) {}
@@ -736,7 +739,8 @@ public:
     std::string get_filename(unsigned display_index, unsigned frame_number) const
     {
         std::string filename = opt.output_prefix;                                       // src/headless.cc:305-309
-        if(opt.display_count > 1) filename += std::to_string(display_index) + "_";
+        if((opt.display_count_total ? opt.display_count_total : opt.display_count) > 1)
+            filename += std::to_string(opt.display_index_base + display_index * opt.display_index_stride) + "_";
         if(!opt.single_frame) filename += std::to_string(frame_number);
         return filename + (opt.output_file_type == EXR ? ".exr" : ".raw");
     }

@@ -9,10 +9,12 @@
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
 //              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1] [--renderer=path-tracer|direct]
+//              [--camera-grid=w,h,x,y --camera-recentering-distance=5 --camera-grid-roll=0]   (light-field grid, one file per view)
 //
 // One process per GPU (include/tauray_hip_comm.hh): start N copies with --process-count=N --process-rank=0..N-1 --device=<HIP index>
 // --comm-id=<file on a shared file system> (rank 0 writes the RCCL id there, the others wait for it); every rank renders its share
-// of each frame, the partial frames meet on rank 0 through trhip_gather_partials, rank 0 stitches, tonemaps and saves.
+// of each frame, the partial frames meet on rank 0 through trhip_gather_partials, rank 0 stitches, tonemaps and saves.  With
+// --shard=views the ranks divide the viewports of a camera grid instead (viewport v on rank v mod N) and save their own views.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -46,6 +48,9 @@ int main(int argc, char** argv)
         bool frames_given = false, animation_flag = false;      // --animation[=name] --framerate=F (src/options.hh:110-129)
         std::string animation_name;
         double framerate = 60.0;
+        int grid_w = 1, grid_h = 1;                                         // --camera-grid=w,h,x,y (src/options.hh camera_grid; generate_cameras)
+        double grid_dx = 0, grid_dy = 0, grid_recentering = 5.0, grid_roll = 0;
+        bool shard_views = false;                                           // --shard=views with --process-count: viewport v on rank v mod N
         int process_rank = -1, process_count = 0, process_device = 0;      // one process per GPU (see above)
         std::string comm_id_path;
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
@@ -91,6 +96,21 @@ int main(int argc, char** argv)
                 }
             }
             else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
+            else if(starts(a, "--camera-grid="))
+            {
+                std::stringstream ss(val("--camera-grid=")); std::string tok; std::vector<double> v;
+                while(std::getline(ss, tok, ',')) v.push_back(std::stod(tok));
+                if(v.size() != 4 || v[0] < 1 || v[1] < 1) throw std::runtime_error("--camera-grid=w,h,x,y");
+                grid_w = (int)v[0]; grid_h = (int)v[1]; grid_dx = v[2]; grid_dy = v[3];
+            }
+            else if(starts(a, "--camera-recentering-distance=")) grid_recentering = std::stod(val("--camera-recentering-distance="));
+            else if(starts(a, "--camera-grid-roll=")) grid_roll = std::stod(val("--camera-grid-roll="));
+            else if(starts(a, "--shard="))
+            {
+                const std::string v = val("--shard=");
+                if(v != "views" && v != "pixels") throw std::runtime_error("--shard=pixels|views");
+                shard_views = v == "views";
+            }
             else if(starts(a, "--process-rank=")) process_rank = std::stoi(val("--process-rank="));
             else if(starts(a, "--process-count=")) process_count = std::stoi(val("--process-count="));
             else if(starts(a, "--device=")) process_device = std::stoi(val("--device="));
@@ -152,6 +172,8 @@ int main(int argc, char** argv)
                             (scene_path.size() > 5 && scene_path.compare(scene_path.size() - 5, 5, ".gltf") == 0);
         scene_data scene = is_glb ? load_glb(scene_path, size.x, size.y) : load_scene_dump(scene_path);
         if(!envmap_path.empty()) set_envmap(scene, envmap_path);      // src/tauray.cc:198-201
+        uint32_t viewports = 1;
+        if(grid_w * grid_h > 1) viewports = generate_cameras(scene, grid_w, grid_h, grid_dx, grid_dy, grid_recentering, grid_roll);      // src/tauray.cc:680-727
         // play(scene, name, !replay, name == "") (src/tauray.cc:252-253); ticks in microseconds per update (:1052)
         scene_animator animator(scene);
         if(animation_flag) animator.play(animation_name, false);
@@ -184,10 +206,31 @@ int main(int argc, char** argv)
         if(!scene.has_tri_lights()) opt.sampling_weights.emissive_triangles = 0;
         opt.projection = (int)scene.projection;
         opt.samples_per_pass = std::min(opt.samples_per_pass, opt.samples_per_pixel);
-        opt.active_viewport_count = 1;
+        opt.active_viewport_count = viewports;
 
         opt.max_frames_in_flight = frames_in_flight;
-        hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = 1;
+        hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = viewports;
+        if(shard_views)
+        {   // view shards: viewport v belongs to rank v mod N; every rank renders, tonemaps and saves its own
+            // views under their global indices, nothing is exchanged
+            if(process_count < 1 || process_rank < 0 || process_rank >= process_count) throw std::runtime_error("--shard=views needs --process-count and --process-rank");
+            if(animated || renderer != "path-tracer") throw std::runtime_error("--shard=views renders still frames with the path tracer");
+            const uint32_t mine = viewports > (uint32_t)process_rank ? (viewports - (uint32_t)process_rank + (uint32_t)process_count - 1) / (uint32_t)process_count : 0;
+            if(mine == 0) return 0;
+            opt.active_viewport_count = mine;
+            hopt.display_count = mine; hopt.display_count_total = viewports; hopt.display_index_base = (unsigned)process_rank; hopt.display_index_stride = (unsigned)process_count;
+            headless vout(hopt);
+            rt_renderer rr({process_device}, scene, size, opt);
+            for(auto& sl: rr.per_device[0].slots) sl.ray_tracer->set_shard((uint32_t)process_rank, (uint32_t)process_count);
+            for(int f = -warmup; f < frames; ++f)
+            {
+                rr.reset_accumulation();
+                rr.render();
+                rr.finish_frame();
+                if(f >= 0) vout.save(*rr.per_device[0].dev, rr.display, (unsigned)f);
+            }
+            return 0;
+        }
         headless out(hopt);
         if(process_count > 0)
         {   // one process per GPU: this process is rank process_rank of process_count

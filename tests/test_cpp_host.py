@@ -197,6 +197,28 @@ def test_cpp_glb_loader_matches_python_loader(tmp_path):
     assert r.returncode == 1 and "not a GLB" in r.stderr
 
 
+def test_cpp_camera_grid_matches_python(tmp_path):
+    """generate_cameras (src/tauray.cc:680-727) in both hosts: `tauray_hip --camera-grid=w,h,x,y` leaves the camera blocks
+    tauray_amd.scene.generate_camera_grid packs (pan in the projection matrix and in camera_data.pan)."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import generate_camera_grid
+    glb = os.path.join(GOLDEN, "test.glb")
+    for (gw, gh, dx, dy, rec, roll) in ((3, 2, 0.02, 0.02, 5.0, 0.0), (9, 5, 0.02, 0.02, 5.0, 0.0), (2, 2, 0.1, 0.05, 3.0, 30.0)):
+        cpp = str(tmp_path / "grid.trsc")
+        subprocess.check_call([CLI, glb, "--width=160", "--height=90", f"--camera-grid={gw},{gh},{dx},{dy}", f"--camera-recentering-distance={rec}",
+                               f"--camera-grid-roll={roll}", f"--dump-scene={cpp}"])
+        d = open(cpp, "rb").read()
+        pos, secs = 8, []
+        for _ in range(12):
+            n = struct.unpack("<Q", d[pos:pos + 8])[0]
+            secs.append(d[pos + 8:pos + 8 + n]); pos += 8 + n
+        got = np.frombuffer(secs[10], np.float32).reshape(gw * gh, 80)
+        sc = load_glb(glb, 160, 90)
+        want = np.concatenate([c.pack() for c in generate_camera_grid(sc.cameras[0], gw, gh, dx, dy, rec, roll)]).view(np.float32).reshape(gw * gh, 80)
+        assert got.shape == want.shape and np.abs(got.astype(np.float64) - want).max() < 2e-6, (gw, gh)
+        assert np.abs(got[:, 76:78]).max() > 0      # the views are panned
+
+
 def test_cpp_animator_matches_python_animator(tmp_path):
     """tr::scene_animator (include/tauray_gltf.hh) against tauray_amd.animation.SceneAnimator on tests/golden/animated.glb: after
     the same number of updates at the same frame rate - default clip by fallback, the named clip "spin", a frame rate whose step
@@ -330,6 +352,35 @@ def test_textured_gltf_renders_the_same_through_both_hosts_and_like_the_oracle(t
     rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
     assert float((rel.max(-1) > 1e-2).mean()) <= 2e-3 and img[..., :3].mean() > 0.01
     assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / float(ref[..., :3].mean()) < 2e-3
+
+
+@pytest.mark.gpu
+def test_cpp_camera_grid_and_view_shards(tmp_path):
+    """BASELINE config 5's shape through the C++ host: a camera grid rendered as the layers of one launch (one file per view,
+    `prefix<view>_.raw`), equal to the Python mirror's views bit for bit; and divided among processes by views (--shard=views:
+    viewport v on rank v mod N, no exchange) the ranks write the same files."""
+    from tauray_amd import renderer as R
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene import generate_camera_grid
+    W, H, gw, gh = 96, 54, 3, 2
+    glb = os.path.join(GOLDEN, "test.glb")
+    scene = load_glb(glb, W, H)
+    scene.cameras = generate_camera_grid(scene.cameras[0], gw, gh, 0.02, 0.02, 5.0)
+    ctx = R.Context(0)
+    rr = R.RtRenderer(ctx, scene, R.options_for_scene(scene, max_bounces=4), (W, H), viewports=gw * gh)
+    rr.render()
+    ref = rr.download("display")
+    common = [glb, f"--width={W}", f"--height={H}", "--max-ray-depth=4", "--filetype=raw", f"--camera-grid={gw},{gh},0.02,0.02"]
+    prefix = str(tmp_path / "grid")
+    subprocess.check_call([CLI] + common + [f"--headless={prefix}"])
+    for v in range(gw * gh):
+        assert np.array_equal(np.fromfile(f"{prefix}{v}_.raw", dtype=np.float32).reshape(H, W, 4), ref[v]), v
+    assert not np.array_equal(ref[0], ref[gw * gh - 1])
+    sprefix = str(tmp_path / "shard")
+    for rank in range(4):      # four ranks for six views: 2, 2, 1, 1
+        subprocess.check_call([CLI] + common + [f"--headless={sprefix}", "--shard=views", "--process-count=4", f"--process-rank={rank}", "--device=0"])
+    for v in range(gw * gh):
+        assert np.array_equal(np.fromfile(f"{sprefix}{v}_.raw", dtype=np.float32).reshape(H, W, 4), ref[v]), ("shard", v)
 
 
 @pytest.mark.gpu
