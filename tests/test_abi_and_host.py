@@ -80,21 +80,6 @@ def test_glb_loader_flattening(test_glb_512):
     assert m["transmittance"][5] == 1.0 and m["albedo_tex_id"][7] == 0 and m["metallic_roughness_factor"][4, 0] == 1.0
 
 
-def test_pure_png_decoder_matches_pillow():
-    PIL = pytest.importorskip("PIL")
-    import io
-    from PIL import Image
-    from tauray_amd.gltf import _decode_png_pure
-    rng = np.random.default_rng(0)
-    for mode, ch in (("RGBA", 4), ("RGB", 3), ("L", 1), ("LA", 2)):
-        a = rng.integers(0, 256, size=(13, 17, ch), dtype=np.uint8)
-        a[:, :, 0] = np.cumsum(a[:, :, 0], axis=1)          # smooth-ish rows exercise the Sub/Up/Paeth filters
-        buf = io.BytesIO()
-        Image.fromarray(a.squeeze() if ch == 1 else a, mode).save(buf, format="PNG")
-        ref = np.array(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA"))
-        assert np.array_equal(_decode_png_pure(buf.getvalue()), ref)
-
-
 def test_camera_packing_and_grid(test_glb_512):
     from tauray_amd import scene as S
     cam = test_glb_512.cameras[0]

@@ -2019,13 +2019,17 @@ def test_set_device_workloads_resizes_python_shares(R, ctx):
 
 
 @pytest.mark.gpu
-def test_profiling_instances_render_the_same_frame(R, ctx):
+@pytest.mark.parametrize("workload", ["sponza_class_60k", "sponza_teapots"])
+def test_profiling_instances_render_the_same_frame(R, ctx, workload):
     """bench.py takes its work counters from the counting instances of the kernels (`k_trace_closest<true, ..>`, `k_shade<true, ..>`)
     and its kernel times from the serialised single-lane schedule (`k_trace_closest<false, true, ..>`, separate shadow launches):
-    both must render the frame of the production instances bit for bit, and count the same rays."""
+    both must render the frame of the production instances bit for bit, and count the same rays.  In the counting schedule the
+    shadow launch of bounce b runs on a side stream next to the closest-hit launch of bounce b + 1: on the million-triangle scene
+    traversal stacks reach 26 entries, past the 16 that live in LDS, so the quad tails of both kernels spill - into regions of
+    their own (PtStage::render), or this comparison fails."""
     from tauray_amd import scenes
     W, H = 640, 360
-    scene = scenes.sponza_class(seed=2, target_tris=60000, width=W, height=H)
+    scene = scenes.sponza_class(seed=2, target_tris=60000, width=W, height=H) if workload == "sponza_class_60k" else scenes.sponza_teapots(width=W, height=H)
     ss = R.SceneStage(ctx, scene)
     opt = R.options_for_scene(scene, max_bounces=4)
     frames, counters = {}, {}
