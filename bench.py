@@ -281,23 +281,26 @@ def main():
     if world > 1 and args.shard == "pixels":
         exchange_name = "torch.distributed (%s)" % args.dist_backend
         if args.exchange == "native" or (args.exchange == "auto" and args.dist_backend == "nccl"):
+            # creating the communicator is collective: first make sure every rank can take part (a rank that cannot load the
+            # library must not leave the others waiting inside ncclCommInitRank), then every rank or none
+            TC, err = None, None
             try:
                 from tauray_amd import comm as TC
+                TC.lib()
+            except Exception as e:
+                err = str(e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            if any(errs):
+                if args.exchange == "native":
+                    raise RuntimeError("native exchange unavailable: " + "; ".join(f"rank {i}: {e}" for i, e in enumerate(errs) if e))
+                if rank == 0:
+                    print("[bench] native exchange unavailable (" + "; ".join(e for e in errs if e) + "): torch.distributed carries the frames", file=sys.stderr)
+            else:
                 box = [TC.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 exchange = TC.NativeExchange(TC.Comm(local_rank, world, rank, box[0]))
                 exchange_name = "libtrhip_comm.so: trhip_gather_partials (grouped ncclSend / ncclRecv, RCCL)"
-            except Exception as e:
-                if args.exchange == "native":
-                    raise
-                print(f"[bench] rank {rank}: native exchange unavailable ({e}); torch.distributed carries the frames", file=sys.stderr)
-                exchange = None
-        ok = [exchange is not None]
-        oks = [None] * world
-        dist.all_gather_object(oks, ok[0])
-        if not all(oks):        # every rank or none
-            exchange = None
-            exchange_name = "torch.distributed (%s)" % args.dist_backend
 
     W, H = args.width, args.height
     scene = scenes.WORKLOADS[args.workload](W, H)
@@ -515,7 +518,10 @@ def main():
                 valu_peak = None
                 roof["valu_calibration_error"] = str(e)
             roof["valu_peak_measured_ginst_per_s"] = round(valu_peak, 1) if valu_peak else None
-            pmc, pmc_err = ({}, "switched off (--no-pmc)") if args.no_pmc else run_pmc_passes(args, B, args.pmc_dump)
+            if world > 1:       # a shard's launches are not the launches of the N = 1 line: the counter passes belong to that line
+                pmc, pmc_err = {}, "N > 1: the counter passes (VALU / L2 / fabric levels) are part of the N = 1 line"
+            else:
+                pmc, pmc_err = ({}, "switched off (--no-pmc)") if args.no_pmc else run_pmc_passes(args, B, args.pmc_dump)
             if pmc_err:
                 roof["pmc_error"] = pmc_err
             lv = level_fractions(pmc.get("k_trace_closest"), avg_ms, valu_peak)

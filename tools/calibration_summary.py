@@ -50,7 +50,8 @@ def main(src, dst):
     f = {}
     for c in out["configs"]:
         p, k = c["plain"], c["counters"]
-        tag = p["kernel"] + (":" + p["footprint"] if "footprint" in p else "") + (":w%d" % p["waves_per_simd"] if "waves_per_simd" in p else "")
+        tag = p["kernel"] + (":" + p["footprint"] if "footprint" in p else "") + (":w%d" % p["waves_per_simd"] if "waves_per_simd" in p else "") \
+            + (":%s:%dnodes" % (p["variant"], p["nodes"]) if "variant" in p else "")
         d = {}
         if "wave_insts" in p:
             if k.get("SQ_INSTS_VALU"):
@@ -62,6 +63,9 @@ def main(src, dst):
             d["ginst_per_s"] = p["ginst_per_s"]
         else:
             nbytes = p.get("bytes", p.get("bytes_lines_128"))
+            if nbytes is None:      # k_cal_gather_var: lines of 128 bytes touched = visits (a node never straddles a line)
+                nbytes = p["visits"] * 128.0
+                d["Gvisits_per_s"] = p["Gvisits_per_s"]
             for cn in ("TCP_TCC_READ_REQ_sum", "TCC_EA0_RDREQ_sum", "TCC_REQ_sum", "TCC_READ_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum"):
                 if k.get(cn):
                     d["bytes_per_" + cn] = round(nbytes / k[cn], 2)

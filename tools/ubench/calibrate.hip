@@ -114,6 +114,24 @@ __global__ __launch_bounds__(256) void k_cal_gather_node(const char* __restrict_
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// The same gather with NLOAD dwordx4 per visit from nodes of NODE_BYTES (what would a smaller node buy: 64-byte nodes read with
+// four loads, 32-byte ones with two?).  The chain is dependent like a traversal.
+template <int NLOAD, int NODE_SHIFT>
+__global__ __launch_bounds__(256) void k_cal_gather_var(const char* __restrict__ base, uint32_t nodes, int visits, float* out) {
+    uint32_t h = pcg(blockIdx.x * 256u + threadIdx.x + 1u);
+    float s = 0;
+    for (int v = 0; v < visits; ++v) {
+        const uint32_t node = h % nodes;
+        const float4* p = reinterpret_cast<const float4*>(base + ((size_t)node << NODE_SHIFT));
+        float4 last = p[0];
+        s += last.x;
+#pragma unroll
+        for (int k = 1; k < NLOAD; ++k) { const float4 q = p[k]; s += q.y; last = q; }
+        h = pcg(h + (uint32_t)__float_as_uint(last.w));
+    }
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 template <class F>
 static double time_ms(int reps, F&& launch) {
     hipEvent_t a, b;
@@ -186,6 +204,25 @@ int main(int argc, char** argv) {
         const double visits = (double)blocks * 256.0 * s.passes;
         printf("{\"kernel\": \"k_cal_gather_node\", \"footprint\": \"%s\", \"visits\": %.0f, \"bytes_112\": %.0f, \"bytes_lines_128\": %.0f, \"ms\": %.4f, \"Gvisits_per_s\": %.2f, \"GBps_112\": %.1f}\n",
                s.tag, visits, visits * 112.0, visits * 128.0, ms, visits / ms / 1e6, visits * 112.0 / ms / 1e6);
+    }
+    // ---- what the node size and the loads per visit cost: the structure of sponza_teapots holds 378 k live nodes of 128 bytes + 48 MB
+    // of triangles; here the same NUMBER of nodes (1 M, 4 M) at 128 / 64 / 32 bytes each, six waves per SIMD
+    {
+        const int blocks = cus * 6, visits = 64;
+        const double nv = (double)blocks * 256.0 * visits;
+        for (uint32_t nodes : {1u << 20, 1u << 22}) {
+            auto run = [&](const char* tag, int bytes, int loads, auto kernel) {
+                const double ms = time_ms(reps, [&] { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, buf, nodes, visits, out); });
+                printf("{\"kernel\": \"k_cal_gather_var\", \"variant\": \"%s\", \"nodes\": %u, \"node_bytes\": %d, \"loads_per_visit\": %d, \"footprint_MB\": %.0f, \"visits\": %.0f, \"ms\": %.4f, \"Gvisits_per_s\": %.2f}\n",
+                       tag, nodes, bytes, loads, (double)nodes * bytes / 1e6, nv, ms, nv / ms / 1e6);
+            };
+            run("128B_7loads", 128, 7, k_cal_gather_var<7, 7>);
+            run("128B_4loads", 128, 4, k_cal_gather_var<4, 7>);
+            run("128B_1load", 128, 1, k_cal_gather_var<1, 7>);
+            run("64B_4loads", 64, 4, k_cal_gather_var<4, 6>);
+            run("64B_2loads", 64, 2, k_cal_gather_var<2, 6>);
+            run("32B_2loads", 32, 2, k_cal_gather_var<2, 5>);
+        }
     }
     return 0;
 }
