@@ -1,4 +1,4 @@
-// tauray_envmap.hh - `--envmap=file.hdr` for the C++ host layer (src/options.hh:125): a Radiance .hdr file becomes the lat-long
+// tauray_envmap.hh - `--envmap=file.hdr|file.exr` for the C++ host layer (src/options.hh:125): a Radiance .hdr or OpenEXR file becomes the lat-long
 // environment map of a tr::scene_data, with the alias table environment_map::generate_alias_table builds for importance sampling
 // (src/environment_map.cc:39-140, importance = shader/alias_table_importance.comp:16-28 evaluated on the host).
 // Same results as the Python mirror (tauray_amd/hdr.py, tauray_amd/scene.py build_alias_table), operation by operation:
@@ -11,6 +11,7 @@
 #include <sstream>
 
 #include "tauray_hip.hh"
+#include "tauray_exr.hh"
 
 namespace tr
 {
@@ -86,7 +87,10 @@ inline std::vector<float> load_hdr(const std::string& path, uint32_t& width, uin
     {
         const int e = rgbe[i * 4 + 3];
         const float scale = e != 0 ? std::ldexp(1.0f, e - 136) : 0.0f;
-        for(int c = 0; c < 3; ++c) out[i * 4 + (size_t)c] = (float)rgbe[i * 4 + (size_t)c] * scale;
+        // "16-bit floats for hdr images" (src/texture.cc:498-500 -> :50-66): clamped to +-65000, rounded to half.  Exact for the
+        // 8-bit mantissas of RGBE except beyond the clamp (a sun disc) and below 2^-24.
+        for(int c = 0; c < 3; ++c)
+            out[i * 4 + (size_t)c] = exr::half_to_float(exr::float_to_half(std::min(std::max((float)rgbe[i * 4 + (size_t)c] * scale, -65000.0f), 65000.0f)));
         out[i * 4 + 3] = 1.0f;
     }
     return out;
@@ -166,7 +170,18 @@ inline std::vector<uint8_t> build_alias_table(const float* rgba, uint32_t w, uin
 inline void set_envmap(scene_data& s, const std::string& path)
 {
     uint32_t w = 0, h = 0;
-    const std::vector<float> px = load_hdr(path, w, h);
+    std::vector<float> px;
+    if(path.size() >= 4 && path.compare(path.size() - 4, 4, ".exr") == 0)
+    {
+        // texture::load_from_file, the `.exr` branch (src/texture.cc:409-429): floats as they are, alpha 1 appended to three channels
+        int n = 0;
+        const std::vector<float> f = exr::load_exr(path, w, h, n);
+        if(n != 3 && n != 4) throw std::runtime_error(path + ": an environment map needs three or four channels");
+        px.resize(size_t(w) * h * 4);
+        for(size_t i = 0; i < size_t(w) * h; ++i)
+            for(int c = 0; c < 4; ++c) px[4 * i + c] = c < n ? f[size_t(n) * i + c] : 1.0f;
+    }
+    else px = load_hdr(path, w, h);
     const uint8_t* p = reinterpret_cast<const uint8_t*>(px.data());
     s.envmap.assign(p, p + px.size() * 4);
     s.envmap_width = w; s.envmap_height = h;

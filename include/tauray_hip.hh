@@ -30,6 +30,7 @@
 #endif
 
 #include "trhip.h"
+#include "tauray_exr.hh"
 
 namespace tr
 {
@@ -685,16 +686,15 @@ using direct_renderer = basic_rt_renderer<direct_stage>;        // direct_render
 
 //==============================================================================
 // headless (src/headless.{hh,cc}): readback + writers.  EXR: scanline file, channels B,G,R[,A] like the reference's,
-// half or float, stored uncompressed or deflated (ZIPS: one scanline per chunk, ZIP: sixteen).  The reference's writer
-// defaults to PIZ (src/headless.hh:56); wavelet coding is not on the hot path and is left out: ZIP is the default here,
-// every EXR reader takes it, and `--compression=none` gives the raw scanlines.
+// half or float, every codec of src/headless.hh:25-32 (include/tauray_exr.hh); PIZ is the default as in the reference
+// (src/headless.hh:56).
 //==============================================================================
 class headless
 {
 public:
     enum image_file_type { EXR = 0, RAW, EMPTY };
     enum pixel_format { RGB16, RGB32, RGBA16, RGBA32 };
-    enum compression_type { NONE = 0, ZIPS = 2, ZIP = 3 };   // values = OpenEXR compression codes; subset of src/headless.hh:25-32
+    enum compression_type { NONE = 0, RLE = 1, ZIPS = 2, ZIP = 3, PIZ = 4 };   // values = OpenEXR compression codes (src/headless.hh:25-32)
 
     struct options
     {
@@ -702,7 +702,7 @@ public:
         std::string output_prefix = "capture";
         image_file_type output_file_type = EXR;
         pixel_format output_format = RGB16;
-        compression_type output_compression = ZIP;      // the reference defaults to PIZ (src/headless.hh:56), see above
+        compression_type output_compression = PIZ;      // src/headless.hh:56
         bool single_frame = false;
         bool skip_nan_check = false;
         unsigned first_frame_index = 0;
@@ -714,27 +714,7 @@ public:
 
     explicit headless(const options& opt): opt(opt) {}
 
-    static uint16_t float_to_half(float f)
-    {
-        uint32_t x; std::memcpy(&x, &f, 4);
-        uint32_t sign = (x >> 16) & 0x8000u, man = x & 0x7FFFFFu;
-        int32_t exp = (int32_t)((x >> 23) & 0xFF);
-        if(exp == 255) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
-        exp = exp - 127 + 15;
-        if(exp >= 31) return (uint16_t)(sign | 0x7C00u);
-        if(exp <= 0)
-        {
-            if(exp < -10) return (uint16_t)sign;
-            man |= 0x800000u;
-            int shift = 14 - exp;
-            uint32_t h = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
-            if(rem > half || (rem == half && (h & 1))) h++;
-            return (uint16_t)(sign | h);
-        }
-        uint32_t h = ((uint32_t)exp << 10) | (man >> 13), rem = man & 0x1FFFu;
-        if(rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
-        return (uint16_t)(sign | h);
-    }
+    static uint16_t float_to_half(float f) { return exr::float_to_half(f); }
 
     std::string get_filename(unsigned display_index, unsigned frame_number) const
     {
@@ -787,86 +767,11 @@ private:
         f.write(reinterpret_cast<const char*>(img), (std::streamsize)(pixels * 16));
     }
 
-    // A deflated EXR chunk: the bytes of the chunk split into even and odd positions (first half | second half), each byte
-    // replaced by its difference to the one before (biased by 128), then zlib.  A chunk that does not shrink is stored raw.
-    static void deflate_chunk(const std::vector<uint8_t>& raw, std::vector<uint8_t>& out)
-    {
-        const size_t n = raw.size(), half = (n + 1) / 2;
-        std::vector<uint8_t> planar(n);
-        for(size_t i = 0; i < n; ++i) planar[(i & 1) ? half + i / 2 : i / 2] = raw[i];
-        for(size_t i = n; i-- > 1;) planar[i] = (uint8_t)(planar[i] - planar[i - 1] + 128);
-        out.clear();
-#ifdef TAURAY_HIP_WITH_ZLIB
-        uLongf len = compressBound((uLong)n);
-        out.resize(len);
-        if(compress(out.data(), &len, planar.data(), (uLong)n) != Z_OK) throw std::runtime_error("EXR: zlib compress failed");
-        out.resize(len);
-#endif
-        if(out.empty() || out.size() >= n) out = raw;
-    }
-
     void write_exr(const std::string& filename, const float* img) const
     {
         const bool alpha = opt.output_format == RGBA16 || opt.output_format == RGBA32;
         const bool half = opt.output_format == RGB16 || opt.output_format == RGBA16;
-        const int nch = alpha ? 4 : 3;
-        const char* names[4] = {"A", "B", "G", "R"};          // alphabetical = file order
-        const int src[4] = {3, 2, 1, 0};
-        const int first = alpha ? 0 : 1;
-        std::vector<uint8_t> out;
-        auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; out.insert(out.end(), b, b + n); };
-        auto put_i32 = [&](int32_t v) { put(&v, 4); };
-        auto put_str = [&](const char* s) { put(s, std::strlen(s) + 1); };
-        auto attr = [&](const char* name, const char* type, int32_t size) { put_str(name); put_str(type); put_i32(size); };
-        put_i32(20000630); put_i32(2);
-        attr("channels", "chlist", nch * (2 + 16) + 1);
-        for(int c = first; c < 4; ++c)
-        {
-            put_str(names[c]);
-            put_i32(half ? 1 : 2); uint8_t plinear[4] = {0, 0, 0, 0}; put(plinear, 4); put_i32(1); put_i32(1);
-        }
-        uint8_t zero = 0; put(&zero, 1);
-        const compression_type comp = opt.output_compression;
-        if(comp != NONE && comp != ZIPS && comp != ZIP) throw std::runtime_error("EXR: unsupported compression");
-        const uint8_t exr_code = (uint8_t)comp;
-        const uint32_t lines = comp == ZIP ? 16u : 1u;      // scanlines per chunk
-#ifndef TAURAY_HIP_WITH_ZLIB
-        if(comp == ZIP || comp == ZIPS) throw std::runtime_error("EXR zip compression needs a build with TAURAY_HIP_WITH_ZLIB");
-#endif
-        attr("compression", "compression", 1); put(&exr_code, 1);
-        int32_t box[4] = {0, 0, (int32_t)opt.size.x - 1, (int32_t)opt.size.y - 1};
-        attr("dataWindow", "box2i", 16); put(box, 16);
-        attr("displayWindow", "box2i", 16); put(box, 16);
-        attr("lineOrder", "lineOrder", 1); put(&zero, 1);
-        float one = 1.0f, origin[2] = {0, 0};
-        attr("pixelAspectRatio", "float", 4); put(&one, 4);
-        attr("screenWindowCenter", "v2f", 8); put(origin, 8);
-        attr("screenWindowWidth", "float", 4); put(&one, 4);
-        put(&zero, 1);
-        const uint32_t n_blocks = (opt.size.y + lines - 1) / lines;
-        const size_t table_pos = out.size();
-        out.resize(out.size() + 8 * size_t(n_blocks));
-        std::vector<uint8_t> raw, packed;
-        for(uint32_t b = 0; b < n_blocks; ++b)
-        {
-            const uint32_t y0 = b * lines, y1 = std::min(opt.size.y, y0 + lines);
-            raw.clear();
-            for(uint32_t y = y0; y < y1; ++y)
-                for(int c = first; c < 4; ++c)
-                    for(uint32_t x = 0; x < opt.size.x; ++x)
-                    {
-                        float v = img[(size_t(y) * opt.size.x + x) * 4 + src[c]];
-                        if(half) { uint16_t h = float_to_half(v); raw.insert(raw.end(), (uint8_t*)&h, (uint8_t*)&h + 2); }
-                        else raw.insert(raw.end(), (uint8_t*)&v, (uint8_t*)&v + 4);
-                    }
-            packed.clear();
-            if(comp == NONE) packed = raw;
-            else deflate_chunk(raw, packed);
-            uint64_t off = out.size();
-            std::memcpy(out.data() + table_pos + 8 * size_t(b), &off, 8);
-            put_i32((int32_t)y0); put_i32((int32_t)packed.size());
-            put(packed.data(), packed.size());
-        }
+        const std::vector<uint8_t> out = exr::encode(img, opt.size.x, opt.size.y, alpha, half, (int)opt.output_compression);
         std::ofstream f(filename, std::ios::binary);
         if(!f) throw std::runtime_error("Failed to write " + filename);
         f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());

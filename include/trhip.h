@@ -59,6 +59,16 @@ int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, con
 int trhip_image_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels_in_file, uint8_t** rgba_out);
 void trhip_image_free(uint8_t* rgba);
 
+/* OpenEXR files (include/tauray_exr.hh; what tinyexr is to the reference).  trhip_exr_decode = read_exr of src/texture.cc:70-163:
+ * a single-part scanline or tiled file (NONE / RLE / ZIPS / ZIP / PIZ; HALF, FLOAT or UINT channels) becomes interleaved floats,
+ * *channels of them per pixel (at most four: R, G, B, A by the first letter of the channel names, or file order when a channel is
+ * called anything else), row 0 = top of the data window.  trhip_exr_encode = the file headless::save_image writes
+ * (src/headless.cc:355-412) from RGBA32F pixels: channels [A,] B, G, R as half or float; compression = the OpenEXR code
+ * (0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ - the reference's default, src/headless.hh:56).  Results are released with trhip_exr_free. */
+int trhip_exr_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels, float** pixels_out);
+int trhip_exr_encode(const float* rgba, uint32_t width, uint32_t height, int alpha, int half, int compression, uint8_t** bytes_out, size_t* size_out);
+void trhip_exr_free(void* p);
+
 /* ---- scene (replaces scene_stage::update's uploads, src/scene_stage.cc:1026-1496) */
 typedef struct trhip_scene_desc {
     const void* instances;            /* 288-byte `instance` records (shader/scene.glsl:43-53) */

@@ -85,6 +85,9 @@ _vp, _u32, _i, _f = C.c_void_p, C.c_uint32, C.c_int, C.c_float
 SYMBOLS = {
     "trhip_image_decode": (_i, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.POINTER(C.c_uint8))]),
     "trhip_image_free": (None, [C.POINTER(C.c_uint8)]),
+    "trhip_exr_decode": (_i, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.POINTER(C.c_float))]),
+    "trhip_exr_encode": (_i, [_vp, _u32, _u32, _i, _i, _i, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
+    "trhip_exr_free": (None, [_vp]),
     "trhip_device_create": (_i, [_i, C.POINTER(_vp)]),
     "trhip_device_destroy": (None, [_vp]),
     "trhip_last_error": (C.c_char_p, []),

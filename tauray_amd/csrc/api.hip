@@ -10,6 +10,7 @@
 #include "trace.h"
 #include "trace_quad.h"
 #include "../../include/tauray_image.hh"
+#include "../../include/tauray_exr.hh"
 
 namespace tr {
 
@@ -268,6 +269,32 @@ int trhip_image_decode(const void* data, size_t bytes, uint32_t* width, uint32_t
     return 0;
 }
 void trhip_image_free(uint8_t* rgba) { free(rgba); }
+
+int trhip_exr_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels, float** pixels_out) {
+    if (!data || !width || !height || !channels || !pixels_out) return set_error("trhip_exr_decode: null argument");
+    try {
+        const tr::exr::image img = tr::exr::read(static_cast<const uint8_t*>(data), bytes);
+        int n = 0;
+        const std::vector<float> px = tr::exr::interleave_like_read_exr(img, n);
+        float* p = static_cast<float*>(malloc(px.size() ? px.size() * 4 : 4));
+        if (!p) return set_error("trhip_exr_decode: out of memory");
+        memcpy(p, px.data(), px.size() * 4);
+        *width = (uint32_t)img.width; *height = (uint32_t)img.height; *channels = (uint32_t)n; *pixels_out = p;
+    } catch (const std::exception& e) { return set_error(e.what()); }
+    return 0;
+}
+int trhip_exr_encode(const float* rgba, uint32_t width, uint32_t height, int alpha, int half, int compression, uint8_t** bytes_out, size_t* size_out) {
+    if (!rgba || !bytes_out || !size_out || !width || !height) return set_error("trhip_exr_encode: null argument or empty image");
+    try {
+        const std::vector<uint8_t> b = tr::exr::encode(rgba, width, height, alpha != 0, half != 0, compression);
+        uint8_t* p = static_cast<uint8_t*>(malloc(b.size()));
+        if (!p) return set_error("trhip_exr_encode: out of memory");
+        memcpy(p, b.data(), b.size());
+        *bytes_out = p; *size_out = b.size();
+    } catch (const std::exception& e) { return set_error(e.what()); }
+    return 0;
+}
+void trhip_exr_free(void* p) { free(p); }
 
 int trhip_device_create(int hip_device, trhip_device** out) {
     if (!out) return set_error("trhip_device_create: null out");

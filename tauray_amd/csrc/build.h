@@ -39,6 +39,7 @@ struct DeviceScene {
     // built by trhip_scene_build_accel
     BvhNode* nodes = nullptr;
     Bvh4Node* nodes4 = nullptr;
+    Bvh4NodeQ* nodesq = nullptr;         // TR_QNODES: quantised copy of nodes4 (built after the collapse and after every refit)
     f4* treetop = nullptr;               // top four levels of nodes4 for the LDS of the trace kernels (TR_TOP_SLOTS)
     bool use_treetop = false;            // set by every build / refit: true only with TRHIP_TREETOP=1 (measured slower)
     TriRecord* tris = nullptr;
@@ -72,7 +73,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4; v.nodesq = nodesq;
         v.treetop = (use_treetop && accel_built && node_count > 0) ? treetop : nullptr;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
@@ -83,6 +84,8 @@ struct DeviceScene {
     void free_accel() {
         if (nodes) (void)hipFree(nodes);
         if (nodes4) (void)hipFree(nodes4);
+        if (nodesq) (void)hipFree(nodesq);
+        nodesq = nullptr;
         if (treetop) (void)hipFree(treetop);
         treetop = nullptr;
         if (tris) (void)hipFree(tris);

@@ -375,6 +375,58 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
 }
 
 
+// Bvh4Node -> Bvh4NodeQ (TR_QNODES).  Per axis: origin = the smallest lo of the node's children, scale = the smallest power of two
+// with (largest hi - origin) / scale <= 255 (and large enough that origin + 255 * scale > origin, so an empty slot's inverted box
+// stays inverted), q_lo = floor, q_hi = ceil - each then stepped outwards until the plane the traversal will reconstruct,
+// rn(origin + q * scale), is on or outside the fp32 plane.
+__global__ __launch_bounds__(BT) void k_quantize4(uint n_nodes, const Bvh4Node* nodes4, Bvh4NodeQ* out) {
+    const uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_nodes) return;
+    const Bvh4Node nd = nodes4[i];
+    const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+    const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+    Bvh4NodeQ q;
+    q.exps = 0;
+    for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
+    q.pad[0] = q.pad[1] = 0;
+    for (int k = 0; k < 3; ++k) {
+        float o = __builtin_huge_valf(), top = -__builtin_huge_valf();
+        for (int c = 0; c < 4; ++c) if (nd.child[c] != 0x7FFFFFFF && lo[k][c] <= hi[k][c]) { o = fminf(o, lo[k][c]); top = fmaxf(top, hi[k][c]); }
+        if (!(o <= top)) { o = 0.0f; top = 0.0f; }      // a node without valid children (never traversed)
+        // exponent: 2^(e - 127) * 255 >= top - o; at least 2^-100, and at least one ulp of the origin
+        int e = 0;
+        (void)frexpf((top - o) / 255.0f, &e);            // (top - o) / 255 = m * 2^e, m in [0.5, 1): 2^e is the first power of two above it
+        int oe = 0;
+        (void)frexpf(fabsf(o), &oe);
+        e = max(e, oe - 22);
+        e = min(max(e + 127, 27), 254);
+        uint qlo = 0, qhi = 0;
+        while (true) {
+            const float scale = __uint_as_float((uint)e << 23);
+            bool fits = true;
+            qlo = 0; qhi = 0;
+            for (int c = 0; c < 4 && fits; ++c) {
+                uint a = 255u, b = 0u;                   // empty slot: inverted
+                if (nd.child[c] != 0x7FFFFFFF && lo[k][c] <= hi[k][c]) {
+                    float fa = floorf((lo[k][c] - o) / scale), fb = ceilf((hi[k][c] - o) / scale);
+                    fa = fminf(fmaxf(fa, 0.0f), 255.0f); fb = fminf(fmaxf(fb, 0.0f), 255.0f);
+                    a = (uint)fa; b = (uint)fb;
+                    while (a > 0u && o + (float)a * scale > lo[k][c]) --a;
+                    while (b < 255u && o + (float)b * scale < hi[k][c]) ++b;
+                    if (o + (float)a * scale > lo[k][c] || o + (float)b * scale < hi[k][c]) fits = false;
+                }
+                qlo |= a << (8 * c); qhi |= b << (8 * c);
+            }
+            if (fits || e >= 254) break;
+            ++e;
+        }
+        q.origin[k] = o;
+        q.exps |= (uint)e << (8 * k);
+        q.q[2 * k] = qlo; q.q[2 * k + 1] = qhi;
+    }
+    out[i] = q;
+}
+
 // shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
 __global__ __launch_bounds__(BT) void k_extract_tri_lights(SceneView sv, const uint* tri_prefix, TriLight* out) {
     uint gid = blockIdx.x * BT + threadIdx.x;
@@ -647,6 +699,9 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         const uint lo = ds.level_offsets[l - 1], cnt = ds.level_offsets[l] - lo;
         if (cnt) hipLaunchKernelGGL(k_refit_level, dim3((cnt + BT - 1) / BT), dim3(BT), 0, stream, cnt, ds.level_nodes + lo, ds.nodes4, ds.tris, ds.node_bounds);
     }
+#if TR_QNODES
+    if (n1 > 0 && ds.nodesq) hipLaunchKernelGGL(k_quantize4, dim3((n1 + BT - 1) / BT), dim3(BT), 0, stream, n1, ds.nodes4, ds.nodesq);
+#endif
     HIPCHK(hipGetLastError());
     if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
@@ -923,6 +978,10 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                     dec = reinterpret_cast<const uint8_t*>(base + o_cdec);
                 }
                 hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, dec, ds.nodes4);
+#if TR_QNODES
+                if (!ds.nodesq) HIPCHK(hipMalloc(&ds.nodesq, n1 * sizeof(Bvh4NodeQ)));
+                hipLaunchKernelGGL(k_quantize4, dim3(iblocks), dim3(BT), 0, stream, n - 1, ds.nodes4, ds.nodesq);
+#endif
 #else
                 hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
 #endif

@@ -161,6 +161,28 @@ struct alignas(128) Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
 
+// The same node with the child boxes quantised to 8 bits per plane against the node's own frame (experiment, TR_QNODES = 1): 64 bytes,
+// two nodes per cache line, four loads per visit instead of seven.  plane = origin_k + q * scale_k with scale_k = 2^(e_k - 127)
+// a power of two (q * scale is exact, the sum rounds once); the builder chooses q so that the plane *as the traversal reconstructs
+// it* lies on or outside the fp32 plane, so the quantised box contains the exact one and hits do not change.  Child references and
+// empty slots (inverted box: lo bytes 255, hi bytes 0) as in Bvh4Node.
+#ifndef TR_QNODES
+#define TR_QNODES 0
+#endif
+struct alignas(64) Bvh4NodeQ {
+    float origin[3];
+    uint exps;            // biased exponents of the three scales: e_x | e_y << 8 | e_z << 16
+    int child[4];
+    uint q[6];            // lox, hix, loy, hiy, loz, hiz; byte c of a word = child c
+    uint pad[2];
+};
+static_assert(sizeof(Bvh4NodeQ) == 64, "Bvh4NodeQ layout");
+#if TR_QNODES
+#define TR_NODES_OF(sv) reinterpret_cast<const Bvh4Node*>((sv).nodesq)
+#else
+#define TR_NODES_OF(sv) (sv).nodes4
+#endif
+
 // Treetop: the top four levels of the 4-wide tree (1 + 4 + 16 + 64 = 85 slots of an implicit complete 4-ary layout, the
 // children of slot s are slots 4 s + 1 ..) copied into the LDS of every trace block.  Stored plane by plane
 // (plane p of slot s at 16 * (p * TR_TOP_SLOTS + s) bytes: planes 0..5 = lox, hix, loy, hiy, loz, hiz rows of the node,
@@ -201,6 +223,7 @@ struct SceneView {
     const BvhNode* nodes;
     const TriRecord* tris;
     const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)
+    const Bvh4NodeQ* nodesq;     // TR_QNODES builds: the quantised copy the traversal reads (same indices)
     const f4* treetop;           // TR_TOP_WORDS floats, see TR_TOP_SLOTS; null = none (queries start at node 0 of nodes4)
     f4 environment_factor;
     int environment_proj;

@@ -354,7 +354,32 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
         c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
         // pins the LDS reads: merged with the other branch they would become flat loads through a selected pointer
         asm volatile("" : "+v"(nxv.x), "+v"(fxv.x), "+v"(nyv.x), "+v"(fyv.x), "+v"(nzv.x), "+v"(fzv.x), "+v"(c0));
-    } else {
+    }
+#if TR_QNODES
+    else {
+        // 64-byte quantised node (common.h Bvh4NodeQ): header, children, 6 x 4 plane bytes in four loads; planes reconstructed as
+        // origin + q * scale (one rounding, the same the builder's conservative choice of q assumed)
+        const char* base = reinterpret_cast<const char*>(nodes);
+        const uint t = (uint)node << 6;
+        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
+        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 16);
+        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
+        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
+        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+        const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
+        const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
+        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
+        const uint qnx = gx ? p0.y : p0.x, qfx = gx ? p0.x : p0.y, qny = gy ? p0.w : p0.z, qfy = gy ? p0.z : p0.w, qnz = gz ? p1.y : p1.x, qfz = gz ? p1.x : p1.y;
+#define TR_QP(w, k, s, o) __builtin_fmaf((float)(((w) >> (8 * (k))) & 0xFFu), s, o)
+        nxv = f4{TR_QP(qnx, 0, sx, ox), TR_QP(qnx, 1, sx, ox), TR_QP(qnx, 2, sx, ox), TR_QP(qnx, 3, sx, ox)};
+        fxv = f4{TR_QP(qfx, 0, sx, ox), TR_QP(qfx, 1, sx, ox), TR_QP(qfx, 2, sx, ox), TR_QP(qfx, 3, sx, ox)};
+        nyv = f4{TR_QP(qny, 0, sy, oy), TR_QP(qny, 1, sy, oy), TR_QP(qny, 2, sy, oy), TR_QP(qny, 3, sy, oy)};
+        fyv = f4{TR_QP(qfy, 0, sy, oy), TR_QP(qfy, 1, sy, oy), TR_QP(qfy, 2, sy, oy), TR_QP(qfy, 3, sy, oy)};
+        nzv = f4{TR_QP(qnz, 0, sz, oz), TR_QP(qnz, 1, sz, oz), TR_QP(qnz, 2, sz, oz), TR_QP(qnz, 3, sz, oz)};
+        fzv = f4{TR_QP(qfz, 0, sz, oz), TR_QP(qfz, 1, sz, oz), TR_QP(qfz, 2, sz, oz), TR_QP(qfz, 3, sz, oz)};
+    }
+#else
+    else {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = (uint)node << 7;
         uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
@@ -367,6 +392,7 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
         const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
         c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
     }
+#endif
     const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
     const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
 #pragma unroll
@@ -418,7 +444,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             }
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, best_t, h);
+                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, best_t, h);
                 if (COUNT) st.nodes++;
                 TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                 if (h.t[0] < __builtin_huge_valf()) {
@@ -492,7 +518,7 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     while (true) {
         if (node >= 0) {
             Hit4 h;
-            box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, tmax, h);
+            box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
             if (COUNT) st.nodes++;
             int next = 0x7FFFFFFF;
 #pragma unroll

@@ -87,7 +87,25 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* 
         nz = *reinterpret_cast<const float*>(lb + r.noz * TR_TOP_SLOTS + s); fz = *reinterpret_cast<const float*>(lb + (r.noz ^ 16u) * TR_TOP_SLOTS + s);
         c = *reinterpret_cast<const int*>(lb + 96u * TR_TOP_SLOTS + s);
         asm volatile("" : "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz), "+v"(c));
-    } else {
+    }
+#if TR_QNODES
+    else {
+        const char* base = reinterpret_cast<const char*>(nodes);
+        const uint t = (uint)node << 6;
+        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
+        c = *reinterpret_cast<const int*>(base + (size_t)t + 16 + ((uint)q << 2));
+        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
+        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
+        const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
+        const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
+        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;
+        const uint sh = (uint)q << 3;
+        nx = __builtin_fmaf((float)(((gx ? p0.y : p0.x) >> sh) & 0xFFu), sx, ox); fx = __builtin_fmaf((float)(((gx ? p0.x : p0.y) >> sh) & 0xFFu), sx, ox);
+        ny = __builtin_fmaf((float)(((gy ? p0.w : p0.z) >> sh) & 0xFFu), sy, oy); fy = __builtin_fmaf((float)(((gy ? p0.z : p0.w) >> sh) & 0xFFu), sy, oy);
+        nz = __builtin_fmaf((float)(((gz ? p1.y : p1.x) >> sh) & 0xFFu), sz, oz); fz = __builtin_fmaf((float)(((gz ? p1.x : p1.y) >> sh) & 0xFFu), sz, oz);
+    }
+#else
+    else {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = ((uint)node << 7) | ((uint)q << 2);
         uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
@@ -97,6 +115,7 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* 
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
         c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
     }
+#endif
     // the arithmetic of box4_intersect for one child
     const float tx0 = (nx - r.org.x) * r.inv_dir.x, tx1 = (fx - r.org.x) * r.inv_dir.x;
     const float ty0 = (ny - r.org.y) * r.inv_dir.y, ty1 = (fy - r.org.y) * r.inv_dir.y;
@@ -263,13 +282,17 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 bool descend = false;
                 if (!at_leaf) {
                     Hit4 h;
-                    box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, best_t, h);
+                    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, best_t, h);
                     if (COUNT) st.nodes++;
                     TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                     if (h.t[0] < __builtin_huge_valf()) {
                         if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
                         if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
-                        if (h.t[1] < __builtin_huge_valf()) { stk.push(spill, h.c[1]); if (TR_PREFETCH >= 1) prefetch_ref(sv, h.c[1]); }
+                        if (h.t[1] < __builtin_huge_valf()) { stk.push(spill, h.c[1]); if (TR_PREFETCH == 1 || TR_PREFETCH == 2) prefetch_ref(sv, h.c[1]); }
+                        if (TR_PREFETCH == 3) {      // the triangle records of the leaf children this phase found: they wait for the wave's next triangle phase
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (h.t[k] < __builtin_huge_valf() && h.c[k] < 0) prefetch_ref(sv, h.c[k]);
+                        }
                         if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                         node = h.c[0];
                         descend = true;
@@ -343,7 +366,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qbest, hitb, t0);
+                const int c = quad_child_box<TOP>(qr, TR_NODES_OF(sv), top, qnode, q, qbest, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
@@ -428,7 +451,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             bool descend = false;
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect<TOP>(r, sv.nodes4, top, node, tmin, tmax, h);
+                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
                 if (COUNT) st.nodes++;
                 int next = 0x7FFFFFFF, last = 0x7FFFFFFF;
 #pragma unroll
@@ -438,7 +461,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                         else { stk.push(spill, h.c[k]); last = h.c[k]; }
                     }
                 }
-                if (TR_PREFETCH >= 2 && last != 0x7FFFFFFF) prefetch_ref(sv, last);
+                if (TR_PREFETCH == 2 && last != 0x7FFFFFFF) prefetch_ref(sv, last);
                 if (next != 0x7FFFFFFF) { node = next; descend = true; }
             } else {
                 const TriRecord tr = sv.tris[~node];
@@ -500,7 +523,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, sv.nodes4, top, qnode, q, qtmax, hitb, t0);
+                const int c = quad_child_box<TOP>(qr, TR_NODES_OF(sv), top, qnode, q, qtmax, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;

@@ -1,9 +1,10 @@
 """Radiance .hdr (RGBE) images: the `--envmap=file.hdr` of the reference (src/options.hh:125; texture::load_from_file ->
 stbi_loadf, src/texture.cc:453-461; environment_map, src/environment_map.cc:11-16).
 
-`load_hdr` returns what stbi_loadf hands the reference plus the alpha channel it appends: (H, W, 4) float32, row 0 = the top
-row of the file (no flip), rgb = mantissa * 2^(exponent - 136) without the half-step other decoders add, 0 for exponent 0,
-alpha 1.  Flat and new-style run-length-encoded scanlines; only the -Y +X orientation, like stb_image."""
+`load_hdr` returns the texels of the texture the reference makes of the file: what stbi_loadf decodes plus the alpha channel
+load_from_file appends, stored as RGBA16F (src/texture.cc:485-500): (H, W, 4) float32 holding half-precision values, row 0 = the
+top row of the file (no flip), rgb = mantissa * 2^(exponent - 136) without the half-step other decoders add, 0 for exponent 0,
+clamped to +-65000; alpha 1.  `set_envmap` also takes `.exr` files (tauray_amd/exr.py; those stay fp32, src/texture.cc:409-429).  Flat and new-style run-length-encoded scanlines; only the -Y +X orientation, like stb_image."""
 from __future__ import annotations
 
 import numpy as np
@@ -60,6 +61,9 @@ def load_hdr(path: str) -> np.ndarray:
     scale = np.where(e != 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0)).astype(np.float32)
     out = np.ones((h, w, 4), dtype=np.float32)
     out[..., :3] = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    # "16-bit floats for hdr images" (src/texture.cc:498-500 -> :50-66): clamped to +-65000 and rounded to half (nearest even).
+    # Exact for RGBE's 8-bit mantissas except beyond the clamp (a sun disc) and below 2^-24.
+    out[..., :3] = np.clip(out[..., :3], np.float32(-65000.0), np.float32(65000.0)).astype(np.float16).astype(np.float32)
     return out
 
 
@@ -101,6 +105,10 @@ def write_hdr(path: str, rgb: np.ndarray, rle: bool = True):
 
 def set_envmap(scene, path: str, factor=(1.0, 1.0, 1.0)):
     """environment_map(dev, path) on a loaded scene (src/tauray.cc:198-201): lat-long projection, factor (1, 1, 1)."""
-    scene.envmap = load_hdr(path)
+    if path.lower().endswith(".exr"):
+        from .exr import load_exr_rgba
+        scene.envmap = load_exr_rgba(path)
+    else:
+        scene.envmap = load_hdr(path)
     scene.environment_factor = (float(factor[0]), float(factor[1]), float(factor[2]), 1.0)      # vec4(factor, 1), src/scene_stage.cc:1345
     return scene

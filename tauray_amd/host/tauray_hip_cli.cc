@@ -137,7 +137,7 @@ int main(int argc, char** argv)
             else if(starts(a, "--compression="))
             {
                 static const std::map<std::string, tr::headless::compression_type> comps = {
-                    {"none", tr::headless::NONE}, {"zips", tr::headless::ZIPS}, {"zip", tr::headless::ZIP}};
+                    {"none", tr::headless::NONE}, {"rle", tr::headless::RLE}, {"zips", tr::headless::ZIPS}, {"zip", tr::headless::ZIP}, {"piz", tr::headless::PIZ}};
                 auto it = comps.find(val("--compression="));
                 if(it == comps.end()) throw std::runtime_error("unknown compression " + val("--compression="));
                 hopt.output_compression = it->second;

@@ -1,6 +1,6 @@
 // Test helper (tests/test_cpp_host.py): writes a synthetic RGBA32F image through tr::headless (include/tauray_hip.hh) with the
 // requested pixel format and compression, and dumps the source pixels next to it.
-// usage: exr_writer_check <width> <height> <pixel_format 0..3> <compression 0|2|3> <out.exr> <out.raw>
+// usage: exr_writer_check <width> <height> <pixel_format 0..3> <compression 0..4> <out.exr> <out.raw>
 #include "tauray_hip.hh"
 #include <random>
 int main(int argc, char** argv) {

@@ -26,7 +26,7 @@ def fresh_cli(tmp_path_factory):
 
 
 def read_simple_exr(path):
-    """Independent reader for the scanline EXR files headless::write_exr emits (no compression, ZIPS, ZIP):
+    """Independent reader for the scanline EXR files headless::write_exr emits (no compression, RLE, ZIPS, ZIP; PIZ see below):
     returns ([channel names in file order], {channel: array}, compression code)."""
     import zlib
     d = open(path, "rb").read()
@@ -46,7 +46,12 @@ def read_simple_exr(path):
         ptype = struct.unpack("<i", c[p:p + 4])[0]; p += 16
         chans.append((n, ptype))
     comp = attrs["compression"][1][0]
-    lines = {0: 1, 2: 1, 3: 16}[comp]
+    if comp == 4:     # PIZ: through include/tauray_exr.hh's decoder, which tests/test_exr.py pins to the reference's own PIZ files
+        from tauray_amd.exr import decode_exr
+        img = decode_exr(d)
+        order = [n for n in "RGBA" if n in [c for c, _ in chans]]
+        return [n for n, _ in chans], {n: img[..., i] for i, n in enumerate(order)}, comp
+    lines = {0: 1, 1: 1, 2: 1, 3: 16}[comp]
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
     n_blocks = (h + lines - 1) // lines
@@ -71,8 +76,18 @@ def read_simple_exr(path):
         raw_size = sum(words) * 2 * w * ny
         buf = d[o:o + nbytes]
         if nbytes < raw_size:
-            assert comp in (2, 3)
-            buf = unpredict(zlib.decompress(buf))
+            assert comp in (1, 2, 3)
+            if comp == 1:     # run lengths: count c < 0 -> -c literal bytes, else the next byte c + 1 times
+                o2, q = bytearray(), 0
+                while q < len(buf):
+                    c = buf[q] - 256 if buf[q] > 127 else buf[q]; q += 1
+                    if c < 0:
+                        o2 += buf[q:q - c]; q -= c
+                    else:
+                        o2 += bytes([buf[q]]) * (c + 1); q += 1
+                buf = unpredict(bytes(o2))
+            else:
+                buf = unpredict(zlib.decompress(buf))
         assert len(buf) == raw_size
         q = 0
         for y in range(yy, yy + ny):
@@ -98,7 +113,7 @@ def test_cli_exists_and_links_only_the_c_abi():
 
 def test_exr_writer_all_compressions(tmp_path):
     """tr::headless writes what src/headless.cc:349-422 writes through tinyexr: scanline EXR, channels in alphabetical order,
-    half or float, NONE / ZIPS / ZIP (default; the reference's PIZ is left out).  Every combination is read back by the independent reader above."""
+    half or float, NONE / RLE / ZIPS / ZIP / PIZ (the default, src/headless.hh:56).  Every combination is read back by the reader above."""
     exe = str(tmp_path / "exr_writer_check")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-DTAURAY_HIP_WITH_ZLIB", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(ROOT, "tests", "exr_writer_check.cc"), "-L" + os.path.join(ROOT, "tauray_amd"), "-ltrhip", "-lz",
@@ -106,7 +121,7 @@ def test_exr_writer_all_compressions(tmp_path):
     sizes = {}
     for (w, h) in ((64, 48), (33, 70), (5, 3), (1, 1)):
         for fmt in range(4):
-            for comp in (0, 2, 3):
+            for comp in (0, 1, 2, 3, 4):
                 exr, raw = str(tmp_path / "o.exr"), str(tmp_path / "o.raw")
                 subprocess.check_call([exe, str(w), str(h), str(fmt), str(comp), exr, raw])
                 names, ch, c = read_simple_exr(exr)
@@ -280,6 +295,29 @@ def test_cpp_envmap_matches_python(tmp_path):
         assert struct.unpack("<II4f", raw[pos:pos + 24]) == (96, 48, 1.0, 1.0, 1.0, 1.0)
     r = subprocess.run([CLI, os.path.join(GOLDEN, "test.glb"), f"--envmap={os.path.join(GOLDEN, 'test.glb')}", f"--dump-scene={dump}"], capture_output=True, text=True)
     assert r.returncode != 0 and "not a Radiance" in r.stderr
+    # the same sky as an OpenEXR file (src/texture.cc:409-429): float channels, three of them -> alpha 1, no half rounding; PIZ and ZIP
+    from tauray_amd import exr
+    from tauray_amd.hdr import set_envmap
+    sky = load_hdr(os.path.join(GOLDEN, "sky.hdr"))
+    sky[..., :3] *= np.float32(1.0 / 3.0)              # not representable in half
+    for comp, half in ((exr.PIZ, False), (exr.ZIP, True)):
+        f = str(tmp_path / "sky.exr")
+        open(f, "wb").write(exr.encode_exr(sky, alpha=False, half=half, compression=comp))
+        subprocess.check_call([CLI, os.path.join(GOLDEN, "test.glb"), "--width=64", "--height=64", f"--envmap={f}", f"--dump-scene={dump}"])
+        raw = open(dump, "rb").read()
+        pos, secs = 8, []
+        for _ in range(12):
+            n = struct.unpack_from("<Q", raw, pos)[0]
+            secs.append(raw[pos + 8:pos + 8 + n])
+            pos += 8 + n
+
+        class S:
+            pass
+        env = set_envmap(S(), f).envmap
+        want = sky.astype(np.float16).astype(np.float32) if half else sky
+        want[..., 3] = 1.0
+        assert np.array_equal(env, want) and env.dtype == np.float32
+        assert secs[8] == env.tobytes() and secs[9] == build_alias_table(env).tobytes(), (comp, half)
 
 
 def test_cli_fails_loudly(scene_dump):
@@ -521,7 +559,7 @@ def test_headless_naming_and_exr_layout(tmp_path, scene_dump):
     assert r.returncode == 0, r.stderr
     assert sorted(os.listdir(tmp_path)) == ["frame0.exr", "frame1.exr"]          # prefix + frame number (src/headless.cc:305-309)
     names, ch, comp = read_simple_exr(prefix + "0.exr")
-    assert comp == 3                                                                 # ZIP by default (the reference: PIZ, src/headless.hh:56)
+    assert comp == 4                                                                 # PIZ by default (src/headless.hh:56)
     assert names == ["B", "G", "R"] and ch["R"].shape == (48, 64)               # B,G,R order, half (src/headless.cc:385-393)
     raw_prefix = str(tmp_path / "single")
     subprocess.check_call([CLI, scene_dump, "--width=64", "--height=48", "--max-ray-depth=2", f"--headless={raw_prefix}", "--filetype=raw"])

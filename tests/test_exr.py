@@ -1,0 +1,230 @@
+"""include/tauray_exr.hh through its C entry points (trhip_exr_decode / trhip_exr_encode): the OpenEXR reader behind `.exr`
+environment maps (read_exr, src/texture.cc:70-163) and the writer behind headless frames (src/headless.cc:355-412, PIZ by default,
+src/headless.hh:56).  No GPU involved.
+
+Pins:
+* the PIZ decoder (bitmap range, wavelet, canonical Huffman codes with the run symbol) against three of the reference's own golden
+  images - 512 x 512 half files Tauray wrote through tinyexr (tests/golden/ref_piz_*.exr = test/references/validate_*.exr; their
+  pixels as tinyexr decodes them are tests/golden/validate_*.npz, tools/make_golden.py);
+* every codec by round trips over sizes that exercise ragged last blocks, odd widths and both wavelet arithmetic modes;
+* the encoders against the reference's tinyexr where the reference checkout is present (the build container)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+REF = "/root/reference"
+
+
+def _picture(w, h, kind, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    if kind == "smooth":
+        a = np.stack([0.5 + 0.5 * np.sin(x * 0.05) * np.cos(y * 0.03), x / max(w, 1) * 1000.0, np.where(y < h / 3, 0.25, 10.0 * rng.random((h, w))),
+                      ((x + y) % 7 != 0).astype(np.float32)], -1)
+    elif kind == "flat":
+        a = np.full((h, w, 4), 0.5)
+    elif kind == "noise":      # all of the half range and beyond: the 16-bit wavelet mode, float words with busy low halves
+        a = np.ldexp(rng.random((h, w, 4)) + 0.5, rng.integers(-30, 20, (h, w, 4))) * rng.choice([-1.0, 1.0], (h, w, 4))
+    else:                      # few distinct values: a dense value range, the 14-bit mode, long runs
+        a = rng.integers(0, 5, (h, w, 4)) * 0.125
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _expected(img, alpha, half):
+    want = img if alpha else img[..., :3]
+    with np.errstate(over="ignore"):
+        return want.astype(np.float16).astype(np.float32) if half else want
+
+
+@pytest.mark.parametrize("name", ["albedo", "view-normal", "path-tracer"])
+def test_piz_decoder_reads_the_reference_goldens(name):
+    from tauray_amd.exr import load_exr
+    img = load_exr(os.path.join(GOLDEN, f"ref_piz_{name}.exr"))
+    want = np.load(os.path.join(GOLDEN, f"validate_{name}.npz"))["rgb"].astype(np.float32)
+    assert img.shape == want.shape == (512, 512, 3)
+    assert np.array_equal(img, want, equal_nan=True)
+    d = open(os.path.join(GOLDEN, f"ref_piz_{name}.exr"), "rb").read()
+    assert d[d.index(b"compression\0compression\0") + 28] == 4        # and they are PIZ files
+
+
+@pytest.mark.parametrize("size", [(1, 1), (5, 3), (64, 48), (33, 70), (517, 33), (130, 65)])
+def test_round_trips_of_every_codec(size):
+    from tauray_amd import exr
+    w, h = size
+    for k, kind in enumerate(("smooth", "flat", "noise", "levels")):
+        img = _picture(w, h, kind, seed=w * 7 + h + k)
+        sizes = {}
+        for comp in (exr.NONE, exr.RLE, exr.ZIPS, exr.ZIP, exr.PIZ):
+            for half in (False, True):
+                for alpha in (False, True):
+                    data = exr.encode_exr(img, alpha=alpha, half=half, compression=comp)
+                    back = exr.decode_exr(data)
+                    assert back.shape == (h, w, 4 if alpha else 3)
+                    assert np.array_equal(back.view(np.uint32), _expected(img, alpha, half).view(np.uint32)), (size, kind, comp, half, alpha)
+                    sizes[(comp, half, alpha)] = len(data)
+        if w * h >= 64 * 48 and kind != "noise":      # they do compress
+            for comp in (exr.RLE, exr.ZIPS, exr.ZIP, exr.PIZ):
+                assert sizes[(comp, True, False)] < sizes[(exr.NONE, True, False)], (size, kind, comp)
+        for key, n in sizes.items():                  # and a block that does not shrink is stored as it is: never much larger than raw
+            assert n <= sizes[(exr.NONE,) + key[1:]] + 16, (size, kind, key)
+
+
+def test_header_and_channel_order_of_written_files():
+    """Channels in alphabetical order - [A,] B, G, R - with the requested pixel type, data window = display window = the image,
+    increasing y, one offset per block of 1 / 1 / 1 / 16 / 32 scanlines (src/headless.cc:364-405 through tinyexr)."""
+    from tauray_amd import exr
+    img = _picture(40, 70, "smooth", 3)
+    for comp, lines in ((exr.NONE, 1), (exr.RLE, 1), (exr.ZIPS, 1), (exr.ZIP, 16), (exr.PIZ, 32)):
+        for half in (False, True):
+            for alpha in (False, True):
+                d = exr.encode_exr(img, alpha=alpha, half=half, compression=comp)
+                assert struct.unpack("<II", d[:8]) == (20000630, 2)
+                pos, attrs = 8, {}
+                while d[pos] != 0:
+                    e = d.index(b"\0", pos); name = d[pos:e].decode(); pos = e + 1
+                    e = d.index(b"\0", pos); pos = e + 1
+                    n = struct.unpack("<i", d[pos:pos + 4])[0]; pos += 4
+                    attrs[name] = d[pos:pos + n]; pos += n
+                pos += 1
+                c, p, chans = attrs["channels"], 0, []
+                while c[p] != 0:
+                    e = c.index(b"\0", p); chans.append((c[p:e].decode(), struct.unpack("<i", c[e + 1:e + 5])[0])); p = e + 17
+                assert chans == [(n, 1 if half else 2) for n in (["A"] if alpha else []) + ["B", "G", "R"]]
+                assert attrs["compression"][0] == comp and attrs["lineOrder"][0] == 0
+                assert struct.unpack("<4i", attrs["dataWindow"]) == struct.unpack("<4i", attrs["displayWindow"]) == (0, 0, 39, 69)
+                blocks = (70 + lines - 1) // lines
+                offsets = struct.unpack(f"<{blocks}Q", d[pos:pos + 8 * blocks])
+                assert offsets[0] == pos + 8 * blocks
+                for b, o in enumerate(offsets):
+                    y, size = struct.unpack("<ii", d[o:o + 8])
+                    assert y == b * lines and (offsets[b + 1] if b + 1 < blocks else len(d)) == o + 8 + size
+
+
+def test_reader_takes_what_read_exr_takes():
+    """Tiled files (one level), a data window that does not start at the origin, FLOAT / HALF / UINT channels side by side, channel
+    names other than R, G, B, A (file order then), decreasing line order: hand-assembled files."""
+    from tauray_amd import exr
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+    def chlist(chans):
+        return b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", t, 0, 1, 1) for n, t in chans) + b"\0"
+
+    w, h = 7, 5
+    rng = np.random.default_rng(5)
+    planes = {"B": rng.random((h, w)).astype(np.float32), "G": rng.random((h, w)).astype(np.float16), "R": rng.integers(0, 1000, (h, w)).astype(np.uint32)}
+    types = {"B": 2, "G": 1, "R": 0}
+
+    def header(extra=b"", flags=2, x0=0, y0=0, names=("B", "G", "R"), order=0):
+        return (struct.pack("<II", 20000630, flags) + attr("channels", "chlist", chlist([(n, types[m]) for n, m in zip(names, ("B", "G", "R"))]))
+                + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", struct.pack("<4i", x0, y0, x0 + w - 1, y0 + h - 1))
+                + attr("displayWindow", "box2i", struct.pack("<4i", 0, 0, 99, 99)) + attr("lineOrder", "lineOrder", bytes([order]))
+                + attr("pixelAspectRatio", "float", struct.pack("<f", 1)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
+                + attr("screenWindowWidth", "float", struct.pack("<f", 1)) + extra + b"\0")
+
+    def rows(y, xs=slice(None)):
+        return b"".join(planes[c][y, xs].tobytes() for c in ("B", "G", "R"))
+
+    want = np.stack([planes["R"].astype(np.float32), planes["G"].astype(np.float32), planes["B"]], -1)
+    # scanlines, window at (-3, 11), chunks stored bottom-up (DECREASING_Y)
+    hd = header(x0=-3, y0=11, order=1)
+    chunks, table, pos = b"", [0] * h, len(hd) + 8 * h
+    for y in reversed(range(h)):
+        table[y] = pos + len(chunks)
+        r = rows(y)
+        chunks += struct.pack("<ii", 11 + y, len(r)) + r
+    got = exr.decode_exr(hd + struct.pack(f"<{h}Q", *table) + chunks)
+    assert np.array_equal(got, want)
+    # tiles of 4 x 2, one level
+    hd = header(extra=attr("tiles", "tiledesc", struct.pack("<IIB", 4, 2, 0)), flags=2 | 0x200)
+    tiles = [(tx, ty) for ty in range(3) for tx in range(2)]
+    chunks, table, pos = b"", [], len(hd) + 8 * len(tiles)
+    for tx, ty in tiles:
+        table.append(pos + len(chunks))
+        body = b"".join(rows(y, slice(tx * 4, min(tx * 4 + 4, w))) for y in range(ty * 2, min(ty * 2 + 2, h)))
+        chunks += struct.pack("<5i", tx, ty, 0, 0, len(body)) + body
+    got = exr.decode_exr(hd + struct.pack(f"<{len(tiles)}Q", *table) + chunks)
+    assert np.array_equal(got, want)
+    # channel names that are not R, G, B, A: file order (src/texture.cc:118-120)
+    hd = header(names=("u", "v", "w"))
+    chunks, table, pos = b"", [], len(hd) + 8 * h
+    for y in range(h):
+        table.append(pos + len(chunks))
+        r = rows(y)
+        chunks += struct.pack("<ii", y, len(r)) + r
+    got = exr.decode_exr(hd + struct.pack(f"<{h}Q", *table) + chunks)
+    assert np.array_equal(got, want[..., ::-1])
+    # multi-part and deep files are refused (src/texture.cc:81), so are the lossy codecs
+    from tauray_amd._lib import TrhipError
+    for flags in (2 | 0x800, 2 | 0x1000):
+        with pytest.raises(TrhipError):
+            exr.decode_exr(header(flags=flags) + struct.pack(f"<{h}Q", *table) + chunks)
+    bad = header().replace(attr("compression", "compression", b"\0"), attr("compression", "compression", b"\6"))
+    with pytest.raises(TrhipError, match="not supported"):
+        exr.decode_exr(bad + struct.pack(f"<{h}Q", *table) + chunks)
+
+
+def test_damaged_files_fail_loudly():
+    from tauray_amd import exr
+    from tauray_amd._lib import TrhipError
+    img = _picture(64, 40, "smooth", 9)
+    for comp in (exr.RLE, exr.ZIP, exr.PIZ):
+        good = exr.encode_exr(img, compression=comp)
+        with pytest.raises(TrhipError):
+            exr.decode_exr(good[:len(good) // 2])                  # truncated
+        with pytest.raises(TrhipError):
+            exr.decode_exr(b"\0" * 64)                             # not an EXR
+        rng = np.random.default_rng(comp)
+        hits = 0
+        for _ in range(40):                                        # flipped bytes in the pixel data: an error or different pixels, never a crash
+            b = bytearray(good)
+            for k in rng.integers(400, len(b), 6):
+                b[k] ^= 1 << int(rng.integers(0, 8))
+            try:
+                exr.decode_exr(bytes(b))
+            except TrhipError:
+                hits += 1
+        assert hits > 0, comp
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "external", "tinyexr.h")), reason="needs the reference checkout (build container only)")
+def test_written_files_are_read_by_the_references_tinyexr(tmp_path):
+    """The other direction of the pin: files from this encoder - all five codecs, half and float - decoded by the tinyexr the
+    reference vendors (tools/exr_to_raw.cc, compiled here against /root/reference/external) give the source pixels."""
+    from tauray_amd import exr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "exr_to_raw")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-I", os.path.join(REF, "external"), os.path.join(root, "tools", "exr_to_raw.cc"), "-o", exe, "-lpthread"])
+    for (w, h) in ((64, 48), (33, 70), (517, 33)):
+        for k, kind in enumerate(("smooth", "noise", "levels")):
+            img = _picture(w, h, kind, seed=k + w)
+            for comp in (exr.NONE, exr.RLE, exr.ZIPS, exr.ZIP, exr.PIZ):
+                for half in (False, True):
+                    f, raw = str(tmp_path / "a.exr"), str(tmp_path / "a.raw")
+                    open(f, "wb").write(exr.encode_exr(img, alpha=(comp == exr.PIZ and kind == "smooth"), half=half, compression=comp))
+                    subprocess.check_call([exe, f, raw], stdout=subprocess.DEVNULL)
+                    d = open(raw, "rb").read()
+                    assert struct.unpack("<ii", d[:8]) == (w, h)
+                    got = np.frombuffer(d[8:], dtype=np.float32).reshape(h, w, 3)
+                    assert np.array_equal(got.view(np.uint32), _expected(img, False, half).view(np.uint32)), (w, h, kind, comp, half)
+
+
+def test_hdr_texels_are_half_precision_like_the_references_texture(tmp_path):
+    """texture::load_from_file stores .hdr files as RGBA16F after clamping to +-65000 (src/texture.cc:498-500, 50-66): RGBE values
+    come through exactly, a sun brighter than that is clamped to 64992 (the half below 65000), values under 2^-25 vanish."""
+    from tauray_amd.hdr import load_hdr
+    px = bytes([200, 100, 50, 128 + 9]) + bytes([255, 128, 1, 128 + 17]) + bytes([128, 64, 255, 100]) + bytes([0, 0, 0, 0]) + bytes([1, 2, 3, 111]) * 4
+    (tmp_path / "t.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n" + px)
+    img = load_hdr(str(tmp_path / "t.hdr"))[0]
+    assert np.array_equal(img[0, :3], np.array([200, 100, 50], np.float32) * 2.0)                       # 2^(137 - 136)
+    assert np.array_equal(img[1, :3], np.array([64992.0, 64992.0, 512.0], np.float32))               # 255 * 512 and 128 * 512 = 65536 clamp
+    assert np.array_equal(img[2, :3], np.zeros(3, np.float32))                                          # 255 * 2^-36: under half of half's smallest subnormal
+    assert np.array_equal(img[3, :3], np.zeros(3, np.float32))
+    assert np.array_equal(img[4, :3], np.array([0.0, 1.0, 2.0], np.float32) * np.float32(2.0 ** -24))     # 0.5, 1, 1.5 steps of 2^-24: ties to even
+    assert (img[:, 3] == 1).all()

@@ -8,6 +8,7 @@ decoded pixel data (float16, exactly the precision of the HALF EXRs) is
 committed, as tests/golden/validate_<name>.npz.
 """
 import os
+import shutil
 import subprocess
 import sys
 
@@ -16,6 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 NAMES = ["distance", "world-pos", "view-pos", "world-normal", "view-normal", "albedo", "path-tracer"]
+PIZ_FIXTURES = ("albedo", "view-normal", "path-tracer")
 
 
 def main():
@@ -32,6 +34,8 @@ def main():
         img16 = img.astype(np.float16)
         assert np.array_equal(img16.astype(np.float32), img) or np.isnan(img).any(), "golden is not exactly half precision"
         np.savez_compressed(os.path.join(ROOT, "tests/golden", f"validate_{n}.npz"), rgb=img16)
+        if n in PIZ_FIXTURES:     # the file itself (PIZ, half: written by Tauray through tinyexr) pins include/tauray_exr.hh's decoder
+            shutil.copyfile(src, os.path.join(ROOT, "tests/golden", f"ref_piz_{n}.exr"))
         print(n, img.shape, "mean", img.reshape(-1, 3).mean(0), "min", img.min(), "max", img.max())
 
 
