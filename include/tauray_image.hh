@@ -6,10 +6,10 @@
 //   * PNG: grey, grey + alpha, RGB, RGBA and palette images of 1 / 2 / 4 / 8 / 16 bits per sample, tRNS transparency, Adam7
 //     interlacing.  16-bit samples become 8-bit ones by rounding v * 255 / 65535 (the reference keeps them as R16G16B16A16Unorm
 //     textures: at most half an 8-bit step apart, the texel store here is RGBA8);
-//   * JPEG: baseline and extended-sequential Huffman files (SOF0 / SOF1, 8 bits per sample), grey or YCbCr (or RGB when an Adobe
-//     marker says so), any sampling factors, restart intervals.  Chroma planes subsampled by two are interpolated linearly
+//   * JPEG: baseline, extended-sequential and progressive Huffman files (SOF0 / SOF1 / SOF2, 8 bits per sample; scans of all or of
+//     single components), grey or YCbCr (or RGB when an Adobe marker says so), any sampling factors, restart intervals.  Chroma planes subsampled by two are interpolated linearly
 //     (the triangle filter libjpeg calls "fancy upsampling"), the inverse DCT is evaluated in floating point.  JPEG leaves both
-//     to the decoder, so decoders agree to a few levels, not to the bit.  Progressive and arithmetic-coded files are refused.
+//     to the decoder, so decoders agree to a few levels, not to the bit.  Arithmetic-coded, lossless and hierarchical files are refused.
 // Row 0 of the result is the top row of the file.  Needs zlib for PNG (TAURAY_HIP_WITH_ZLIB).
 #ifndef TAURAY_IMAGE_HH
 #define TAURAY_IMAGE_HH
@@ -159,7 +159,7 @@ inline decoded decode_png(const uint8_t* data, size_t size)
 }
 
 //---------------------------------------------------------------------------------------------------------------------
-// JPEG (baseline / extended sequential, Huffman, 8 bit)
+// JPEG (baseline / extended sequential / progressive, Huffman, 8 bit)
 namespace jpeg_detail
 {
 struct huffman
@@ -261,7 +261,10 @@ inline void idct8x8(const float* coef, uint8_t* out, size_t stride)
 inline decoded decode_jpeg(const uint8_t* data, size_t size)
 {
     using namespace jpeg_detail;
-    struct component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; size_t pw = 0, ph = 0; std::vector<uint8_t> plane; };
+    // bw x bh: blocks of the component in whole MCUs (what interleaved scans walk); sbw x sbh: the blocks that cover the image
+    // (what a scan of this component alone walks, T.81 A.2.3)
+    struct component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; size_t bw = 0, bh = 0, sbw = 0, sbh = 0, pw = 0, ph = 0;
+                       std::vector<int16_t> coef; std::vector<uint8_t> plane; };
     uint16_t qt[4][64] = {};
     bool qt_defined[4] = {false, false, false, false};
     huffman dc[4], ac[4];
@@ -269,16 +272,18 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
     decoded out;
     int restart_interval = 0, adobe_transform = -1;
     int hmax = 1, vmax = 1;
+    bool progressive = false;
+    size_t mcux = 0, mcuy = 0;
     size_t pos = 2;
     auto be16 = [&](size_t o) { if(o + 2 > size) throw std::runtime_error("image: truncated JPEG"); return (int)((data[o] << 8) | data[o + 1]); };
     bool decoded_scan = false;
-    while(pos + 4 <= size && !decoded_scan)
+    while(pos + 4 <= size)
     {
         if(data[pos] != 0xFF) { ++pos; continue; }
         const uint8_t m = data[pos + 1];
         if(m == 0xFF) { ++pos; continue; }
         pos += 2;
-        if(m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if(m == 0x00 || m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;      // stuffed bytes and restart markers left over from a scan
         if(m == 0xD9) break;
         const int len = be16(pos);
         if(len < 2 || pos + (size_t)len > size) throw std::runtime_error("image: truncated JPEG segment");
@@ -307,9 +312,11 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
                 o += 17 + total;
             }
         }
-        else if(m == 0xC0 || m == 0xC1)
+        else if(m == 0xC0 || m == 0xC1 || m == 0xC2)
         {
+            if(!comps.empty()) throw std::runtime_error("image: JPEG with more than one frame");
             if(n < 6 || seg[0] != 8) throw std::runtime_error("image: JPEG with other than 8 bits per sample");
+            progressive = m == 0xC2;
             out.h = (uint32_t)((seg[1] << 8) | seg[2]); out.w = (uint32_t)((seg[3] << 8) | seg[4]);
             const int nc = seg[5];
             if((nc != 1 && nc != 3) || n < 6 + 3 * nc || out.w == 0 || out.h == 0) throw std::runtime_error("image: JPEG with " + std::to_string(nc) + " components");
@@ -320,68 +327,178 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
                 if(comps[(size_t)i].h < 1 || comps[(size_t)i].h > 4 || comps[(size_t)i].v < 1 || comps[(size_t)i].v > 4) throw std::runtime_error("image: bad JPEG sampling factors");
                 hmax = std::max(hmax, comps[(size_t)i].h); vmax = std::max(vmax, comps[(size_t)i].v);
             }
+            mcux = (out.w + 8 * (size_t)hmax - 1) / (8 * (size_t)hmax); mcuy = (out.h + 8 * (size_t)vmax - 1) / (8 * (size_t)vmax);
+            for(component& c: comps)
+            {
+                c.bw = mcux * (size_t)c.h; c.bh = mcuy * (size_t)c.v;
+                c.sbw = ((out.w * (size_t)c.h + (size_t)hmax - 1) / (size_t)hmax + 7) / 8;
+                c.sbh = ((out.h * (size_t)c.v + (size_t)vmax - 1) / (size_t)vmax + 7) / 8;
+                c.coef.assign(c.bw * c.bh * 64, 0);
+            }
         }
-        else if(m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC) || m == 0xC3)
-            throw std::runtime_error(m == 0xC2 ? "image: progressive JPEG files are not read (baseline / extended sequential only)" : "image: unsupported JPEG coding process");
+        else if((m >= 0xC3 && m <= 0xCF && m != 0xC8 && m != 0xCC))
+            throw std::runtime_error("image: unsupported JPEG coding process (lossless, hierarchical or arithmetic)");
         else if(m == 0xDD && n >= 2) restart_interval = (seg[0] << 8) | seg[1];
         else if(m == 0xEE && n >= 12 && !std::memcmp(seg, "Adobe", 5)) adobe_transform = seg[11];
         else if(m == 0xDA)
         {
             if(comps.empty()) throw std::runtime_error("image: JPEG scan before the frame header");
-            const int ns = seg[0];
-            if(ns != (int)comps.size() || n < 1 + 2 * ns + 3) throw std::runtime_error("image: JPEG scans of a subset of the components are not read");
+            const int ns = n >= 1 ? seg[0] : 0;
+            if(ns < 1 || ns > (int)comps.size() || n < 1 + 2 * ns + 3) throw std::runtime_error("image: bad JPEG scan header");
+            component* sc[4] = {nullptr, nullptr, nullptr, nullptr};
+            const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+            if(!progressive ? (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) : (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13 || Ah > 13))
+                throw std::runtime_error("image: bad JPEG scan parameters");
             for(int i = 0; i < ns; ++i)
             {
-                component* c = nullptr;
-                for(component& k: comps) if(k.id == seg[1 + 2 * i]) c = &k;
-                if(!c) throw std::runtime_error("image: JPEG scan names an unknown component");
+                for(component& k: comps) if(k.id == seg[1 + 2 * i]) sc[i] = &k;
+                if(!sc[i]) throw std::runtime_error("image: JPEG scan names an unknown component");
+                component* c = sc[i];
                 c->td = seg[2 + 2 * i] >> 4; c->ta = seg[2 + 2 * i] & 15;
-                if(c->td > 3 || c->ta > 3 || !dc[c->td].defined || !ac[c->ta].defined || !qt_defined[c->tq]) throw std::runtime_error("image: JPEG scan uses an undefined table");
+                const bool need_dc = Ss == 0 && Ah == 0, need_ac = Se > 0;
+                if(c->td > 3 || c->ta > 3 || (need_dc && !dc[c->td].defined) || (need_ac && !ac[c->ta].defined)) throw std::runtime_error("image: JPEG scan uses an undefined table");
+                c->pred = 0;
             }
-            const size_t mcux = (out.w + 8 * (size_t)hmax - 1) / (8 * (size_t)hmax), mcuy = (out.h + 8 * (size_t)vmax - 1) / (8 * (size_t)vmax);
-            for(component& c: comps) { c.pw = mcux * 8 * (size_t)c.h; c.ph = mcuy * 8 * (size_t)c.v; c.plane.assign(c.pw * c.ph, 0); c.pred = 0; }
             bit_reader br{data + pos + (size_t)len, data + size};
-            float block[64];
+            int eobrun = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            // one 8x8 block of this scan (T.81 F.2.2 sequential; G.2 progressive: DC first / refinement, AC first / refinement with
+            // end-of-band runs)
+            auto refine = [&](int16_t& v) { if(br.bit() && (v & p1) == 0) v = (int16_t)(v + (v >= 0 ? p1 : m1)); };
+            auto block = [&](component& c, int16_t* b) {
+                if(!progressive)
+                {
+                    const int t = decode_symbol(br, dc[c.td]);
+                    c.pred += extend(br.bits(t), t);
+                    b[0] = (int16_t)c.pred;
+                    for(int k = 1; k < 64;)
+                    {
+                        const int rs = decode_symbol(br, ac[c.ta]);
+                        const int r = rs >> 4, s = rs & 15;
+                        if(s == 0) { if(r == 15) { k += 16; continue; } break; }
+                        k += r;
+                        if(k > 63) throw std::runtime_error("image: JPEG coefficient index out of range");
+                        b[zigzag[k]] = (int16_t)extend(br.bits(s), s);
+                        ++k;
+                    }
+                }
+                else if(Ss == 0)
+                {
+                    if(Ah == 0)
+                    {
+                        const int t = decode_symbol(br, dc[c.td]);
+                        c.pred += extend(br.bits(t), t);
+                        b[0] = (int16_t)(c.pred * p1);
+                    }
+                    else if(br.bit()) b[0] = (int16_t)(b[0] | p1);
+                }
+                else if(Ah == 0)
+                {
+                    if(eobrun > 0) { --eobrun; return; }
+                    for(int k = Ss; k <= Se;)
+                    {
+                        const int rs = decode_symbol(br, ac[c.ta]);
+                        const int r = rs >> 4, s = rs & 15;
+                        if(s == 0)
+                        {
+                            if(r < 15) { eobrun = (1 << r) - 1; if(r) eobrun += br.bits(r); break; }
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if(k > Se) throw std::runtime_error("image: JPEG coefficient index out of range");
+                        b[zigzag[k]] = (int16_t)(extend(br.bits(s), s) * p1);
+                        ++k;
+                    }
+                }
+                else
+                {
+                    int k = Ss;
+                    if(eobrun == 0)
+                    {
+                        for(; k <= Se; ++k)
+                        {
+                            const int rs = decode_symbol(br, ac[c.ta]);
+                            int r = rs >> 4;
+                            const int s = rs & 15;
+                            int value = 0;
+                            if(s)
+                            {
+                                if(s != 1) throw std::runtime_error("image: bad JPEG refinement code");
+                                value = br.bit() ? p1 : m1;
+                            }
+                            else if(r != 15)
+                            {
+                                eobrun = 1 << r;
+                                if(r) eobrun += br.bits(r);
+                                break;
+                            }
+                            // over the coefficients that are non-zero already (one correction bit each) and r zero ones
+                            for(; k <= Se; ++k)
+                            {
+                                int16_t& v = b[zigzag[k]];
+                                if(v != 0) refine(v);
+                                else if(--r < 0) break;
+                            }
+                            if(s && k <= Se) b[zigzag[k]] = (int16_t)value;
+                        }
+                    }
+                    if(eobrun > 0)
+                    {
+                        for(; k <= Se; ++k) { int16_t& v = b[zigzag[k]]; if(v != 0) refine(v); }
+                        --eobrun;
+                    }
+                }
+            };
+            const bool interleaved = ns > 1;
+            const size_t nx = interleaved ? mcux : sc[0]->sbw, ny = interleaved ? mcuy : sc[0]->sbh;
             size_t mcu_count = 0;
-            for(size_t my = 0; my < mcuy; ++my)
-                for(size_t mx = 0; mx < mcux; ++mx)
+            for(size_t my = 0; my < ny; ++my)
+                for(size_t mx = 0; mx < nx; ++mx)
                 {
                     if(restart_interval && mcu_count && mcu_count % (size_t)restart_interval == 0)
                     {
-                        // skip to the RSTn marker, reset the predictors
+                        // skip to the RSTn marker, reset the predictors and the end-of-band run
                         const uint8_t* q = br.p;
                         while(q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
                         br.p = q + 2 <= br.end ? q + 2 : br.end;
                         br.reset();
-                        for(component& c: comps) c.pred = 0;
+                        for(int i = 0; i < ns; ++i) sc[i]->pred = 0;
+                        eobrun = 0;
                     }
-                    for(component& c: comps)
-                        for(int by = 0; by < c.v; ++by)
-                            for(int bx = 0; bx < c.h; ++bx)
-                            {
-                                for(float& f: block) f = 0;
-                                const int t = decode_symbol(br, dc[c.td]);
-                                c.pred += extend(br.bits(t), t);
-                                block[0] = (float)(c.pred * (int)qt[c.tq][0]);
-                                for(int k = 1; k < 64;)
-                                {
-                                    const int rs = decode_symbol(br, ac[c.ta]);
-                                    const int r = rs >> 4, s = rs & 15;
-                                    if(s == 0) { if(r == 15) { k += 16; continue; } break; }
-                                    k += r;
-                                    if(k > 63) throw std::runtime_error("image: JPEG coefficient index out of range");
-                                    block[zigzag[k]] = (float)(extend(br.bits(s), s) * (int)qt[c.tq][zigzag[k]]);
-                                    ++k;
-                                }
-                                idct8x8(block, c.plane.data() + ((my * (size_t)c.v + (size_t)by) * 8) * c.pw + (mx * (size_t)c.h + (size_t)bx) * 8, c.pw);
-                            }
+                    if(interleaved)
+                    {
+                        for(int i = 0; i < ns; ++i)
+                            for(int by = 0; by < sc[i]->v; ++by)
+                                for(int bx = 0; bx < sc[i]->h; ++bx)
+                                    block(*sc[i], sc[i]->coef.data() + ((my * (size_t)sc[i]->v + (size_t)by) * sc[i]->bw + mx * (size_t)sc[i]->h + (size_t)bx) * 64);
+                    }
+                    else block(*sc[0], sc[0]->coef.data() + (my * sc[0]->bw + mx) * 64);
                     ++mcu_count;
                 }
             decoded_scan = true;
+            pos = (size_t)(br.p - data);      // markers and stuffed bytes the reader stopped in front of are skipped above
+            continue;
         }
         pos += (size_t)len;
     }
     if(!decoded_scan) throw std::runtime_error("image: JPEG without image data");
+    // coefficients -> samples
+    for(component& c: comps)
+    {
+        if(!qt_defined[c.tq]) throw std::runtime_error("image: JPEG component without a quantisation table");
+        c.pw = c.bw * 8; c.ph = c.bh * 8;
+        c.plane.assign(c.pw * c.ph, 0);
+        float blk[64];
+        for(size_t by = 0; by < c.bh; ++by)
+            for(size_t bx = 0; bx < c.bw; ++bx)
+            {
+                const int16_t* q = c.coef.data() + (by * c.bw + bx) * 64;
+                for(int i = 0; i < 64; ++i) blk[i] = (float)((int)q[i] * (int)qt[c.tq][i]);
+                idct8x8(blk, c.plane.data() + by * 8 * c.pw + bx * 8, c.pw);
+            }
+        std::vector<int16_t>().swap(c.coef);
+    }
     // upsample every component to full resolution
     const size_t W = out.w, H = out.h;
     std::vector<std::vector<uint8_t>> full(comps.size());

@@ -52,7 +52,7 @@ int trhip_stream_wait_peer(trhip_device* dev, void* stream, trhip_device* on_dev
 int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, const void* src, size_t bytes, void* stream);
 
 /* ---- texture files (host only, no device involved).  What stb_image does for the reference's glTF loader through tinygltf
- * (src/gltf.cc:520-576): a PNG (any colour type and bit depth, interlaced or not) or a baseline / extended-sequential JPEG file
+ * (src/gltf.cc:520-576): a PNG (any colour type and bit depth, interlaced or not) or a baseline / extended-sequential / progressive JPEG file
  * in memory becomes RGBA8, row 0 = top row of the file (include/tauray_image.hh; the C++ loader includes that header, the
  * Python mirror calls this entry point, so both flatten a scene to the same bytes).  *rgba_out is released with
  * trhip_image_free.  channels_in_file: 1 grey, 2 grey + alpha, 3 RGB, 4 RGBA. */
