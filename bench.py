@@ -56,6 +56,7 @@ PMC_PASSES = {
            "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
     "tcc": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"],
     "l2": ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"],
+    "l1": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "GRBM_GUI_ACTIVE"],
 }
 HOT_KERNELS = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_shade": "shade"}
 
@@ -198,7 +199,7 @@ def run_pmc_passes(args, B, dump_dir=None):
     return dict(out), ("; ".join(errors) if errors else None)
 
 
-def level_fractions(pmc_k, avg_ms, valu_peak_ginst):
+def level_fractions(pmc_k, avg_ms, valu_peak_ginst, l1_peak_gacc=None):
     """Per-level rates of one kernel from its per-launch counters and its un-profiled launch time.  Factors: profiles/r3/calibration.json
     (one TCP_TCC_READ_REQ = one 128-byte line; one TCC_EA0_RDREQ = 128 bytes unless counted as _32B; write requests 64 / 32 bytes)."""
     s = avg_ms * 1e-3
@@ -211,6 +212,17 @@ def level_fractions(pmc_k, avg_ms, valu_peak_ginst):
                       "insts_per_launch": int(pmc_k["SQ_INSTS_VALU"]),
                       "wait_fraction": round(pmc_k["SQ_WAIT_ANY"] / pmc_k["SQ_WAVE_CYCLES"], 3) if pmc_k.get("SQ_WAVE_CYCLES") else None,
                       "hw_lanes_per_inst": round(pmc_k["SQ_THREAD_CYCLES_VALU"] / pmc_k["SQ_INSTS_VALU"], 1) if pmc_k.get("SQ_THREAD_CYCLES_VALU") else None}
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc_k and l1_peak_gacc:
+        # the vector L1 (TCP) of a CU takes one cache-line (tag) access per clock (tools/ubench/l1_tags.hip; the peak is measured in
+        # this run by trhip_calibrate_l1); a lane's seven 16-byte loads of one node are seven accesses to one line
+        a = pmc_k["TCP_TOTAL_CACHE_ACCESSES_sum"] / s / 1e9
+        lv["l1"] = {"achieved": round(a, 1), "peak": round(l1_peak_gacc, 1), "unit": "Gaccess/s", "frac": round(a / l1_peak_gacc, 4),
+                    "line_accesses_per_launch": int(pmc_k["TCP_TOTAL_CACHE_ACCESSES_sum"])}
+        if pmc_k.get("GRBM_GUI_ACTIVE") and "avg_us_l1" in pmc_k:
+            # share of the L1s' cycles spent stalled, under the counters' own launch time (256 TCPs; GRBM_GUI_ACTIVE sums 8 XCDs)
+            cyc = pmc_k["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
+            lv["l1"]["stalled_waiting_for_l2"] = round(pmc_k.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / cyc, 3)
+            lv["l1"]["stalled_on_tag_conflicts"] = round(pmc_k.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0) / cyc, 3)
     if "TCP_TCC_READ_REQ_sum" in pmc_k:
         b = pmc_k["TCP_TCC_READ_REQ_sum"] * 128.0 + pmc_k.get("TCP_TCC_WRITE_REQ_sum", 0.0) * 64.0
         lv["l2"] = {"achieved": round(b / s / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(b / s / 1e9 / L2_PEAK_GBS, 4), "bytes_per_launch": int(b),
@@ -518,13 +530,19 @@ def main():
                 valu_peak = None
                 roof["valu_calibration_error"] = str(e)
             roof["valu_peak_measured_ginst_per_s"] = round(valu_peak, 1) if valu_peak else None
+            try:
+                l1_peak = ctx.calibrate_l1()
+            except Exception as e:
+                l1_peak = None
+                roof["l1_calibration_error"] = str(e)
+            roof["l1_peak_measured_gaccess_per_s"] = round(l1_peak, 1) if l1_peak else None
             if world > 1:       # a shard's launches are not the launches of the N = 1 line: the counter passes belong to that line
                 pmc, pmc_err = {}, "N > 1: the counter passes (VALU / L2 / fabric levels) are part of the N = 1 line"
             else:
                 pmc, pmc_err = ({}, "switched off (--no-pmc)") if args.no_pmc else run_pmc_passes(args, B, args.pmc_dump)
             if pmc_err:
                 roof["pmc_error"] = pmc_err
-            lv = level_fractions(pmc.get("k_trace_closest"), avg_ms, valu_peak)
+            lv = level_fractions(pmc.get("k_trace_closest"), avg_ms, valu_peak, l1_peak)
             # rays per wave-level instruction of the traversal: node visits of the closest-hit rays / node phases (a phase = one pass of
             # a wave over the node code, one ray per lane or one ray per quad); the hardware lane count (hw_lanes_per_inst) counts a
             # quad's four lanes as four
@@ -542,12 +560,17 @@ def main():
                 if "fabric" in lv:
                     roof["traffic"] = lv["fabric"]["bytes_per_launch"]
                     roof["traffic_note"] = "L2-miss bytes per launch (read requests x 128 B + write requests x 64 / 32 B; counters under rocprofv3 in this run)"
-                roof["bound_note"] = ("no level is near its peak: the kernel waits on dependent node fetches (wait_fraction) at %d waves per SIMD"
-                                      % 6) if lv[b]["frac"] < 0.6 else None
+                if b == "l1":
+                    roof["bound_note"] = ("the busiest unit is the vector L1 of every CU: a traversal step reads its 128-byte node with seven 16-byte loads per "
+                                          "lane, seven line accesses at one per clock and CU; the rest of the L1s' cycles go to waiting for L2 data "
+                                          "(levels.l1.stalled_waiting_for_l2) - the kernel is a chain of dependent fetches at six waves per SIMD")
+                else:
+                    roof["bound_note"] = ("no level is near its peak: the kernel waits on dependent node fetches (wait_fraction) at %d waves per SIMD"
+                                          % 6) if lv[b]["frac"] < 0.6 else None
             roof["other_kernels"] = {k: {"avg_launch_ms": round(kernel_avg_ms[k], 4), "levels": {n: {"frac": d["frac"], "achieved": d["achieved"], "unit": d["unit"]}
-                                                                                                  for n, d in level_fractions(pmc.get(k), kernel_avg_ms[k], valu_peak).items()}}
+                                                                                                  for n, d in level_fractions(pmc.get(k), kernel_avg_ms[k], valu_peak, l1_peak).items()}}
                                      for k in ("k_trace_shadow", "k_shade")}
-            roof["pmc_source"] = "rocprofv3 --pmc passes run by this process (bench.py --pmc-child); factors: profiles/r3/calibration.json"
+            roof["pmc_source"] = "rocprofv3 --pmc passes run by this process (bench.py --pmc-child); factors: profiles/r3/calibration.json, l1_tag_rate.json"
         result["roofline"] = roof
 
     # ---- CPU baseline: the oracle (a port; the reference has no CPU path) on the host cores, rank 0, N = 1 only

@@ -280,6 +280,12 @@ int trhip_pt_get_phase_counters(trhip_pt* pt, trhip_phase_counters* out);   /* s
  * in 10^9 wave-level instructions per second (MI355X_MICROARCH.md: 2 cycles per wave64 instruction on a SIMD-32; the clock is
  * what the box sustains).  The peak of the VALU roofline in bench.py; about 2 ms of device time. */
 int trhip_calibrate_valu(trhip_device* dev, float* ginst_per_s);
+/* Peak rate at which the vector L1 caches (TCP, one per CU) take cache-line accesses, in 10^9 accesses per second over the device:
+ * independent 16-byte loads out of an L1-resident footprint, every lane of a wave in a 128-byte line of its own (64 accesses per
+ * wave instruction).  One access per clock and CU (tools/ubench/l1_tags.hip, profiles/r3/l1_tag_rate.json) - what the counter
+ * TCP_TOTAL_CACHE_ACCESSES counts, and the peak of the L1 level of bench.py's roofline: a traversal step reads its node with seven
+ * loads per lane, seven accesses to one line.  About 1 ms of device time. */
+int trhip_calibrate_l1(trhip_device* dev, float* gaccesses_per_s);
 
 /* ---- feature_stage (src/feature_stage.cc:22-104): 0 albedo, 1 world normal, 2 view normal, 3 world pos,
  *      4 view pos, 5 distance, 6 world motion, 7 view motion, 8 screen motion, 9 instance id */

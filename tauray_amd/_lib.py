@@ -133,6 +133,7 @@ SYMBOLS = {
     "trhip_pt_get_timings": (_i, [_vp, C.POINTER(TimingsC)]),
     "trhip_pt_get_phase_counters": (_i, [_vp, C.POINTER(PhaseCountersC)]),
     "trhip_calibrate_valu": (_i, [_vp, C.POINTER(C.c_float)]),
+    "trhip_calibrate_l1": (_i, [_vp, C.POINTER(C.c_float)]),
     "trhip_feature_render": (_i, [_vp, _i, C.POINTER(DistributionC), _i, _u32, _f, C.POINTER(_f), _vp, _u32, _u32, _vp]),
     "trhip_trace_closest": (_i, [_vp, _u32, _vp, _vp, _i, _vp, _vp]),
     "trhip_trace_shadow": (_i, [_vp, _u32, _vp, _vp, _vp]),

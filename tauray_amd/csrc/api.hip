@@ -87,6 +87,26 @@ __global__ __launch_bounds__(KB) void k_calibrate_fma(float* out, int iters, flo
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// trhip_calibrate_l1: independent global_load_dwordx4 out of a 16 KB footprint (the same addresses for every wave: L1 hits), every
+// lane in a 128-byte line of its own - 64 line (tag) accesses per wave instruction
+__global__ __launch_bounds__(KB) void k_calibrate_l1(const char* base, int iters, float* out) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const char* p = base + (size_t)(threadIdx.x & 63u) * 128u;
+    v4 acc = {0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+        v4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const char* q = p + (u & 1) * 8192 + ((u >> 1) & 1) * 16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(q) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    if (acc.x == 123.456f) out[0] = acc.y + acc.z + acc.w;
+}
+
 // ray-level hooks
 // TOP: through the treetop in LDS, like the frame's trace kernels (so that the ray-level parity tests cover that path).
 // Whole waves walk the ray list together and use the wave-level traversal with its quad-cooperative tail (trace_quad.h),
@@ -687,6 +707,34 @@ int trhip_calibrate_valu(trhip_device* dev, float* ginst_per_s) {
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *ginst_per_s = best;
+    return 0;
+}
+
+int trhip_calibrate_l1(trhip_device* dev, float* gaccesses_per_s) {
+    DEVCHK(dev);
+    if (!gaccesses_per_s) return set_error("trhip_calibrate_l1: null out");
+    int cus = 256;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev->hip_device));
+    const int blocks = cus * 4, iters = 400;       // four waves per SIMD; two already reach the rate (tools/ubench/l1_tags.hip)
+    char* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, 16384 + 64));
+    HIPCHK(hipMemset(buf, 0, 16384 + 64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    float best = 0.0f;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(hipEventRecord(a, nullptr));
+        hipLaunchKernelGGL(k_calibrate_l1, dim3(blocks), dim3(KB), 0, nullptr, buf, iters, reinterpret_cast<float*>(dev->overflow_flag));
+        HIPCHK(hipEventRecord(b, nullptr));
+        HIPCHK(hipEventSynchronize(b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        const float g = (float)((double)blocks * (KB / 64) * (double)iters * 8.0 * 64.0 / ((double)ms * 1e6));
+        if (rep > 0 && g > best) best = g;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(buf);
+    *gaccesses_per_s = best;
     return 0;
 }
 

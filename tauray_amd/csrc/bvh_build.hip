@@ -411,9 +411,13 @@ __global__ __launch_bounds__(BT) void k_quantize4(uint n_nodes, const Bvh4Node* 
                     float fa = floorf((lo[k][c] - o) / scale), fb = ceilf((hi[k][c] - o) / scale);
                     fa = fminf(fmaxf(fa, 0.0f), 255.0f); fb = fminf(fmaxf(fb, 0.0f), 255.0f);
                     a = (uint)fa; b = (uint)fb;
-                    while (a > 0u && o + (float)a * scale > lo[k][c]) --a;
-                    while (b < 255u && o + (float)b * scale < hi[k][c]) ++b;
-                    if (o + (float)a * scale > lo[k][c] || o + (float)b * scale < hi[k][c]) fits = false;
+                    // both readings of a byte must contain the fp32 plane: the fp32 reconstruction rn(o + q * scale) (TR_QNODES = 1)
+                    // and the exact o + q * scale the folded slab test works with (TR_QNODES = 2; exact in double)
+                    const double od = (double)o, sd = (double)scale;
+                    while (a > 0u && (o + (float)a * scale > lo[k][c] || od + (double)a * sd > (double)lo[k][c])) --a;
+                    while (b < 255u && (o + (float)b * scale < hi[k][c] || od + (double)b * sd < (double)hi[k][c])) ++b;
+                    if (o + (float)a * scale > lo[k][c] || o + (float)b * scale < hi[k][c] || od + (double)a * sd > (double)lo[k][c] ||
+                        od + (double)b * sd < (double)hi[k][c]) fits = false;
                 }
                 qlo |= a << (8 * c); qhi |= b << (8 * c);
             }

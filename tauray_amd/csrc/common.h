@@ -177,10 +177,17 @@ struct alignas(64) Bvh4NodeQ {
     uint pad[2];
 };
 static_assert(sizeof(Bvh4NodeQ) == 64, "Bvh4NodeQ layout");
+// TR_QNODES = 1: planes rebuilt as fp32 (origin + q * scale), then the fp32 slab test, in both traversal loops; = 2: the decode
+// folded into the slab test of the per-lane loop (trace.h), the quad tail keeps reading the fp32 nodes.
 #if TR_QNODES
 #define TR_NODES_OF(sv) reinterpret_cast<const Bvh4Node*>((sv).nodesq)
 #else
 #define TR_NODES_OF(sv) (sv).nodes4
+#endif
+#if TR_QNODES == 1
+#define TR_QUAD_NODES_OF(sv) reinterpret_cast<const Bvh4Node*>((sv).nodesq)
+#else
+#define TR_QUAD_NODES_OF(sv) (sv).nodes4
 #endif
 
 // Treetop: the top four levels of the 4-wide tree (1 + 4 + 16 + 64 = 85 slots of an implicit complete 4-ary layout, the

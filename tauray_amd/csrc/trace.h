@@ -355,7 +355,43 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
         // pins the LDS reads: merged with the other branch they would become flat loads through a selected pointer
         asm volatile("" : "+v"(nxv.x), "+v"(fxv.x), "+v"(nyv.x), "+v"(fyv.x), "+v"(nzv.x), "+v"(fzv.x), "+v"(c0));
     }
-#if TR_QNODES
+#if TR_QNODES == 2
+    else {
+        // 64-byte quantised node, decode folded into the slab test: t = q * (scale / d) + (origin - o) / d per plane, one conversion
+        // and one multiply-add where the fp32 node has a subtraction and a multiplication.  scale / d is exact (a power of two);
+        // (origin - o) / d carries two roundings relative to its own size, so it is moved outwards by 2^-22 of its size - the
+        // box the test sees contains the exact quantised box, which contains the fp32 box (k_quantize4 checks that in double).
+        const char* base = reinterpret_cast<const char*>(nodes);
+        const uint t = (uint)node << 6;
+        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
+        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 16);
+        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
+        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
+        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+        const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * r.inv_dir.x, ay = __uint_as_float((hd.w & 0xFF00u) << 15) * r.inv_dir.y,
+                    az = __uint_as_float((hd.w & 0xFF0000u) << 7) * r.inv_dir.z;
+        const float bx = (__uint_as_float(hd.x) - r.org.x) * r.inv_dir.x, by = (__uint_as_float(hd.y) - r.org.y) * r.inv_dir.y,
+                    bz = (__uint_as_float(hd.z) - r.org.z) * r.inv_dir.z;
+        const float K = 2.384185791015625e-07f;      // 2^-22
+        const float bnx = __builtin_fmaf(-K, __builtin_fabsf(bx), bx), bfx = __builtin_fmaf(K, __builtin_fabsf(bx), bx);
+        const float bny = __builtin_fmaf(-K, __builtin_fabsf(by), by), bfy = __builtin_fmaf(K, __builtin_fabsf(by), by);
+        const float bnz = __builtin_fmaf(-K, __builtin_fabsf(bz), bz), bfz = __builtin_fmaf(K, __builtin_fabsf(bz), bz);
+        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
+        const uint qnx = gx ? p0.y : p0.x, qfx = gx ? p0.x : p0.y, qny = gy ? p0.w : p0.z, qfy = gy ? p0.z : p0.w, qnz = gz ? p1.y : p1.x, qfz = gz ? p1.x : p1.y;
+#define TR_QB(w, k) (float)(((w) >> (8 * (k))) & 0xFFu)
+#define TR_QSLAB(k) { \
+        const float tx0 = __builtin_fmaf(TR_QB(qnx, k), ax, bnx), tx1 = __builtin_fmaf(TR_QB(qfx, k), ax, bfx); \
+        const float ty0 = __builtin_fmaf(TR_QB(qny, k), ay, bny), ty1 = __builtin_fmaf(TR_QB(qfy, k), ay, bfy); \
+        const float tz0 = __builtin_fmaf(TR_QB(qnz, k), az, bnz), tz1 = __builtin_fmaf(TR_QB(qfz, k), az, bfz); \
+        const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin)); \
+        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD; \
+        h.t[k] = t0 <= t1 ? t0 : __builtin_huge_valf(); }
+        TR_QSLAB(0) TR_QSLAB(1) TR_QSLAB(2) TR_QSLAB(3)
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
+        return;
+    }
+#elif TR_QNODES
     else {
         // 64-byte quantised node (common.h Bvh4NodeQ): header, children, 6 x 4 plane bytes in four loads; planes reconstructed as
         // origin + q * scale (one rounding, the same the builder's conservative choice of q assumed)

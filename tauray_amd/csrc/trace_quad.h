@@ -88,7 +88,7 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* 
         c = *reinterpret_cast<const int*>(lb + 96u * TR_TOP_SLOTS + s);
         asm volatile("" : "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz), "+v"(c));
     }
-#if TR_QNODES
+#if TR_QNODES == 1
     else {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = (uint)node << 6;
@@ -366,7 +366,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, TR_NODES_OF(sv), top, qnode, q, qbest, hitb, t0);
+                const int c = quad_child_box<TOP>(qr, TR_QUAD_NODES_OF(sv), top, qnode, q, qbest, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
@@ -523,7 +523,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, TR_NODES_OF(sv), top, qnode, q, qtmax, hitb, t0);
+                const int c = quad_child_box<TOP>(qr, TR_QUAD_NODES_OF(sv), top, qnode, q, qtmax, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;

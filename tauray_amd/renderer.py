@@ -156,6 +156,12 @@ class Context:
         check(_lib.lib().trhip_calibrate_valu(self.h, C.byref(g)))
         return float(g.value)
 
+    def calibrate_l1(self) -> float:
+        """Peak rate of cache-line accesses of the vector L1 caches of the device, in 10^9 accesses per second."""
+        g = C.c_float()
+        check(_lib.lib().trhip_calibrate_l1(self.h, C.byref(g)))
+        return float(g.value)
+
     def close(self):
         if self.h:
             _lib.lib().trhip_device_destroy(self.h)
