@@ -56,9 +56,18 @@ def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, ieee=
 def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION):
     assert np.isfinite(img).all(), f"{what}: non-finite output"
     rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
-    bad = float((rel.max(-1) > REL_TOL).mean())
-    mean_err = abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / max(float(ref[..., :3].mean()), 1e-6)
+    off = rel.max(-1) > REL_TOL
+    bad = float(off.mean())
     assert bad <= max_bad, f"{what}: {bad:.4%} pixels differ by more than {REL_TOL}"
+    # The image mean catches a small bias everywhere, which the per-pixel tolerance would let through.  It is taken over the pixels
+    # inside the tolerance, with values capped at a hundred times the frame's mean: one pixel can hold a highlight thousands of
+    # times the mean (a sphere light in a near-mirror panel: GGX's D at small roughness amplifies an ulp of n.h to 1-2 %, 7193 vs
+    # 7338 or 15632 vs 15772 in frames of mean 2.4-3.0 - found by tools/fuzz_campaign.sh, profiles/r3/fuzz_campaign.txt; bit-equal
+    # to the oracle under IEEE shading arithmetic) and would decide the statistic alone
+    good = ~off
+    cap = 100.0 * max(float(np.abs(ref[..., :3]).mean()), 1e-6)
+    a, b = np.minimum(img[..., :3][good], cap), np.minimum(ref[..., :3][good], cap)
+    mean_err = abs(float(a.mean()) - float(b.mean())) / max(float(b.mean()), 1e-6)
     assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
     assert np.array_equal(img[..., 3], ref[..., 3]), f"{what}: alpha differs"
 
@@ -1649,8 +1658,9 @@ def test_random_option_combinations(R, ctx, oracle):
     sc = _zoo_scene()
     ss = R.SceneStage(ctx, sc)
     osc = oracle.OracleScene(sc)
-    rng = np.random.default_rng(2024)
-    for k in range(48):
+    # TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS: longer campaigns with other seeds (run by hand; profiles/r3/fuzz_campaign.txt)
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "2024")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS", "48"))):
         per_pass = int(rng.choice([1, 1, 2, 3]))
         kw = dict(
             max_bounces=int(rng.integers(1, 7)), sampler=int(rng.integers(0, 4)), film=int(rng.integers(0, 3)), film_radius=float(rng.choice([0.5, 1.0, 1.5])),
@@ -1667,12 +1677,21 @@ def test_random_option_combinations(R, ctx, oracle):
         ref = None
         for f in range(frames):
             ref = osc.render_pt(opt, 96, 96, frame_counter=f, samples_accumulated=f * kw["samples_per_pixel"], color=ref)
-        assert np.isfinite(ref).all(), f"draw {k}: the oracle produced a non-finite pixel with {kw}"
+        nf = ~np.isfinite(ref).all(-1)
+        if nf.any():
+            # the reference's own NaN (material_bsdf_sample's inf / inf at grazing refraction): rare - no draw of the
+            # suite's seed, a handful in a thousand (tools/fuzz_campaign.sh) - and the HIP path must produce it in the same pixels
+            # when it computes in the oracle's arithmetic; the other pixels are compared as usual
+            assert nf.mean() < 1e-3, f"draw {k}: the oracle produced {int(nf.sum())} non-finite pixels with {kw}"
+            strict = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, ieee=True, **kw)
+            assert np.array_equal(~np.isfinite(strict).all(-1), nf), f"draw {k}: non-finite pixels differ from the oracle's with {kw}"
+            img = np.where(nf[..., None], np.float32(0), img)
+            ref = np.where(nf[..., None], np.float32(0), ref)
         _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s)")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3, 12])
+@pytest.mark.parametrize("seed", [1, 2, 3, 12] + [int(x) for x in os.environ.get("TRHIP_FUZZ_SOUPS", "").split()])
 def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
     """Hit parity on geometry no modeller would export: 20 000 random triangles of wildly different sizes (1e-3 .. 1e2), needles,
     zero-area triangles, exact duplicates, coplanar overlapping sheets, a few non-opaque instances; closest-hit and shadow
@@ -1804,8 +1823,8 @@ def test_random_cameras(R, ctx, oracle):
     import copy
     from tauray_amd import scene as S
     base = _zoo_scene()
-    rng = np.random.default_rng(31)
-    for k in range(20):
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "31")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "20"))):
         sc = copy.copy(base)
         cam = S.Camera()
         kind = k % 3
@@ -1855,8 +1874,8 @@ def test_random_lights(R, ctx, oracle):
     import copy
     from tauray_amd import scene as S
     base = _zoo_scene()
-    rng = np.random.default_rng(77)
-    for k in range(16):
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "77")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "16"))):
         sc = copy.copy(base)
         pls = []
         for _ in range(int(rng.integers(0, 6))):
@@ -1891,9 +1910,9 @@ def test_random_materials(R, ctx, oracle):
     import copy
     from tauray_amd import scene as S
     base = _zoo_scene()
-    rng = np.random.default_rng(5150)
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "5150")))
     corner = lambda: float(rng.choice([0.0, 1.0, rng.uniform(0, 1), rng.uniform(0, 1)]))
-    for k in range(12):
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "12"))):
         sc = copy.copy(base)
         sc.instances = base.instances.copy()
         for i in range(9):
