@@ -1399,6 +1399,59 @@ def test_ragged_shards(R, ctx):
 
 
 @pytest.mark.gpu
+def test_random_shard_geometries(R, ctx):
+    """Seeded draws of what a multi-GPU job can look like: frame sizes that are not multiples of anything, 1-12 devices, scanlines or
+    shuffled strips, equal shares or the uneven ones a load balancer hands out (some of them empty), one or several viewports:
+    every device's partial frame rendered on this GPU and stitched (trhip_stitch_batch) must equal the unsharded frame bit for
+    bit.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns (tools/fuzz_campaign.sh)."""
+    import copy
+    from tauray_amd import distribution as D
+    from tauray_amd import scene as S
+    from tauray_amd.gltf import load_glb
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "9")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "16"))):
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 130))
+        if k % 4 == 0:
+            W = int(rng.choice([8, 64, 128, 136]))            # whole 8x8 tiles in x: the tiled launch order (csrc/shading.h launch_coord)
+        world = int(rng.integers(1, 13))
+        strategy = int(rng.choice([D.DISTRIBUTION_SCANLINE, D.DISTRIBUTION_SHUFFLED_STRIPS]))
+        views = int(rng.choice([1, 1, 1, 3]))
+        shares = np.full(world, 1.0 / world)
+        if rng.uniform() < 0.5:                               # a load balancer's shares, zeros included
+            shares = rng.uniform(0, 1, world) * (rng.uniform(0, 1, world) > 0.2)
+            shares = shares / shares.sum() if shares.sum() > 0 else np.full(world, 1.0 / world)
+        scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+        if views > 1:
+            scene = copy.copy(scene)
+            scene.cameras = S.generate_camera_grid(scene.cameras[0], views, 1, 0.3, 0.3, 5.0)
+        ss = R.SceneStage(ctx, scene)
+        kw = dict(max_bounces=int(rng.integers(1, 4)), sampler=int(rng.integers(0, 4)))
+        what = f"draw {k}: {W}x{H}, {views} view(s), {world} devices, strategy {strategy}, shares {np.round(shares, 3).tolist()}, {kw}"
+        full = _render_hip(R, ctx, ss, scene, (W, H), viewports=views, **kw)
+        opt = R.options_for_scene(scene, **kw)
+        dists, cum = [], 0.0
+        for i in range(world):
+            dists.append(D.get_device_distribution_params((W, H), strategy, cum, float(shares[i]), i, world, i == 0))
+            cum += float(shares[i])
+        primary = ctx.alloc(W * H * 16 * views).zero()
+        parts, pd = [], []
+        for i, d in enumerate(dists):
+            tw, th = D.get_distribution_target_size(d)
+            pt = R.PathTracerStage(ctx, ss, opt, d)
+            if i == 0:
+                pt.run(primary, views)
+            else:
+                buf = ctx.alloc(max(tw * th * views, 1) * 16).zero()
+                if tw * th > 0:
+                    pt.run(buf, views)
+                parts.append(buf); pd.append(d)
+            pt.close()
+        R.StitchStage(ctx, (W, H)).run_all(pd, parts, primary, viewports=views)
+        got = primary.download((views, H, W, 4))
+        assert np.array_equal(got, full), f"{what}: {(got != full).any(-1).sum()} pixels differ"
+
+
+@pytest.mark.gpu
 def test_texture_edge_cases(R, ctx, oracle):
     """Textures that are not powers of two (3x5, 1x1, 7x2), texture coordinates far outside [0, 1] (repeat wrapping,
     negative values), all four material textures at once (albedo with alpha, metallic-roughness, normal map, emission)."""
