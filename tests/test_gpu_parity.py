@@ -2017,8 +2017,13 @@ def _in_process_job(R, scene, opt, size, world, strategy, F, frames, workloads=N
     for f in range(0, frames, B):      # B frames per render(): B layers of the display image
         for r in list(range(1, world)) + [0]:
             rrs[r].render()
+        slot_stream = rrs[0].current.stream if world == 1 else None
+        if slot_stream is not None:      # a single rank keeps the whole frame on its slot's stream (RtRenderer.render): order the copy behind it
+            ctxs[0].stream_wait(None, slot_stream)
         rc = _lib.lib().trhip_copy_peer(ctxs[0].h, hist.data_ptr() + f * W * H * 16, ctxs[0].h, rrs[0].display.data_ptr(), B * W * H * 16, None)
         assert rc == 0
+        if slot_stream is not None:      # ... and the slot's next frame behind the copy
+            ctxs[0].stream_wait(slot_stream, None)
     for rr in rrs:
         rr.sync()
     out = hist.download((frames, H, W, 4))
@@ -2054,6 +2059,34 @@ def test_in_process_ranks_exchange_is_stream_ordered(R, ctx, world, strategy, F,
     got = _in_process_job(R, scene, opt, (W, H), world, strategy, F, frames, B=B)      # B > 1: frame batches (frames_per_launch)
     wrong = [f for f in range(frames) if not np.array_equal(got[f], ref[f])]
     assert not wrong, f"frames {wrong[:10]} differ from the single-rank frames"
+
+
+@pytest.mark.gpu
+def test_random_in_process_jobs(R, ctx):
+    """Seeded draws of multi-rank jobs in one process: 1-8 ranks on fake devices, scanlines or strips, 1-6 frames in flight, 1-4
+    frames per launch, even or load-balancer shares (zeros included), frame sizes that are not multiples of anything - nothing but
+    stream order between the ranks' path tracing, their sends, the stitch and the tonemap; every display frame must equal the
+    single-rank frame of the same index bit for bit.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns."""
+    from tauray_amd.gltf import load_glb
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "13")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "6"))):
+        scale = int(os.environ.get("TRHIP_FUZZ_SCALE", "1"))      # larger frames: longer kernels, more room for a missing dependency to show
+        W, H = scale * int(rng.integers(24, 320)), scale * int(rng.integers(16, 200))
+        world = int(rng.integers(1, 9))
+        strategy = int(rng.choice([1, 2]))
+        F, B = int(rng.integers(1, 7)), int(rng.choice([1, 1, 2, 3, 4]))
+        frames = B * int(rng.integers(2, 7))
+        workloads = None
+        if world > 1 and rng.uniform() < 0.5:
+            w = rng.uniform(0.05, 1, world) * (rng.uniform(0, 1, world) > 0.15)
+            workloads = (w / w.sum()).tolist() if w.sum() > 0 else None
+        scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+        opt = R.options_for_scene(scene, max_bounces=int(rng.integers(1, 4)))
+        ref = _single_rank_frames(R, ctx, scene, opt, (W, H), frames)
+        got = _in_process_job(R, scene, opt, (W, H), world, strategy, F, frames, workloads=workloads, B=B)
+        wrong = [f for f in range(frames) if not np.array_equal(got[f], ref[f])]
+        assert not wrong, (f"draw {k}: {W}x{H}, {world} ranks, strategy {strategy}, {F} in flight, {B} per launch, shares {workloads}: "
+                           f"frames {wrong[:10]} of {frames} differ from the single-rank frames")
 
 
 @pytest.mark.gpu
