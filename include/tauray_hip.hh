@@ -78,9 +78,21 @@ inline uvec2 get_distribution_target_size(const distribution_params& p)
     return get_distribution_render_size(p);
 }
 
-inline uvec2 get_distribution_target_max_size(const distribution_params& p)   // src/distribution_strategy.cc:21-31
+// src/distribution_strategy.cc:21-31 returns the frame size for shuffled strips.  The ids a device can be handed reach past the
+// pixel count, though: the 2^b regions are padded to a common size (45 x 51 = 2 295 pixels are 16 regions of 144 = 2 304 ids), a
+// device with (nearly) the whole frame gets `count` > pixels, and its partial image - `count` pixels in rows of size.x - is a row
+// taller than the frame.  The reference's targets are Vulkan images, whose out-of-bounds stores are dropped and whose padded ids
+// fall on no pixel anyway; a linear buffer needs the padded range, or the last valid pixels of such a share are written past its end
+// (found by tests/test_cpp_host.py::test_cpp_random_multi_device_runs: workloads 0, 1 on two devices).
+inline uvec2 get_distribution_target_max_size(const distribution_params& p)
 {
-    if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS) return p.size;
+    if(p.strategy == DISTRIBUTION_SHUFFLED_STRIPS)
+    {
+        unsigned n = p.size.x * p.size.y, b = 31;
+        while((n >> b) < 128 && b > 0) b--;                  // calculate_shuffled_strips_b
+        const size_t regions = size_t(1) << b, padded = ((size_t(n) + regions - 1) / regions) << b;
+        return uvec2{p.size.x, (unsigned)((padded + p.size.x - 1) / p.size.x)};
+    }
     return get_distribution_target_size(p);
 }
 

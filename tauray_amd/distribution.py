@@ -35,9 +35,16 @@ def get_distribution_target_size(p: DistributionParams):   # :6-19
     return get_distribution_render_size(p)
 
 
-def get_distribution_target_max_size(p: DistributionParams):   # :21-31
+def get_distribution_target_max_size(p: DistributionParams):   # :21-31, with the padded id range (see include/tauray_hip.hh)
     if p.strategy == DISTRIBUTION_SHUFFLED_STRIPS:
-        return (p.size[0], p.size[1])
+        # the regions are padded to a common size, so a device with (nearly) the whole frame is handed more ids than there are pixels
+        # and its partial image is a row taller than the frame; the reference's Vulkan image drops those stores, a buffer must hold them
+        n = p.size[0] * p.size[1]
+        b = 31
+        while (n >> b) < 128 and b > 0:
+            b -= 1
+        padded = ((n + (1 << b) - 1) >> b) << b
+        return (p.size[0], (padded + p.size[0] - 1) // p.size[0])
     return get_distribution_target_size(p)
 
 

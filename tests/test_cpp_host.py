@@ -597,6 +597,37 @@ def test_cpp_frames_in_flight_write_the_same_files(tmp_path, scene_dump):
 
 
 @pytest.mark.gpu
+def test_cpp_random_multi_device_runs(tmp_path, scene_dump):
+    """Seeded draws of what the C++ host can be asked for: frame sizes that are not multiples of anything, 1-8 fake devices, scanlines
+    or shuffled strips, 1-5 frame slots, uneven device workloads with zeros, 1-3 bounces, several frames: the files must be the bytes of
+    the single-device, one-frame-at-a-time run.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns."""
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "17")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "5"))):
+        W, H = int(rng.integers(1, 260)), int(rng.integers(1, 160))
+        frames = int(rng.integers(1, 7))
+        common = [CLI, scene_dump, f"--width={W}", f"--height={H}", f"--max-ray-depth={int(rng.integers(1, 4))}", f"--frames={frames}", "--filetype=raw"]
+        devices = int(rng.integers(1, 9))
+        extra = [f"--fake-devices={devices}", f"--frames-in-flight={int(rng.integers(1, 6))}",
+                 "--distribution-strategy=" + str(rng.choice(["scanline", "shuffled-strips"]))]
+        if devices > 1 and rng.uniform() < 0.5:
+            w = rng.uniform(0.05, 1, devices) * (rng.uniform(0, 1, devices) > 0.15)
+            if w.sum() > 0:
+                # the last device is offered everything: set_device_workloads clamps a ratio to what is left (src/rt_renderer.cc:151), and
+                # ratios that sum to less than one leave the rest of the frame to nobody there as here (a first version of this test
+                # rounded them to four digits and found the last pixel black)
+                extra.append("--device-workloads=" + ",".join([f"{x:.6f}" for x in (w / w.sum())[:-1]] + ["1"]))
+        a, b = str(tmp_path / f"one{k}_"), str(tmp_path / f"many{k}_")
+        subprocess.check_call(common + [f"--headless={a}"])
+        r = subprocess.run(common + [f"--headless={b}"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, f"draw {k}: {' '.join(common[2:] + extra)}: {r.stderr[-400:]}"
+        for f in range(frames):
+            fa, fb = (f"{a}{f}.raw", f"{b}{f}.raw") if frames > 1 else (f"{a}.raw", f"{b}.raw")
+            x, y = open(fa, "rb").read(), open(fb, "rb").read()
+            assert len(x) == W * H * 16 and x == y, f"draw {k}: {' '.join(common[2:] + extra)}: frame {f} differs"
+            os.remove(fa); os.remove(fb)
+
+
+@pytest.mark.gpu
 def test_cpp_set_device_workloads_resizes_the_shares(tmp_path, scene_dump):
     """rt_renderer::set_device_workloads (src/rt_renderer.cc:135-183) with shuffled strips: shares that grow past the even
     split (the non-primary targets are allocated with get_distribution_target_max_size) still give the single-device frame."""
@@ -610,3 +641,11 @@ def test_cpp_set_device_workloads_resizes_the_shares(tmp_path, scene_dump):
             assert open(f"{a}{f}.raw", "rb").read() == open(f"{b}{f}.raw", "rb").read(), f"{tag}: frame {f} differs"
     r = subprocess.run(common + [f"--headless={a}", "--fake-devices=2", "--device-workloads=1"], capture_output=True, text=True)
     assert r.returncode != 0 and "one ratio per device" in r.stderr
+    # a non-display device with the whole frame of a size whose strips are padded (45 x 51 = 2 295 pixels, 16 regions of 144 = 2 304 ids):
+    # its partial image is a row taller than the frame (get_distribution_target_max_size in include/tauray_hip.hh)
+    small = [CLI, scene_dump, "--width=45", "--height=51", "--max-ray-depth=3", "--frames=2", "--filetype=raw"]
+    c, d = str(tmp_path / "small_one"), str(tmp_path / "small_all_on_1")
+    subprocess.check_call(small + [f"--headless={c}"])
+    subprocess.check_call(small + [f"--headless={d}", "--fake-devices=2", "--frames-in-flight=2", "--distribution-strategy=shuffled-strips", "--device-workloads=0,1"])
+    for f in range(2):
+        assert open(f"{c}{f}.raw", "rb").read() == open(f"{d}{f}.raw", "rb").read(), f"45x51, workloads 0,1: frame {f} differs"

@@ -14,3 +14,9 @@ done
 TRHIP_FUZZ_SOUPS="${4:-21 22 23 24 25 26 27 28}" timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "random_triangle_soups" > $OUT/soups.txt 2>&1
 echo "soups: $(tail -1 $OUT/soups.txt)"
 grep -E "^(FAILED|E  )" $OUT/soups.txt | head -20
+# the C++ host with fake devices
+for seed in ${1:-101 202 303}; do
+  TRHIP_FUZZ_SEED=$seed TRHIP_FUZZ_DRAWS_SMALL=${3:-60} timeout 1500 python -m pytest tests/test_cpp_host.py -m gpu -q -k cpp_random_multi_device > $OUT/cpp_$seed.txt 2>&1
+  echo "cpp host, seed $seed: $(tail -1 $OUT/cpp_$seed.txt)"
+  grep -E "^(FAILED|E  )" $OUT/cpp_$seed.txt | cut -c1-400 | head -6
+done
