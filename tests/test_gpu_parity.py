@@ -1840,8 +1840,10 @@ def test_refit_sequences_equal_rebuilds(R, ctx):
     from tauray_amd.gltf import load_glb
     from tauray_amd.scene import from_glm, to_glm, trs_matrix
 
+    seed, steps = int(os.environ.get("TRHIP_FUZZ_SEED", "12")), int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "12"))
+
     def sequence(refit):
-        rng = np.random.default_rng(12)
+        rng = np.random.default_rng(seed)
         scene = load_glb(os.path.join(GOLDEN, "test.glb"), 96, 96)
         ss = R.SceneStage(ctx, scene)
         sp = scene.spans[4]
@@ -1850,7 +1852,7 @@ def test_refit_sequences_equal_rebuilds(R, ctx):
         ss.set_skin(4, skins)
         base = [from_glm(scene.instances["model"][i]) for i in range(len(scene.instances))]
         frames = []
-        for step in range(12):
+        for step in range(steps):
             for i in rng.choice(np.arange(4, len(scene.instances)), size=2, replace=False):
                 m = trs_matrix(rng.uniform(-0.4, 0.4, 3), rng.normal(size=4) * (0.2, 0.2, 0.2, 1.0) + (0, 0, 0, 1), rng.uniform(0.7, 1.3, 3)) @ base[i]
                 scene.instances["model_prev"][i] = scene.instances["model"][i]
