@@ -387,6 +387,8 @@ public:
     }
     // one stage per frame slot: slot k of F renders frames k, k + F, ... (rt_stage::frame_counter, src/rt_stage.cc:81-86)
     void set_frame_counter(uint32_t frame_counter) { check(trhip_pt_set_frame_counter(pt, frame_counter)); }
+    // `frames` consecutive frames per run(): the target holds frames * active_viewport_count layers, frame-major (trhip_pt_set_frame_batch)
+    void set_frame_batch(uint32_t frames) { check(trhip_pt_set_frame_batch(pt, frames)); frame_batch = frames; }
     // slices of a frame run concurrently inside the stage: 0 = automatic, 1 = none (several frames in flight instead)
     void set_lanes(int lanes) { check(trhip_pt_set_lanes(pt, lanes)); }
     // view / sample shard of a multi-device job: global viewport and sample addressing
@@ -398,7 +400,7 @@ public:
     void run(void* stream = nullptr)
     {
         uvec2 ts = get_distribution_target_size(opt.distribution);
-        check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count, stream));
+        check(trhip_pt_render(pt, color, ts.x, ts.y, (uint32_t)opt.active_viewport_count * frame_batch, stream));
     }
     // the same frame into a gbuffer (src/gbuffer.hh: the entries path_tracer.rgen writes); null members are skipped
     using gbuffer_target = trhip_pt_targets;
@@ -415,6 +417,7 @@ public:
     void* color;
     options opt;
     trhip_pt* pt = nullptr;
+    uint32_t frame_batch = 1;
 };
 
 // direct_stage (src/direct_stage.{hh,cc}): first hit + samples_per_pass light samples, same surface as path_tracer_stage.
@@ -499,6 +502,10 @@ public:
         // still running; `display` and finish_frame() refer to the frame render() was last called for, frame_slots[k] to
         // the others.
         int max_frames_in_flight = 1;
+        // Frames per launch: B > 1 makes every render() call B consecutive frames (trhip_pt_set_frame_batch): every image holds
+        // B * active_viewport_count layers, frame-major, and `display` B tonemapped frames.  For frames that do not accumulate.
+        // Bigger launches: less of a frame is the tail of its kernels (the pipelined figure of bench.py uses two).
+        int frames_per_launch = 1;
     };
 
     // `devices`: HIP device index per logical device (repeat an index for --fake-devices); device 0 displays.
@@ -510,10 +517,13 @@ public:
         const int n_slots = std::max(this->opt.max_frames_in_flight, 1);
         if(n_slots > 1 && this->opt.accumulate)
             throw std::runtime_error("rt_renderer: accumulating frames depend on each other, frames in flight must be 1");
+        batch = (uint32_t)std::max(this->opt.frames_per_launch, 1);
+        if(batch > 1 && this->opt.accumulate)
+            throw std::runtime_error("rt_renderer: accumulating frames depend on each other, frames per launch must be 1");
         per_device.resize(devices.size());
         std::vector<double> ratios(devices.size(), 1.0 / devices.size());
         double cumulative = 0;
-        const size_t layers = this->opt.active_viewport_count;
+        const size_t layers = this->opt.active_viewport_count * batch;
         display_bytes = size_t(size.x) * size.y * 16 * layers;
         for(size_t i = 0; i < devices.size(); ++i)
         {
@@ -538,6 +548,7 @@ public:
                 po.distribution = d.dist;
                 sl.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, sl.color, po);
                 if(n_slots > 1) sl.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
+                if(batch > 1) sl.ray_tracer->set_frame_batch(batch);
                 if(i != 0) sl.gbuffer_copy = per_device[0].dev->alloc(d.max_bytes);   // receive buffer on the display device
             }
             d.dev->sync();
@@ -594,9 +605,9 @@ public:
     // rt_renderer::render (src/rt_renderer.cc:84-133): ray tracers -> transfers -> stitch -> tonemap.  Enqueues only.
     void render()
     {
-        const size_t k = frame_index % frame_slots.size();
+        const size_t k = (frame_index / batch) % frame_slots.size();
         current_slot = (int)k;
-        const uint32_t layers = (uint32_t)opt.active_viewport_count;
+        const uint32_t layers = (uint32_t)opt.active_viewport_count * batch;
         device& display_device = *per_device[0].dev;
         void* const display_stream = per_device[0].slots[k].stream;
         for(size_t i = 0; i < per_device.size(); ++i)
@@ -604,7 +615,7 @@ public:
             per_device_data& d = per_device[i];
             slot_data& sl = d.slots[k];
             if(!opt.accumulate) sl.ray_tracer->reset_accumulated_samples();
-            if(frame_slots.size() > 1) sl.ray_tracer->set_frame_counter(frame_index);   // one stage per slot: slot k renders frames k, k + N, ...
+            if(frame_slots.size() > 1 || batch > 1) sl.ray_tracer->set_frame_counter(frame_index);   // one stage per slot: slot k renders frames k, k + N, ... (B at a time)
             if(i != 0)   // the slot's previous frame has been stitched on the display device: its receive buffer is free
                 check(trhip_stream_wait_peer(d.dev->h, sl.stream, display_device.h, display_stream));
             sl.ray_tracer->run(sl.stream);
@@ -628,7 +639,7 @@ public:
         }
         display = frame_slots[k].display;
         tonemap->run(per_device[0].slots[k].color, display, size, layers, display_stream);
-        frame_index++;
+        frame_index += batch;
         accumulated_frames++;
     }
 
@@ -684,6 +695,7 @@ public:
     struct frame_slot { void* display = nullptr; };   // tonemapped RGBA32F on the display device
     std::vector<frame_slot> frame_slots;   // options.max_frames_in_flight of them (at least one)
     int current_slot = -1;
+    uint32_t batch = 1;                    // options.frames_per_launch
     uint32_t frame_index = 0;
     uvec2 size;
     options opt;
@@ -741,6 +753,7 @@ public:
     size_t save(device& dev, const void* display_image, unsigned frame_number)
     {
         const size_t pixels = size_t(opt.size.x) * opt.size.y;
+        if(opt.output_file_type == EMPTY && opt.skip_nan_check) return 0;      // nothing to look at, nothing to write: no readback
         std::vector<float> mem(pixels * 4 * opt.display_count);
         check(trhip_download(dev.h, mem.data(), display_image, mem.size() * 4, nullptr));
         size_t nan_pixels = 0;

@@ -8,7 +8,8 @@
 //              [--frames=1] [--fake-devices=N | --devices=0,1,...] [--distribution-strategy=scanline|shuffled-strips]
 //              [--filetype=exr|raw|none] [--format=rgb16|rgb32|rgba16|rgba32] [--tonemap=filmic|linear|gamma-correction|
 //              reinhard|reinhard-luminance] [--exposure=1] [--gamma=2.2] [--sampler=uniform-random|sobol-owen|sobol-z2|sobol-z3]
-//              [--rng-seed=0] [--accumulation] [-t] [--warmup-frames=0] [--frames-in-flight=1] [--renderer=path-tracer|direct]
+//              [--rng-seed=0] [--accumulation] [-t] [--skip-nan-check] [--warmup-frames=0] [--frames-in-flight=1] [--frames-per-launch=1]
+//              [--renderer=path-tracer|direct]
 //              [--camera-grid=w,h,x,y --camera-recentering-distance=5 --camera-grid-roll=0]   (light-field grid, one file per view)
 //
 // One process per GPU (include/tauray_hip_comm.hh): start N copies with --process-count=N --process-rank=0..N-1 --device=<HIP index>
@@ -18,6 +19,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <sstream>
 
@@ -39,7 +41,7 @@ int main(int argc, char** argv)
     {
         std::string scene_path, prefix = "capture";
         uvec2 size{1280, 720};
-        int frames = 1, warmup = 0, fake_devices = 1, frames_in_flight = 1;
+        int frames = 1, warmup = 0, fake_devices = 1, frames_in_flight = 1, frames_per_launch = 1;
         std::string renderer = "path-tracer";
         std::vector<int> devices;
         bool timing = false;
@@ -63,6 +65,7 @@ int main(int argc, char** argv)
             std::string a = argv[i];
             auto val = [&](const char* key) { return a.substr(std::strlen(key)); };
             if(a == "-t") timing = true;
+            else if(a == "--skip-nan-check") hopt.skip_nan_check = true;     // headless::options::skip_nan_check (src/headless.hh:74); with --filetype=none: no readback at all
             else if(a == "--accumulation") opt.accumulate = true;
             else if(a == "--pre-transform-vertices") opt.pre_transformed_vertices = true;
             else if(starts(a, "--width=")) size.x = (uint32_t)std::stoul(val("--width="));
@@ -96,6 +99,7 @@ int main(int argc, char** argv)
                 }
             }
             else if(starts(a, "--frames-in-flight=")) frames_in_flight = std::max(1, std::stoi(val("--frames-in-flight=")));
+            else if(starts(a, "--frames-per-launch=")) frames_per_launch = std::max(1, std::stoi(val("--frames-per-launch=")));   // rt_renderer::options::frames_per_launch
             else if(starts(a, "--camera-grid="))
             {
                 std::stringstream ss(val("--camera-grid=")); std::string tok; std::vector<double> v;
@@ -209,6 +213,7 @@ int main(int argc, char** argv)
         opt.active_viewport_count = viewports;
 
         opt.max_frames_in_flight = frames_in_flight;
+        opt.frames_per_launch = frames_per_launch;
         hopt.size = size; hopt.output_prefix = prefix; hopt.display_count = viewports;
         if(shard_views)
         {   // view shards: viewport v belongs to rank v mod N; every rank renders, tonemaps and saves its own
@@ -263,25 +268,41 @@ int main(int argc, char** argv)
             if(workloads.size() != rr.per_device.size()) throw std::runtime_error("--device-workloads needs one ratio per device");
             rr.set_device_workloads(workloads);
         }
-        if(frames_in_flight > 1 && !animated)
+        if((frames_in_flight > 1 || frames_per_launch > 1) && !animated)
         {   // frame f renders while the frames before it are read back, compressed and written (the reference overlaps
-            // its save workers with the next frames the same way, src/headless.cc:349-422)
-            std::vector<int> in_slot(frames_in_flight, -1);
+            // its save workers with the next frames the same way, src/headless.cc:349-422); with --frames-per-launch=B a slot
+            // holds B consecutive frames, frame-major in its display image
+            const int B = frames_per_launch, none = std::numeric_limits<int>::min();
+            const size_t frame_bytes = size_t(size.x) * size.y * 16 * opt.active_viewport_count;
+            std::vector<int> in_slot(frames_in_flight, none);      // the first frame of the launch a slot holds (negative: warm-up)
             auto retire = [&](int k) {
-                if(in_slot[k] < 0) return;
+                if(in_slot[k] == none) return;
                 rr.finish_slot(k);
-                out.save(*rr.per_device[0].dev, rr.frame_slots[k].display, (unsigned)in_slot[k]);
-                in_slot[k] = -1;
+                for(int b = 0; b < B; ++b)
+                {
+                    const int f = in_slot[k] + b;
+                    if(f >= 0 && f < frames)
+                        out.save(*rr.per_device[0].dev, static_cast<const char*>(rr.frame_slots[k].display) + size_t(b) * frame_bytes, (unsigned)f);
+                }
+                in_slot[k] = none;
             };
-            for(int f = -warmup; f < frames; ++f)
+            auto t0 = std::chrono::high_resolution_clock::now();
+            bool started = false;
+            for(int f = -warmup; f < frames; f += B)
             {
-                const int k = (int)(rr.frame_index % (uint32_t)frames_in_flight);
-                retire(k);                               // the slot's previous frame must be on disk before it is reused
+                const int k = (int)((rr.frame_index / (uint32_t)B) % (uint32_t)frames_in_flight);
+                retire(k);                               // the slot's previous frames must be on disk before it is reused
+                if(!started && f >= 0) { rr.finish_all(); t0 = std::chrono::high_resolution_clock::now(); started = true; }   // -t: the warm-up is over
                 rr.render();
-                in_slot[k] = f < 0 ? -1 : f;
-                if(f < 0) rr.finish_slot(k);
+                in_slot[k] = f;
             }
-            for(int n = 0; n < frames_in_flight; ++n) retire((int)((rr.frame_index + n) % (uint32_t)frames_in_flight));
+            for(int n = 0; n < frames_in_flight; ++n) retire((int)((rr.frame_index / (uint32_t)B + n) % (uint32_t)frames_in_flight));
+            if(timing)
+            {
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+                const int counted = ((frames + B - 1) / B) * B;      // whole launches, like the loop above
+                std::cout << "FRAMES " << counted << " (" << frames_in_flight << " in flight, " << B << " per launch): " << ms << " ms, " << ms / counted << " ms per frame\n";
+            }
             return 0;
         }
         for(int f = -warmup; f < frames; ++f)
@@ -316,7 +337,7 @@ int main(int argc, char** argv)
         {
             direct_renderer::options dopt;
             static_cast<path_tracer_stage::options&>(dopt) = opt;
-            dopt.tonemap = opt.tonemap; dopt.accumulate = opt.accumulate; dopt.max_frames_in_flight = opt.max_frames_in_flight;
+            dopt.tonemap = opt.tonemap; dopt.accumulate = opt.accumulate; dopt.max_frames_in_flight = opt.max_frames_in_flight; dopt.frames_per_launch = opt.frames_per_launch;
             direct_renderer rr(devices, scene, size, dopt);
             return run(rr);
         }

@@ -589,7 +589,11 @@ def test_cpp_frames_in_flight_write_the_same_files(tmp_path, scene_dump):
     # distribution strategies - the same bytes as one device, one frame at a time
     for tag, extra in (("scan", ["--fake-devices=8", "--frames-in-flight=4", "--distribution-strategy=scanline"]),
                        ("strips", ["--fake-devices=8", "--frames-in-flight=4", "--distribution-strategy=shuffled-strips"]),
-                       ("two", ["--fake-devices=2", "--frames-in-flight=2"])):
+                       ("two", ["--fake-devices=2", "--frames-in-flight=2"]),
+                       # rt_renderer::options::frames_per_launch: B consecutive frames per render() (trhip_pt_set_frame_batch), seven frames
+                       # are two launches of three and one of which a single frame is kept; alone, with slots, across devices
+                       ("batch3", ["--frames-per-launch=3"]), ("batch2_slots3", ["--frames-per-launch=2", "--frames-in-flight=3"]),
+                       ("batch3_strips", ["--fake-devices=4", "--frames-per-launch=3", "--frames-in-flight=2", "--distribution-strategy=shuffled-strips"])):
         c = str(tmp_path / tag)
         subprocess.check_call(common + [f"--headless={c}"] + extra)
         for f in range(7):
@@ -599,7 +603,7 @@ def test_cpp_frames_in_flight_write_the_same_files(tmp_path, scene_dump):
 @pytest.mark.gpu
 def test_cpp_random_multi_device_runs(tmp_path, scene_dump):
     """Seeded draws of what the C++ host can be asked for: frame sizes that are not multiples of anything, 1-8 fake devices, scanlines
-    or shuffled strips, 1-5 frame slots, uneven device workloads with zeros, 1-3 bounces, several frames: the files must be the bytes of
+    or shuffled strips, 1-5 frame slots, 1-4 frames per launch, uneven device workloads with zeros, 1-3 bounces, several frames: the files must be the bytes of
     the single-device, one-frame-at-a-time run.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns."""
     rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "17")))
     for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "5"))):
@@ -607,7 +611,7 @@ def test_cpp_random_multi_device_runs(tmp_path, scene_dump):
         frames = int(rng.integers(1, 7))
         common = [CLI, scene_dump, f"--width={W}", f"--height={H}", f"--max-ray-depth={int(rng.integers(1, 4))}", f"--frames={frames}", "--filetype=raw"]
         devices = int(rng.integers(1, 9))
-        extra = [f"--fake-devices={devices}", f"--frames-in-flight={int(rng.integers(1, 6))}",
+        extra = [f"--fake-devices={devices}", f"--frames-in-flight={int(rng.integers(1, 6))}", f"--frames-per-launch={int(rng.choice([1, 1, 2, 3, 4]))}",
                  "--distribution-strategy=" + str(rng.choice(["scanline", "shuffled-strips"]))]
         if devices > 1 and rng.uniform() < 0.5:
             w = rng.uniform(0.05, 1, devices) * (rng.uniform(0, 1, devices) > 0.15)
