@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/fuzz; mkdir -p $OUT
 cd $R
 for seed in ${1:-101 202 303}; do
   TRHIP_FUZZ_SEED=$seed TRHIP_FUZZ_DRAWS=${2:-300} TRHIP_FUZZ_DRAWS_SMALL=${3:-60} timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q \
-      -k "random_option_combinations or random_cameras or random_lights or random_materials or random_shard_geometries or random_in_process_jobs or refit_sequences_equal_rebuilds" > $OUT/seed_$seed.txt 2>&1
+      -k "random_option_combinations or random_cameras or random_lights or random_materials or random_shard_geometries or random_in_process_jobs or refit_sequences_equal_rebuilds or random_direct_and_gbuffer_targets" > $OUT/seed_$seed.txt 2>&1
   echo "seed $seed: $(tail -1 $OUT/seed_$seed.txt)"
   grep -E "^(FAILED|E  )" $OUT/seed_$seed.txt | head -20
 done
