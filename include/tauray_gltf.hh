@@ -506,7 +506,8 @@ inline void calculate_normals(std::vector<vertex>& v, const std::vector<uint32_t
 // mesh::calculate_tangents (src/mesh.cc:145-185); only the first vertex of a triangle accumulates, as in the reference
 inline void calculate_tangents(std::vector<vertex>& v, const std::vector<uint32_t>& idx)
 {
-    auto normalize3 = [](float* a) { const float l = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); a[0] /= l; a[1] /= l; a[2] /= l; };
+    // glm::normalize: v * inversesqrt(dot(v, v)), the reciprocal square root as 1 / sqrt in float - not a division by the length
+    auto normalize3 = [](float* a) { const float inv = 1.0f / std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); a[0] *= inv; a[1] *= inv; a[2] *= inv; };
     std::vector<std::array<float, 4>> acc(v.size(), std::array<float, 4>{0, 0, 0, 0});
     for(size_t i = 0; i + 2 < idx.size(); i += 3)
     {

@@ -121,19 +121,44 @@ class _Glb:
         return arr
 
 
+def _dot3(a, b):
+    """glm::dot of vec3 rows in float32: (x * x' + y * y') + z * z', every step rounded."""
+    return a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 2] * b[:, 2]
+
+
+def _cross3(a, b):
+    """glm::cross: (a.y b.z - b.y a.z, a.z b.x - b.z a.x, a.x b.y - b.x a.y) in float32."""
+    return np.stack([a[:, 1] * b[:, 2] - b[:, 1] * a[:, 2], a[:, 2] * b[:, 0] - b[:, 2] * a[:, 0], a[:, 0] * b[:, 1] - b[:, 0] * a[:, 1]], axis=1).astype(np.float32)
+
+
+def _hard_normals(pos, tri):
+    d0 = pos[tri[:, 1]] - pos[tri[:, 0]]
+    d1 = pos[tri[:, 2]] - pos[tri[:, 0]]
+    hn = _cross3(d0, d1)
+    ln = np.sqrt(_dot3(hn, hn))
+    ok = ln > np.float32(1e-6)
+    hn[ok] = hn[ok] / ln[ok, None]
+    return d0, d1, hn
+
+
 def _calculate_normals(vertices, indices):
-    """mesh::calculate_normals (src/mesh.cc:113-143)."""
+    """mesh::calculate_normals (src/mesh.cc:113-143), operation by operation like include/tauray_gltf.hh: the hard normals are added
+    triangle after triangle (np.add.at walks its index array in order: v0, v1, v2 of triangle 0, then triangle 1, ...), so a vertex's
+    sum is rounded in the reference's order."""
     pos = vertices["pos"].astype(np.float32)
     tri = indices.reshape(-1, 3)
-    hn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]]).astype(np.float32)
-    ln = np.linalg.norm(hn, axis=1)
-    hn[ln > 1e-6] /= ln[ln > 1e-6, None]
+    _, _, hn = _hard_normals(pos, tri)
     n = np.zeros_like(pos)
-    for k in range(3):
-        np.add.at(n, tri[:, k], hn)
-    ln = np.linalg.norm(n, axis=1)
-    n[ln > 1e-6] /= ln[ln > 1e-6, None]
+    np.add.at(n, tri.reshape(-1), np.repeat(hn, 3, axis=0))
+    ln = np.sqrt(_dot3(n, n))
+    ok = ln > np.float32(1e-6)
+    n[ok] = n[ok] / ln[ok, None]
     vertices["normal"] = n
+
+
+def _normalize3(v):
+    """glm::normalize: v * inversesqrt(dot(v, v)) with the reciprocal square root as 1 / sqrt in float32."""
+    return v * (np.float32(1.0) / np.sqrt(_dot3(v, v)))[:, None]
 
 
 def _calculate_tangents(vertices, indices):
@@ -142,23 +167,16 @@ def _calculate_tangents(vertices, indices):
     uv = vertices["uv"].astype(np.float32)
     nrm = vertices["normal"].astype(np.float32)
     tri = indices.reshape(-1, 3)
-    d0 = pos[tri[:, 1]] - pos[tri[:, 0]]
-    d1 = pos[tri[:, 2]] - pos[tri[:, 0]]
-    hn = np.cross(d0, d1)
-    ln = np.linalg.norm(hn, axis=1)
-    hn[ln > 1e-6] /= ln[ln > 1e-6, None]
-    uv0 = uv[tri[:, 1]] - uv[tri[:, 0]]
-    uv1 = uv[tri[:, 2]] - uv[tri[:, 0]]
-    with np.errstate(invalid="ignore", divide="ignore"):
-        ht = uv1[:, 1:2] * d0 - uv0[:, 1:2] * d1
-        ht = ht / np.linalg.norm(ht, axis=1, keepdims=True)
-        hb = uv1[:, 0:1] * d1 - uv0[:, 0:1] * d0
-        hb = hb / np.linalg.norm(hb, axis=1, keepdims=True)
-        sign = np.where(np.einsum("ij,ij->i", np.cross(hn, ht), hb) < 0, -1.0, 1.0).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        d0, d1, hn = _hard_normals(pos, tri)
+        uv0 = uv[tri[:, 1]] - uv[tri[:, 0]]
+        uv1 = uv[tri[:, 2]] - uv[tri[:, 0]]
+        ht = _normalize3(uv1[:, 1:2] * d0 - uv0[:, 1:2] * d1)
+        hb = _normalize3(uv1[:, 0:1] * d1 - uv0[:, 0:1] * d0)
+        sign = np.where(_dot3(_cross3(hn, ht), hb) < 0, -1.0, 1.0).astype(np.float32)
         t = np.zeros((len(pos), 4), dtype=np.float32)
         np.add.at(t, tri[:, 0], np.concatenate([ht, sign[:, None]], axis=1).astype(np.float32))
-        t3 = t[:, :3] - nrm * np.einsum("ij,ij->i", nrm, t[:, :3])[:, None]
-        t3 = t3 / np.linalg.norm(t3, axis=1, keepdims=True)
+        t3 = _normalize3(t[:, :3] - nrm * _dot3(nrm, t[:, :3])[:, None])
     vertices["tangent"][:, :3] = t3
     vertices["tangent"][:, 3] = np.where(t[:, 3] < 0, -1.0, 1.0)
 
