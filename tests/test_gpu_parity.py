@@ -74,6 +74,8 @@ def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION):
 
 @pytest.fixture(scope="module")
 def glb128(R, ctx, test_glb_128):
+    # A device holds one scene: the tests that take this fixture come first in the file, before any test uploads a scene of its own
+    # to `ctx` (every later test builds its SceneStage itself).
     return R.SceneStage(ctx, test_glb_128)
 
 
@@ -293,58 +295,6 @@ def test_direct_stage_matches_oracle(R, ctx, glb128, test_glb_128, oracle, oracl
         assert float((np.abs(got[n][..., 3] - ref[n][..., 3]) > 1e-4 * (np.abs(ref[n][..., 3]) + 1.0)).mean()) <= MAX_BAD_FRACTION, f"direct {name}: {n} alpha"
     # sanity: direct light only - darker than the path tracer's image, and not black
     assert 0.01 < float(got["color"][..., :3].mean())
-
-
-@pytest.mark.gpu
-def test_random_direct_and_gbuffer_targets(R, ctx, oracle):
-    """Seeded draws over the two stages that write a gbuffer - direct_stage and path_tracer_stage with targets - on the zoo scene:
-    samples per pass and per pixel, sampler, film filter, tri-light mode, NEE weights, hidden lights, white first-bounce albedo,
-    transparent background, bounces, one or two accumulated frames; colour, the demodulated diffuse / reflection targets and the
-    first-hit AOVs against the oracle.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns (tools/fuzz_campaign.sh)."""
-    sc = _zoo_scene()
-    ss = R.SceneStage(ctx, sc)
-    osc = oracle.OracleScene(sc)
-    names = ["color", "diffuse", "reflection", "albedo", "normal", "pos", "instance_id"]
-    W = H = 96
-    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "23")))
-    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "8"))):
-        direct = bool(rng.integers(0, 2))
-        per_pass = int(rng.choice([1, 1, 2, 4]))
-        kw = dict(max_bounces=int(rng.integers(1, 5)), sampler=int(rng.integers(0, 4)), film=int(rng.integers(0, 3)), film_radius=float(rng.choice([0.5, 1.0])),
-                  tri_light_mode=int(rng.integers(0, 3)), nee_point=float(rng.choice([0.0, 1.0, 2.5])), nee_directional=float(rng.choice([0.0, 1.0])),
-                  hide_lights=int(rng.integers(0, 2)), use_white_albedo_on_first_bounce=int(rng.integers(0, 2)), transparent_background=int(rng.integers(0, 2)),
-                  samples_per_pass=per_pass, samples_per_pixel=per_pass * int(rng.integers(1, 3)), rng_seed=int(rng.choice([0, 0, 5])))
-        frames = int(rng.integers(1, 3))
-        # a third of the draws with the shading kernels at IEEE arithmetic.  The AOVs of a jittered first hit (film filters draw the
-        # sub-pixel offset with sin / cos, ocml's against glibc's in the oracle) agree to a few 1e-5 then, to 1e-4 with the default arithmetic
-        ieee = k % 3 == 0
-        what = f"draw {k}: {'direct' if direct else 'path tracer'} {kw}, {frames} frame(s), {'IEEE' if ieee else 'default'} arithmetic"
-        st = (R.DirectStage if direct else R.PathTracerStage)(ctx, ss, R.options_for_scene(sc, **kw), _dup((W, H)))
-        st.set_shading_arithmetic(ieee)
-        bufs = {n: ctx.alloc(W * H * R.PathTracerStage.TARGETS[n][0] * 4).zero() for n in names}
-        for _ in range(frames):
-            st.run_targets(bufs)
-        got = {n: np.frombuffer(bufs[n].download((1, H, W, R.PathTracerStage.TARGETS[n][0])).tobytes(), dtype=R.PathTracerStage.TARGETS[n][1])
-                  .reshape(1, H, W, R.PathTracerStage.TARGETS[n][0]) for n in names}
-        assert st.counters()["stack_overflows"] == 0
-        st.close()
-        oopt = oracle.options_for_scene(sc, **kw)
-        ref = None
-        for f in range(frames):
-            ref = osc.render_pt_targets(oopt, W, H, names, frame_counter=f, samples_accumulated=kw["samples_per_pixel"] * f, targets=ref, direct=direct)
-        nf = ~np.isfinite(ref["color"]).all(-1)
-        if nf.any():      # the reference's own NaN (DESIGN.md section 2): rare; those pixels are left out here (test_random_option_combinations pins them)
-            assert nf.mean() < 1e-3, what
-            for n in ("color", "diffuse", "reflection"):
-                got[n] = np.where(nf[..., None], np.float32(0), got[n]); ref[n] = np.where(nf[..., None], np.float32(0), ref[n])
-        _compare(got["color"], ref["color"], what + ": color")
-        assert np.array_equal(got["instance_id"], ref["instance_id"]), what
-        for n, tol in (("albedo", 1e-6), ("normal", 5e-5 if ieee else 1e-4), ("pos", 5e-5 if ieee else 1e-4)):
-            assert float(np.nanmax(np.abs(got[n] - ref[n]))) <= tol * max(1.0, float(np.nanmax(np.abs(ref[n])))), f"{what}: {n}"
-        for n in ("diffuse", "reflection"):
-            rel = np.abs(got[n][..., :3] - ref[n][..., :3]) / (np.abs(ref[n][..., :3]) + 1e-2)
-            assert float((rel.max(-1) > REL_TOL).mean()) <= MAX_BAD_FRACTION, f"{what}: {n}"
-            assert float((np.abs(got[n][..., 3] - ref[n][..., 3]) > 1e-4 * (np.abs(ref[n][..., 3]) + 1.0)).mean()) <= MAX_BAD_FRACTION, f"{what}: {n} alpha"
 
 
 def test_pre_transformed_vertices(R, ctx, glb128, test_glb_128, oracle, oracle_scene_128):
@@ -2043,6 +1993,58 @@ def test_random_materials(R, ctx, oracle):
         got = _render_targets_hip(R, ctx, ss, sc, (112, 112), ["material", "albedo"], max_bounces=2)
         want = osc.render_pt_targets(oracle.options_for_scene(sc, max_bounces=2), 112, 112, ["material", "albedo"])
         assert np.allclose(got["material"], want["material"], atol=1e-6) and np.allclose(got["albedo"], want["albedo"], atol=1e-6), f"draw {k}"
+
+
+@pytest.mark.gpu
+def test_random_direct_and_gbuffer_targets(R, ctx, oracle):
+    """Seeded draws over the two stages that write a gbuffer - direct_stage and path_tracer_stage with targets - on the zoo scene:
+    samples per pass and per pixel, sampler, film filter, tri-light mode, NEE weights, hidden lights, white first-bounce albedo,
+    transparent background, bounces, one or two accumulated frames; colour, the demodulated diffuse / reflection targets and the
+    first-hit AOVs against the oracle.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns (tools/fuzz_campaign.sh)."""
+    sc = _zoo_scene()
+    ss = R.SceneStage(ctx, sc)
+    osc = oracle.OracleScene(sc)
+    names = ["color", "diffuse", "reflection", "albedo", "normal", "pos", "instance_id"]
+    W = H = 96
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "23")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "8"))):
+        direct = bool(rng.integers(0, 2))
+        per_pass = int(rng.choice([1, 1, 2, 4]))
+        kw = dict(max_bounces=int(rng.integers(1, 5)), sampler=int(rng.integers(0, 4)), film=int(rng.integers(0, 3)), film_radius=float(rng.choice([0.5, 1.0])),
+                  tri_light_mode=int(rng.integers(0, 3)), nee_point=float(rng.choice([0.0, 1.0, 2.5])), nee_directional=float(rng.choice([0.0, 1.0])),
+                  hide_lights=int(rng.integers(0, 2)), use_white_albedo_on_first_bounce=int(rng.integers(0, 2)), transparent_background=int(rng.integers(0, 2)),
+                  samples_per_pass=per_pass, samples_per_pixel=per_pass * int(rng.integers(1, 3)), rng_seed=int(rng.choice([0, 0, 5])))
+        frames = int(rng.integers(1, 3))
+        # a third of the draws with the shading kernels at IEEE arithmetic.  The AOVs of a jittered first hit (film filters draw the
+        # sub-pixel offset with sin / cos, ocml's against glibc's in the oracle) agree to a few 1e-5 then, to 1e-4 with the default arithmetic
+        ieee = k % 3 == 0
+        what = f"draw {k}: {'direct' if direct else 'path tracer'} {kw}, {frames} frame(s), {'IEEE' if ieee else 'default'} arithmetic"
+        st = (R.DirectStage if direct else R.PathTracerStage)(ctx, ss, R.options_for_scene(sc, **kw), _dup((W, H)))
+        st.set_shading_arithmetic(ieee)
+        bufs = {n: ctx.alloc(W * H * R.PathTracerStage.TARGETS[n][0] * 4).zero() for n in names}
+        for _ in range(frames):
+            st.run_targets(bufs)
+        got = {n: np.frombuffer(bufs[n].download((1, H, W, R.PathTracerStage.TARGETS[n][0])).tobytes(), dtype=R.PathTracerStage.TARGETS[n][1])
+                  .reshape(1, H, W, R.PathTracerStage.TARGETS[n][0]) for n in names}
+        assert st.counters()["stack_overflows"] == 0
+        st.close()
+        oopt = oracle.options_for_scene(sc, **kw)
+        ref = None
+        for f in range(frames):
+            ref = osc.render_pt_targets(oopt, W, H, names, frame_counter=f, samples_accumulated=kw["samples_per_pixel"] * f, targets=ref, direct=direct)
+        nf = ~np.isfinite(ref["color"]).all(-1)
+        if nf.any():      # the reference's own NaN (DESIGN.md section 2): rare; those pixels are left out here (test_random_option_combinations pins them)
+            assert nf.mean() < 1e-3, what
+            for n in ("color", "diffuse", "reflection"):
+                got[n] = np.where(nf[..., None], np.float32(0), got[n]); ref[n] = np.where(nf[..., None], np.float32(0), ref[n])
+        _compare(got["color"], ref["color"], what + ": color")
+        assert np.array_equal(got["instance_id"], ref["instance_id"]), what
+        for n, tol in (("albedo", 1e-6), ("normal", 5e-5 if ieee else 1e-4), ("pos", 5e-5 if ieee else 1e-4)):
+            assert float(np.nanmax(np.abs(got[n] - ref[n]))) <= tol * max(1.0, float(np.nanmax(np.abs(ref[n])))), f"{what}: {n}"
+        for n in ("diffuse", "reflection"):
+            rel = np.abs(got[n][..., :3] - ref[n][..., :3]) / (np.abs(ref[n][..., :3]) + 1e-2)
+            assert float((rel.max(-1) > REL_TOL).mean()) <= MAX_BAD_FRACTION, f"{what}: {n}"
+            assert float((np.abs(got[n][..., 3] - ref[n][..., 3]) > 1e-4 * (np.abs(ref[n][..., 3]) + 1.0)).mean()) <= MAX_BAD_FRACTION, f"{what}: {n} alpha"
 
 
 # ----------------------------------------------------------------------------------------------------------
