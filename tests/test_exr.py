@@ -201,7 +201,9 @@ def test_written_files_are_read_by_the_references_tinyexr(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "exr_to_raw")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-I", os.path.join(REF, "external"), os.path.join(root, "tools", "exr_to_raw.cc"), "-o", exe, "-lpthread"])
-    for (w, h) in ((64, 48), (33, 70), (517, 33)):
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "0")))      # TRHIP_FUZZ_DRAWS_SMALL further random sizes (a campaign by hand)
+    sizes = [(64, 48), (33, 70), (517, 33)] + [(int(rng.integers(1, 700)), int(rng.integers(1, 140))) for _ in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "0")))]
+    for (w, h) in sizes:
         for k, kind in enumerate(("smooth", "noise", "levels")):
             img = _picture(w, h, kind, seed=k + w)
             for comp in (exr.NONE, exr.RLE, exr.ZIPS, exr.ZIP, exr.PIZ):

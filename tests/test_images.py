@@ -160,6 +160,76 @@ def test_a_progressive_file_cut_after_its_first_scan_is_a_picture_of_block_means
     assert np.abs(blocks[:, 0, :, 0] - means).max() <= 2.0
 
 
+def test_random_images_match_pillow():
+    """Seeded draws: sizes from 1 x 1 to a few hundred pixels that are multiples of nothing, PNG in every mode Pillow writes (1-bit, grey,
+    grey + alpha, palette with and without transparency, RGB, RGBA, 16-bit grey) at several compression levels, JPEG at qualities 1-100
+    with 4:4:4 / 4:2:2 / 4:2:0 chroma, grey, progressive or sequential, optimised tables, restart intervals in blocks or rows.  PNG must
+    agree exactly, JPEG to a few levels.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "7")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "40"))):
+        w, h = int(rng.integers(1, 260)), int(rng.integers(1, 200))
+        a = _picture(w, h, seed=int(rng.integers(0, 1 << 30)))
+        if rng.uniform() < 0.5:
+            mode = str(rng.choice(["1", "L", "LA", "P", "PA", "RGB", "RGBA", "I;16"]))
+            what = f"draw {k}: PNG {mode} {w}x{h}"
+            if mode == "1":
+                img = PIL.fromarray(a[..., 0] > 128)
+            elif mode == "L":
+                img = PIL.fromarray(a[..., 0], "L")
+            elif mode == "LA":
+                img = PIL.fromarray(a[..., [0, 3]].copy(), "LA")
+            elif mode in ("P", "PA"):
+                img = PIL.fromarray(a[..., :3].copy(), "RGB").quantize(int(rng.choice([2, 7, 16, 200])))
+                if mode == "PA":
+                    img.info["transparency"] = int(rng.integers(0, 2))
+            elif mode == "RGB":
+                img = PIL.fromarray(a[..., :3].copy(), "RGB")
+            elif mode == "RGBA":
+                img = PIL.fromarray(a, "RGBA")
+            else:
+                img = PIL.fromarray((a[..., 0].astype(np.uint16) * 257 + rng.integers(0, 200, (h, w)).astype(np.uint16)), "I;16")
+            b = io.BytesIO()
+            kw = {"compress_level": int(rng.integers(0, 10))}
+            if mode == "PA":
+                kw["transparency"] = img.info["transparency"]
+            img.save(b, "PNG", **kw)
+            data = b.getvalue()
+            got, ch = decode(data)
+            if mode == "I;16":
+                v = np.array(PIL.open(io.BytesIO(data))).astype(np.uint32)
+                want = ((v * 255 + 32767) // 65535).astype(np.uint8)      # rounded v * 255 / 65535
+                assert np.array_equal(got[..., 0], want) and np.array_equal(got[..., 1], want) and (got[..., 3] == 255).all(), what
+            else:
+                ref = np.array(PIL.open(io.BytesIO(data)).convert("RGBA"))
+                assert got.shape == ref.shape and np.array_equal(got, ref), f"{what}: {int((got != ref).any(-1).sum())} pixels differ"
+        else:
+            grey = rng.uniform() < 0.25
+            kw = {"quality": int(rng.integers(1, 101))}
+            if not grey:
+                kw["subsampling"] = int(rng.integers(0, 3))
+            if rng.uniform() < 0.5:
+                kw["progressive"] = True
+            if rng.uniform() < 0.3:
+                kw["optimize"] = True
+            r = rng.uniform()
+            if r < 0.25:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+            elif r < 0.4:
+                kw["restart_marker_rows"] = int(rng.integers(1, 4))
+            what = f"draw {k}: JPEG {'L' if grey else 'RGB'} {w}x{h} {kw}"
+            data = _save(a[..., 0].copy() if grey else a[..., :3].copy(), "L" if grey else "RGB", "JPEG", **kw)
+            got, ch = decode(data)
+            ref = np.array(PIL.open(io.BytesIO(data)).convert("RGBA")).astype(int)
+            d = np.abs(got.astype(int) - ref)
+            assert got.shape == (h, w, 4) and ch == (1 if grey else 3) and (got[..., 3] == 255).all(), what
+            if not grey and kw["subsampling"] and w <= 4:
+                continue      # libjpeg replicates chroma instead of interpolating it when a chroma row has at most two samples (jdsample.c)
+            # coarse quantisation (quality below ~20) leaves the two inverse DCTs and chroma filters further apart on single pixels
+            lim = 6 if kw["quality"] >= 25 else 14
+            assert d.max() <= lim and d[..., :3].mean() <= 0.6, f"{what}: max {int(d.max())}, mean {float(d.mean()):.3f}"
+
+
 def test_unreadable_files_fail_loudly():
     from tauray_amd import _lib
     a = _picture(16, 16)[..., :3].copy()
