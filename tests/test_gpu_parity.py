@@ -2257,6 +2257,16 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 # the shading kernels of the command-line option set exist at IEEE fp32 too (TRHIP_SHADE_FAST=0; csrc/shade_fast.hip)
                 "ieee_shade": {"TRHIP_SHADE_FAST": "0"}, "ieee_generic_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0"},
                 "ieee_general_last_bounce": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_LAST": "0"}}
+    # TRHIP_FUZZ_SWITCH_COMBOS=N (with TRHIP_FUZZ_SEED): N random combinations of the switches that keep the default arithmetic, by hand
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "1")))
+    for k in range(int(os.environ.get("TRHIP_FUZZ_SWITCH_COMBOS", "0"))):
+        pick = lambda key, values: {key: str(rng.choice(values))} if rng.uniform() < 0.5 else {}
+        combo = {}
+        for key, values in (("TRHIP_LANES", ["1", "2", "3", "4"]), ("TRHIP_FUSED", ["0", "1"]), ("TRHIP_OVERLAP", ["0", "1"]), ("TRHIP_GRID_BLOCKS", ["64", "300", "1024", "4096"]),
+                            ("TRHIP_SHADE_BLOCKS", ["32", "100", "2048"]), ("TRHIP_TREETOP", ["0", "1"]), ("TRHIP_SHADE_LAST", ["0", "1"]), ("TRHIP_BUILDER", ["lbvh", "ploc"]),
+                            ("TRHIP_BVH_OPT", ["0", "3", "8"]), ("TRHIP_COLLAPSE", ["greedy", "cost"]), ("TRHIP_PRESPLIT", ["0", "20", "100"])):
+            combo.update(pick(key, values))
+        variants[f"combo{k}_" + "_".join(f"{a[6:]}{b}" for a, b in combo.items())] = combo
     frames = {}
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
