@@ -182,6 +182,9 @@ inline void set_envmap(scene_data& s, const std::string& path)
             for(int c = 0; c < 4; ++c) px[4 * i + c] = c < n ? f[size_t(n) * i + c] : 1.0f;
     }
     else px = load_hdr(path, w, h);
+    // an infinite or NaN texel (an .exr written with half overflow, say) makes every entry of the alias table NaN and every sample of
+    // the frame with it; the reference renders that, this loader says so
+    for(float v: px) if(!std::isfinite(v)) throw std::runtime_error(path + ": the environment map holds non-finite texels");
     const uint8_t* p = reinterpret_cast<const uint8_t*>(px.data());
     s.envmap.assign(p, p + px.size() * 4);
     s.envmap_width = w; s.envmap_height = h;

@@ -110,5 +110,7 @@ def set_envmap(scene, path: str, factor=(1.0, 1.0, 1.0)):
         scene.envmap = load_exr_rgba(path)
     else:
         scene.envmap = load_hdr(path)
+    if not np.isfinite(scene.envmap).all():      # like include/tauray_envmap.hh: the alias table and every sample would be NaN
+        raise ValueError(f"{path}: the environment map holds non-finite texels")
     scene.environment_factor = (float(factor[0]), float(factor[1]), float(factor[2]), 1.0)      # vec4(factor, 1), src/scene_stage.cc:1345
     return scene

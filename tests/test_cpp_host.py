@@ -320,6 +320,60 @@ def test_cpp_envmap_matches_python(tmp_path):
         assert secs[8] == env.tobytes() and secs[9] == build_alias_table(env).tobytes(), (comp, half)
 
 
+def test_cpp_envmap_random_images_match_python(tmp_path):
+    """Seeded random environment maps - sizes that are multiples of nothing, a few bright texels over a dim sky, black texels, whole black
+    rows, values beyond half precision - as .hdr (run-length encoded and flat) and as .exr: the C++ host's texels and alias table equal the
+    Python mirror's byte for byte.  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL run longer campaigns."""
+    from tauray_amd import exr
+    from tauray_amd.hdr import set_envmap, write_hdr
+    from tauray_amd.scene import build_alias_table
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "19")))
+    dump = str(tmp_path / "env.trsc")
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "3"))):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 100))
+        sky = (rng.uniform(0, 1, (h, w, 3)) ** 4 * rng.choice([0.01, 1.0, 50.0])).astype(np.float32)
+        for _ in range(int(rng.integers(0, 4))):
+            sky[int(rng.integers(0, h)), int(rng.integers(0, w))] = rng.uniform(1e3, 2e5, 3)      # suns, some past the half-precision clamp
+        if rng.uniform() < 0.3:
+            sky[int(rng.integers(0, h))] = 0
+        if rng.uniform() < 0.3:
+            sky[rng.uniform(0, 1, (h, w)) < 0.3] = 0
+        kind = k % 3
+        f = str(tmp_path / ("sky.exr" if kind == 2 else "sky.hdr"))
+        if kind == 2:
+            half = bool(rng.integers(0, 2))
+            if half:
+                sky = np.minimum(sky, np.float32(6e4))      # a half file cannot hold more; infinite texels are refused (below)
+            rgba = np.concatenate([sky, np.ones((h, w, 1), np.float32)], axis=-1)
+            open(f, "wb").write(exr.encode_exr(rgba, alpha=False, half=half, compression=int(rng.choice([exr.NONE, exr.ZIP, exr.PIZ]))))
+        else:
+            write_hdr(f, sky, rle=kind == 0)
+        subprocess.check_call([CLI, os.path.join(GOLDEN, "test.glb"), "--width=32", "--height=32", f"--envmap={f}", f"--dump-scene={dump}"])
+        raw = open(dump, "rb").read()
+        pos, secs = 8, []
+        for _ in range(12):
+            n = struct.unpack_from("<Q", raw, pos)[0]
+            secs.append(raw[pos + 8:pos + 8 + n])
+            pos += 8 + n
+
+        class S:
+            pass
+        env = set_envmap(S(), f).envmap
+        assert env.shape == (h, w, 4) and secs[8] == env.tobytes(), f"draw {k}: {w}x{h} kind {kind}: texels differ"
+        assert secs[9] == build_alias_table(env).tobytes(), f"draw {k}: {w}x{h} kind {kind}: alias tables differ"
+    # a texel that overflowed to infinity on its way into a half file: both hosts refuse the map instead of rendering NaN
+    f = str(tmp_path / "inf.exr")
+    rgba = np.ones((4, 8, 4), np.float32); rgba[1, 2, 0] = 1e6
+    open(f, "wb").write(exr.encode_exr(rgba, alpha=False, half=True, compression=exr.ZIP))
+    r = subprocess.run([CLI, os.path.join(GOLDEN, "test.glb"), "--width=32", "--height=32", f"--envmap={f}", f"--dump-scene={dump}"], capture_output=True, text=True)
+    assert r.returncode != 0 and "non-finite" in r.stderr
+
+    class S2:
+        pass
+    with pytest.raises(ValueError, match="non-finite"):
+        set_envmap(S2(), f)
+
+
 def test_cli_fails_loudly(scene_dump):
     r = subprocess.run([CLI, "/nonexistent.trsc"], capture_output=True, text=True)
     assert r.returncode == 1 and "Failed to open" in r.stderr
