@@ -401,8 +401,11 @@ struct glb_file
     // accessor as rows of doubles (exact for every component type glTF has)
     std::vector<double> accessor(int index, int& components, size_t& count) const
     {
+        if(index < 0 || (size_t)index >= doc.at("accessors").size()) throw std::runtime_error("glTF: accessor index out of range");
         const json& a = doc.at("accessors").at((size_t)index);
-        const json& bv = doc.at("bufferViews").at((size_t)a.integer("bufferView", 0));
+        const int view = a.integer("bufferView", -1);
+        if(view < 0 || (size_t)view >= doc.at("bufferViews").size()) throw std::runtime_error("glTF: bufferView index out of range");
+        const json& bv = doc.at("bufferViews").at((size_t)view);
         const std::vector<uint8_t>& bin = buffer_of(bv);
         const int ct = a.integer("componentType", 0);
         const std::string& type = a.at("type").str;
@@ -413,7 +416,12 @@ struct glb_file
         const size_t base = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
         size_t stride = (size_t)bv.number("byteStride", 0);
         if(!stride) stride = size_t(sz) * components;
-        if(count && base + stride * (count - 1) + size_t(sz) * components > bin.size()) throw std::runtime_error("glTF: accessor exceeds the buffer");
+        if(a.number("count", 0) < 0 || bv.number("byteOffset", 0) < 0 || a.number("byteOffset", 0) < 0 || bv.number("byteLength", 0) < 0)
+            throw std::runtime_error("glTF: negative count or offset");
+        // an accessor lives inside its bufferView, a bufferView inside its buffer (glTF 2.0 section 3.6.2)
+        const size_t view_len = (size_t)bv.number("byteLength", 0), in_view = (size_t)a.number("byteOffset", 0);
+        if((size_t)bv.number("byteOffset", 0) + view_len > bin.size()) throw std::runtime_error("glTF: bufferView exceeds the buffer");
+        if(count && (count > bin.size() || in_view + stride * (count - 1) + size_t(sz) * components > view_len)) throw std::runtime_error("glTF: accessor exceeds its bufferView");
         std::vector<double> out(count * components);
         for(size_t i = 0; i < count; ++i)
             for(int c = 0; c < components; ++c)
@@ -660,9 +668,11 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         for(const json& p: mesh.at("primitives").arr)
         {
             vertex_group vg;
-            if(p.integer("material", -1) >= 0)
+            if(p.has("material"))
             {
-                vg.mat = create_material(g, j.at("materials").at((size_t)p.integer("material", 0)));
+                const int mi = p.integer("material", -1);
+                if(mi < 0 || (size_t)mi >= list("materials").size()) throw std::runtime_error("glTF: material index out of range");
+                vg.mat = create_material(g, j.at("materials").at((size_t)mi));
                 if(lo.force_single_sided && vg.mat.transmittance == 0) vg.mat.flags &= ~1u;
                 if(lo.force_double_sided) vg.mat.flags |= 1u;
             }
@@ -678,9 +688,23 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
             const std::vector<double> pos = g.accessor(at.integer("POSITION", -1), nc, count);
             vg.vertices.assign(count, vertex{});
             for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].pos[k] = (float)pos[i * nc + k];
-            if(at.has("NORMAL")) { int c; size_t n; auto a = g.accessor(at.integer("NORMAL", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].normal[k] = (float)a[i * c + k]; }
-            if(at.has("TEXCOORD_0")) { int c; size_t n; auto a = g.accessor(at.integer("TEXCOORD_0", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 2; ++k) vg.vertices[i].uv[k] = (float)a[i * c + k]; }
-            if(at.has("TANGENT")) { int c; size_t n; auto a = g.accessor(at.integer("TANGENT", 0), c, n); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 4; ++k) vg.vertices[i].tangent[k] = (float)a[i * c + k]; }
+            if(nc < 3) throw std::runtime_error("glTF: POSITION needs three components");
+            auto attribute = [&](const char* name, int want, int& c) {      // an attribute has a value for every vertex and enough components
+                size_t n;
+                std::vector<double> a = g.accessor(at.integer(name, -1), c, n);
+                if(n < count || c < want) throw std::runtime_error(std::string("glTF: attribute ") + name + " is shorter than POSITION");
+                return a;
+            };
+            if(at.has("NORMAL")) { int c; auto a = attribute("NORMAL", 3, c); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 3; ++k) vg.vertices[i].normal[k] = (float)a[i * c + k]; }
+            if(at.has("TEXCOORD_0")) { int c; auto a = attribute("TEXCOORD_0", 2, c); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 2; ++k) vg.vertices[i].uv[k] = (float)a[i * c + k]; }
+            if(at.has("TANGENT")) { int c; auto a = attribute("TANGENT", 4, c); for(size_t i = 0; i < count; ++i) for(int k = 0; k < 4; ++k) vg.vertices[i].tangent[k] = (float)a[i * c + k]; }
+            if(p.has("indices"))
+            {   // unsigned integers (glTF 2.0 section 3.7.2.1)
+                const int ia = p.integer("indices", -1);
+                if(ia < 0 || (size_t)ia >= list("accessors").size()) throw std::runtime_error("glTF: accessor index out of range");
+                const int ict = j.at("accessors").at((size_t)ia).integer("componentType", 0);
+                if(ict != 5121 && ict != 5123 && ict != 5125) throw std::runtime_error("glTF: indices must be unsigned integers");
+            }
             if(p.has("indices")) { int c; size_t n; auto a = g.accessor(p.integer("indices", 0), c, n); vg.indices.resize(n * c); for(size_t i = 0; i < a.size(); ++i) vg.indices[i] = (uint32_t)a[i]; }
             else { vg.indices.resize(count); for(size_t i = 0; i < count; ++i) vg.indices[i] = (uint32_t)i; }
             for(uint32_t ix: vg.indices) if(ix >= count) throw std::runtime_error("glTF: index out of range");
@@ -734,7 +758,11 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     };
 
     auto anim = std::make_shared<gltf_animation>();
+    std::vector<char> visited(list("nodes").size(), 0);
     std::function<void(int, const mat4d&, int)> visit = [&](int node_index, const mat4d& parent, int parent_index) {
+        if(node_index < 0 || (size_t)node_index >= visited.size()) throw std::runtime_error("glTF: node index out of range");
+        if(visited[(size_t)node_index]) throw std::runtime_error("glTF: node " + std::to_string(node_index) + " is reached twice: the node hierarchy must be a forest");
+        visited[(size_t)node_index] = 1;
         const json& node = j.at("nodes").at((size_t)node_index);
         gltf_animation::node& rec = anim->nodes[node_index];
         rec = gltf_animation::node{};
@@ -769,7 +797,9 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         {
             double sto = 0;
             if(tr) if(const json* m = tr->find("mesh")) sto = m->number("shadow_terminator_offset", 0.0);
-            for(const vertex_group& vg: models.at((size_t)node.integer("mesh", 0)))
+            const int mesh_index = node.integer("mesh", -1);
+            if(mesh_index < 0 || (size_t)mesh_index >= models.size()) throw std::runtime_error("glTF: mesh index out of range");
+            for(const vertex_group& vg: models[(size_t)mesh_index])
             {   // one INSTANCE record (src/scene_stage.cc:1085-1114)
                 instance in{};
                 in.light_base_id = -1; in.sh_grid_index = -1;
@@ -791,7 +821,9 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         }
         if(node.has("camera"))
         {
-            const json& c = j.at("cameras").at((size_t)node.integer("camera", 0));
+            const int camera_index = node.integer("camera", -1);
+            if(camera_index < 0 || (size_t)camera_index >= list("cameras").size()) throw std::runtime_error("glTF: camera index out of range");
+            const json& c = j.at("cameras").at((size_t)camera_index);
             gltf_camera cam{};
             cam.transform = glob;
             if(c.at("type").str == "perspective")
@@ -816,7 +848,12 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
         }
         if(const json* kl = ext ? ext->find("KHR_lights_punctual") : nullptr)
         {
-            const json& l = j.at("extensions").at("KHR_lights_punctual").at("lights").at((size_t)kl->integer("light", 0));
+            const json* all_ext = j.find("extensions");
+            const json* punctual = all_ext ? all_ext->find("KHR_lights_punctual") : nullptr;
+            const json* light_list = punctual ? punctual->find("lights") : nullptr;
+            const int light_index = kl->integer("light", -1);
+            if(!light_list || light_index < 0 || (size_t)light_index >= light_list->size()) throw std::runtime_error("glTF: light index out of range");
+            const json& l = light_list->arr[(size_t)light_index];
             double color[3] = {1, 1, 1};
             if(const json* c = l.find("color")) for(int k = 0; k < 3; ++k) color[k] = c->at((size_t)k).num;
             const double intensity = l.number("intensity", 1.0);

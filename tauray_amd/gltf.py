@@ -106,19 +106,35 @@ class _Glb:
         raise ValueError("glTF: image without bufferView or uri")
 
     def accessor(self, idx) -> np.ndarray:
-        a = self.json["accessors"][idx]
-        bv = self.json["bufferViews"][a["bufferView"]]
+        a = _item(self.json.get("accessors", []), idx, "accessor")
+        bv = _item(self.json.get("bufferViews", []), a.get("bufferView", -1), "bufferView")
+        if a["componentType"] not in _COMP or a["type"] not in _NCOMP:
+            raise ValueError("glTF: unsupported accessor type")
         dt, sz = _COMP[a["componentType"]]
         nc = _NCOMP[a["type"]]
         base = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
         stride = bv.get("byteStride", 0) or sz * nc
         count = a["count"]
-        buf = self.buffers[bv.get("buffer", 0)]
+        buf = _item(self.buffers, bv.get("buffer", 0), "buffer")
+        if count < 0 or bv.get("byteOffset", 0) < 0 or a.get("byteOffset", 0) < 0 or bv.get("byteLength", 0) < 0:
+            raise ValueError("glTF: negative count or offset")
+        # an accessor lives inside its bufferView, a bufferView inside its buffer (glTF 2.0 section 3.6.2)
+        if bv.get("byteOffset", 0) + bv.get("byteLength", 0) > len(buf):
+            raise ValueError("glTF: bufferView exceeds the buffer")
+        if count and a.get("byteOffset", 0) + stride * (count - 1) + sz * nc > bv.get("byteLength", 0):
+            raise ValueError("glTF: accessor exceeds its bufferView")
         if stride == sz * nc:
             arr = np.frombuffer(buf, dtype=dt, count=count * nc, offset=base).reshape(count, nc)
         else:
             arr = np.stack([np.frombuffer(buf, dtype=dt, count=nc, offset=base + i * stride) for i in range(count)])
         return arr
+
+
+def _item(seq, index, what):
+    """seq[index] for an index out of a file: integers inside the list only (Python would take -1 for the last element)."""
+    if not isinstance(index, int) or isinstance(index, bool) or index < 0 or index >= len(seq):
+        raise ValueError(f"glTF: {what} index out of range")
+    return seq[index]
 
 
 def _dot3(a, b):
@@ -241,8 +257,8 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
     for mesh in j.get("meshes", []):
         groups = []
         for p in mesh["primitives"]:
-            if "material" in p and p["material"] >= 0:
-                mat = _create_material(g, j["materials"][p["material"]])
+            if "material" in p:
+                mat = _create_material(g, _item(j.get("materials", []), p["material"], "material"))
                 if force_single_sided and mat["transmittance"] == 0:
                     mat["flags"] &= ~np.uint32(S.MATERIAL_FLAG_DOUBLE_SIDED)
                 if force_double_sided:
@@ -251,17 +267,29 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 mat = S.make_material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0)
             at = p["attributes"]
             pos = g.accessor(at["POSITION"]).astype(np.float32)
+            if pos.shape[1] < 3:
+                raise ValueError("glTF: POSITION needs three components")
             v = np.zeros(len(pos), dtype=S.VERTEX)
             v["pos"] = pos[:, :3]
+
+            def attribute(name, want):      # an attribute has a value for every vertex and enough components
+                a = g.accessor(at[name])
+                if len(a) < len(pos) or a.shape[1] < want:
+                    raise ValueError(f"glTF: attribute {name} is shorter than POSITION")
+                return a.astype(np.float32)[:len(pos), :want]
             if "NORMAL" in at:
-                v["normal"] = g.accessor(at["NORMAL"]).astype(np.float32)[:, :3]
+                v["normal"] = attribute("NORMAL", 3)
             if "TEXCOORD_0" in at:
-                uv = g.accessor(at["TEXCOORD_0"])
-                v["uv"] = uv.astype(np.float32)[:, :2]
+                v["uv"] = attribute("TEXCOORD_0", 2)
             if "TANGENT" in at:
-                v["tangent"] = g.accessor(at["TANGENT"]).astype(np.float32)[:, :4]
+                v["tangent"] = attribute("TANGENT", 4)
             if "indices" in p:
-                idx = g.accessor(p["indices"]).astype(np.uint32).reshape(-1)
+                if _item(j.get("accessors", []), p["indices"], "accessor").get("componentType") not in (5121, 5123, 5125):
+                    raise ValueError("glTF: indices must be unsigned integers")      # glTF 2.0 section 3.7.2.1
+                raw = g.accessor(p["indices"]).reshape(-1)
+                idx = raw.astype(np.uint32)
+                if len(raw) and (raw.min() < 0 or raw.max() >= len(pos)):
+                    raise ValueError("glTF: index out of range")
             else:
                 idx = np.arange(len(pos), dtype=np.uint32)
             if "NORMAL" not in at:
@@ -286,9 +314,14 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
     node_globals, skinned_pending = {}, []
     nodes, roots = {}, []
 
+    visited = set()
+
     def visit(node_index, parent, parent_index=-1):
         nonlocal voff, ioff
-        node = j["nodes"][node_index]
+        node = _item(j.get("nodes", []), node_index, "node")
+        if node_index in visited:
+            raise ValueError(f"glTF: node {node_index} is reached twice: the node hierarchy must be a forest")
+        visited.add(node_index)
         tr = node.get("extensions", {}).get("TR_data")
         if tr and "light" in tr:
             if "angle" in tr["light"]:
@@ -313,7 +346,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
             sto = 0.0
             if tr and "mesh" in tr:
                 sto = float(tr["mesh"].get("shadow_terminator_offset", 0.0))
-            for mat, v, idx, skin in models[node["mesh"]]:
+            for mat, v, idx, skin in _item(models, node["mesh"], "mesh"):
                 if "skin" in node and skin is not None:
                     # glTF places skinned meshes at the origin; the loader enforces it (src/gltf.cc:777-784)
                     skinned_pending.append((len(inst_list), node["skin"], skin))
@@ -328,7 +361,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
                 ioff += len(idx)
 
         if "camera" in node:
-            c = j["cameras"][node["camera"]]
+            c = _item(j.get("cameras", []), node["camera"], "camera")
             cam = S.Camera(transform=glob)
             if c["type"] == "perspective":
                 pp = c["perspective"]
@@ -346,7 +379,7 @@ def load_glb(path: str, width: int = 512, height: int = 512, aspect_ratio: float
 
         kl = node.get("extensions", {}).get("KHR_lights_punctual")
         if kl is not None:
-            l = j["extensions"]["KHR_lights_punctual"]["lights"][kl["light"]]
+            l = _item(j.get("extensions", {}).get("KHR_lights_punctual", {}).get("lights", []), kl["light"], "light")
             color = np.array(l.get("color", [1, 1, 1]), dtype=np.float64) * float(l.get("intensity", 1.0))
             angle, radius = light_meta["angle"], light_meta["radius"]
 

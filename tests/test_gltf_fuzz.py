@@ -259,3 +259,80 @@ def test_random_glb_files_load_the_same_in_both_hosts(tmp_path):
         os.remove(glb)
         loaded += 1
     assert loaded > 0.6 * (loaded + refused), f"only {loaded} of {loaded + refused} random files load"
+
+
+def _mutate(rng, data):
+    """One of the ways a file goes wrong: an accessor count multiplied, a bufferView moved past the buffer, the binary chunk cut short, an
+    index accessor pointing at floats, node / mesh / bufferView references out of range (-1 included: Python would take the last element),
+    vertex indices beyond the vertex count, a node that is its own child."""
+    jl = struct.unpack("<I", data[12:16])[0]
+    j = json.loads(data[20:20 + jl])
+    bn = bytes(data[20 + jl + 8:])
+    m = int(rng.integers(0, 8))
+    if m == 0:
+        a = j["accessors"][int(rng.integers(0, len(j["accessors"])))]
+        a["count"] = int(a["count"] * rng.choice([3, 50, 10000]))
+    elif m == 1:
+        v = j["bufferViews"][int(rng.integers(0, len(j["bufferViews"])))]
+        v["byteOffset"] = int(v.get("byteOffset", 0) + rng.choice([len(bn), 1 << 30]))
+    elif m == 2:
+        bn = bn[:int(len(bn) * rng.uniform(0, 0.9))]
+    elif m == 3:
+        for me in j["meshes"]:
+            for p in me["primitives"]:
+                if "indices" in p:
+                    p["indices"] = p["attributes"]["POSITION"]
+    elif m == 4:
+        j["nodes"][int(rng.integers(0, len(j["nodes"])))]["mesh"] = int(rng.choice([len(j["meshes"]) + 3, -1]))
+    elif m == 5:
+        j["accessors"][int(rng.integers(0, len(j["accessors"])))]["bufferView"] = int(rng.choice([len(j["bufferViews"]) + 2, -1]))
+    elif m == 6:
+        b = bytearray(bn)
+        for me in j["meshes"]:
+            for p in me["primitives"]:
+                if "indices" in p:
+                    a = j["accessors"][p["indices"]]
+                    off = j["bufferViews"][a["bufferView"]].get("byteOffset", 0) + a.get("byteOffset", 0)
+                    sz = {5121: 1, 5123: 2, 5125: 4}[a["componentType"]]
+                    b[off:off + sz] = b"\xff" * sz
+        bn = bytes(b)
+    else:
+        j["nodes"][0]["children"] = [0]
+    js = json.dumps(j).encode()
+    js += b" " * (-len(js) % 4)
+    bn += b"\0" * (-len(bn) % 4)
+    return struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(bn)) + struct.pack("<I4s", len(js), b"JSON") + js + struct.pack("<I4s", len(bn), b"BIN\0") + bn, m
+
+
+def test_malformed_glb_files_are_refused_alike(tmp_path):
+    """Mutated random files: both loaders must end with an error message or with the same scene - never with a crash (the first version of
+    this test found the C++ loader recursing into a node cycle until the stack ran out, the Python one taking index -1 for the last mesh
+    and copying out-of-range vertex indices into the scene)."""
+    from tauray_amd.gltf import load_glb
+    from tauray_amd.scene_io import write_scene_dump
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "5")))
+    kinds = set()
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "40"))):
+        data, kind = _mutate(rng, _random_glb(rng))
+        glb = str(tmp_path / "m.glb")
+        open(glb, "wb").write(data)
+        cpp, py = str(tmp_path / "cpp.trsc"), str(tmp_path / "py.trsc")
+        r = subprocess.run([CLI, glb, "--width=32", "--height=32", f"--dump-scene={cpp}"], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 1), f"draw {k}, mutation {kind}: the C++ loader died with {r.returncode}: {r.stderr[-300:]}"
+        assert r.returncode == 0 or r.stderr.strip(), f"draw {k}: an error without a message"
+        try:
+            write_scene_dump(load_glb(glb, 32, 32), py)
+            py_ok = True
+        except ValueError:
+            py_ok = False
+        except Exception as e:      # noqa: BLE001  (TrhipError of the image decoder and the like)
+            py_ok = False
+            assert type(e).__name__ != "RecursionError", f"draw {k}, mutation {kind}: {e}"
+        assert (r.returncode == 0) == py_ok, f"draw {k}, mutation {kind}: C++ {'loads' if r.returncode == 0 else 'refuses (' + r.stderr.strip()[-120:] + ')'}, Python {'loads' if py_ok else 'refuses'}"
+        if py_ok:
+            a, b = _sections(cpp), _sections(py)
+            for n in NAMES:
+                if n != "cameras":
+                    assert a[n] == b[n], f"draw {k}, mutation {kind}: {n} differs"
+        kinds.add(kind)
+    assert len(kinds) >= 5
