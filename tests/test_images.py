@@ -230,6 +230,43 @@ def test_random_images_match_pillow():
             assert d.max() <= lim and d[..., :3].mean() <= 0.6, f"{what}: max {int(d.max())}, mean {float(d.mean()):.3f}"
 
 
+def test_damaged_images_end_in_an_error_or_an_image():
+    """Bit flips, truncation and overwritten stretches in PNG and JPEG files (sequential and progressive): the decoder answers with an
+    error or with an image of the announced size - it is fed files from the outside world (a campaign of 4 500 such files by hand:
+    profiles/r3/fuzz_campaign.txt).  TRHIP_FUZZ_SEED / TRHIP_FUZZ_DRAWS_SMALL for more."""
+    import os
+    from tauray_amd import _lib
+    rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "2")))
+    decoded = refused = 0
+    for k in range(int(os.environ.get("TRHIP_FUZZ_DRAWS_SMALL", "200"))):
+        w, h = int(rng.integers(1, 80)), int(rng.integers(1, 60))
+        a = _picture(w, h, seed=k)
+        r = rng.uniform()
+        if r < 0.35:
+            data = _save(a[..., :3].copy(), "RGB", "JPEG", quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)), progressive=bool(rng.integers(0, 2)))
+        elif r < 0.5:
+            data = _save(a[..., 0].copy(), "L", "JPEG", quality=50, progressive=bool(rng.integers(0, 2)))
+        else:
+            data = _save(a, "RGBA", "PNG") if r < 0.75 else _save(a[..., :3].copy(), "RGB", "PNG")
+        b = bytearray(data)
+        m = rng.uniform()
+        if m < 0.6:
+            for q in rng.integers(2, len(b), int(rng.integers(1, 8))):
+                b[q] ^= 1 << int(rng.integers(0, 8))
+        elif m < 0.8:
+            b = b[:int(rng.integers(2, len(b)))]
+        else:
+            q = int(rng.integers(2, len(b)))
+            b[q:q + int(rng.integers(1, 20))] = bytes(rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8))
+        try:
+            img, _ = decode(bytes(b))
+            assert img.ndim == 3 and img.shape[2] == 4 and img.shape[0] > 0 and img.shape[1] > 0
+            decoded += 1
+        except _lib.TrhipError:
+            refused += 1
+    assert decoded > 0 and refused > 0
+
+
 def test_unreadable_files_fail_loudly():
     from tauray_amd import _lib
     a = _picture(16, 16)[..., :3].copy()
