@@ -738,6 +738,9 @@ inline image read(const uint8_t* d, size_t n)
     std::vector<int> wpp;
     size_t pixel_bytes = 0;
     for(const channel& c : img.channels) { wpp.push_back(c.pixel_type == PIXEL_HALF ? 1 : 2); pixel_bytes += c.pixel_type == PIXEL_HALF ? 2 : 4; }
+    // A data window that promises more than the file can hold (one damaged byte is enough) must not cost gigabytes before a chunk fails:
+    // none of the codecs expands by more than about a thousand to one (deflate 1032 : 1; PIZ's run code repeats a word 256 times)
+    if((uint64_t)img.width * (uint64_t)img.height * pixel_bytes > (uint64_t)n * 2048 + 65536) throw std::runtime_error("EXR: the data window does not fit the file");
     img.planes.assign(img.channels.size(), std::vector<float>((size_t)img.width * img.height, 0.0f));
     std::vector<uint8_t> raw;
     // a decoded block -> planes

@@ -76,6 +76,9 @@ inline decoded decode_png(const uint8_t* data, size_t size)
         if(interlace && ((size_t)adam7[p][0] >= w || (size_t)adam7[p][1] >= h)) pw[p] = ph[p] = 0;
         if(pw[p] && ph[p]) total += (row_bytes(pw[p]) + 1) * ph[p];
     }
+    // A header that promises more than its data can hold (a flipped bit in the width is enough) must not cost gigabytes and minutes
+    // before the inflate fails: deflate expands by at most 1032 : 1, and stb_image's cap on a side (1 << 24) bounds the arithmetic.
+    if(w > (1u << 24) || h > (1u << 24) || total > idat.size() * 1032 + 1024) throw std::runtime_error("image: PNG dimensions do not fit its data");
     std::vector<uint8_t> raw(total);
     uLongf raw_len = (uLongf)raw.size();
     if(uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) throw std::runtime_error("image: PNG inflate failed");
@@ -328,6 +331,9 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
                 hmax = std::max(hmax, comps[(size_t)i].h); vmax = std::max(vmax, comps[(size_t)i].v);
             }
             mcux = (out.w + 8 * (size_t)hmax - 1) / (8 * (size_t)hmax); mcuy = (out.h + 8 * (size_t)vmax - 1) / (8 * (size_t)vmax);
+            // every MCU costs the entropy-coded data at least a bit: a frame header that promises more MCUs than the file has bits is
+            // damaged, and taking it at its word would allocate and transform gigabytes of coefficients
+            if(mcux * mcuy > size * 8) throw std::runtime_error("image: JPEG dimensions do not fit its data");
             for(component& c: comps)
             {
                 c.bw = mcux * (size_t)c.h; c.bh = mcuy * (size_t)c.v;
