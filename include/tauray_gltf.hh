@@ -72,12 +72,16 @@ public:
     json parse() { json v = value(); ws(); return v; }
 private:
     const char *p, *end;
+    int depth = 0;      // nesting of the value being parsed: a file of nothing but '[' must end in a message, not in the end of the stack
+    struct nest { int& d; explicit nest(int& d): d(d) { ++d; } ~nest() { --d; } };
     [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("glTF JSON: ") + what); }
     void ws() { while(p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
     json value()
     {
         ws();
         if(p >= end) fail("unexpected end");
+        const nest level(depth);
+        if(depth > 200) fail("nested too deeply");
         json v;
         if(*p == '{')
         {

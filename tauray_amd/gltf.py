@@ -71,7 +71,7 @@ class _Glb:
                 clen, ctype = struct.unpack("<II", d[off:off + 8])
                 body = d[off + 8:off + 8 + clen]
                 if ctype == 0x4E4F534A:
-                    self.json = json.loads(body)
+                    self.json = _loads(body)
                 elif ctype == 0x004E4942:
                     glb_bin = body
                 off += 8 + clen
@@ -79,7 +79,7 @@ class _Glb:
                 raise ValueError("not a GLB file")
         else:
             try:
-                self.json = json.loads(d)
+                self.json = _loads(d)
             except Exception:
                 raise ValueError("not a GLB file") from None
         self.buffers = []
@@ -128,6 +128,14 @@ class _Glb:
         else:
             arr = np.stack([np.frombuffer(buf, dtype=dt, count=nc, offset=base + i * stride) for i in range(count)])
         return arr
+
+
+def _loads(text):
+    """json.loads with the loader's kind of error for text nested beyond what either host parses (the C++ host stops at 200 levels)."""
+    try:
+        return json.loads(text)
+    except RecursionError:
+        raise ValueError("glTF JSON: nested too deeply") from None
 
 
 def _item(seq, index, what):

@@ -336,3 +336,12 @@ def test_malformed_glb_files_are_refused_alike(tmp_path):
                     assert a[n] == b[n], f"draw {k}, mutation {kind}: {n} differs"
         kinds.add(kind)
     assert len(kinds) >= 5
+    # a JSON chunk of nothing but brackets: a message from both, not the end of the C++ host's stack
+    js = b'{"asset":{"version":"2.0"},"x":' + b"[" * 100000 + b"]" * 100000 + b"}"
+    js += b" " * (-len(js) % 4)
+    deep = str(tmp_path / "deep.glb")
+    open(deep, "wb").write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js)) + struct.pack("<I4s", len(js), b"JSON") + js)
+    r = subprocess.run([CLI, deep, f"--dump-scene={tmp_path / 'x.trsc'}"], capture_output=True, text=True)
+    assert r.returncode == 1 and "nested too deeply" in r.stderr
+    with pytest.raises(ValueError, match="nested too deeply"):
+        load_glb(deep, 32, 32)
