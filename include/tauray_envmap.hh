@@ -44,6 +44,8 @@ inline std::vector<float> load_hdr(const std::string& path, uint32_t& width, uin
         width = (uint32_t)w; height = (uint32_t)h;
     }
     const size_t w = width, h = height;
+    // a resolution line that promises more than the data can hold: a run code repeats a byte 127 times at best
+    if(w > (1u << 24) || h > (1u << 24) || w * h * 4 > (raw.size() - pos) * 64 + 1024) throw std::runtime_error(path + ": the .hdr resolution does not fit the file");
     std::vector<uint8_t> rgbe(w * h * 4);
     bool flat = w < 8 || w >= 32768;
     auto need = [&](size_t n) { if(pos + n > raw.size()) throw std::runtime_error(path + ": truncated .hdr data"); };

@@ -32,6 +32,10 @@ def load_hdr(path: str) -> np.ndarray:
     if len(tok) != 4 or tok[0] != b"-Y" or tok[2] != b"+X":
         raise ValueError(f"{path}: unsupported .hdr data layout")
     h, w = int(tok[1]), int(tok[3])
+    if h <= 0 or w <= 0:
+        raise ValueError(f"{path}: unsupported .hdr data layout")
+    if w > (1 << 24) or h > (1 << 24) or w * h * 4 > (len(raw) - pos) * 64 + 1024:      # a run code repeats a byte 127 times at best
+        raise ValueError(f"{path}: the .hdr resolution does not fit the file")
     rgbe = np.zeros((h, w, 4), dtype=np.uint8)
     data = np.frombuffer(raw, dtype=np.uint8)
     flat = w < 8 or w >= 32768
