@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="roofline without the rocprofv3 counter passes (issue rate and traffic stay null)")
-    ap.add_argument("--pmc-timeout", type=float, default=150.0, help="seconds one counter pass may take")
+    ap.add_argument("--pmc-timeout", type=float, default=75.0, help="seconds one counter pass may take")
     ap.add_argument("--pmc-child", action="store_true", help="internal: render a few serialised frames and exit (what the counter passes profile)")
     ap.add_argument("--pmc-dump", default=None, help="directory that keeps the per-kernel counter summary of the passes (profiles/)")
     ap.add_argument("--rendezvous-only", action="store_true",
