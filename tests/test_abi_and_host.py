@@ -155,3 +155,22 @@ def test_load_balancer_follows_the_reference():
     assert lb2.workloads == [1.0, 0.0]
     assert lb2.update([1.0, 0.0]) == [1.0, 0.0]           # 0 / 0 = NaN: skipped
     assert LoadBalancer(3, [2.0, 2.0]).workloads == pytest.approx([0.5, 0.5, 0.0])
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: include/trhip.h and include/trhip_comm.h compile as C99 with -pedantic, without a warning, and a C program
+    links against the two libraries (what a cgo / JNI / Rust-FFI binding of the reference would sit on)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "trhip.h"\n#include "trhip_comm.h"\n#include <stdio.h>\n'
+                   "int main(void) {\n    trhip_pt_options o; trhip_distribution d; trhip_scene_desc s; trhip_counters c;\n"
+                   "    (void)o; (void)d; (void)s; (void)c;\n"
+                   '    printf("%u %u %u [%s]\\n", (unsigned)sizeof(o), (unsigned)sizeof(d), (unsigned)sizeof(trhip_accel_info), trhip_last_error());\n'
+                   "    return trhip_comm_size(0);\n}\n")
+    exe = str(tmp_path / "abi")
+    lib = os.path.join(ROOT, "tauray_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, str(src),
+                        "-L" + lib, "-ltrhip", "-ltrhip_comm", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split()[:3] == ["96", "24", "48"], out.stdout + out.stderr
