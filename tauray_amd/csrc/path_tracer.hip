@@ -79,6 +79,9 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     // the ray is fetched together with the path's flags, not behind them: one round trip less before the traversal starts, and a
     // queue holds live paths only (the flag matters at bounce 0, where the ids are all launch ids)
     if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
+    // payload.random_seed of this trace: k_raygen stored the seed of bounce 0, every closest-hit trace advances it once
+    // (path_tracer.glsl:387-403; DESIGN.md on the any-hit hash)
+    for (int b = 0; b < bounce; ++b) pcg(misc.x);
     HitRecord hit;
     const bool include_lights = !(P.opt.hide_lights && bounce == 0);
     const uint before = st.nodes;

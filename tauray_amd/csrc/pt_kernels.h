@@ -307,7 +307,14 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
         bool active = qi < n;
         uint id = 0;
         u4 misc = {0, 0, 0, 1};
-        if (active) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; active = !(misc.w & 1u); }
+        if (active) {
+            id = queue ? queue[qi] : qi + P.id_offset;
+            // PathBuffers::misc is written by k_raygen only.  What this kernel wants from it on a queue-driven bounce of the
+            // command-line option set - the path's launch id - is the path id itself (the Sobol index is for the Sobol samplers, the
+            // dead flag for bounce 0, where the ids are all launch ids): 16 bytes per path and bounce not read
+            if (CLI && queue) misc = u4{0u, 0u, id, 0u};
+            else { misc = pb.misc[id]; active = !(misc.w & 1u); }
+        }
         bool alive = false;        // continues to the next bounce
         bool want_shadow = false;
         f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
@@ -325,7 +332,8 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
             bool have = bounce == 0;
             f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
             u4 rs = pb.rng[id];
-            pcg(misc.x);   // the any-hit seed advances once per closest-hit trace
+            // (payload.random_seed advances once per closest-hit trace: closest_lane derives the seed of its bounce from the one k_raygen
+            // stored, so no kernel rewrites misc)
 
             // ---- get_intersection_info (path_tracer.glsl:91-201)
             SampledMaterial mat;
@@ -481,7 +489,6 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
                 pb.atten_alpha[id] = F4(attenuation, 0);
                 if (bounce == 0) pb.plobes[id] = pl;
                 pb.rng[id] = rs;
-                pb.misc[id] = misc;
             }
         }
         // ---- queue compaction (wave ballots)
