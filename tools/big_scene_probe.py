@@ -29,8 +29,16 @@ for millions in [float(x) for x in (sys.argv[1:] or ["4", "16", "48"])]:
     ctx.sync(); t_frame = (time.time() - t0) / 5
     c = pt.counters()
     img = buf.download((H, W, 4))
+    prod = R.PathTracerStage(ctx, ss, opt, DistributionParams((W, H), DISTRIBUTION_DUPLICATE, 0, 1, True))      # the production kernels
+    for _ in range(3):
+        prod.reset_accumulated_samples(); prod.run(buf)
+    ctx.sync(); t0 = time.time()
+    for _ in range(20):
+        prod.reset_accumulated_samples(); prod.run(buf)
+    ctx.sync(); t_prod = (time.time() - t0) / 20
+    prod.close()
     t0 = time.time(); ss.update_instances(scene.instances, refit=True); ctx.sync(); t_refit = time.time() - t0
     print(f"{scene.spans['triangle_count'].sum() / 1e6:.2f} M triangles: generated in {t_gen:.1f} s, upload + build {t_up:.2f} s ({ss.accel}), refit {t_refit * 1e3:.1f} ms, "
-          f"frame (counting instance) {t_frame * 1e3:.2f} ms, {(c['closest_rays'] + c['shadow_rays']) / 5 / 1e6:.2f} M rays, {c['node_visits'] / max(c['closest_rays'] + c['shadow_rays'], 1):.2f} visits/ray, "
+          f"frame {t_prod * 1e3:.2f} ms (counting instance {t_frame * 1e3:.2f} ms), {(c['closest_rays'] + c['shadow_rays']) / 5 / 1e6:.2f} M rays, {c['node_visits'] / max(c['closest_rays'] + c['shadow_rays'], 1):.2f} visits/ray, "
           f"overflow {c['stack_overflows']}, finite {bool(np.isfinite(img).all())}, mean {float(img[..., :3].mean()):.4f}, device memory in use {mem():.1f} GiB", flush=True)
     pt.close(); del ss
