@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pt_kernels.h"
+#include "trace_packet.h"
 
 namespace tr {
 
@@ -208,6 +209,46 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         closest_lane<COUNT, TOP>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, s_top, st, overflow, max_vis, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
+}
+
+// The primary rays of a frame (bounce 0: the ids are launch ids, dealt to waves as 8 x 8 pixel tiles by launch_coord): a wave walks the
+// tree once for its 64 rays (trace_packet.h).  Same hit records as k_trace_closest at bounce 0.
+template <bool COUNT>
+__global__ __launch_bounds__(KB) void k_trace_primary(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
+    __shared__ int s_pstack[(KB / 64) * TR_PACKET_STACK];
+    int* wave_stack = s_pstack + (threadIdx.x >> 6) * TR_PACKET_STACK;
+    const uint n = P.n_ids;
+    TraceStats st = {};
+    uint rays = 0;
+    int overflow = 0;
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    bool first = true;
+    while (true) {
+        uint base = 0;
+        if (first) base = wave_id * 64u;
+        else {
+            if (n <= n_waves * 64u) break;
+            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[BC_CUR_CLOSEST], 64u);
+            base = __shfl(base, 0);
+        }
+        first = false;
+        if (base >= n) break;
+        const uint qi = base + (threadIdx.x & 63);
+        bool valid = qi < n;
+        uint id = 0;
+        u4 misc = {0, 0, 0, 1};
+        f4 o = F4(0), d = F4(0);
+        if (valid) { id = qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
+        HitRecord hit;
+        const uint before = st.nodes;
+        trace_closest_packet<0, COUNT>(sv, valid, F3(o), F3(d), 0.0f, __builtin_huge_valf(), !P.opt.hide_lights, misc.x, wave_stack, hit, st, overflow);
+        if (COUNT) st.cnodes += st.nodes - before;
+        if (valid) {
+            pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
+            rays++;
+        }
+    }
+    flush_trace_counters<COUNT>(P, pb, overflow, 3000, rays, 0u, st, 0u);
 }
 
 // With the treetop in LDS six blocks fit a CU (26 KB each): ask for the registers of six waves, not of eight.
@@ -977,6 +1018,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         hipLaunchKernelGGL(top ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
+                            // TRHIP_PACKET=1: the primary rays of a frame travel together (8 x 8 pixel tiles per wave): one walk per wave
+                            static const bool packet = getenv("TRHIP_PACKET") && atoi(getenv("TRHIP_PACKET")) != 0;
+                            if (packet && bounce == 0 && !top) {
+                                if (count) hipLaunchKernelGGL(k_trace_primary<true>, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bc);
+                                else hipLaunchKernelGGL(k_trace_primary<false>, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bc);
+                                return;
+                            }
                             auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
                                             : (timing ? (top ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)
                                                       : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>));
