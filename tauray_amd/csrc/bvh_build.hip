@@ -43,12 +43,14 @@ TR_DEV void locate_triangle(const uint* tri_prefix, uint instance_count, uint gi
 // centroid bounds used to quantise Morton codes.
 __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* tri_prefix, const uint8_t* non_opaque,
                                                      TriRecord* tris_unsorted, uint* cbounds /*6 flipped uints of the centroid bounds; [16..21] the same for the triangles' bounds*/) {
-    uint gid = blockIdx.x * BT + threadIdx.x;
     float cmin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
     float cmax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
     float smin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
     float smax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
-    if (gid < sv.tri_count) {
+    // a bounded grid walks the triangles: the twelve bounds end in twelve atomics per block on two cache lines, and 16 000 waves of
+    // them (one set per wave of a grid of one thread per triangle) took a millisecond of a 4 ms rebuild - the atomics of a line are
+    // served one after the other ("Atomics")
+    for (uint gid = blockIdx.x * BT + threadIdx.x; gid < sv.tri_count; gid += gridDim.x * BT) {
         uint inst, prim;
         locate_triangle(tri_prefix, sv.instance_count, gid, inst, prim);
         const MeshSpan sp = sv.spans[inst];
@@ -68,10 +70,11 @@ __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* t
         tris_unsorted[gid] = t;
         f3 lo = min3(min3(p0, p1), p2), hi = max3(max3(p0, p1), p2);
         f3 c = (lo + hi) * 0.5f;
-        cmin[0] = cmax[0] = c.x; cmin[1] = cmax[1] = c.y; cmin[2] = cmax[2] = c.z;
-        smin[0] = lo.x; smin[1] = lo.y; smin[2] = lo.z; smax[0] = hi.x; smax[1] = hi.y; smax[2] = hi.z;
+        const float cc[3] = {c.x, c.y, c.z}, ll[3] = {lo.x, lo.y, lo.z}, hh[3] = {hi.x, hi.y, hi.z};
+        for (int k = 0; k < 3; ++k) { cmin[k] = fminf(cmin[k], cc[k]); cmax[k] = fmaxf(cmax[k], cc[k]); smin[k] = fminf(smin[k], ll[k]); smax[k] = fmaxf(smax[k], hh[k]); }
     }
-    // wave reduce, then one atomic per wave
+    // wave reduce, block reduce through LDS, then one set of atomics per block
+    __shared__ float s_red[BT / 64][12];
     for (int k = 0; k < 3; ++k) {
         float mn = cmin[k], mx = cmax[k], sn = smin[k], sx = smax[k];
         for (int off = 32; off > 0; off >>= 1) {
@@ -80,7 +83,14 @@ __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* t
             sn = fminf(sn, __shfl_xor(sn, off));
             sx = fmaxf(sx, __shfl_xor(sx, off));
         }
-        if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        if ((threadIdx.x & 63) == 0) { float* w = s_red[threadIdx.x >> 6]; w[k] = mn; w[3 + k] = mx; w[6 + k] = sn; w[9 + k] = sx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = (int)threadIdx.x;
+        float mn = s_red[0][k], mx = s_red[0][3 + k], sn = s_red[0][6 + k], sx = s_red[0][9 + k];
+        for (int w = 1; w < BT / 64; ++w) { mn = fminf(mn, s_red[w][k]); mx = fmaxf(mx, s_red[w][3 + k]); sn = fminf(sn, s_red[w][6 + k]); sx = fmaxf(sx, s_red[w][9 + k]); }
+        if (mn <= mx) {
             atomicMin(&cbounds[k], float_flip(mn));
             atomicMax(&cbounds[3 + k], float_flip(mx));
             atomicMin(&cbounds[16 + k], float_flip(sn));     // bounds of the triangles themselves: the grid of the pre-split
@@ -282,6 +292,80 @@ __global__ __launch_bounds__(BT) void k_ploc_compact(const uint* c_ptr, uint* c_
     uint p = pos[i];
     cref[p] = in_ref[i];
     for (int k = 0; k < 6; ++k) cbox[6 * (size_t)p + k] = in_box[6 * (size_t)i + k];
+}
+
+// The last rounds in one workgroup: once PLOC_TAIL clusters or fewer are left, a round of three grid launches and a scan is all
+// launch latency (a 1 M triangle build spent about thirty of its seventy-odd rounds there, 20-30 us each).  The clusters move into LDS, one per
+// thread, and the same three steps - nearest neighbour, merge of the mutual pairs, compaction - repeat between barriers until one
+// cluster is left.  Same neighbour choice (ascending scan, first minimum wins) and same merge rule as the grid kernels, so the
+// same tree; node ids come from the same allocator.
+#define PLOC_TAIL 1024
+__global__ __launch_bounds__(PLOC_TAIL) void k_ploc_tail(const uint* c_ptr, uint n_leaves, uint radius, const int* cref, const float* cbox, uint* alloc, int2* children,
+                                                         float* node_box, uint* subtree_size, int* parent_internal, uint* rounds_out) {
+    __shared__ float s_box[6][PLOC_TAIL];
+    __shared__ int s_ref[PLOC_TAIL];
+    __shared__ uint s_nn[PLOC_TAIL];
+    __shared__ uint s_wave[PLOC_TAIL / 64];
+    const uint i = threadIdx.x, lane = i & 63u, w = i >> 6;
+    uint c = *c_ptr;
+    if (i < c) {
+        s_ref[i] = cref[i];
+        for (int k = 0; k < 6; ++k) s_box[k][i] = cbox[6 * (size_t)i + k];
+    }
+    __syncthreads();
+    uint rounds = 0;
+    while (c > 1) {
+        uint bj = i;
+        float mine[6];
+        if (i < c) {
+            for (int k = 0; k < 6; ++k) mine[k] = s_box[k][i];
+            const uint lo = i > radius ? i - radius : 0, hi = min(c - 1, i + radius);
+            float best = __builtin_huge_valf();
+            for (uint j = lo; j <= hi; ++j) {
+                if (j == i) continue;
+                const float other[6] = {s_box[0][j], s_box[1][j], s_box[2][j], s_box[3][j], s_box[4][j], s_box[5][j]};
+                const float a = merged_area(mine, other);
+                if (a < best) { best = a; bj = j; }
+            }
+        }
+        s_nn[i] = bj;
+        __syncthreads();
+        bool keep = false;
+        int ref = 0;
+        if (i < c) {
+            const uint j = bj;
+            const bool mutual = j != i && s_nn[j] == i;
+            if (!(mutual && i > j)) {
+                keep = true;
+                ref = s_ref[i];
+                if (mutual) {
+                    const int other = s_ref[j];
+                    for (int k = 0; k < 3; ++k) { mine[k] = fminf(mine[k], s_box[k][j]); mine[3 + k] = fmaxf(mine[3 + k], s_box[3 + k][j]); }
+                    const uint id = (n_leaves - 2u) - atomicAdd(alloc, 1u);
+                    children[id] = make_int2(ref, other);
+                    if (ref >= 0) parent_internal[ref] = (int)id;
+                    if (other >= 0) parent_internal[other] = (int)id;
+                    for (int k = 0; k < 6; ++k) node_box[6 * (size_t)id + k] = mine[k];
+                    subtree_size[id] = (ref < 0 ? 1u : subtree_size[ref]) + (other < 0 ? 1u : subtree_size[other]);
+                    ref = (int)id;
+                }
+            }
+        }
+        const unsigned long long kept = __ballot(keep);
+        if (lane == 0) s_wave[w] = (uint)__popcll(kept);
+        __syncthreads();   // every read of this round's clusters is done, and the subtree sizes written above are visible to the block
+        uint before = 0, total = 0;
+        for (uint k = 0; k < PLOC_TAIL / 64; ++k) { const uint v = s_wave[k]; total += v; before += k < w ? v : 0u; }
+        if (keep) {
+            const uint p = before + (uint)__popcll(kept & ((1ull << lane) - 1ull));
+            s_ref[p] = ref;
+            for (int k = 0; k < 6; ++k) s_box[k][p] = mine[k];
+        }
+        c = total;
+        ++rounds;
+        __syncthreads();
+    }
+    if (i == 0) *rounds_out = rounds;
 }
 
 __global__ __launch_bounds__(BT) void k_ploc_init(uint n, int* cref) {
@@ -810,7 +894,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         BvhNode* nodes2 = ds.nodes;
 #endif
         const uint tblocks = (n_tri + BT - 1) / BT;
-        hipLaunchKernelGGL(k_pretransform, dim3(tblocks), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
+        hipLaunchKernelGGL(k_pretransform, dim3(tblocks < 1024u ? tblocks : 1024u), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
         bool split_done = false;
         if (presplit) {
             // the Morton grid the split planes come from: the bounds of the triangles
@@ -904,7 +988,13 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 HIPCHK(hipMemcpyAsync(c_dev, &n, 4, hipMemcpyHostToDevice, stream));
                 uint c = n;   // last cluster count the host has seen (upper bound of the live count)
                 int rounds = 0;
+                const bool tail = !getenv("TRHIP_PLOC_NO_TAIL");
                 while (c > 1) {
+                    if (tail && c <= PLOC_TAIL) {   // the rest in one workgroup; its round count stays on the device (cbounds[10])
+                        hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PLOC_TAIL), 0, stream, c_dev + (rounds & 1), n, (uint)ds.ploc_radius, cref[0], cbox[0], alloc,
+                                           children, node_box, ranges, parent_internal, cbounds + 10);
+                        break;
+                    }
                     // rounds between host checks: few while the grids are large (an over-sized grid costs), many once they are small
                     const int batch = c > (1u << 16) ? 2 : (c > 4096 ? 4 : 8);
                     const uint cb = (c + BT - 1) / BT;
