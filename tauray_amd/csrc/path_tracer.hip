@@ -65,6 +65,9 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
     pb.atten_alpha[i] = F4(1, 1, 1, 1);          // attenuation = 1
     pb.rng[i] = ls.rs;
     pb.misc[i] = misc;
+#if TR_OCC_CACHE
+    pb.occ[i] = ~0u;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -126,7 +129,24 @@ TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffer
     const bool valid = qi < n;
     f4 o = F4(0), d = F4(0), c = F4(0);
     if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; c = pb.sh_contrib[qi]; }
-#if TR_BVH4 && TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
+#if TR_OCC_CACHE
+    // Result-preserving: visibility 0 is 0 whichever opaque triangle gives it, and the test is the one the walk would make at that leaf.
+    bool walk = valid;
+    uint occluder = ~0u;
+    if (valid) {
+        const uint cached = pb.occ[__float_as_uint(d.w)];
+        if (cached != ~0u && ray_is_finite(F3(o), F3(d))) {
+            const TriRecord tr = sv.tris[cached];
+            const RayPre r = make_ray(F3(o), F3(d));
+            float t, bu, bv;
+            if (tri_intersect(r, F3(tr.v0[0], tr.v0[1], tr.v0[2]), F3(tr.v1[0], tr.v1[1], tr.v1[2]), F3(tr.v2[0], tr.v2[1], tr.v2[2]), P.opt.min_ray_dist, o.w, t, bu, bv)) walk = false;
+            if (COUNT) st.tris++;
+        }
+    }
+    float vis = trace_shadow_wave4<COUNT, TOP>(sv, walk, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, top, st, overflow, &occluder);
+    if (valid && !walk) vis = 0.0f;
+    else if (valid && vis == 0.0f && occluder != ~0u) pb.occ[__float_as_uint(d.w)] = occluder;
+#elif TR_BVH4 && TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
     float vis = trace_shadow_wave4<COUNT, TOP>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, top, st, overflow);
 #else
     float vis = 1.0f;
@@ -733,6 +753,9 @@ void PtStage::free_buffers() {
     void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
                     pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.surf, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+#if TR_OCC_CACHE
+    if (pb.occ) (void)hipFree(pb.occ);
+#endif
     uint *counters = pb.counters, *bounce = pb.bounce;
     int* qspill = pb.qspill;
     pb = PathBuffers{};
@@ -756,6 +779,9 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     HIPCHK(hipMalloc(&pb.misc, n * 16)); HIPCHK(hipMalloc(&pb.hit, n * 16)); HIPCHK(hipMalloc(&pb.sum_color, n * 16));
     HIPCHK(hipMalloc(&pb.sh_org_tmax, n * 16)); HIPCHK(hipMalloc(&pb.sh_dir_id, n * 16)); HIPCHK(hipMalloc(&pb.sh_contrib, n * 16));
     HIPCHK(hipMalloc(&pb.sh_lobes, n * 8));
+#if TR_OCC_CACHE
+    HIPCHK(hipMalloc(&pb.occ, n * 4));
+#endif
     if (lobe_sums) { HIPCHK(hipMalloc(&pb.sum_diffuse, n * 16)); HIPCHK(hipMalloc(&pb.sum_reflection, n * 16)); }
     HIPCHK(hipMalloc(&pb.queue[0], n * 4)); HIPCHK(hipMalloc(&pb.queue[1], n * 4));
     impl->capacity = n;
@@ -985,6 +1011,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             const size_t o = (size_t)lane * n;
             lb.org_pdf += o; lb.dir_reg += o; lb.atten_alpha += o; lb.diffuse += o; lb.reflection += o; lb.plobes += o; lb.first_mat += o; lb.first_emis += o;
             lb.rng += o; lb.misc += o; lb.hit += o;
+#if TR_OCC_CACHE
+            lb.occ += o;
+#endif
         }
         c.blocks_all = (c.LP.n_ids + KB - 1) / KB;
         // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue

@@ -38,6 +38,9 @@ struct PathBuffers {
     uint* bounce;
     f4* surf;         // TRHIP_SHADE_SPLIT: 5 f4 per path, what k_surface hands to k_shade (see SurfRecord below); null otherwise
     int* qspill;      // deep stack entries of the quad-cooperative tail of the closest-hit waves (trace_quad.h): 16 * TR_QSPILL words per wave of a launch
+#if TR_OCC_CACHE
+    uint* occ;        // experiment: leaf slot of the opaque triangle that occluded the path's previous shadow ray, ~0 for none
+#endif
     uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
 

@@ -21,6 +21,9 @@ namespace tr {
                            // thin end of a wave, 16 after it; re-measured on the static-build tree: 12 / 16 / 24 / 32 = 3.89 / 3.85 /
                            // 3.81 / 3.79 ms per frame, and 3 / 5 / 6 eighths of the live lanes instead of half: 3.84 / 3.84 / 3.88
 #endif
+#ifndef TR_OCC_CACHE
+#define TR_OCC_CACHE 0     // 1: a shadow ray tests the opaque triangle that occluded the path's previous shadow ray before it walks the tree
+#endif
 #ifndef TR_VOTE_SHADOW_WAVE
 #define TR_VOTE_SHADOW_WAVE 16   // the same vote in the per-lane loop of trace_shadow_wave4 (0: none); 8 / 16 measured: -1 ... -2 % shadow time
 #endif

@@ -426,7 +426,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
 // calls this; returns the product of (1 - alpha) over the non-opaque hits, 0 after an opaque one.
 template <bool COUNT, bool TOP>
 TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, const QuadCtx& qc,
-                                const float* top, TraceStats& st, int& overflow) {
+                                const float* top, TraceStats& st, int& overflow, uint* occluder = nullptr) {
     float visibility = 1.0f;
     bool live = valid && sv.tri_count > 0 && ray_is_finite(org, dir);
     RayPre r = make_ray(org, dir);
@@ -469,7 +469,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 float t, bu, bv;
                 f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
                 if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
-                    if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
+                    if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; if (TR_OCC_CACHE && occluder) *occluder = (uint)~node; }
                     else {
                         if (COUNT) st.alpha++;
                         const float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
@@ -495,6 +495,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         float lvis = q == 0 ? owner_vis : 1.0f;     // the owner's product so far rides in lane 0 of the quad
         bool qlive = deal.has_ray;
         int pend = -1;
+        int qocc = -1;
         while (true) {
             int w = pend >= 0 ? 1 : 0;
             w |= qrot1(w); w |= qrot2(w);
@@ -509,7 +510,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     float t, bu, bv;
                     f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
                     if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, qtmax, t, bu, bv)) {
-                        if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
+                        if (!(tr.inst_flags & 0x80000000u)) { lvis = 0.0f; if (TR_OCC_CACHE) qocc = pend; }
                         else {
                             if (COUNT) st.alpha++;
                             lvis *= 1.0f - candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
@@ -538,6 +539,12 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         const float rv = bpermf(back, v);
         const int ro = bperm(back, qo);
         if (live) { visibility = rv; overflow += ro; }
+        if (TR_OCC_CACHE) {      // the opaque occluder one of the quad's lanes found (any of them, if several did in the same phase)
+            int m = qocc;
+            m = max(m, qrot1(m)); m = max(m, qrot2(m));
+            const int rocc = bperm(back, m);
+            if (live && occluder && rocc >= 0) *occluder = (uint)rocc;
+        }
     }
     overflow += stk.overflow;
     return visibility;
