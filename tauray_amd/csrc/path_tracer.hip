@@ -560,6 +560,53 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
     }
 }
 
+// Experiment (TRHIP_REORDER=E): the queue of the next bounce, window by window of E * 256 entries, stably sorted by the
+// octant of the ray direction, so that the 64 rays of a closest-hit wave start near each other (the queue keeps screen order within a k_shade
+// block) AND head the same way.  Queue order is scheduling only: every path carries its own state, the frame is the same bits.
+template <int E>
+__global__ __launch_bounds__(KB) void k_reorder_queue(PathBuffers pb, const uint* count_ptr, uint* queue) {
+    __shared__ uint s_cnt[E * (KB / 64)][8];
+    __shared__ uint s_oct[8];
+    const uint n = *count_ptr;
+    const uint lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint base = blockIdx.x * (E * KB); base < n; base += gridDim.x * (E * KB)) {
+        uint id[E], oct[E], rank[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint i = base + e * KB + threadIdx.x;
+            id[e] = i < n ? queue[i] : 0u;
+            oct[e] = 8u;
+            if (i < n) { const f4 d = pb.dir_reg[id[e]]; oct[e] = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            rank[e] = 0;
+#pragma unroll
+            for (uint o = 0; o < 8; ++o) {
+                const unsigned long long m = __ballot(oct[e] == o);
+                if (oct[e] == o) rank[e] = (uint)__popcll(m & ((1ull << lane) - 1ull));
+                if (lane == o) s_cnt[e * (KB / 64) + wave][o] = (uint)__popcll(m);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {      // per octant: running offsets over the groups, in queue order
+            uint run = 0;
+            for (int g = 0; g < E * (KB / 64); ++g) { const uint c = s_cnt[g][threadIdx.x]; s_cnt[g][threadIdx.x] = run; run += c; }
+            s_oct[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (oct[e] < 8u) {
+                uint pos = rank[e] + s_cnt[e * (KB / 64) + wave][oct[e]];
+                for (uint o = 0; o < oct[e]; ++o) pos += s_oct[o];
+                queue[base + pos] = id[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
@@ -1082,6 +1129,13 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         else if (count) hipLaunchKernelGGL((k_shade<true, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        static const int reorder = getenv("TRHIP_REORDER") ? atoi(getenv("TRHIP_REORDER")) : 0;
+                        if (reorder > 0 && bounce < opt.max_bounces - 1) {
+                            const uint rb = std::max(1u, std::min(blocks_all / (uint)reorder, 2048u));
+                            if (reorder >= 16) hipLaunchKernelGGL(k_reorder_queue<16>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
+                            else if (reorder >= 4) hipLaunchKernelGGL(k_reorder_queue<4>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
+                            else hipLaunchKernelGGL(k_reorder_queue<1>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
+                        }
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
