@@ -425,11 +425,12 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
                                                   const uint8_t* dec, Bvh4Node* nodes4) {
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= n_internal) return;
-    int cand[4];
+    constexpr int W = TR_BVH8 ? 8 : 4;
+    int cand[W];
     cand[0] = children[i].x; cand[1] = children[i].y;
     int ncand = 2;
     if (dec) ncand = collapse_children(children, dec, (int)i, cand);
-    while (!dec && ncand < 4) {
+    while (!dec && ncand < W) {
         int best = -1; float best_area = -1.0f;
         for (int c = 0; c < ncand; ++c) {
             if (cand[c] < 0) continue;
@@ -442,22 +443,77 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
         const int2 ch = children[cand[best]];
         cand[best] = ch.x; cand[ncand++] = ch.y;
     }
-    Bvh4Node out;
-    for (int c = 0; c < 4; ++c) {
-        if (c < ncand) {
-            const float* b = cand[c] >= 0 ? node_box + 6 * (size_t)cand[c] : leaf_box + 6 * (size_t)(~cand[c]);
-            out.lox[c] = b[0]; out.loy[c] = b[1]; out.loz[c] = b[2]; out.hix[c] = b[3]; out.hiy[c] = b[4]; out.hiz[c] = b[5];
-            out.child[c] = cand[c] >= 0 ? new_id[cand[c]] : cand[c];
-        } else {
-            out.lox[c] = out.loy[c] = out.loz[c] = __builtin_huge_valf();
-            out.hix[c] = out.hiy[c] = out.hiz[c] = -__builtin_huge_valf();
-            out.child[c] = 0x7FFFFFFF;
+    for (int half = 0; half < W / 4; ++half) {
+        Bvh4Node out;
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * half + c;
+            if (k < ncand) {
+                const float* b = cand[k] >= 0 ? node_box + 6 * (size_t)cand[k] : leaf_box + 6 * (size_t)(~cand[k]);
+                out.lox[c] = b[0]; out.loy[c] = b[1]; out.loz[c] = b[2]; out.hix[c] = b[3]; out.hiy[c] = b[4]; out.hiz[c] = b[5];
+                out.child[c] = cand[k] >= 0 ? new_id[cand[k]] : cand[k];
+            } else {
+                out.lox[c] = out.loy[c] = out.loz[c] = __builtin_huge_valf();
+                out.hix[c] = out.hiy[c] = out.hiz[c] = -__builtin_huge_valf();
+                out.child[c] = 0x7FFFFFFF;
+            }
+            out.pad[c] = 0;
         }
-        out.pad[c] = 0;
+        nodes4[(size_t)(W / 4) * (size_t)new_id[i] + (size_t)half] = out;
     }
-    nodes4[new_id[i]] = out;
 }
 
+
+// Two Bvh4Node halves (TR_BVH8 collapse) -> Bvh8NodeQ (TR_BVH8 = 2), the rule of k_quantize4 below with eight children.
+__global__ __launch_bounds__(BT) void k_quantize8(uint n_nodes, const Bvh4Node* nodes4, Bvh8NodeQ* out) {
+    const uint i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_nodes) return;
+    const Bvh4Node h0 = nodes4[2 * (size_t)i], h1 = nodes4[2 * (size_t)i + 1];
+    Bvh8NodeQ q;
+    q.exps = 0;
+    for (int c = 0; c < 4; ++c) { q.child[c] = h0.child[c]; q.child[4 + c] = h1.child[c]; }
+    for (int c = 0; c < 8; ++c) q.pad[c] = 0;
+    for (int k = 0; k < 3; ++k) {
+        float lo[8], hi[8];
+        for (int c = 0; c < 4; ++c) {
+            lo[c] = k == 0 ? h0.lox[c] : (k == 1 ? h0.loy[c] : h0.loz[c]); hi[c] = k == 0 ? h0.hix[c] : (k == 1 ? h0.hiy[c] : h0.hiz[c]);
+            lo[4 + c] = k == 0 ? h1.lox[c] : (k == 1 ? h1.loy[c] : h1.loz[c]); hi[4 + c] = k == 0 ? h1.hix[c] : (k == 1 ? h1.hiy[c] : h1.hiz[c]);
+        }
+        float o = __builtin_huge_valf(), top = -__builtin_huge_valf();
+        for (int c = 0; c < 8; ++c) if (q.child[c] != 0x7FFFFFFF && lo[c] <= hi[c]) { o = fminf(o, lo[c]); top = fmaxf(top, hi[c]); }
+        if (!(o <= top)) { o = 0.0f; top = 0.0f; }
+        int e = 0;
+        (void)frexpf((top - o) / 255.0f, &e);
+        int oe = 0;
+        (void)frexpf(fabsf(o), &oe);
+        e = max(e, oe - 22);
+        e = min(max(e + 127, 27), 254);
+        uint qlo[2], qhi[2];
+        while (true) {
+            const float scale = __uint_as_float((uint)e << 23);
+            bool fits = true;
+            qlo[0] = qlo[1] = qhi[0] = qhi[1] = 0;
+            for (int c = 0; c < 8 && fits; ++c) {
+                uint a = 255u, b = 0u;
+                if (q.child[c] != 0x7FFFFFFF && lo[c] <= hi[c]) {
+                    float fa = floorf((lo[c] - o) / scale), fb = ceilf((hi[c] - o) / scale);
+                    fa = fminf(fmaxf(fa, 0.0f), 255.0f); fb = fminf(fmaxf(fb, 0.0f), 255.0f);
+                    a = (uint)fa; b = (uint)fb;
+                    const double od = (double)o, sd = (double)scale;
+                    while (a > 0u && (o + (float)a * scale > lo[c] || od + (double)a * sd > (double)lo[c])) --a;
+                    while (b < 255u && (o + (float)b * scale < hi[c] || od + (double)b * sd < (double)hi[c])) ++b;
+                    if (o + (float)a * scale > lo[c] || o + (float)b * scale < hi[c] || od + (double)a * sd > (double)lo[c] || od + (double)b * sd < (double)hi[c]) fits = false;
+                }
+                qlo[c >> 2] |= a << (8 * (c & 3)); qhi[c >> 2] |= b << (8 * (c & 3));
+            }
+            if (fits || e >= 254) break;
+            ++e;
+        }
+        q.origin[k] = o;
+        q.exps |= (uint)e << (8 * k);
+        q.q[4 * k] = qlo[0]; q.q[4 * k + 1] = qlo[1]; q.q[4 * k + 2] = qhi[0]; q.q[4 * k + 3] = qhi[1];
+    }
+    out[i] = q;
+}
 
 // Bvh4Node -> Bvh4NodeQ (TR_QNODES).  Per axis: origin = the smallest lo of the node's children, scale = the smallest power of two
 // with (largest hi - origin) / scale <= 255 (and large enough that origin + 255 * scale > origin, so an empty slot's inverted box
@@ -871,8 +927,8 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         if (n1 > 0) {
 #if TR_BVH4
             // traversal addresses a node's planes with 32-bit byte offsets (node << 7 | plane)
-            if ((uint64_t)n1 * sizeof(Bvh4Node) > 0xFFFFFFFFull) return set_error("trhip_scene_build_accel: more than 2^25 nodes");
-            HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node)));
+            if ((uint64_t)n1 * sizeof(Bvh4Node) * (TR_BVH8 ? 2 : 1) > 0xFFFFFFFFull) return set_error("trhip_scene_build_accel: more than 2^25 nodes");
+            HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node) * (TR_BVH8 ? 2 : 1)));
 #else
             HIPCHK(hipMalloc(&ds.nodes, n1 * sizeof(BvhNode)));
 #endif
@@ -1064,7 +1120,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
 #if TR_BVH4
                 const uint8_t* dec = nullptr;
-                if (dp_collapse) {
+                if (dp_collapse && !TR_BVH8) {
                     OptTree t{(uint)(n - 1), n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
                     if (!optimise) hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);
                     HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
@@ -1075,6 +1131,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
 #if TR_QNODES
                 if (!ds.nodesq) HIPCHK(hipMalloc(&ds.nodesq, n1 * sizeof(Bvh4NodeQ)));
                 hipLaunchKernelGGL(k_quantize4, dim3(iblocks), dim3(BT), 0, stream, n - 1, ds.nodes4, ds.nodesq);
+#elif TR_BVH8 == 2
+                if (!ds.nodesq) HIPCHK(hipMalloc(&ds.nodesq, n1 * sizeof(Bvh8NodeQ)));
+                hipLaunchKernelGGL(k_quantize8, dim3(iblocks), dim3(BT), 0, stream, n - 1, ds.nodes4, reinterpret_cast<Bvh8NodeQ*>(ds.nodesq));
 #endif
 #else
                 hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);

@@ -149,6 +149,9 @@ struct alignas(64) BvhNode {
 static_assert(sizeof(BvhNode) == 64, "node layout");
 
 #ifndef TR_BVH4
+#ifndef TR_BVH8
+#define TR_BVH8 0         // experiment: 8-wide nodes as two adjacent Bvh4Node lines (node n = lines 2n, 2n + 1); per-lane loops only (build with -DTR_QUAD_SWITCH=0)
+#endif
 #define TR_BVH4 1         // 1: traverse the 4-wide fp32 nodes (SceneView::nodes4); 0: the binary nodes they are collapsed from
 #endif
 // 4-wide node, one 128-byte line: child boxes in SoA (one dwordx4 per plane), child references as in BvhNode
@@ -166,6 +169,16 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
 // a power of two (q * scale is exact, the sum rounds once); the builder chooses q so that the plane *as the traversal reconstructs
 // it* lies on or outside the fp32 plane, so the quantised box contains the exact one and hits do not change.  Child references and
 // empty slots (inverted box: lo bytes 255, hi bytes 0) as in Bvh4Node.
+// Experiment TR_BVH8 = 2: eight children in one 128-byte line, planes quantised as in Bvh4NodeQ (96 bytes used: six 16-byte loads per visit).
+// q[4 * axis + 0 / 1] = lo planes of children 0-3 / 4-7, q[4 * axis + 2 / 3] = hi planes; empty slots inverted (lo 255, hi 0).
+struct alignas(128) Bvh8NodeQ {
+    float origin[3];
+    uint exps;
+    int child[8];
+    uint q[12];
+    uint pad[8];
+};
+static_assert(sizeof(Bvh8NodeQ) == 128, "Bvh8NodeQ layout");
 #ifndef TR_QNODES
 #define TR_QNODES 0
 #endif

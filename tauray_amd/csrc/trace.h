@@ -449,6 +449,49 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
     h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
 }
 
+#if TR_BVH8
+// Eight children of node `node`: entry distances (huge = missed) and references.  TR_BVH8 = 1: two fp32 halves (lines 2n, 2n + 1);
+// TR_BVH8 = 2: one quantised line (common.h Bvh8NodeQ).
+template <bool TOP>
+TR_DEV void box8_intersect(const RayPre& r, const SceneView& sv, const float* top, int node, float tmin, float tmax, float* ht, int* hc) {
+#if TR_BVH8 == 2
+    // the quantised line: planes reconstructed first (origin + q * scale, one rounding - what k_quantize8 checked), then the fp32 slab test.
+    // (The decode folded into the slab test, as TR_QNODES = 2 has it, was tried here too: its NaNs for rays that start on a plane of the
+    // node frame make some shadow rays of the path tracer visit whole subtrees - 1.8 s per frame - although every frame stays the same bits.)
+    const char* base = reinterpret_cast<const char*>(sv.nodesq);
+    const uint t = (uint)node << 7;
+    const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
+    const int4 ca = *reinterpret_cast<const int4*>(base + (size_t)t + 16), cb = *reinterpret_cast<const int4*>(base + (size_t)t + 32);
+    const uint4 px = *reinterpret_cast<const uint4*>(base + (size_t)t + 48), py = *reinterpret_cast<const uint4*>(base + (size_t)t + 64),
+                pz = *reinterpret_cast<const uint4*>(base + (size_t)t + 80);
+    const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
+    const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
+    const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
+    const uint qnx[2] = {gx ? px.z : px.x, gx ? px.w : px.y}, qfx[2] = {gx ? px.x : px.z, gx ? px.y : px.w};
+    const uint qny[2] = {gy ? py.z : py.x, gy ? py.w : py.y}, qfy[2] = {gy ? py.x : py.z, gy ? py.y : py.w};
+    const uint qnz[2] = {gz ? pz.z : pz.x, gz ? pz.w : pz.y}, qfz[2] = {gz ? pz.x : pz.z, gz ? pz.y : pz.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int w = k >> 2, sh = 8 * (k & 3);
+        const float tx0 = (__builtin_fmaf((float)((qnx[w] >> sh) & 0xFFu), sx, ox) - r.org.x) * r.inv_dir.x, tx1 = (__builtin_fmaf((float)((qfx[w] >> sh) & 0xFFu), sx, ox) - r.org.x) * r.inv_dir.x;
+        const float ty0 = (__builtin_fmaf((float)((qny[w] >> sh) & 0xFFu), sy, oy) - r.org.y) * r.inv_dir.y, ty1 = (__builtin_fmaf((float)((qfy[w] >> sh) & 0xFFu), sy, oy) - r.org.y) * r.inv_dir.y;
+        const float tz0 = (__builtin_fmaf((float)((qnz[w] >> sh) & 0xFFu), sz, oz) - r.org.z) * r.inv_dir.z, tz1 = (__builtin_fmaf((float)((qfz[w] >> sh) & 0xFFu), sz, oz) - r.org.z) * r.inv_dir.z;
+        const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin));
+        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
+        ht[k] = t0 <= t1 ? t0 : __builtin_huge_valf();
+    }
+    int c0 = ca.x, c1 = ca.y, c2 = ca.z, c3 = ca.w, c4 = cb.x, c5 = cb.y, c6 = cb.z, c7 = cb.w;
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));
+    hc[0] = c0; hc[1] = c1; hc[2] = c2; hc[3] = c3; hc[4] = c4; hc[5] = c5; hc[6] = c6; hc[7] = c7;
+#else
+    Hit4 h0, h1;
+    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, 2 * node, tmin, tmax, h0);
+    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, 2 * node + 1, tmin, tmax, h1);
+    for (int k = 0; k < 4; ++k) { ht[k] = h0.t[k]; hc[k] = h0.c[k]; ht[4 + k] = h1.t[k]; hc[4 + k] = h1.c[k]; }
+#endif
+}
+#endif
+
 #define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
                        h.t[a] = sw ? tb : ta; h.t[b] = sw ? ta : tb; h.c[a] = sw ? cb : ca; h.c[b] = sw ? ca : cb; }
 
@@ -481,6 +524,42 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     else st.ph_tri++;
                 }
             }
+#if TR_BVH8
+            if (node >= 0) {
+                float ht[8];
+                int hc[8];
+                box8_intersect<TOP>(r, sv, top, node, tmin, best_t, ht, hc);
+                if (COUNT) st.nodes++;
+#if defined(TR_BVH8_NEAREST_ONLY)
+                // no sort: the nearest child is entered, the others are pushed in slot order
+                float bt = __builtin_huge_valf(); int bc = 0x7FFFFFFF;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (ht[k] < __builtin_huge_valf()) {
+                        const bool nearer = ht[k] < bt;
+                        const int out = nearer ? bc : hc[k];
+                        if (nearer) { bt = ht[k]; bc = hc[k]; }
+                        if (out != 0x7FFFFFFF) stk.push(spill, out);
+                    }
+                }
+                if (bc != 0x7FFFFFFF) { if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); node = bc; continue; }
+            } else {
+#else
+#define TR_CE8(a, b) { const bool sw = ht[b] < ht[a]; const float ta = ht[a], tb = ht[b]; const int ca = hc[a], cb = hc[b]; \
+                       ht[a] = sw ? tb : ta; ht[b] = sw ? ta : tb; hc[a] = sw ? cb : ca; hc[b] = sw ? ca : cb; }
+                TR_CE8(0, 1) TR_CE8(2, 3) TR_CE8(4, 5) TR_CE8(6, 7) TR_CE8(0, 2) TR_CE8(1, 3) TR_CE8(4, 6) TR_CE8(5, 7) TR_CE8(1, 2) TR_CE8(5, 6)
+                TR_CE8(0, 4) TR_CE8(3, 7) TR_CE8(1, 5) TR_CE8(2, 6) TR_CE8(1, 4) TR_CE8(3, 6) TR_CE8(2, 4) TR_CE8(3, 5) TR_CE8(3, 4)
+#undef TR_CE8
+                if (ht[0] < __builtin_huge_valf()) {
+#pragma unroll
+                    for (int k = 7; k >= 1; --k) if (ht[k] < __builtin_huge_valf()) stk.push(spill, hc[k]);
+                    if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
+                    node = hc[0];
+                    continue;
+                }
+            } else {
+#endif
+#else
             if (node >= 0) {
                 Hit4 h;
                 box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, best_t, h);
@@ -495,6 +574,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     continue;
                 }
             } else {
+#endif
                 const TriRecord tr = sv.tris[~node];
                 if (COUNT) st.tris++;
                 float t, bu, bv;
@@ -556,17 +636,34 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
     while (true) {
         if (node >= 0) {
-            Hit4 h;
-            box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
-            if (COUNT) st.nodes++;
             int next = 0x7FFFFFFF;
+#if TR_BVH8
+            {
+                float ht[8];
+                int hc[8];
+                box8_intersect<TOP>(r, sv, top, node, tmin, tmax, ht, hc);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (h.t[k] < __builtin_huge_valf()) {
-                    if (next == 0x7FFFFFFF) next = h.c[k];
-                    else stk.push(spill, h.c[k]);
+                for (int k = 0; k < 8; ++k) {
+                    if (ht[k] < __builtin_huge_valf()) {
+                        if (next == 0x7FFFFFFF) next = hc[k];
+                        else stk.push(spill, hc[k]);
+                    }
                 }
             }
+#else
+            {
+                Hit4 h;
+                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (h.t[k] < __builtin_huge_valf()) {
+                        if (next == 0x7FFFFFFF) next = h.c[k];
+                        else stk.push(spill, h.c[k]);
+                    }
+                }
+            }
+#endif
+            if (COUNT) st.nodes++;
             if (next != 0x7FFFFFFF) { node = next; continue; }
         } else {
             const TriRecord tr = sv.tris[~node];
