@@ -1746,6 +1746,47 @@ def test_random_option_combinations(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_triangle_counts_around_the_one_workgroup_clustering(R, ctx, oracle, monkeypatch):
+    """The builder clusters the last 1 024 clusters in one workgroup (csrc/bvh_build.hip k_ploc_tail) - scenes of 1 024 triangles or fewer
+    never see a grid round.  Hit parity (bit-exact closest hits, equal visibility) at the sizes where that path starts, ends and is skipped,
+    with the one-workgroup rounds and with every round as grid launches (TRHIP_PLOC_NO_TAIL=1)."""
+    from tauray_amd import scene as S
+    for n in (1, 2, 3, 5, 63, 64, 65, 1000, 1023, 1024, 1025, 1500, 2047, 2049, 5000):
+        rng = np.random.default_rng(1000 + n)
+        centre = rng.normal(size=(n, 3)) * 3.0
+        tri = (centre[:, None, :] + rng.normal(size=(n, 3, 3)) * 10.0 ** rng.uniform(-2, 0.5, size=(n, 1, 1))).astype(np.float32)
+        verts = np.zeros(3 * n, dtype=S.VERTEX)
+        verts["pos"] = tri.reshape(-1, 3)
+        verts["normal"] = (0, 0, 1)
+        verts["tangent"] = (1, 0, 0, 1)
+        cam = S.Camera(fov=60, aspect=1.0)
+        cam.transform = S.trs_matrix((0, 0, 30))
+        sc = S.SceneDesc(instances=S.make_instance(np.eye(4), S.make_material(albedo=(0.5, 0.5, 0.5, 1.0), metallic=0.0, roughness=0.5, double_sided=True)),
+                         spans=np.array([(0, 3 * n, 0, n)], dtype=S.MESH_SPAN), vertices=verts, indices=np.arange(3 * n, dtype=np.uint32), cameras=[cam]).finalize(True)
+        osc = oracle.OracleScene(sc)
+        m = 8000
+        org = (rng.normal(size=(m, 3)) * 6.0).astype(np.float32)
+        d = (-org + rng.normal(size=(m, 3)) * 3.0).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([org, np.full((m, 1), 1e-4, np.float32), d, np.full((m, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+        srays = rays.copy()
+        srays[:, 7] = rng.uniform(0.5, 20.0, size=m)
+        o, os_ = osc.trace_closest(rays, None), osc.trace_shadow(srays)
+        for mode in ("tail", "grid"):
+            if mode == "grid": monkeypatch.setenv("TRHIP_PLOC_NO_TAIL", "1")
+            ss = R.SceneStage(ctx, sc)
+            monkeypatch.delenv("TRHIP_PLOC_NO_TAIL", raising=False)
+            assert ss.accel["leaf_count"] == n and ss.accel["triangle_count"] == n
+            g = ss.trace_closest(rays, None)
+            for k in ("instance_id", "primitive_id"):
+                assert np.array_equal(g[k], o[k]), f"{n} triangles, {mode}: {k}"
+            assert np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32)), f"{n} triangles, {mode}: t"
+            gs = ss.trace_shadow(srays)
+            assert np.array_equal(gs == 0, os_ == 0), f"{n} triangles, {mode}: visibility"
+        if n >= 5: assert (o["instance_id"] >= 0).mean() > 0.02, f"{n} triangles: the rays miss the cloud"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 2, 3, 12] + [int(x) for x in os.environ.get("TRHIP_FUZZ_SOUPS", "").split()])
 def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
     """Hit parity on geometry no modeller would export: 20 000 random triangles of wildly different sizes (1e-3 .. 1e2), needles,
