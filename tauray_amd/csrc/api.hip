@@ -467,6 +467,7 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     s.vertex_count = d->vertex_count; s.index_count = d->index_count; s.tri_count = prefix.back();
     s.gather_emissive_triangles = d->gather_emissive_triangles;
     s.host_tri_light_count = d->gather_emissive_triangles ? tri_lights : 0;
+    if (int rc = build_shade_tris(s, -1, nullptr)) return rc;
     return 0;
 }
 

@@ -26,6 +26,7 @@ struct DeviceScene {
     CameraData* prev_cameras = nullptr;  // defaults to a copy of `cameras`
     uint8_t* non_opaque = nullptr;
     uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
+    ShadeTri* shade_tris = nullptr;      // index_count / 3 records, or null (see common.h ShadeTri)
     // scene_stage's pre-transformed vertex copy (shader/pre_transform.comp): one span per instance; vertices built on first use
     std::vector<MeshSpan> host_spans, host_world_spans;
     MeshSpan* world_spans = nullptr;
@@ -73,7 +74,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4; v.nodesq = nodesq;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4; v.nodesq = nodesq;
         v.treetop = (use_treetop && accel_built && node_count > 0) ? treetop : nullptr;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
@@ -107,7 +108,7 @@ struct DeviceScene {
         free_accel();
         free_skins();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
-                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch};
+                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch, shade_tris};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = DeviceScene();
     }
@@ -115,6 +116,7 @@ struct DeviceScene {
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);
 int ensure_world_vertices(DeviceScene& ds, hipStream_t stream);
+int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream);   // instance < 0: every mesh (after an upload); else the mesh of that instance (after skinning)
 int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms, uint joint_count, hipStream_t stream);   // skinning.comp
 int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info);   // same tree, new boxes (after trhip_scene_update_instances)   // pre_transform.comp per instance
 

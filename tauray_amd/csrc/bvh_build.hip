@@ -5,6 +5,8 @@
 //   -> depth-first relabelling -> in-place collapse to 4-wide fp32 nodes (128 B) + 48-byte triangle records.
 // trhip_scene_refit_accel keeps the tree and recomputes its boxes level by level.  Also here: extract_tri_lights
 // (shader/extract_tri_lights.comp:17-54) and the pre-transformed vertex copy (shader/pre_transform.comp:26-42).
+#include <algorithm>
+#include <vector>
 #include "build.h"
 
 #include <rocprim/rocprim.hpp>
@@ -682,6 +684,67 @@ __global__ __launch_bounds__(BT) void k_skinning(uint vertex_count, const Vertex
     destination[i] = dst;
 }
 
+__global__ __launch_bounds__(BT) void k_build_shade_tris(uint n_spans, const MeshSpan* spans, const Vertex* vertices, const uint* indices, ShadeTri* out) {
+    const MeshSpan sp = spans[blockIdx.y];
+    const Vertex* vb = vertices + sp.vertex_offset;
+    const uint* ix = indices + sp.index_offset;
+    ShadeTri* o = out + sp.index_offset / 3u;
+    for (uint t = blockIdx.x * BT + threadIdx.x; t < sp.triangle_count; t += gridDim.x * BT) {
+        ShadeTri r;
+        r.v[0] = vb[ix[3 * t]]; r.v[1] = vb[ix[3 * t + 1]]; r.v[2] = vb[ix[3 * t + 2]];
+        o[t] = r;
+    }
+}
+
+// The per-triangle vertex records k_shade reads (common.h ShadeTri).  A record is addressed by index_offset / 3 + primitive, so every
+// span must start at a whole triangle and two spans over the same indices must use the same vertices; a scene that does not
+// (none the loaders produce) simply has no records and is shaded by the general kernels.
+int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream) {
+    if (instance < 0) {
+        if (ds.shade_tris) { (void)hipFree(ds.shade_tris); ds.shade_tris = nullptr; }
+        if (ds.index_count < 3 || ds.instance_count == 0 || getenv("TRHIP_NO_SHADE_TRIS")) return 0;
+        std::vector<MeshSpan> unique;
+        {
+            std::vector<MeshSpan> sorted(ds.host_spans);
+            std::sort(sorted.begin(), sorted.end(), [](const MeshSpan& a, const MeshSpan& b) { return a.index_offset != b.index_offset ? a.index_offset < b.index_offset : a.triangle_count > b.triangle_count; });
+            uint64_t end = 0;      // first index not covered by the records so far
+            for (const MeshSpan& sp : sorted) {
+                if (sp.triangle_count == 0) continue;
+                if (sp.index_offset % 3u != 0) return 0;
+                if (!unique.empty() && sp.index_offset < end) {      // overlaps the previous mesh: fine if it is (part of) the same mesh
+                    const MeshSpan& u = unique.back();
+                    if (sp.vertex_offset != u.vertex_offset || (sp.index_offset - u.index_offset) % 3u != 0 || (uint64_t)sp.index_offset + 3ull * sp.triangle_count > end) return 0;
+                    continue;
+                }
+                unique.push_back(sp);
+                end = (uint64_t)sp.index_offset + 3ull * sp.triangle_count;
+            }
+        }
+        if (unique.empty()) return 0;
+        HIPCHK(hipMalloc(&ds.shade_tris, (size_t)(ds.index_count / 3u) * sizeof(ShadeTri)));
+        MeshSpan* dev_spans = nullptr;
+        HIPCHK(hipMalloc(&dev_spans, unique.size() * sizeof(MeshSpan)));
+        HIPCHK(hipMemcpyAsync(dev_spans, unique.data(), unique.size() * sizeof(MeshSpan), hipMemcpyHostToDevice, stream));
+        uint most = 0;
+        for (const MeshSpan& sp : unique) most = std::max(most, sp.triangle_count);
+        for (size_t first = 0; first < unique.size(); first += 65535u) {
+            const uint count = (uint)std::min<size_t>(65535u, unique.size() - first);
+            hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((most + BT - 1) / BT, 1024u), count), dim3(BT), 0, stream, count, dev_spans + first, ds.vertices, ds.indices, ds.shade_tris);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        (void)hipFree(dev_spans);
+        return 0;
+    }
+    if (!ds.shade_tris) return 0;
+    // one mesh again (its vertices were skinned): the span of the instance, read from the device copy of the spans
+    const MeshSpan& sp = ds.host_spans[(size_t)instance];
+    if (sp.triangle_count == 0) return 0;
+    hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((sp.triangle_count + BT - 1) / BT, 1024u), 1), dim3(BT), 0, stream, 1u, ds.spans + instance, ds.vertices, ds.indices, ds.shade_tris);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms, uint joint_count, hipStream_t stream) {
     if (instance >= ds.skin_slots.size() || !ds.skin_slots[instance].source) return set_error("trhip_scene_skin: instance has no skin (trhip_scene_set_skin)");
     DeviceScene::SkinSlot& k = ds.skin_slots[instance];
@@ -697,6 +760,7 @@ int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms,
     hipLaunchKernelGGL(k_skinning, dim3((k.vertex_count + BT - 1) / BT), dim3(BT), 0, stream, k.vertex_count, k.source, k.skins, k.joints, joint_count,
                        ds.vertices + sp.vertex_offset);
     HIPCHK(hipGetLastError());
+    if (int rc = build_shade_tris(ds, (int)instance, stream)) return rc;
     HIPCHK(hipStreamSynchronize(stream));   // the host array may be reused by the caller
     return 0;
 }

@@ -129,10 +129,14 @@ struct TriLight { f3 pos[3]; uint emission_factor, instance_id, primitive_id; ui
 struct AliasEntry { uint alias_id, probability; float pdf, alias_pdf; };
 struct CameraData { m4 view, view_inverse, view_proj, proj_inverse; f4 origin, dof_params, projection_info, pan; };
 struct MeshSpan { uint vertex_offset, vertex_count, index_offset, triangle_count; };
+// The three vertices of one indexed triangle side by side (144 bytes): what k_shade reads for a hit instead of three indices and three
+// 48-byte vertices from up to six cache lines.  Record index = index_offset / 3 + primitive (instances of one mesh share the records);
+// built at upload and after skinning (csrc/bvh_build.hip build_shade_tris), absent when the spans do not allow that index.
+struct ShadeTri { Vertex v[3]; };
 struct Skin { uint joints[4]; float weights[4]; };   // mesh::skin_data (src/mesh.hh:32-36), `skin` of shader/skinning.comp:10-14
 struct TextureInfo { uint width, height, texel_offset, pad; };
 #pragma pack(pop)
-static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288, "layout");
+static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288 && sizeof(ShadeTri) == 144, "layout");
 static_assert(sizeof(DirectionalLight) == 32 && sizeof(PointLight) == 64 && sizeof(TriLight) == 64, "layout");
 static_assert(sizeof(CameraData) == 320 && sizeof(AliasEntry) == 16, "layout");
 
@@ -240,6 +244,7 @@ struct SceneView {
     const CameraData* prev_cameras;   // camera_pair.previous (shader/scene.glsl:176-185)
     const MeshSpan* obj_spans;        // the uploaded model-space vertices even when `vertices` is the pre-transformed copy
     const Vertex* obj_vertices;
+    const ShadeTri* shade_tris;  // null = none
     const BvhNode* nodes;
     const TriRecord* tris;
     const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)

@@ -911,7 +911,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     }
     const bool count = count_work != 0;
     static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
-    const bool cli_set = cli_instances && is_cli_default_set(opt);     // k_shade<.., CLI>
+    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr;     // k_shade<.., CLI>: reads the ShadeTri records
     // ... which exist twice: at IEEE fp32 here and, the default, at the accuracy Vulkan asks of the reference's GLSL (shade_fast.hip)
     static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
     const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
                 surface = true;
                 if (COUNT) surf++;
                 if (SPLIT) load_surface(pb.surf, P.n_launch, id, v, mat);
-                else shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat);
+                else shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, CLI);
                 mat.albedo.w = 1.0f;
                 if (P.nee_tri) {
                     tri_pdf = v.tri_light_pdf;

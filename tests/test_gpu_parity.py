@@ -2295,6 +2295,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"}, "generic_shade": {"TRHIP_SHADE_CLI": "0"},
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
                 "packet_primary": {"TRHIP_PACKET": "1"},      # the primary rays of a wave on one walk (csrc/trace_packet.h)
+                "no_triangle_records": {"TRHIP_NO_SHADE_TRIS": "1"},      # no ShadeTri records: the general k_shade with indexed vertex fetches (IEEE fp32)
                 "reordered_queue": {"TRHIP_REORDER": "4"},      # the next bounce's queue sorted by direction octant (k_reorder_queue)
                 "ploc_grid_rounds": {"TRHIP_PLOC_NO_TAIL": "1"},      # every clustering round as grid launches (csrc/bvh_build.hip k_ploc_tail otherwise)
                 "presplit": {"TRHIP_PRESPLIT": "40"}, "presplit_lbvh": {"TRHIP_PRESPLIT": "100", "TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "0"},
@@ -2315,7 +2316,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT", "TRHIP_SHADE_FAST", "TRHIP_PACKET", "TRHIP_PLOC_NO_TAIL", "TRHIP_REORDER"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT", "TRHIP_SHADE_FAST", "TRHIP_PACKET", "TRHIP_PLOC_NO_TAIL", "TRHIP_REORDER", "TRHIP_NO_SHADE_TRIS"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
@@ -2327,6 +2328,6 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     # schedule, tree and kernel instance renders the same bits (the general k_shade only exists at IEEE fp32)
     ieee = frames["ieee_shade"]
     for tag, f in frames.items():
-        base = ieee if tag in ("ieee_shade", "ieee_generic_shade", "ieee_general_last_bounce", "generic_shade", "shade_split") else ref
+        base = ieee if tag in ("ieee_shade", "ieee_generic_shade", "ieee_general_last_bounce", "generic_shade", "shade_split", "no_triangle_records") else ref
         assert np.array_equal(f, base), f"{tag}: {int((f != base).any(-1).sum())} pixels differ from the {'IEEE' if base is ieee else 'default'} frame"
     _compare(ref[None], ieee[None], "default shading arithmetic vs IEEE fp32")
