@@ -1746,6 +1746,41 @@ def test_random_option_combinations(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_scenes_without_triangle_records_render_the_same(R, ctx):
+    """The command-line k_shade reads a hit's vertices from per-triangle records addressed by index_offset / 3 + primitive (csrc/common.h
+    ShadeTri).  A scene whose spans do not start at whole triangles, or whose meshes share indices over different vertices, gets no
+    records and the general kernel: the same frame bit for bit at IEEE fp32 (the general kernel's arithmetic)."""
+    import copy
+    from tauray_amd.gltf import load_glb
+    base = load_glb(os.path.join(GOLDEN, "test.glb"), 96, 96)
+    shifted = copy.copy(base)      # one unused index in front: every span starts one index later
+    shifted.indices = np.concatenate([np.zeros(1, np.uint32), base.indices])
+    shifted.spans = base.spans.copy()
+    shifted.spans["index_offset"] += 1
+    # a second, different copy of the vertices (other normals and texture coordinates) used by the odd instances - over the same indices
+    # (no records possible: one index triangle, two sets of vertices) and over a copy of the indices (records possible)
+    other = base.vertices.copy()
+    other["normal"] = other["normal"][:, [1, 2, 0]]
+    other["uv"] = 1.0 - other["uv"]
+    twin = copy.copy(base)
+    twin.vertices = np.concatenate([base.vertices, other])
+    twin.spans = base.spans.copy()
+    twin.spans["vertex_offset"][1::2] += len(base.vertices)
+    twin_own = copy.copy(twin)
+    twin_own.indices = np.concatenate([base.indices, base.indices])
+    twin_own.spans = twin.spans.copy()
+    twin_own.spans["index_offset"][1::2] += len(base.indices)
+    frames = {}
+    for tag, sc in (("records", base), ("shifted indices", shifted), ("shared indices", twin), ("own indices", twin_own)):
+        ss = R.SceneStage(ctx, sc)
+        frames[tag] = _render_hip(R, ctx, ss, sc, (96, 96), ieee=True, max_bounces=3)
+        assert np.isfinite(frames[tag]).all() and frames[tag][..., :3].mean() > 1e-3
+    for a, b in (("shifted indices", "records"), ("shared indices", "own indices")):
+        assert np.array_equal(frames[a], frames[b]), f"{a} vs {b}: {int((frames[a] != frames[b]).any(-1).sum())} pixels differ"
+    assert not np.array_equal(frames["own indices"], frames["records"]), "the second set of vertices changed nothing"
+
+
+@pytest.mark.gpu
 def test_triangle_counts_around_the_one_workgroup_clustering(R, ctx, oracle, monkeypatch):
     """The builder clusters the last 1 024 clusters in one workgroup (csrc/bvh_build.hip k_ploc_tail) - scenes of 1 024 triangles or fewer
     never see a grid round.  Hit parity (bit-exact closest hits, equal visibility) at the sizes where that path starts, ends and is skipped,
