@@ -106,6 +106,10 @@ typedef struct trhip_accel_info {
                                          several references (csrc/bvh_presplit.h); node_count = leaf_count - 1 */
 } trhip_accel_info;
 
+/* Copies the scene to the device (the reference's buffers byte for byte) and derives, next to them, one 144-byte record
+ * per index triangle with its three vertices side by side, which the shading kernel of the command-line option set reads instead of
+ * indices + vertices (same values, fewer cache lines; rebuilt for a mesh by trhip_scene_skin).  Spans that do not start at a whole
+ * triangle, or that share indices over different vertex ranges, are valid input: such a scene gets no records and the general kernels. */
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
 /* Moving lights: replaces the 64-byte point / spot light records and the 32-byte directional light records of the uploaded
