@@ -2332,6 +2332,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "packet_primary": {"TRHIP_PACKET": "1"},      # the primary rays of a wave on one walk (csrc/trace_packet.h)
                 "no_triangle_records": {"TRHIP_NO_SHADE_TRIS": "1"},      # no ShadeTri records: the general k_shade with indexed vertex fetches (IEEE fp32)
                 "reordered_queue": {"TRHIP_REORDER": "4"},      # the next bounce's queue sorted by direction octant (k_reorder_queue)
+                "reordered_queue_wide": {"TRHIP_REORDER": "16", "TRHIP_LANES": "2"},
                 "ploc_grid_rounds": {"TRHIP_PLOC_NO_TAIL": "1"},      # every clustering round as grid launches (csrc/bvh_build.hip k_ploc_tail otherwise)
                 "presplit": {"TRHIP_PRESPLIT": "40"}, "presplit_lbvh": {"TRHIP_PRESPLIT": "100", "TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "0"},
                 # the shading kernels of the command-line option set exist at IEEE fp32 too (TRHIP_SHADE_FAST=0; csrc/shade_fast.hip)
