@@ -757,6 +757,7 @@ enum { T_CLOSEST = 0, T_SHADOW = 1, T_SHADE = 2, T_RAYGEN = 3, T_RESOLVE = 4, T_
 struct PtStage::Impl {
     PathBuffers pb{};
     size_t capacity = 0;
+    float prev_frame_ms = 0.0f;        // device time of the stage's previous frame (0 = unknown): picks the enqueue order of the lanes
     size_t qspill_lane_words = 0;      // one region of PathBuffers::qspill: the largest trace launch of a lane
     size_t qspill_regions = 0;         // regions allocated: one per lane in use, two for a single lane whose shadow launches run on the side stream
     hipEvent_t ev[2]{};
@@ -976,6 +977,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         (void)hipEventRecord(sp.b, on);
         impl->pending.push_back(sp);
     };
+    if (timing_pending) {      // how long the previous frame of this stage took, if it is over (one frame at a time: always): picks the enqueue order below
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) impl->prev_frame_ms = ms;
+        else (void)hipGetLastError();
+    }
     HIPCHK(hipEventRecord(ev[0], stream));
     if (direct) {   // direct_stage: one lane on the caller's stream (src/direct_stage.cc:104-127)
         if (!pb.sh_cweight) HIPCHK(hipMalloc(&pb.sh_cweight, impl->capacity * 16));
@@ -1070,7 +1076,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     }
     const int passes = passes_total;
     // every launch of one pass of one lane
-    auto enqueue_pass = [&](int lane, int pass) -> int {
+    // `only`: -2 = the whole pass; otherwise one step of it, so that the steps of several lanes can be enqueued in turn
+    // (-1 = ray generation, 0 .. max_bounces - 1 = that bounce, max_bounces = accumulation and resolve)
+    auto enqueue_pass = [&](int lane, int pass, int only) -> int {
         LaneCtx& c = lane_ctx[lane];
         const hipStream_t ls = c.ls;
         PtParams& LP = c.LP;
@@ -1082,10 +1090,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             for (int s = 0; s < opt.samples_per_pass; ++s) {
                 LP.sample_in_pass = (uint)s;
                 LP.rng_sample = shard_sample_base + shard_sample_stride * (LP.previous_samples + LP.sample_in_pass);
-                timed(T_RAYGEN, ls, [&] {
+                if (only == -2 || only == -1) timed(T_RAYGEN, ls, [&] {
                     hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
                 });
                 for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
+                    if (only != -2 && only != bounce) continue;
                     const uint* q = bounce == 0 ? nullptr : lb.queue[bounce & 1];
                     uint* qn = lb.queue[(bounce + 1) & 1];
                     uint* bc = lb.bounce + BC_STRIDE * bounce;
@@ -1157,9 +1166,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         if (overlap) { HIPCHK(hipEventRecord(impl->ev_join, impl->side)); shadow_in_flight = true; }
                     }
                 }
+                if (only != -2 && only != opt.max_bounces) continue;
                 if (shadow_in_flight) { HIPCHK(hipStreamWaitEvent(ls, impl->ev_join, 0)); shadow_in_flight = false; }
                 if (!LP.fused_resolve) hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, ls, LP, lb);
             }
+            if (only != -2 && only != opt.max_bounces) return 0;
             // sample lanes: the targets have seen pass - 1 before this pass blends into them
             if (sample_lanes && pass > 0) HIPCHK(hipStreamWaitEvent(ls, impl->pass_done[(pass - 1) % n_lanes], 0));
             timed(T_RESOLVE, ls, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, ls, LP, lb); });
@@ -1167,11 +1178,28 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         }
         return 0;
     };
+    // Enqueue order of the lanes of a one-pass frame (same bits either way; profiles/r3/enqueue_order_ab.txt).  Lane after lane leaves
+    // the lanes a dozen launches (~60 us of host time) apart, so they run out of phase - one shades while another traces - which is
+    // worth 3 % on a 4.2 ms frame (sponza_teapots); step by step in turn keeps them in phase, which is worth 6 % on a 2.2 ms frame
+    // (test.glb) and costs 3 % on the long one; lanes one or two steps apart gain on neither.  So: in turn when the previous frame
+    // of this stage took less than 3 ms, lane after lane otherwise.  TRHIP_ENQUEUE=lanes | step | skew<k> pins the order.
+    static const char* order_env = getenv("TRHIP_ENQUEUE");
+    const bool interleave = order_env ? strcmp(order_env, "lanes") != 0 : (impl->prev_frame_ms > 0.0f && impl->prev_frame_ms < 3.0f);
     if (sample_lanes) {
-        for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(pass % lanes_used, pass)) return rc;
+        for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(pass % lanes_used, pass, -2)) return rc;
+    } else if (interleave && lanes_used > 1 && passes == 1 && opt.samples_per_pass == 1) {
+        // TRHIP_ENQUEUE=skew<k>: lane l runs k steps behind lane l - 1 (0 = all lanes in step)
+        static const int skew = (order_env && !strncmp(order_env, "skew", 4)) ? atoi(order_env + 4) : 0;
+        const int n_steps = opt.max_bounces + 2;
+        for (int t = 0; t < n_steps + skew * (lanes_used - 1); ++t)
+            for (int lane = 0; lane < lanes_used; ++lane) {
+                const int step = t - skew * lane;
+                if (step < 0 || step >= n_steps) continue;
+                if (int rc = enqueue_pass(lane, 0, step - 1)) return rc;
+            }
     } else {
         for (int lane = 0; lane < lanes_used; ++lane)
-            for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(lane, pass)) return rc;
+            for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(lane, pass, -2)) return rc;
     }
     if (n_lanes > 1) {   // join
         HIPCHK(hipEventRecord(impl->ev_join, impl->side));

@@ -2331,6 +2331,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
                 "packet_primary": {"TRHIP_PACKET": "1"},      # the primary rays of a wave on one walk (csrc/trace_packet.h)
                 "no_triangle_records": {"TRHIP_NO_SHADE_TRIS": "1"},      # no ShadeTri records: the general k_shade with indexed vertex fetches (IEEE fp32)
+                "lanes_enqueued_in_turn": {"TRHIP_ENQUEUE": "step"}, "lanes_enqueued_a_step_apart": {"TRHIP_ENQUEUE": "skew1"},      # instead of lane after lane (the first frame of a stage)
                 "reordered_queue": {"TRHIP_REORDER": "4"},      # the next bounce's queue sorted by direction octant (k_reorder_queue)
                 "reordered_queue_wide": {"TRHIP_REORDER": "16", "TRHIP_LANES": "2"},
                 "ploc_grid_rounds": {"TRHIP_PLOC_NO_TAIL": "1"},      # every clustering round as grid launches (csrc/bvh_build.hip k_ploc_tail otherwise)
@@ -2352,7 +2353,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT", "TRHIP_SHADE_FAST", "TRHIP_PACKET", "TRHIP_PLOC_NO_TAIL", "TRHIP_REORDER", "TRHIP_NO_SHADE_TRIS"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_TREETOP", "TRHIP_SHADE_SPLIT", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_PRESPLIT", "TRHIP_SHADE_FAST", "TRHIP_PACKET", "TRHIP_PLOC_NO_TAIL", "TRHIP_REORDER", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
