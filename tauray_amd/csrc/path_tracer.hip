@@ -930,16 +930,18 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     static const int lanes_env = getenv("TRHIP_LANES") ? atoi(getenv("TRHIP_LANES")) : PT_LANES;
     static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);
     // Small frames (the shards of a multi-GPU job) are bound by the latency of one ray's dependent fetches per kernel, not
-    // by throughput; extra hardware queues only add dispatch latency there (measured: 1 M paths 1.68 ms on one lane, 1.94 ms
-    // on four; 2 M paths 3.87 ms vs 3.10 ms).
-    static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)1500000;
+    // by throughput, and below ~200 k paths extra hardware queues only add dispatch latency (130 k paths: 0.74 ms on one lane, 0.75 on
+    // two, 0.79 on four).  Above that lanes pay again since the round-3 kernels and grids (one frame at a time, sponza_teapots:
+    // 261 k paths 1.07 -> 0.90 ms on two lanes, 518 k 1.61 -> 1.28 ms on four, 1.04 M 2.71 -> 2.36 ms on four;
+    // profiles/r3/small_frame_lanes.txt) - round 2's threshold of 1.5 M paths had outlived the kernels it was measured on.
+    static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)200000;
     //  * sample lanes (a frame of two or more one-sample passes, the offline case - BASELINE config 3 is 4096 of them): the lanes
     //    take turns with whole samples instead of sharing one, each with path state of its own, so that up to four samples are
     //    in flight like the frames of a renderer with frame slots (3.4 instead of 4.0 ms per sample on sponza_class).  A pass
     //    ends in k_resolve, which blends into the targets and therefore runs in pass order: each one waits for the previous
     //    pass's, on whatever lane that ran.
     const int n_lanes = sample_lanes ? sample_lane_count
-                                     : (timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(lanes_env, PT_LANES)))));
+                                     : (timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(n < 2 * lanes_min_paths ? std::min(lanes_env, 2) : lanes_env, PT_LANES)))));
     // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
     static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
     const bool first_hit_targets = targets.albedo || targets.material || targets.normal || targets.pos || targets.instance_id || targets.screen_motion;
