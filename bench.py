@@ -578,7 +578,30 @@ def main():
         from oracle import binding as OB
         osc = OB.OracleScene(scene)
         oopt = OB.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, sampler=args.sampler)
-        cores = os.cpu_count() or 1
+        # threads: what this process may actually run on - its affinity mask, bounded by the cgroup's CPU quota - not os.cpu_count()
+        affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+        except (OSError, ValueError):
+            try:
+                q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    quota = q / per
+            except (OSError, ValueError):
+                pass
+        cores = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
+        # one thread first, on a quarter-size frame of the same camera (the full frame would take a minute): the rate the threads scale from
+        w1, h1 = max(W // 4, 16), max(H // 4, 16)
+        osc.reset_counters()
+        t0 = time.perf_counter()
+        osc.render_pt(oopt, w1, h1, frame_counter=0, threads=1, viewports=args.views)
+        dt1 = time.perf_counter() - t0
+        oc1 = osc.counters()
+        one_thread = (oc1["closest_rays"] + oc1["shadow_rays"]) / dt1 / 1e6
+        osc.reset_counters()
         frames = 0
         t0 = time.perf_counter()
         while True:
@@ -593,7 +616,10 @@ def main():
         tauray_bin = shutil.which("tauray")
         result["cpu_baseline"] = {
             "value": round((oc["closest_rays"] + oc["shadow_rays"]) / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full {W}x{H} frame(s) of the same workload, {dt:.1f} s of wall time, OpenMP over rows",
+            "threads_used": cores, "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+            "mray_per_s_one_thread": round(one_thread, 4), "one_thread_sample": f"one {w1}x{h1} frame, {dt1:.1f} s",
+            "scaling_efficiency": round((oc["closest_rays"] + oc["shadow_rays"]) / dt / 1e6 / (one_thread * cores), 3),
+            "sample": f"{frames} full {W}x{H} frame(s) of the same workload, {dt:.1f} s of wall time, OpenMP schedule(dynamic) over 16x16 tiles",
             "ms_per_frame": round(dt / frames * 1e3, 1),
             # north_star asks for Tauray's raster fallback on the host cores beside the number: it needs a Vulkan software ICD and a
             # compiled Tauray; neither can be installed here

@@ -767,12 +767,12 @@ inline image read(const uint8_t* d, size_t n)
         for(int b = 0; b < blocks; ++b)
         {
             size_t at = (size_t)u64(table + 8 * (size_t)b);
-            if(at + 8 > n) throw std::runtime_error("EXR: bad chunk offset");
+            if(at > n || n - at < 8) throw std::runtime_error("EXR: bad chunk offset");
             int32_t y, size;
             std::memcpy(&y, d + at, 4); std::memcpy(&size, d + at + 4, 4);
             at += 8;
             const int row = y - dw[1];
-            if(row < 0 || row >= img.height || size < 0 || at + (size_t)size > n) throw std::runtime_error("EXR: bad chunk");
+            if(row < 0 || row >= img.height || size < 0 || (size_t)size > n - at) throw std::runtime_error("EXR: bad chunk");
             const int ny = std::min(lines, img.height - row);
             raw.resize(pixel_bytes * (size_t)img.width * (size_t)ny);
             decompress_block(img.compression, d + at, (size_t)size, raw, img.width, ny, wpp);
@@ -789,12 +789,12 @@ inline image read(const uint8_t* d, size_t n)
         for(int t = 0; t < tx_n * ty_n; ++t)
         {
             size_t at = (size_t)u64(table + 8 * (size_t)t);
-            if(at + 20 > n) throw std::runtime_error("EXR: bad tile offset");
+            if(at > n || n - at < 20) throw std::runtime_error("EXR: bad tile offset");
             int32_t h[5];
             std::memcpy(h, d + at, 20);
             at += 20;
             if(h[2] != 0 || h[3] != 0) continue;
-            if(h[0] < 0 || h[0] >= tx_n || h[1] < 0 || h[1] >= ty_n || h[4] < 0 || at + (size_t)h[4] > n) throw std::runtime_error("EXR: bad tile");
+            if(h[0] < 0 || h[0] >= tx_n || h[1] < 0 || h[1] >= ty_n || h[4] < 0 || (size_t)h[4] > n - at) throw std::runtime_error("EXR: bad tile");
             const int x0 = h[0] * tile_w, y0 = h[1] * tile_h;
             const int nx = std::min(tile_w, img.width - x0), ny = std::min(tile_h, img.height - y0);
             raw.resize(pixel_bytes * (size_t)nx * (size_t)ny);

@@ -416,16 +416,24 @@ struct glb_file
         components = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
         const int sz = ct == 5120 || ct == 5121 ? 1 : ct == 5122 || ct == 5123 ? 2 : ct == 5125 || ct == 5126 ? 4 : 0;
         if(!components || !sz) throw std::runtime_error("glTF: unsupported accessor type");
-        count = (size_t)a.number("count", 0);
-        const size_t base = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
-        size_t stride = (size_t)bv.number("byteStride", 0);
-        if(!stride) stride = size_t(sz) * components;
-        if(a.number("count", 0) < 0 || bv.number("byteOffset", 0) < 0 || a.number("byteOffset", 0) < 0 || bv.number("byteLength", 0) < 0)
-            throw std::runtime_error("glTF: negative count or offset");
+        // every number below comes from the file: checked as doubles before any of them becomes a size_t (a negative or huge double
+        // cast to size_t is undefined), and the extent of the accessor is compared without a product that could wrap
+        const double d_count = a.number("count", 0), d_vo = bv.number("byteOffset", 0), d_ao = a.number("byteOffset", 0),
+                     d_len = bv.number("byteLength", 0), d_stride = bv.number("byteStride", 0);
+        const double lim = (double)bin.size();
+        if(!(d_count >= 0 && d_vo >= 0 && d_ao >= 0 && d_len >= 0 && d_stride >= 0)) throw std::runtime_error("glTF: negative count, offset or stride");
+        if(d_count > lim || d_vo > lim || d_ao > lim || d_len > lim) throw std::runtime_error("glTF: accessor exceeds its buffer");
+        const size_t elem = size_t(sz) * (size_t)components;
+        // byteStride: 4 ... 252 (glTF 2.0 section 5.11) and at least one element, 0 = tightly packed
+        if(d_stride != 0 && (d_stride < (double)elem || d_stride > 252)) throw std::runtime_error("glTF: byteStride out of range");
+        count = (size_t)d_count;
+        const size_t base = (size_t)d_vo + (size_t)d_ao;
+        const size_t stride = d_stride != 0 ? (size_t)d_stride : elem;
         // an accessor lives inside its bufferView, a bufferView inside its buffer (glTF 2.0 section 3.6.2)
-        const size_t view_len = (size_t)bv.number("byteLength", 0), in_view = (size_t)a.number("byteOffset", 0);
-        if((size_t)bv.number("byteOffset", 0) + view_len > bin.size()) throw std::runtime_error("glTF: bufferView exceeds the buffer");
-        if(count && (count > bin.size() || in_view + stride * (count - 1) + size_t(sz) * components > view_len)) throw std::runtime_error("glTF: accessor exceeds its bufferView");
+        const size_t view_len = (size_t)d_len, in_view = (size_t)d_ao;
+        if((size_t)d_vo > bin.size() || view_len > bin.size() - (size_t)d_vo) throw std::runtime_error("glTF: bufferView exceeds the buffer");
+        if(count && (in_view > view_len || view_len - in_view < elem || count - 1 > (view_len - in_view - elem) / stride))
+            throw std::runtime_error("glTF: accessor exceeds its bufferView");
         std::vector<double> out(count * components);
         for(size_t i = 0; i < count; ++i)
             for(int c = 0; c < components; ++c)

@@ -12,8 +12,11 @@
 #include "trhip_comm.h"
 
 #include <chrono>
+#include <cstring>
+#include <ctime>
 #include <fstream>
 #include <thread>
+#include <sys/stat.h>
 
 namespace tr
 {
@@ -24,28 +27,54 @@ inline void check_comm(int rc)
 }
 
 // The 128-byte RCCL id has to reach every rank by the caller's means; for processes that share a file system: rank 0 writes
-// it to `path` (atomically, through a rename), the others wait for the file.
-inline std::vector<char> exchange_comm_id_through_file(const std::string& path, int rank, double timeout_seconds = 120.0)
+// it to `path` (atomically, through a rename), the others wait for the file.  A file left behind by an earlier or crashed job
+// must not be taken for this job's: the file starts with a 16-byte header - "TRHIPCID" + a 64-bit nonce the launcher hands to
+// every rank (`--comm-nonce`, e.g. its pid or start time) - and a reader only accepts a file that carries its own nonce.  Rank 0
+// removes whatever is at `path` before it creates the id, and removes the file again once the communicator exists on every rank
+// (remove_comm_id_file after trhip_comm_create returns, which is collective).  Without a nonce (0) readers fall back to the
+// age of the file: one written more than `stale_seconds` before the reader started belongs to another job.
+inline std::vector<char> exchange_comm_id_through_file(const std::string& path, int rank, uint64_t nonce = 0, double timeout_seconds = 120.0,
+                                                       double stale_seconds = 60.0)
 {
+    static const char magic[8] = {'T', 'R', 'H', 'I', 'P', 'C', 'I', 'D'};
     std::vector<char> id(TRHIP_COMM_ID_BYTES);
     if(rank == 0)
     {
+        std::remove(path.c_str());      // a previous job's file: no reader of this job may see it once our id exists
         check_comm(trhip_comm_unique_id(id.data()));
         const std::string tmp = path + ".tmp";
-        { std::ofstream f(tmp, std::ios::binary); f.write(id.data(), (std::streamsize)id.size()); if(!f) throw std::runtime_error("cannot write " + tmp); }
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(magic, 8); f.write(reinterpret_cast<const char*>(&nonce), 8); f.write(id.data(), (std::streamsize)id.size());
+            if(!f) throw std::runtime_error("cannot write " + tmp);
+        }
         if(std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
         return id;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    const std::time_t wall0 = std::time(nullptr);
     while(true)
     {
         std::ifstream f(path, std::ios::binary);
-        if(f && f.read(id.data(), (std::streamsize)id.size())) return id;
+        char head[16];
+        if(f && f.read(head, 16) && std::memcmp(head, magic, 8) == 0 && f.read(id.data(), (std::streamsize)id.size()))
+        {
+            uint64_t file_nonce; std::memcpy(&file_nonce, head + 8, 8);
+            bool ours = file_nonce == nonce;
+            if(ours && nonce == 0)
+            {   // no nonce to tell jobs apart: a file much older than this process is a leftover
+                struct stat st;
+                if(::stat(path.c_str(), &st) == 0) ours = std::difftime(wall0, st.st_mtime) <= stale_seconds;
+            }
+            if(ours) return id;
+        }
         if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
-            throw std::runtime_error("timed out waiting for the communicator id in " + path);
+            throw std::runtime_error("timed out waiting for the communicator id of this job in " + path);
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
 }
+// rank 0, after trhip_comm_create has returned (every rank has read the id by then: the call is collective)
+inline void remove_comm_id_file(const std::string& path, int rank) { if(rank == 0) std::remove(path.c_str()); }
 
 template<typename Pipeline>
 class basic_process_rt_renderer

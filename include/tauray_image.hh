@@ -375,6 +375,7 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
                 if(!progressive)
                 {
                     const int t = decode_symbol(br, dc[c.td]);
+                    if(t > 15) throw std::runtime_error("image: JPEG DC difference category out of range");   // T.81 F.1.2.1: SSSS <= 11 (15 at 12 bits); a DHT symbol is any byte
                     c.pred += extend(br.bits(t), t);
                     b[0] = (int16_t)c.pred;
                     for(int k = 1; k < 64;)
@@ -393,6 +394,7 @@ inline decoded decode_jpeg(const uint8_t* data, size_t size)
                     if(Ah == 0)
                     {
                         const int t = decode_symbol(br, dc[c.td]);
+                        if(t > 15) throw std::runtime_error("image: JPEG DC difference category out of range");
                         c.pred += extend(br.bits(t), t);
                         b[0] = (int16_t)(c.pred * p1);
                     }

@@ -1994,6 +1994,13 @@ static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, co
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
+    const int tiles_x = (int)((rays.x + 15u) / 16u), n_tiles = tiles_x * (int)((rays.y + 15u) / 16u);
+    int n_threads = 1;
+#ifdef _OPENMP
+    n_threads = std::max(omp_get_max_threads(), 1);
+#endif
+    const int tiles_per_grab = std::max(1, std::min(16, n_tiles / (n_threads * 16)));
+    const int n_grabs = (n_tiles + tiles_per_grab - 1) / tiles_per_grab;
     for (int pass = 0; pass < passes; ++pass) {
         uint previous_samples = (uint)pass * (uint)opt->samples_per_pass;
         for (uint z = 0; z < viewport_count; ++z) {
@@ -2002,14 +2009,22 @@ static int render_targets_impl(oracle_scene* s, const oracle_pt_options* opt, co
                 thread_counters tc;
                 pt_ctx lc = c;
                 lc.tc = &tc;
-#pragma omp for schedule(dynamic, 4)
-                for (int y = 0; y < (int)rays.y; ++y) {
-                    for (uint x = 0; x < rays.x; ++x) {
-                        launch_ctx L = base;
-                        L.launch_id = {x, (uint)y, z};
-                        L.viewport = s->shard_vp_base + z * s->shard_vp_stride;
-                        if (direct) direct_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
-                        else pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
+                // 16 x 16 pixel tiles handed out sixteen at a time; launch ids are independent, so the order is
+                // scheduling only.  Sixteen tiles per grab would leave a 256-thread host two grabs per thread at 1080p, so the grab
+                // shrinks until every thread can expect at least sixteen of them.
+#pragma omp for schedule(dynamic, 1)
+                for (int g = 0; g < n_grabs; ++g) {
+                    for (int t = g * tiles_per_grab; t < std::min((g + 1) * tiles_per_grab, n_tiles); ++t) {
+                        const uint x0 = (uint)(t % tiles_x) * 16u, y0 = (uint)(t / tiles_x) * 16u;
+                        for (uint y = y0; y < std::min(y0 + 16u, rays.y); ++y) {
+                            for (uint x = x0; x < std::min(x0 + 16u, rays.x); ++x) {
+                                launch_ctx L = base;
+                                L.launch_id = {x, y, z};
+                                L.viewport = s->shard_vp_base + z * s->shard_vp_stride;
+                                if (direct) direct_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
+                                else pt_invocation(lc, L, previous_samples, samples_accumulated, *targets, target_w, target_h);
+                            }
+                        }
                     }
                 }
 #pragma omp critical

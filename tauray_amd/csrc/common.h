@@ -91,10 +91,14 @@ TR_HD bool any_nan(f3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 TR_DEV float tsin(float x) { return __sinf(x); }
 TR_DEV float tcos(float x) { return __cosf(x); }
 TR_DEV float tpow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+// a base that is a difference which can round a few ulps below zero (1 - cos at normal incidence): exp2(y * log2(x)) is NaN there where
+// the C library's powf of the IEEE build returns -1e-35 for an odd integer exponent; clamped, both modes stay finite and agree to that
+TR_DEV float tpow_ge0(float x, float y) { return tpow(x < 0.0f ? 0.0f : x, y); }
 #else
 TR_HD float tsin(float x) { return sinf(x); }
 TR_HD float tcos(float x) { return cosf(x); }
 TR_HD float tpow(float x, float y) { return powf(x, y); }
+TR_HD float tpow_ge0(float x, float y) { return powf(x, y); }
 #endif
 
 // column-major matrices, as glm / GLSL

@@ -213,7 +213,7 @@ TR_DEV float fresnel_importance(float cos_d, const SampledMaterial& mat) {  // g
         if (sin_theta2 >= 1.0f) return 1.0f;
         cos_d = sqrtf(1.0f - sin_theta2);
     } else if (mat.ior_in == mat.ior_out) return 0.0f;
-    return mat.f0 + (fmax2(1.0f - mat.roughness, mat.f0) - mat.f0) * tpow(1.0f - cos_d, 5.0f);
+    return mat.f0 + (fmax2(1.0f - mat.roughness, mat.f0) - mat.f0) * tpow_ge0(1.0f - cos_d, 5.0f);
 }
 TR_DEV float ggx_masking(float v_dot_n, float v_dot_h, float a) {           // ggx.glsl:82-87
     float a2 = a * a;

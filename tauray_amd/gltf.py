@@ -116,8 +116,11 @@ class _Glb:
         stride = bv.get("byteStride", 0) or sz * nc
         count = a["count"]
         buf = _item(self.buffers, bv.get("buffer", 0), "buffer")
-        if count < 0 or bv.get("byteOffset", 0) < 0 or a.get("byteOffset", 0) < 0 or bv.get("byteLength", 0) < 0:
-            raise ValueError("glTF: negative count or offset")
+        if count < 0 or bv.get("byteOffset", 0) < 0 or a.get("byteOffset", 0) < 0 or bv.get("byteLength", 0) < 0 or bv.get("byteStride", 0) < 0:
+            raise ValueError("glTF: negative count, offset or stride")
+        # byteStride: 4 ... 252 and at least one element (glTF 2.0 section 5.11), 0 = tightly packed; as include/tauray_gltf.hh
+        if bv.get("byteStride", 0) and not (sz * nc <= bv["byteStride"] <= 252):
+            raise ValueError("glTF: byteStride out of range")
         # an accessor lives inside its bufferView, a bufferView inside its buffer (glTF 2.0 section 3.6.2)
         if bv.get("byteOffset", 0) + bv.get("byteLength", 0) > len(buf):
             raise ValueError("glTF: bufferView exceeds the buffer")

@@ -13,7 +13,8 @@
 //              [--camera-grid=w,h,x,y --camera-recentering-distance=5 --camera-grid-roll=0]   (light-field grid, one file per view)
 //
 // One process per GPU (include/tauray_hip_comm.hh): start N copies with --process-count=N --process-rank=0..N-1 --device=<HIP index>
-// --comm-id=<file on a shared file system> (rank 0 writes the RCCL id there, the others wait for it); every rank renders its share
+// --comm-id=<file on a shared file system> [--comm-nonce=<number every rank of this job gets, e.g. the launcher's pid>] (rank 0 writes the RCCL id
+// there under that nonce, the others wait for a file that carries it; rank 0 removes the file once the communicator exists); every rank renders its share
 // of each frame, the partial frames meet on rank 0 through trhip_gather_partials, rank 0 stitches, tonemaps and saves.  With
 // --shard=views the ranks divide the viewports of a camera grid instead (viewport v on rank v mod N) and save their own views.
 #include <cstdlib>
@@ -55,6 +56,7 @@ int main(int argc, char** argv)
         bool shard_views = false;                                           // --shard=views with --process-count: viewport v on rank v mod N
         int process_rank = -1, process_count = 0, process_device = 0;      // one process per GPU (see above)
         std::string comm_id_path;
+        uint64_t comm_nonce = 0;
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
@@ -119,6 +121,7 @@ int main(int argc, char** argv)
             else if(starts(a, "--process-count=")) process_count = std::stoi(val("--process-count="));
             else if(starts(a, "--device=")) process_device = std::stoi(val("--device="));
             else if(starts(a, "--comm-id=")) comm_id_path = val("--comm-id=");
+            else if(starts(a, "--comm-nonce=")) comm_nonce = std::stoull(val("--comm-nonce="));
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
             else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
             else if(starts(a, "--exposure=")) opt.tonemap.exposure = std::stof(val("--exposure="));
@@ -242,8 +245,9 @@ int main(int argc, char** argv)
             if(process_rank < 0 || process_rank >= process_count) throw std::runtime_error("--process-rank must be in [0, --process-count)");
             if(comm_id_path.empty()) throw std::runtime_error("--process-count needs --comm-id=<file every rank can read>");
             if(renderer != "path-tracer" || animated) throw std::runtime_error("--process-count renders still frames with the path tracer");
-            const std::vector<char> id = exchange_comm_id_through_file(comm_id_path, process_rank);
+            const std::vector<char> id = exchange_comm_id_through_file(comm_id_path, process_rank, comm_nonce);
             process_rt_renderer rr(process_device, process_rank, process_count, id.data(), scene, size, opt);
+            remove_comm_id_file(comm_id_path, process_rank);   // the communicator exists on every rank: the file has done its job
             if(!workloads.empty()) rr.set_device_workloads(workloads);
             for(int f = -warmup; f < frames; ++f)
             {

@@ -111,6 +111,42 @@ def test_cli_exists_and_links_only_the_c_abi():
     assert "libtrhip.so" in needed and "libtorch" not in needed and "libpython" not in needed
 
 
+def test_comm_id_file_is_not_taken_from_another_job(tmp_path):
+    """exchange_comm_id_through_file (include/tauray_hip_comm.hh): a rank other than 0 accepts the id file only when it carries the job's
+    nonce - a file of an earlier or crashed job (other nonce, no header, or, without a nonce, older than the reader) is waited out."""
+    import struct
+    import time
+    exe = str(tmp_path / "comm_id_file_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "comm_id_file_check.cc"),
+                           "-L" + os.path.join(ROOT, "tauray_amd"), "-ltrhip", "-ltrhip_comm", "-Wl,-rpath," + os.path.join(ROOT, "tauray_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    path = str(tmp_path / "job.id")
+    run = lambda nonce, timeout=0.3: subprocess.run([exe, path, str(nonce), str(timeout)], capture_output=True, text=True, check=True).stdout.strip()
+    write = lambda nonce, first: open(path, "wb").write(b"TRHIPCID" + struct.pack("<Q", nonce) + bytes([first]) + bytes(127))
+    assert run(7) == "timeout"                     # no file
+    open(path, "wb").write(bytes([9]) * 128)       # a file of the old format (a bare id): not ours
+    assert run(7) == "timeout" and run(0) == "timeout"
+    write(5, 11)                                   # another job's nonce
+    assert run(7) == "timeout"
+    write(7, 12)
+    assert run(7) == "id 12"
+    write(0, 13)                                   # no nonce: a fresh file is taken ...
+    assert run(0) == "id 13"
+    old = time.time() - 3600
+    os.utime(path, (old, old))                     # ... an hour-old one is a leftover
+    assert run(0) == "timeout"
+    # the writer arrives while the reader waits
+    os.remove(path)
+    p = subprocess.Popen([exe, path, "42", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    write(41, 1)
+    time.sleep(0.2)
+    tmp = path + ".tmp"
+    open(tmp, "wb").write(b"TRHIPCID" + struct.pack("<Q", 42) + bytes([77]) + bytes(127))
+    os.rename(tmp, path)
+    assert p.communicate(timeout=30)[0].strip() == "id 77"
+
+
 def test_exr_writer_all_compressions(tmp_path):
     """tr::headless writes what src/headless.cc:349-422 writes through tinyexr: scanline EXR, channels in alphabetical order,
     half or float, NONE / RLE / ZIPS / ZIP / PIZ (the default, src/headless.hh:56).  Every combination is read back by the reader above."""
@@ -489,7 +525,7 @@ def test_cpp_one_process_per_gpu_mode_with_one_rank(tmp_path, scene_dump):
         r = subprocess.run([CLI] + common + [f"--headless={prefix}", "--process-count=1", "--process-rank=0", "--device=0", f"--comm-id={idf}", "-t"] + extra,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert os.path.getsize(idf) == 128 and "RANK 0" in r.stdout
+        assert not os.path.exists(idf) and "RANK 0" in r.stdout      # rank 0 removes the id file once the communicator exists
         for f in range(3):
             assert np.array_equal(np.fromfile(f"{prefix}{f}.raw", dtype=np.float32), np.fromfile(f"{ref_prefix}{f}.raw", dtype=np.float32)), (tag, f)
     r = subprocess.run([CLI] + common + ["--process-count=2", "--process-rank=2", f"--comm-id={tmp_path / 'x.id'}"], capture_output=True, text=True)

@@ -264,12 +264,18 @@ def test_random_glb_files_load_the_same_in_both_hosts(tmp_path):
 def _mutate(rng, data):
     """One of the ways a file goes wrong: an accessor count multiplied, a bufferView moved past the buffer, the binary chunk cut short, an
     index accessor pointing at floats, node / mesh / bufferView references out of range (-1 included: Python would take the last element),
-    vertex indices beyond the vertex count, a node that is its own child."""
+    vertex indices beyond the vertex count, a node that is its own child, a byteStride that overflows the extent arithmetic."""
     jl = struct.unpack("<I", data[12:16])[0]
     j = json.loads(data[20:20 + jl])
     bn = bytes(data[20 + jl + 8:])
-    m = int(rng.integers(0, 8))
-    if m == 0:
+    m = int(rng.integers(0, 9))
+    if m == 8:      # a hostile byteStride: 2^63 wraps `stride * (count - 1)` to a small number in 64-bit arithmetic; 1 is below any element; 1e30 and -8 are no sizes
+        v = j["bufferViews"][int(rng.integers(0, len(j["bufferViews"])))]
+        v["byteStride"] = [2 ** 63, 2 ** 62, 1, 1e30, -8, 256][int(rng.integers(0, 6))]
+        for a in j["accessors"]:      # make sure an accessor with several elements reads through it
+            if j["bufferViews"][a["bufferView"]] is v and a["count"] > 2:
+                a["count"] = 3
+    elif m == 0:
         a = j["accessors"][int(rng.integers(0, len(j["accessors"])))]
         a["count"] = int(a["count"] * rng.choice([3, 50, 10000]))
     elif m == 1:
