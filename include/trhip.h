@@ -102,8 +102,7 @@ typedef struct trhip_accel_info {
     float build_ms;                   /* device time of the whole build */
     float bounds_min[3], bounds_max[3];
     uint32_t node_bytes;              /* bytes one node visit reads (112: six box planes + child refs of a 4-wide node) */
-    uint32_t leaf_count;              /* leaves of the tree: triangle_count, or more when a static build split large triangles into
-                                         several references (csrc/bvh_presplit.h); node_count = leaf_count - 1 */
+    uint32_t leaf_count;              /* leaves of the tree (= triangle_count: one triangle per leaf); node_count = leaf_count - 1 */
 } trhip_accel_info;
 
 /* Copies the scene to the device (the reference's buffers byte for byte) and derives, next to them, one 144-byte record

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int f
     HitRecord hit;
     TraceStats st = {};
     int overflow = 0;
-    trace_closest_any<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
+    trace_closest4<1, false>(sv, ray_origin, dir, min_ray_dist, __builtin_huge_valf(), false, 0u, s_stack + threadIdx.x, hit, st, overflow);
     if (overflow) *overflow_flag = 1;
     f4 data = default_value;
     if (hit.instance_id >= 0) {
@@ -108,16 +108,12 @@ __global__ __launch_bounds__(KB) void k_calibrate_l1(const char* base, int iters
 }
 
 // ray-level hooks
-// TOP: through the treetop in LDS, like the frame's trace kernels (so that the ray-level parity tests cover that path).
 // Whole waves walk the ray list together and use the wave-level traversal with its quad-cooperative tail (trace_quad.h),
 // which is what the frame's closest-hit kernels run.
-template <bool TOP>
 __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
                                                       HitRecord* out, uint* overflow_flag, int* qspill) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    if (TOP) load_treetop(sv, s_top);
     int* my_stack = s_stack + threadIdx.x;
     QuadCtx qc;
     qc.wave_stack = s_stack + (threadIdx.x & ~63u);
@@ -132,29 +128,26 @@ __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, cons
         if (valid) for (int k = 0; k < 8; ++k) r[k] = rays[(size_t)i * 8 + k];
         const uint seed = (valid && seeds) ? seeds[i] : 0u;
         HitRecord hit;
-#if TR_BVH4 && TR_QUAD_SWITCH > 0
-        if (seeds) trace_closest_wave4<0, false, TOP>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, qc, s_top, hit, st, overflow);
-        else trace_closest_wave4<1, false, TOP>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, qc, s_top, hit, st, overflow);
+#if TR_QUAD_SWITCH > 0
+        if (seeds) trace_closest_wave4<0, false>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, qc, hit, st, overflow);
+        else trace_closest_wave4<1, false>(sv, valid, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, qc, hit, st, overflow);
 #else
         if (valid) {
-            if (seeds) trace_closest_any<0, false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, hit, st, overflow, s_top);
-            else trace_closest_any<1, false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow, s_top);
+            if (seeds) trace_closest4<0, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, seed, my_stack, hit, st, overflow);
+            else trace_closest4<1, false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], include_lights != 0, 0u, my_stack, hit, st, overflow);
         }
 #endif
         if (valid) out[i] = hit;
     }
     if (overflow) *overflow_flag = 1;
 }
-template <bool TOP>
 __global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
-    if (TOP) load_treetop(sv, s_top);
     int overflow = 0;
     TraceStats st = {};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {
         const float* r = rays + (size_t)i * 8;
-        out[i] = trace_shadow_any<false, TOP>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow, s_top);
+        out[i] = trace_shadow4<false>(sv, F3(r[0], r[1], r[2]), F3(r[4], r[5], r[6]), r[3], r[7], s_stack + threadIdx.x, st, overflow);
     }
     if (overflow) *overflow_flag = 1;
 }
@@ -574,7 +567,6 @@ int trhip_scene_build_accel(trhip_device* dev, trhip_accel_info* out) {
     if (const char* r = getenv("TRHIP_PLOC_RADIUS")) dev->scene.ploc_radius = std::max(1, atoi(r));
     if (const char* o = getenv("TRHIP_BVH_OPT")) dev->scene.optimise_rounds = std::max(0, atoi(o));
     if (const char* o = getenv("TRHIP_BVH_OPT_MOD")) dev->scene.optimise_modulus = std::max(1, atoi(o));
-    if (const char* o = getenv("TRHIP_PRESPLIT")) dev->scene.presplit_percent = std::min(200, std::max(0, atoi(o)));
     if (const char* c = getenv("TRHIP_COLLAPSE")) dev->scene.collapse_by_cost = std::string(c) != "greedy";
     if (const char* l = getenv("TRHIP_NODE_LAYOUT")) dev->scene.dfs_layout = std::string(l) == "build" ? 0 : 1;
     return build_accel(dev->scene, nullptr, out);
@@ -771,8 +763,7 @@ int trhip_trace_closest(trhip_device* dev, uint32_t n, const void* rays_dev, con
     if (n == 0) return 0;
     uint blocks = std::min((n + KB - 1) / KB, QUERY_BLOCKS);
     if (!dev->qspill) HIPCHK(hipMalloc(&dev->qspill, (size_t)QUERY_BLOCKS * (KB / 64) * 16u * TR_QSPILL * sizeof(int)));
-    const bool top = TR_BVH4 && dev->scene.view().treetop != nullptr;
-    hipLaunchKernelGGL(top ? k_query_closest<true> : k_query_closest<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+    hipLaunchKernelGGL(k_query_closest, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
                        (const uint*)seeds_dev, include_lights, (HitRecord*)hits_dev, dev->overflow_flag, dev->qspill);
     HIPCHK(hipGetLastError());
     return 0;
@@ -782,8 +773,7 @@ int trhip_trace_shadow(trhip_device* dev, uint32_t n, const void* rays_dev, void
     if (!dev->scene.accel_built) return set_error("trhip_trace_shadow: call trhip_scene_build_accel first");
     if (n == 0) return 0;
     uint blocks = std::min((n + KB - 1) / KB, 2048u);
-    const bool top = TR_BVH4 && dev->scene.view().treetop != nullptr;
-    hipLaunchKernelGGL(top ? k_query_shadow<true> : k_query_shadow<false>, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
+    hipLaunchKernelGGL(k_query_shadow, dim3(blocks), dim3(KB), 0, (hipStream_t)stream, dev->scene.view(), n, (const float*)rays_dev,
                        (float*)visibility_dev, dev->overflow_flag);
     HIPCHK(hipGetLastError());
     return 0;

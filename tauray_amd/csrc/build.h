@@ -40,9 +40,6 @@ struct DeviceScene {
     // built by trhip_scene_build_accel
     BvhNode* nodes = nullptr;
     Bvh4Node* nodes4 = nullptr;
-    Bvh4NodeQ* nodesq = nullptr;         // TR_QNODES: quantised copy of nodes4 (built after the collapse and after every refit)
-    f4* treetop = nullptr;               // top four levels of nodes4 for the LDS of the trace kernels (TR_TOP_SLOTS)
-    bool use_treetop = false;            // set by every build / refit: true only with TRHIP_TREETOP=1 (measured slower)
     TriRecord* tris = nullptr;
     TriLight* tri_lights = nullptr;
     uint node_count = 0, tri_light_count = 0;
@@ -50,9 +47,7 @@ struct DeviceScene {
     uint build_rounds = 0;
     int ploc_radius = 16;                // neighbour search radius of the PLOC rounds (TRHIP_PLOC_RADIUS)
     int optimise_rounds = 8;             // reinsertion rounds after the build (bvh_optimize.h; TRHIP_BVH_OPT)
-    int presplit_percent = 0;            // static builds: extra triangle references a pre-split may spend, in percent of the triangle count (bvh_presplit.h;
-                                         // TRHIP_PRESPLIT).  Off: measured +2 ... +8 % node visits for -5 ... -15 % triangle tests, frames 0-3 % slower (profiles/r3/presplit_sweep.txt)
-    uint leaf_count = 0;                 // leaves of the tree = records in `tris`: the triangles, or their references after a pre-split
+    uint leaf_count = 0;                 // leaves of the tree = records in `tris`
     uint accel_tri_count = 0;            // triangle count of the scene the structure was built for
     bool collapse_by_cost = true;        // 4-wide nodes chosen by least area sum (k_collapse_cost) instead of greedily (TRHIP_COLLAPSE=greedy)
     bool fast_build = false;             // trhip_scene_set_build_mode: no optimisation rounds
@@ -74,8 +69,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.nodes = nodes; v.tris = tris; v.nodes4 = nodes4; v.nodesq = nodesq;
-        v.treetop = (use_treetop && accel_built && node_count > 0) ? treetop : nullptr;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.tris = tris; v.nodes4 = nodes4;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
@@ -85,10 +79,6 @@ struct DeviceScene {
     void free_accel() {
         if (nodes) (void)hipFree(nodes);
         if (nodes4) (void)hipFree(nodes4);
-        if (nodesq) (void)hipFree(nodesq);
-        nodesq = nullptr;
-        if (treetop) (void)hipFree(treetop);
-        treetop = nullptr;
         if (tris) (void)hipFree(tris);
         if (tri_lights) (void)hipFree(tri_lights);
         nodes = nullptr; nodes4 = nullptr; tris = nullptr; tri_lights = nullptr; node_count = 0; tri_light_count = 0; accel_built = false;

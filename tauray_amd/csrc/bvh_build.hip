@@ -415,7 +415,6 @@ __global__ __launch_bounds__(BT) void k_emit_nodes(uint n_internal, const int2* 
 }  // namespace
 }  // namespace tr
 #include "bvh_optimize.h"
-#include "bvh_presplit.h"
 namespace tr {
 namespace {
 
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
                                                   const uint8_t* dec, Bvh4Node* nodes4) {
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= n_internal) return;
-    constexpr int W = TR_BVH8 ? 8 : 4;
+    constexpr int W = 4;
     int cand[W];
     cand[0] = children[i].x; cand[1] = children[i].y;
     int ncand = 2;
@@ -445,132 +444,20 @@ __global__ __launch_bounds__(BT) void k_collapse4(uint n_internal, const int2* c
         const int2 ch = children[cand[best]];
         cand[best] = ch.x; cand[ncand++] = ch.y;
     }
-    for (int half = 0; half < W / 4; ++half) {
-        Bvh4Node out;
-        for (int c = 0; c < 4; ++c) {
-            const int k = 4 * half + c;
-            if (k < ncand) {
-                const float* b = cand[k] >= 0 ? node_box + 6 * (size_t)cand[k] : leaf_box + 6 * (size_t)(~cand[k]);
-                out.lox[c] = b[0]; out.loy[c] = b[1]; out.loz[c] = b[2]; out.hix[c] = b[3]; out.hiy[c] = b[4]; out.hiz[c] = b[5];
-                out.child[c] = cand[k] >= 0 ? new_id[cand[k]] : cand[k];
-            } else {
-                out.lox[c] = out.loy[c] = out.loz[c] = __builtin_huge_valf();
-                out.hix[c] = out.hiy[c] = out.hiz[c] = -__builtin_huge_valf();
-                out.child[c] = 0x7FFFFFFF;
-            }
-            out.pad[c] = 0;
+    Bvh4Node out;
+    for (int c = 0; c < 4; ++c) {
+        if (c < ncand) {
+            const float* b = cand[c] >= 0 ? node_box + 6 * (size_t)cand[c] : leaf_box + 6 * (size_t)(~cand[c]);
+            out.lox[c] = b[0]; out.loy[c] = b[1]; out.loz[c] = b[2]; out.hix[c] = b[3]; out.hiy[c] = b[4]; out.hiz[c] = b[5];
+            out.child[c] = cand[c] >= 0 ? new_id[cand[c]] : cand[c];
+        } else {
+            out.lox[c] = out.loy[c] = out.loz[c] = __builtin_huge_valf();
+            out.hix[c] = out.hiy[c] = out.hiz[c] = -__builtin_huge_valf();
+            out.child[c] = 0x7FFFFFFF;
         }
-        nodes4[(size_t)(W / 4) * (size_t)new_id[i] + (size_t)half] = out;
+        out.pad[c] = 0;
     }
-}
-
-
-// Two Bvh4Node halves (TR_BVH8 collapse) -> Bvh8NodeQ (TR_BVH8 = 2), the rule of k_quantize4 below with eight children.
-__global__ __launch_bounds__(BT) void k_quantize8(uint n_nodes, const Bvh4Node* nodes4, Bvh8NodeQ* out) {
-    const uint i = blockIdx.x * BT + threadIdx.x;
-    if (i >= n_nodes) return;
-    const Bvh4Node h0 = nodes4[2 * (size_t)i], h1 = nodes4[2 * (size_t)i + 1];
-    Bvh8NodeQ q;
-    q.exps = 0;
-    for (int c = 0; c < 4; ++c) { q.child[c] = h0.child[c]; q.child[4 + c] = h1.child[c]; }
-    for (int c = 0; c < 8; ++c) q.pad[c] = 0;
-    for (int k = 0; k < 3; ++k) {
-        float lo[8], hi[8];
-        for (int c = 0; c < 4; ++c) {
-            lo[c] = k == 0 ? h0.lox[c] : (k == 1 ? h0.loy[c] : h0.loz[c]); hi[c] = k == 0 ? h0.hix[c] : (k == 1 ? h0.hiy[c] : h0.hiz[c]);
-            lo[4 + c] = k == 0 ? h1.lox[c] : (k == 1 ? h1.loy[c] : h1.loz[c]); hi[4 + c] = k == 0 ? h1.hix[c] : (k == 1 ? h1.hiy[c] : h1.hiz[c]);
-        }
-        float o = __builtin_huge_valf(), top = -__builtin_huge_valf();
-        for (int c = 0; c < 8; ++c) if (q.child[c] != 0x7FFFFFFF && lo[c] <= hi[c]) { o = fminf(o, lo[c]); top = fmaxf(top, hi[c]); }
-        if (!(o <= top)) { o = 0.0f; top = 0.0f; }
-        int e = 0;
-        (void)frexpf((top - o) / 255.0f, &e);
-        int oe = 0;
-        (void)frexpf(fabsf(o), &oe);
-        e = max(e, oe - 22);
-        e = min(max(e + 127, 27), 254);
-        uint qlo[2], qhi[2];
-        while (true) {
-            const float scale = __uint_as_float((uint)e << 23);
-            bool fits = true;
-            qlo[0] = qlo[1] = qhi[0] = qhi[1] = 0;
-            for (int c = 0; c < 8 && fits; ++c) {
-                uint a = 255u, b = 0u;
-                if (q.child[c] != 0x7FFFFFFF && lo[c] <= hi[c]) {
-                    float fa = floorf((lo[c] - o) / scale), fb = ceilf((hi[c] - o) / scale);
-                    fa = fminf(fmaxf(fa, 0.0f), 255.0f); fb = fminf(fmaxf(fb, 0.0f), 255.0f);
-                    a = (uint)fa; b = (uint)fb;
-                    const double od = (double)o, sd = (double)scale;
-                    while (a > 0u && (o + (float)a * scale > lo[c] || od + (double)a * sd > (double)lo[c])) --a;
-                    while (b < 255u && (o + (float)b * scale < hi[c] || od + (double)b * sd < (double)hi[c])) ++b;
-                    if (o + (float)a * scale > lo[c] || o + (float)b * scale < hi[c] || od + (double)a * sd > (double)lo[c] || od + (double)b * sd < (double)hi[c]) fits = false;
-                }
-                qlo[c >> 2] |= a << (8 * (c & 3)); qhi[c >> 2] |= b << (8 * (c & 3));
-            }
-            if (fits || e >= 254) break;
-            ++e;
-        }
-        q.origin[k] = o;
-        q.exps |= (uint)e << (8 * k);
-        q.q[4 * k] = qlo[0]; q.q[4 * k + 1] = qlo[1]; q.q[4 * k + 2] = qhi[0]; q.q[4 * k + 3] = qhi[1];
-    }
-    out[i] = q;
-}
-
-// Bvh4Node -> Bvh4NodeQ (TR_QNODES).  Per axis: origin = the smallest lo of the node's children, scale = the smallest power of two
-// with (largest hi - origin) / scale <= 255 (and large enough that origin + 255 * scale > origin, so an empty slot's inverted box
-// stays inverted), q_lo = floor, q_hi = ceil - each then stepped outwards until the plane the traversal will reconstruct,
-// rn(origin + q * scale), is on or outside the fp32 plane.
-__global__ __launch_bounds__(BT) void k_quantize4(uint n_nodes, const Bvh4Node* nodes4, Bvh4NodeQ* out) {
-    const uint i = blockIdx.x * BT + threadIdx.x;
-    if (i >= n_nodes) return;
-    const Bvh4Node nd = nodes4[i];
-    const float* lo[3] = {nd.lox, nd.loy, nd.loz};
-    const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
-    Bvh4NodeQ q;
-    q.exps = 0;
-    for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
-    q.pad[0] = q.pad[1] = 0;
-    for (int k = 0; k < 3; ++k) {
-        float o = __builtin_huge_valf(), top = -__builtin_huge_valf();
-        for (int c = 0; c < 4; ++c) if (nd.child[c] != 0x7FFFFFFF && lo[k][c] <= hi[k][c]) { o = fminf(o, lo[k][c]); top = fmaxf(top, hi[k][c]); }
-        if (!(o <= top)) { o = 0.0f; top = 0.0f; }      // a node without valid children (never traversed)
-        // exponent: 2^(e - 127) * 255 >= top - o; at least 2^-100, and at least one ulp of the origin
-        int e = 0;
-        (void)frexpf((top - o) / 255.0f, &e);            // (top - o) / 255 = m * 2^e, m in [0.5, 1): 2^e is the first power of two above it
-        int oe = 0;
-        (void)frexpf(fabsf(o), &oe);
-        e = max(e, oe - 22);
-        e = min(max(e + 127, 27), 254);
-        uint qlo = 0, qhi = 0;
-        while (true) {
-            const float scale = __uint_as_float((uint)e << 23);
-            bool fits = true;
-            qlo = 0; qhi = 0;
-            for (int c = 0; c < 4 && fits; ++c) {
-                uint a = 255u, b = 0u;                   // empty slot: inverted
-                if (nd.child[c] != 0x7FFFFFFF && lo[k][c] <= hi[k][c]) {
-                    float fa = floorf((lo[k][c] - o) / scale), fb = ceilf((hi[k][c] - o) / scale);
-                    fa = fminf(fmaxf(fa, 0.0f), 255.0f); fb = fminf(fmaxf(fb, 0.0f), 255.0f);
-                    a = (uint)fa; b = (uint)fb;
-                    // both readings of a byte must contain the fp32 plane: the fp32 reconstruction rn(o + q * scale) (TR_QNODES = 1)
-                    // and the exact o + q * scale the folded slab test works with (TR_QNODES = 2; exact in double)
-                    const double od = (double)o, sd = (double)scale;
-                    while (a > 0u && (o + (float)a * scale > lo[k][c] || od + (double)a * sd > (double)lo[k][c])) --a;
-                    while (b < 255u && (o + (float)b * scale < hi[k][c] || od + (double)b * sd < (double)hi[k][c])) ++b;
-                    if (o + (float)a * scale > lo[k][c] || o + (float)b * scale < hi[k][c] || od + (double)a * sd > (double)lo[k][c] ||
-                        od + (double)b * sd < (double)hi[k][c]) fits = false;
-                }
-                qlo |= a << (8 * c); qhi |= b << (8 * c);
-            }
-            if (fits || e >= 254) break;
-            ++e;
-        }
-        q.origin[k] = o;
-        q.exps |= (uint)e << (8 * k);
-        q.q[2 * k] = qlo; q.q[2 * k + 1] = qhi;
-    }
-    out[i] = q;
+    nodes4[(size_t)new_id[i]] = out;
 }
 
 // shader/extract_tri_lights.comp:17-54 (all emissive instances in one launch)
@@ -820,53 +707,7 @@ __global__ __launch_bounds__(BT) void k_refit_level(uint count, const uint* leve
     for (int k = 0; k < 3; ++k) { node_bounds[6 * (size_t)id + k] = lo[k]; node_bounds[6 * (size_t)id + 3 + k] = hi[k]; }
 }
 
-// The top four levels of the 4-wide tree in the plane-major layout the trace kernels keep in LDS (common.h, TR_TOP_SLOTS).
-// One block; level by level, one thread per slot.  Slots the tree does not fill keep inverted boxes and are never referenced.
-__global__ __launch_bounds__(128) void k_build_treetop(const Bvh4Node* nodes4, uint node_count, f4* top) {
-    __shared__ int slot_node[TR_TOP_SLOTS];
-    const uint t = threadIdx.x;
-    if (t < TR_TOP_SLOTS) {
-        slot_node[t] = (t == 0 && node_count > 0) ? 0 : -1;
-        const float inf = __builtin_huge_valf();
-        for (int p = 0; p < 6; ++p) top[p * TR_TOP_SLOTS + t] = (p & 1) ? F4(-inf) : F4(inf);
-        int4 e = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF);
-        reinterpret_cast<int4*>(top)[6 * TR_TOP_SLOTS + t] = e;
-    }
-    __syncthreads();
-    for (uint first = 0, count = 1; first < TR_TOP_SLOTS; first += count, count *= 4) {
-        if (t >= first && t < first + count && slot_node[t] >= 0) {
-            const Bvh4Node nd = nodes4[slot_node[t]];
-            const float* rows[6] = {nd.lox, nd.hix, nd.loy, nd.hiy, nd.loz, nd.hiz};
-            for (int p = 0; p < 6; ++p) top[p * TR_TOP_SLOTS + t] = F4(rows[p][0], rows[p][1], rows[p][2], rows[p][3]);
-            int ref[4];
-            for (int k = 0; k < 4; ++k) {
-                const int c = nd.child[k];
-                ref[k] = c;
-                if (t < TR_TOP_INNER && c >= 0 && c != 0x7FFFFFFF) { slot_node[4 * t + 1 + k] = c; ref[k] = TR_TOP_FLAG | (int)(4 * t + 1 + k); }
-            }
-            reinterpret_cast<int4*>(top)[6 * TR_TOP_SLOTS + t] = make_int4(ref[0], ref[1], ref[2], ref[3]);
-        }
-        __syncthreads();
-    }
-}
-
-static int build_treetop(DeviceScene& ds, hipStream_t stream) {
-#if TR_BVH4
-    // off unless TRHIP_TREETOP=1: measured slower (profiles/r2/treetop_ab.json)
-    static const bool enabled = getenv("TRHIP_TREETOP") && atoi(getenv("TRHIP_TREETOP")) != 0;
-    ds.use_treetop = enabled;
-    if (!enabled || !ds.nodes4 || ds.node_count == 0) return 0;     // no kernel, no allocation while the feature is off
-    if (!ds.treetop) HIPCHK(hipMalloc(&ds.treetop, TR_TOP_WORDS * sizeof(float)));
-    hipLaunchKernelGGL(k_build_treetop, dim3(1), dim3(128), 0, stream, ds.nodes4, ds.node_count, ds.treetop);
-    HIPCHK(hipGetLastError());
-#endif
-    return 0;
-}
-
 int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
-#if !TR_BVH4
-    return set_error("trhip_scene_refit_accel: this build traverses the binary tree; rebuild instead");
-#else
     const uint n = ds.leaf_count;      // records in ds.tris: triangles, or the references of a pre-split build (their leaf boxes grow to the whole triangle here)
     if (ds.accel_tri_count != ds.tri_count || ds.accel_capacity == 0xFFFFFFFFu || (n > 0 && !ds.tris) || (n > 1 && !ds.nodes4))
         return set_error("trhip_scene_refit_accel: no acceleration structure to refit; call trhip_scene_build_accel first");
@@ -907,11 +748,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         const uint lo = ds.level_offsets[l - 1], cnt = ds.level_offsets[l] - lo;
         if (cnt) hipLaunchKernelGGL(k_refit_level, dim3((cnt + BT - 1) / BT), dim3(BT), 0, stream, cnt, ds.level_nodes + lo, ds.nodes4, ds.tris, ds.node_bounds);
     }
-#if TR_QNODES
-    if (n1 > 0 && ds.nodesq) hipLaunchKernelGGL(k_quantize4, dim3((n1 + BT - 1) / BT), dim3(BT), 0, stream, n1, ds.nodes4, ds.nodesq);
-#endif
     HIPCHK(hipGetLastError());
-    if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
     if (ds.gather_emissive_triangles && ds.host_tri_light_count > 0 && ds.tri_lights) {
         HIPCHK(hipMemsetAsync(ds.tri_lights, 0, (size_t)ds.host_tri_light_count * sizeof(TriLight), stream));
@@ -930,7 +767,6 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         for (int k = 0; k < 3; ++k) { info->bounds_min[k] = ds.bounds_lo[k]; info->bounds_max[k] = ds.bounds_hi[k]; }
     }
     return 0;
-#endif
 }
 
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
@@ -946,12 +782,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     // triangle count does not change: a rebuild (dynamic scenes) performs no allocation at all.
     size_t plan_bytes = 0;
     auto plan = [&](size_t bytes) { size_t o = plan_bytes; plan_bytes += (bytes + 255) & ~(size_t)255; return o; };
-    // Static builds split large triangles into several references first (bvh_presplit.h): the tree then has more leaves than the
-    // scene has triangles.  n_tri = triangles, n = leaves (known once the splits are counted), n_cap = what everything is sized for.
+    // n_tri = triangles = leaves; n_cap = what everything is sized for
     const uint n_tri = n_scene;
-    const bool presplit = TR_BVH4 && ds.presplit_percent > 0 && !ds.fast_build && n_tri > 64;
-    const uint split_budget = presplit ? (uint)std::min<uint64_t>((uint64_t)n_tri * (uint)ds.presplit_percent / 100u, 0x7FFFFFFFull - n_tri) : 0u;
-    const uint n_cap = n_tri + split_budget;
+    const uint n_cap = n_tri;
     uint n = n_tri;
     const size_t n1 = n_cap > 1 ? n_cap - 1 : 0;     // inner nodes the buffers hold
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -965,14 +798,12 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                  o_sizes = plan(n1 * 4), o_parent = plan(n1 * 4), o_parent_leaf = plan((size_t)n_cap * 4), o_node_box = plan(n1 * 24),
                  o_arrive = plan(n1 * 4), o_cref0 = plan((size_t)n_cap * 4), o_cref1 = plan((size_t)n_cap * 4), o_cbox0 = plan((size_t)n_cap * 24),
                  o_cbox1 = plan((size_t)n_cap * 24), o_nn = plan((size_t)n_cap * 4), o_valid = plan(((size_t)n_cap + BT) * 4), o_pos = plan(((size_t)n_cap + BT) * 4),
-                 o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(TR_BVH4 ? n1 * sizeof(BvhNode) : 0);
+                 o_scan = plan(scan_bytes + 16), o_new_id = plan(n1 * 4), o_nodes2 = plan(n1 * sizeof(BvhNode));
     const bool optimise = ds.optimise_rounds > 0 && !ds.fast_build && n_tri > 2;
     const size_t n_all_cap = (size_t)n_cap + n1;
-    const bool dp_collapse = TR_BVH4 && ds.collapse_by_cost && !ds.fast_build && n_tri > 2;   // a fast build keeps the greedy choice (the cost pass would double its time)
+    const bool dp_collapse = ds.collapse_by_cost && !ds.fast_build && n_tri > 2;   // a fast build keeps the greedy choice (the cost pass would double its time)
     const size_t o_uparent = plan(optimise || dp_collapse ? n_all_cap * 4 : 0), o_moves = plan(optimise ? n_all_cap * sizeof(OptMove) : 0), o_lock = plan(optimise ? n_all_cap * 8 : 0),
                  o_optstat = plan(64), o_ccost = plan(dp_collapse ? n1 * 12 : 0), o_cdec = plan(dp_collapse ? n1 : 0);
-    const size_t o_prio = plan(presplit ? (size_t)n_tri * 4 : 0), o_count = plan(presplit ? ((size_t)n_tri + BT) * 4 : 0), o_offset = plan(presplit ? ((size_t)n_tri + BT) * 4 : 0),
-                 o_refs = plan(presplit ? (size_t)n_cap * sizeof(TriRecord) : 0), o_ref_box = plan(presplit ? (size_t)n_cap * 24 : 0), o_totals = plan(PRESPLIT_CANDIDATES * 8);
     if (plan_bytes > ds.scratch_bytes) {
         if (ds.scratch) (void)hipFree(ds.scratch);
         ds.scratch = nullptr; ds.scratch_bytes = 0;
@@ -989,13 +820,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         ds.free_accel();
         if (n_cap > 0) HIPCHK(hipMalloc(&ds.tris, (size_t)n_cap * sizeof(TriRecord)));
         if (n1 > 0) {
-#if TR_BVH4
             // traversal addresses a node's planes with 32-bit byte offsets (node << 7 | plane)
-            if ((uint64_t)n1 * sizeof(Bvh4Node) * (TR_BVH8 ? 2 : 1) > 0xFFFFFFFFull) return set_error("trhip_scene_build_accel: more than 2^25 nodes");
-            HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node) * (TR_BVH8 ? 2 : 1)));
-#else
-            HIPCHK(hipMalloc(&ds.nodes, n1 * sizeof(BvhNode)));
-#endif
+            if ((uint64_t)n1 * sizeof(Bvh4Node) > 0xFFFFFFFFull) return set_error("trhip_scene_build_accel: more than 2^25 nodes");
+            HIPCHK(hipMalloc(&ds.nodes4, n1 * sizeof(Bvh4Node)));
         }
         ds.accel_capacity = n_cap;
     }
@@ -1008,85 +835,13 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         uint* ranges = reinterpret_cast<uint*>(base + o_sizes);   // subtree sizes (leaves per internal node)
         int *parent_internal = reinterpret_cast<int*>(base + o_parent), *parent_leaf = reinterpret_cast<int*>(base + o_parent_leaf);
         uint* arrive = reinterpret_cast<uint*>(base + o_arrive);
-#if TR_BVH4
         BvhNode* nodes2 = reinterpret_cast<BvhNode*>(base + o_nodes2);   // binary nodes: only the collapse input
-#else
-        BvhNode* nodes2 = ds.nodes;
-#endif
         const uint tblocks = (n_tri + BT - 1) / BT;
         hipLaunchKernelGGL(k_pretransform, dim3(tblocks < 1024u ? tblocks : 1024u), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
-        bool split_done = false;
-        if (presplit) {
-            // the Morton grid the split planes come from: the bounds of the triangles
-            uint hb[6];
-            HIPCHK(hipMemcpyAsync(hb, cbounds + 16, sizeof(hb), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            SplitGrid g;
-            for (int k = 0; k < 3; ++k) {
-                g.lo[k] = float_unflip(hb[k]);
-                g.ext[k] = float_unflip(hb[3 + k]) - g.lo[k];
-                g.inv[k] = g.ext[k] > 0.0f ? 2097152.0f / g.ext[k] : 0.0f;
-            }
-            float* prio = reinterpret_cast<float*>(base + o_prio);
-            uint *count = reinterpret_cast<uint*>(base + o_count), *offset = reinterpret_cast<uint*>(base + o_offset);
-            unsigned long long* totals = reinterpret_cast<unsigned long long*>(base + o_totals);
-            uint* max_bits = cbounds + 24;
-            hipLaunchKernelGGL(k_split_priority, dim3(tblocks), dim3(BT), 0, stream, n_tri, unsorted, g, prio, max_bits);
-            uint mb = 0;
-            HIPCHK(hipMemcpyAsync(&mb, max_bits, 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            float pmax;
-            memcpy(&pmax, &mb, 4);
-            if (pmax > 0.0f && split_budget > 0) {
-                // the largest scale whose split counts fit the budget: two passes over PRESPLIT_CANDIDATES scales each (geometric
-                // from "the largest priority gets one split" upwards, then linear inside the bracket found)
-                float lo_scale = 0.0f, hi_scale = 0.0f;
-                SplitScales sc;
-                unsigned long long h_tot[PRESPLIT_CANDIDATES];
-                for (int pass = 0; pass < 2; ++pass) {
-                    for (int c = 0; c < PRESPLIT_CANDIDATES; ++c)
-                        sc.s[c] = pass == 0 ? (1.0f / pmax) * exp2f(0.75f * (float)c) : lo_scale + (hi_scale - lo_scale) * (float)(c + 1) / (float)(PRESPLIT_CANDIDATES + 1);
-                    HIPCHK(hipMemsetAsync(totals, 0, sizeof(h_tot), stream));
-                    hipLaunchKernelGGL(k_split_totals, dim3(tblocks), dim3(BT), 0, stream, n_tri, prio, sc, totals);
-                    HIPCHK(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, stream));
-                    HIPCHK(hipStreamSynchronize(stream));
-                    int best = -1;
-                    for (int c = 0; c < PRESPLIT_CANDIDATES; ++c) if (h_tot[c] <= split_budget) best = c;
-                    const float lo_new = best >= 0 ? sc.s[best] : lo_scale;
-                    const float hi_new = best + 1 < PRESPLIT_CANDIDATES ? sc.s[best + 1] : (pass == 0 ? sc.s[PRESPLIT_CANDIDATES - 1] : hi_scale);
-                    if (pass == 0 && best < 0) { lo_scale = 0.0f; hi_scale = sc.s[0]; }
-                    else { lo_scale = lo_new; hi_scale = hi_new; }
-                }
-                if (lo_scale > 0.0f) {
-                    hipLaunchKernelGGL(k_split_counts, dim3(tblocks), dim3(BT), 0, stream, n_tri, prio, lo_scale, count);
-                    HIPCHK(rocprim::exclusive_scan(base + o_scan, scan_bytes, count, offset, 0u, tblocks * BT, rocprim::plus<uint>(), stream));
-                    uint last[2] = {0, 0};
-                    HIPCHK(hipMemcpyAsync(&last[0], offset + (n_tri - 1), 4, hipMemcpyDeviceToHost, stream));
-                    HIPCHK(hipMemcpyAsync(&last[1], count + (n_tri - 1), 4, hipMemcpyDeviceToHost, stream));
-                    HIPCHK(hipStreamSynchronize(stream));
-                    const uint n_refs = last[0] + last[1];
-                    if (n_refs > n_cap) return set_error("pre-split: reference count exceeds its budget");
-                    if (n_refs > n_tri) {
-                        TriRecord* refs = reinterpret_cast<TriRecord*>(base + o_refs);
-                        float* ref_box = reinterpret_cast<float*>(base + o_ref_box);
-                        hipLaunchKernelGGL(k_split_emit, dim3(tblocks), dim3(BT), 0, stream, n_tri, unsorted, offset, count, g, refs, ref_box);
-                        n = n_refs;
-                        const uint rblocks = (n + BT - 1) / BT;
-                        hipLaunchKernelGGL(k_morton_refs, dim3(rblocks), dim3(BT), 0, stream, n, ref_box, g, keys, vals);
-                        HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
-                        hipLaunchKernelGGL(k_gather_refs, dim3(rblocks), dim3(BT), 0, stream, n, refs, ref_box, vals_sorted, ds.tris, leaf_box);
-                        split_done = true;
-                        if (getenv("TRHIP_DEBUG")) fprintf(stderr, "[trhip] pre-split: %u triangles -> %u references (budget %u, scale %g)\n", n_tri, n, split_budget, lo_scale);
-                    }
-                }
-            }
-        }
         const uint blocks = (n + BT - 1) / BT;
-        if (!split_done) {
-            hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
-            HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
-            hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
-        }
+        hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
+        HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
+        hipLaunchKernelGGL(k_gather_leaves, dim3(blocks), dim3(BT), 0, stream, n, unsorted, vals_sorted, ds.tris, leaf_box);
         const size_t n_all = (size_t)n + (n > 1 ? n - 1 : 0);
         if (n > 1) {
             const uint iblocks = (n - 1 + BT - 1) / BT;
@@ -1178,13 +933,12 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                 }
                 parent_internal = t.parent;     // the first n - 1 entries are the inner nodes' parents
             }
-            if (ds.builder != 0 || ds.dfs_layout || TR_BVH4 || optimise) {
+            {
                 int* new_id = reinterpret_cast<int*>(base + o_new_id);
                 if (ds.dfs_layout) hipLaunchKernelGGL(k_dfs_order, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, ranges, parent_internal, new_id);
                 else hipLaunchKernelGGL(k_identity, dim3(iblocks), dim3(BT), 0, stream, n - 1, new_id);
-#if TR_BVH4
                 const uint8_t* dec = nullptr;
-                if (dp_collapse && !TR_BVH8) {
+                if (dp_collapse) {
                     OptTree t{(uint)(n - 1), n, children, node_box, leaf_box, reinterpret_cast<int*>(base + o_uparent)};
                     if (!optimise) hipLaunchKernelGGL(k_opt_parents, dim3(iblocks), dim3(BT), 0, stream, t);
                     HIPCHK(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, stream));
@@ -1192,16 +946,6 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
                     dec = reinterpret_cast<const uint8_t*>(base + o_cdec);
                 }
                 hipLaunchKernelGGL(k_collapse4, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, dec, ds.nodes4);
-#if TR_QNODES
-                if (!ds.nodesq) HIPCHK(hipMalloc(&ds.nodesq, n1 * sizeof(Bvh4NodeQ)));
-                hipLaunchKernelGGL(k_quantize4, dim3(iblocks), dim3(BT), 0, stream, n - 1, ds.nodes4, ds.nodesq);
-#elif TR_BVH8 == 2
-                if (!ds.nodesq) HIPCHK(hipMalloc(&ds.nodesq, n1 * sizeof(Bvh8NodeQ)));
-                hipLaunchKernelGGL(k_quantize8, dim3(iblocks), dim3(BT), 0, stream, n - 1, ds.nodes4, reinterpret_cast<Bvh8NodeQ*>(ds.nodesq));
-#endif
-#else
-                hipLaunchKernelGGL(k_emit_nodes, dim3(iblocks), dim3(BT), 0, stream, n - 1, children, node_box, leaf_box, new_id, ds.nodes);
-#endif
             }
         }
         HIPCHK(hipGetLastError());
@@ -1209,7 +953,6 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     ds.leaf_count = n;
     ds.node_count = n > 1 ? n - 1 : 0;
     ds.accel_tri_count = n_tri;
-    if (int rc = build_treetop(ds, stream)) return rc;
     ds.accel_built = true;
     // tri lights
     ds.tri_light_count = 0;
@@ -1233,7 +976,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         info->triangle_count = n_tri;
         info->leaf_count = n;
         info->node_count = ds.node_count;
-        info->node_bytes = TR_BVH4 ? 112u : 64u;
+        info->node_bytes = 112u;
         info->tri_light_count = ds.tri_light_count;
         info->build_ms = ms;
         for (int k = 0; k < 3; ++k) { info->bounds_min[k] = float_unflip(hb[k]); info->bounds_max[k] = float_unflip(hb[3 + k]); }

@@ -147,7 +147,8 @@ static_assert(sizeof(CameraData) == 320 && sizeof(AliasEntry) == 16, "layout");
 // ---------------------------------------------------------------------------
 // Acceleration structure in HBM
 // ---------------------------------------------------------------------------
-// 64-byte BVH2 node: both child boxes + child references.
+// 64-byte BVH2 node: both child boxes + child references.  What the builder clusters, optimises and then collapses into
+// Bvh4Node; never traversed.
 //   child >= 0 : internal node index;  child < 0 : leaf, triangle index = ~child
 struct alignas(64) BvhNode {
     float lo0[3], hi0[3], lo1[3], hi1[3];
@@ -156,12 +157,6 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node layout");
 
-#ifndef TR_BVH4
-#ifndef TR_BVH8
-#define TR_BVH8 0         // experiment: 8-wide nodes as two adjacent Bvh4Node lines (node n = lines 2n, 2n + 1); per-lane loops only (build with -DTR_QUAD_SWITCH=0)
-#endif
-#define TR_BVH4 1         // 1: traverse the 4-wide fp32 nodes (SceneView::nodes4); 0: the binary nodes they are collapsed from
-#endif
 // 4-wide node, one 128-byte line: child boxes in SoA (one dwordx4 per plane), child references as in BvhNode
 // (>= 0 inner node, < 0 ~triangle).  Empty slots hold an inverted box (lo = +inf, hi = -inf) and are never hit.
 struct alignas(128) Bvh4Node {
@@ -171,55 +166,6 @@ struct alignas(128) Bvh4Node {
     int pad[4];
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
-
-// The same node with the child boxes quantised to 8 bits per plane against the node's own frame (experiment, TR_QNODES = 1): 64 bytes,
-// two nodes per cache line, four loads per visit instead of seven.  plane = origin_k + q * scale_k with scale_k = 2^(e_k - 127)
-// a power of two (q * scale is exact, the sum rounds once); the builder chooses q so that the plane *as the traversal reconstructs
-// it* lies on or outside the fp32 plane, so the quantised box contains the exact one and hits do not change.  Child references and
-// empty slots (inverted box: lo bytes 255, hi bytes 0) as in Bvh4Node.
-// Experiment TR_BVH8 = 2: eight children in one 128-byte line, planes quantised as in Bvh4NodeQ (96 bytes used: six 16-byte loads per visit).
-// q[4 * axis + 0 / 1] = lo planes of children 0-3 / 4-7, q[4 * axis + 2 / 3] = hi planes; empty slots inverted (lo 255, hi 0).
-struct alignas(128) Bvh8NodeQ {
-    float origin[3];
-    uint exps;
-    int child[8];
-    uint q[12];
-    uint pad[8];
-};
-static_assert(sizeof(Bvh8NodeQ) == 128, "Bvh8NodeQ layout");
-#ifndef TR_QNODES
-#define TR_QNODES 0
-#endif
-struct alignas(64) Bvh4NodeQ {
-    float origin[3];
-    uint exps;            // biased exponents of the three scales: e_x | e_y << 8 | e_z << 16
-    int child[4];
-    uint q[6];            // lox, hix, loy, hiy, loz, hiz; byte c of a word = child c
-    uint pad[2];
-};
-static_assert(sizeof(Bvh4NodeQ) == 64, "Bvh4NodeQ layout");
-// TR_QNODES = 1: planes rebuilt as fp32 (origin + q * scale), then the fp32 slab test, in both traversal loops; = 2: the decode
-// folded into the slab test of the per-lane loop (trace.h), the quad tail keeps reading the fp32 nodes.
-#if TR_QNODES
-#define TR_NODES_OF(sv) reinterpret_cast<const Bvh4Node*>((sv).nodesq)
-#else
-#define TR_NODES_OF(sv) (sv).nodes4
-#endif
-#if TR_QNODES == 1
-#define TR_QUAD_NODES_OF(sv) reinterpret_cast<const Bvh4Node*>((sv).nodesq)
-#else
-#define TR_QUAD_NODES_OF(sv) (sv).nodes4
-#endif
-
-// Treetop: the top four levels of the 4-wide tree (1 + 4 + 16 + 64 = 85 slots of an implicit complete 4-ary layout, the
-// children of slot s are slots 4 s + 1 ..) copied into the LDS of every trace block.  Stored plane by plane
-// (plane p of slot s at 16 * (p * TR_TOP_SLOTS + s) bytes: planes 0..5 = lox, hix, loy, hiy, loz, hiz rows of the node,
-// plane 6 = child references) so that lanes reading the same plane of different slots hit different LDS banks.  A child
-// reference with TR_TOP_FLAG set names a treetop slot; the references of the last treetop level are global node ids.
-#define TR_TOP_SLOTS 85
-#define TR_TOP_INNER 21          // slots 0..20 (levels 0..2) have their children in the treetop
-#define TR_TOP_FLAG 0x40000000
-#define TR_TOP_WORDS (7 * TR_TOP_SLOTS * 4)
 
 // 48-byte world-space triangle record, stored in Morton (leaf) order.
 //   inst_flags: bits 0..30 instance id, bit 31 = non-opaque (runs the any-hit path)
@@ -249,11 +195,8 @@ struct SceneView {
     const MeshSpan* obj_spans;        // the uploaded model-space vertices even when `vertices` is the pre-transformed copy
     const Vertex* obj_vertices;
     const ShadeTri* shade_tris;  // null = none
-    const BvhNode* nodes;
     const TriRecord* tris;
-    const Bvh4Node* nodes4;      // 4-wide fp32 nodes (TR_BVH4 builds; `nodes` is then null)
-    const Bvh4NodeQ* nodesq;     // TR_QNODES builds: the quantised copy the traversal reads (same indices)
-    const f4* treetop;           // TR_TOP_WORDS floats, see TR_TOP_SLOTS; null = none (queries start at node 0 of nodes4)
+    const Bvh4Node* nodes4;      // the 4-wide fp32 nodes the traversal reads; node 0 is the root
     f4 environment_factor;
     int environment_proj;
     uint instance_count, point_light_count, directional_light_count, tri_light_count;

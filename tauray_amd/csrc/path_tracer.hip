@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "pt_kernels.h"
-#include "trace_packet.h"
 
 namespace tr {
 
@@ -22,7 +21,7 @@ namespace {
 // Register budgets of the traversal kernels (waves per SIMD): the loops are latency-bound, so the shadow kernel runs at
 // the full 8 waves (<= 64 VGPRs); the closest-hit kernel sorts four children and spills below 80 VGPRs, 6 waves win.
 #ifndef TR_CLOSEST_WAVES
-#define TR_CLOSEST_WAVES (TR_BVH4 ? 6 : 8)
+#define TR_CLOSEST_WAVES 6
 #endif
 #ifndef TR_SHADOW_WAVES
 #define TR_SHADOW_WAVES 8
@@ -65,17 +64,14 @@ __global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuf
     pb.atten_alpha[i] = F4(1, 1, 1, 1);          // attenuation = 1
     pb.rng[i] = ls.rs;
     pb.misc[i] = misc;
-#if TR_OCC_CACHE
-    pb.occ[i] = ~0u;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
 // The closest-hit rays of queue slots base .. base + 63 (path_tracer.glsl:387-403), one wave: trace, store the hit records of
 // the paths.  Every lane of the wave calls this; the traversal re-deals the last rays of the chunk over quads (trace_quad.h).
-template <bool COUNT, bool TOP>
+template <bool COUNT>
 TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, const uint* queue, uint qi, uint n, int* lds_stack,
-                         const QuadCtx& qc, const float* top, TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
+                         const QuadCtx& qc, TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
     bool valid = qi < n;
     uint id = 0;
     u4 misc = {0, 0, 0, 1};
@@ -89,12 +85,12 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     HitRecord hit;
     const bool include_lights = !(P.opt.hide_lights && bounce == 0);
     const uint before = st.nodes;
-#if TR_BVH4 && TR_QUAD_SWITCH > 0
-    trace_closest_wave4<0, COUNT, TOP>(sv, valid, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights, misc.x,
-                                       lds_stack, qc, top, hit, st, overflow);
+#if TR_QUAD_SWITCH > 0
+    trace_closest_wave4<0, COUNT>(sv, valid, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights, misc.x,
+                                  lds_stack, qc, hit, st, overflow);
 #else
-    if (valid) trace_closest_any<0, COUNT, TOP>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                                misc.x, lds_stack, hit, st, overflow, top);
+    if (valid) trace_closest4<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
+                                        misc.x, lds_stack, hit, st, overflow);
 #endif
     if (COUNT) st.cnodes += st.nodes - before;      // every lane: in the quad tail lane 0 of a quad counts for the quad's ray
     if (!valid) return;
@@ -123,34 +119,17 @@ TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb) 
 
 // The shadow rays of slots base .. base + 63 of the bounce's shadow queue, one wave: contrib *= shadow_ray(...)
 // (path_tracer.glsl:35-52, 462-463) and add_demodulated_color of the result.  Every lane of the wave calls this.
-template <bool COUNT, bool TOP>
-TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, const QuadCtx& qc, const float* top,
+template <bool COUNT>
+TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, const QuadCtx& qc,
                         TraceStats& st, int& overflow, uint& rays) {
     const bool valid = qi < n;
     f4 o = F4(0), d = F4(0), c = F4(0);
     if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; c = pb.sh_contrib[qi]; }
-#if TR_OCC_CACHE
-    // Result-preserving: visibility 0 is 0 whichever opaque triangle gives it, and the test is the one the walk would make at that leaf.
-    bool walk = valid;
-    uint occluder = ~0u;
-    if (valid) {
-        const uint cached = pb.occ[__float_as_uint(d.w)];
-        if (cached != ~0u && ray_is_finite(F3(o), F3(d))) {
-            const TriRecord tr = sv.tris[cached];
-            const RayPre r = make_ray(F3(o), F3(d));
-            float t, bu, bv;
-            if (tri_intersect(r, F3(tr.v0[0], tr.v0[1], tr.v0[2]), F3(tr.v1[0], tr.v1[1], tr.v1[2]), F3(tr.v2[0], tr.v2[1], tr.v2[2]), P.opt.min_ray_dist, o.w, t, bu, bv)) walk = false;
-            if (COUNT) st.tris++;
-        }
-    }
-    float vis = trace_shadow_wave4<COUNT, TOP>(sv, walk, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, top, st, overflow, &occluder);
-    if (valid && !walk) vis = 0.0f;
-    else if (valid && vis == 0.0f && occluder != ~0u) pb.occ[__float_as_uint(d.w)] = occluder;
-#elif TR_BVH4 && TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
-    float vis = trace_shadow_wave4<COUNT, TOP>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, top, st, overflow);
+#if TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
+    float vis = trace_shadow_wave4<COUNT>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, st, overflow);
 #else
     float vis = 1.0f;
-    if (valid) vis = trace_shadow_any<COUNT, TOP>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow, top);
+    if (valid) vis = trace_shadow4<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow);
 #endif
     if (!valid) return;
     const uint id = __float_as_uint(d.w);
@@ -201,14 +180,11 @@ TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int o
 // at kernel start) and later chunks from a device-side cursor, which starts past the statically assigned range.
 // SOLO only names the instance launched while detailed timing serialises the frame, so that a profiler lists the
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
-// TOP: the block keeps the top four levels of the tree in LDS (load_treetop) and traversals start there.
-template <bool COUNT, bool SOLO, bool TOP>
+template <bool COUNT, bool SOLO>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     TraceStats st = {};
@@ -226,58 +202,15 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         }
         first = false;
         if (base >= n) break;
-        closest_lane<COUNT, TOP>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, s_top, st, overflow, max_vis, rays);
+        closest_lane<COUNT>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, st, overflow, max_vis, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
 }
 
-// The primary rays of a frame (bounce 0: the ids are launch ids, dealt to waves as 8 x 8 pixel tiles by launch_coord): a wave walks the
-// tree once for its 64 rays (trace_packet.h).  Same hit records as k_trace_closest at bounce 0.
 template <bool COUNT>
-__global__ __launch_bounds__(KB) void k_trace_primary(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
-    __shared__ int s_pstack[(KB / 64) * TR_PACKET_STACK];
-    int* wave_stack = s_pstack + (threadIdx.x >> 6) * TR_PACKET_STACK;
-    const uint n = P.n_ids;
-    TraceStats st = {};
-    uint rays = 0;
-    int overflow = 0;
-    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
-    bool first = true;
-    while (true) {
-        uint base = 0;
-        if (first) base = wave_id * 64u;
-        else {
-            if (n <= n_waves * 64u) break;
-            if ((threadIdx.x & 63) == 0) base = n_waves * 64u + atomicAdd(&bc[BC_CUR_CLOSEST], 64u);
-            base = __shfl(base, 0);
-        }
-        first = false;
-        if (base >= n) break;
-        const uint qi = base + (threadIdx.x & 63);
-        bool valid = qi < n;
-        uint id = 0;
-        u4 misc = {0, 0, 0, 1};
-        f4 o = F4(0), d = F4(0);
-        if (valid) { id = qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
-        HitRecord hit;
-        const uint before = st.nodes;
-        trace_closest_packet<0, COUNT>(sv, valid, F3(o), F3(d), 0.0f, __builtin_huge_valf(), !P.opt.hide_lights, misc.x, wave_stack, hit, st, overflow);
-        if (COUNT) st.cnodes += st.nodes - before;
-        if (valid) {
-            pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-            rays++;
-        }
-    }
-    flush_trace_counters<COUNT>(P, pb, overflow, 3000, rays, 0u, st, 0u);
-}
-
-// With the treetop in LDS six blocks fit a CU (26 KB each): ask for the registers of six waves, not of eight.
-template <bool COUNT, bool TOP>
-__global__ __launch_bounds__(KB, TOP ? (TR_SHADOW_WAVES < 6 ? TR_SHADOW_WAVES : 6) : TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
+__global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = bc[BC_SHADOW];
     TraceStats st = {};
@@ -295,7 +228,7 @@ __global__ __launch_bounds__(KB, TOP ? (TR_SHADOW_WAVES < 6 ? TR_SHADOW_WAVES : 
         }
         first = false;
         if (base >= n) break;
-        shadow_lane<COUNT, TOP>(sv, P, pb, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, s_top, st, overflow, rays);
+        shadow_lane<COUNT>(sv, P, pb, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, st, overflow, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 2000, 0u, rays, st, 0u);
 }
@@ -304,13 +237,10 @@ __global__ __launch_bounds__(KB, TOP ? (TR_SHADOW_WAVES < 6 ? TR_SHADOW_WAVES : 
 // state arrays), and in the lane schedule a launch lasts as long as its slowest wave: one launch with one tail instead of
 // two launches with two.  Chunk g of the launch is a closest-hit chunk while g < chunks_c (the longer rays go first), a
 // shadow chunk afterwards.
-template <bool TOP>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
     __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ __attribute__((aligned(16))) float s_top[TOP ? TR_TOP_WORDS : 4];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    if (TOP) load_treetop(sv, s_top);
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint nc = bc[BC_QUEUE], ns = bc_prev[BC_SHADOW];
     const uint chunks_c = (nc + 63u) >> 6, total = chunks_c + ((ns + 63u) >> 6);
@@ -329,8 +259,8 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView 
         }
         first = false;
         if (g >= total) break;
-        if (g < chunks_c) closest_lane<false, TOP>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, qc, s_top, st, overflow, max_vis, closest_rays);
-        else shadow_lane<false, TOP>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, qc, s_top, st, overflow, shadow_rays);
+        if (g < chunks_c) closest_lane<false>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, qc, st, overflow, max_vis, closest_rays);
+        else shadow_lane<false>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, qc, st, overflow, shadow_rays);
     }
     flush_trace_counters<false>(P, pb, overflow, 3000 + bounce, closest_rays, shadow_rays, st, max_vis);
 }
@@ -413,24 +343,6 @@ __global__ __launch_bounds__(KB) void k_first_hit_gbuffer(SceneView sv, PtParams
         mat.albedo = F4(0);
     }
     write_first_hit_gbuffer(sv, P, misc.z, v, mat, surface, h);
-}
-
-#ifndef TR_SURFACE_WAVES
-#define TR_SURFACE_WAVES 5
-#endif
-__global__ __launch_bounds__(KB, TR_SURFACE_WAVES) void k_surface(SceneView sv, PtParams P, PathBuffers pb, const uint* queue, const uint* bc) {
-    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
-    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n; qi += gridDim.x * KB) {
-        const uint id = queue ? queue[qi] : qi + P.id_offset;
-        const int4 h = pb.hit[id];
-        if (h.x < 0 || (pb.misc[id].w & 1u)) continue;
-        const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id];
-        SurfacePoint v;
-        SampledMaterial mat;
-        shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), F3(d4), F3(o4), P.nee_tri != 0, P.opt.tri_light_mode,
-                      P.opt.pre_transformed_vertices != 0, v, mat);
-        store_surface(pb.surf, P.n_launch, id, v, mat);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -560,53 +472,6 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
     }
 }
 
-// Experiment (TRHIP_REORDER=E): the queue of the next bounce, window by window of E * 256 entries, stably sorted by the
-// octant of the ray direction, so that the 64 rays of a closest-hit wave start near each other (the queue keeps screen order within a k_shade
-// block) AND head the same way.  Queue order is scheduling only: every path carries its own state, the frame is the same bits.
-template <int E>
-__global__ __launch_bounds__(KB) void k_reorder_queue(PathBuffers pb, const uint* count_ptr, uint* queue) {
-    __shared__ uint s_cnt[E * (KB / 64)][8];
-    __shared__ uint s_oct[8];
-    const uint n = *count_ptr;
-    const uint lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint base = blockIdx.x * (E * KB); base < n; base += gridDim.x * (E * KB)) {
-        uint id[E], oct[E], rank[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint i = base + e * KB + threadIdx.x;
-            id[e] = i < n ? queue[i] : 0u;
-            oct[e] = 8u;
-            if (i < n) { const f4 d = pb.dir_reg[id[e]]; oct[e] = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            rank[e] = 0;
-#pragma unroll
-            for (uint o = 0; o < 8; ++o) {
-                const unsigned long long m = __ballot(oct[e] == o);
-                if (oct[e] == o) rank[e] = (uint)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == o) s_cnt[e * (KB / 64) + wave][o] = (uint)__popcll(m);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 8) {      // per octant: running offsets over the groups, in queue order
-            uint run = 0;
-            for (int g = 0; g < E * (KB / 64); ++g) { const uint c = s_cnt[g][threadIdx.x]; s_cnt[g][threadIdx.x] = run; run += c; }
-            s_oct[threadIdx.x] = run;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (oct[e] < 8u) {
-                uint pos = rank[e] + s_cnt[e * (KB / 64) + wave][oct[e]];
-                for (uint o = 0; o < oct[e]; ++o) pos += s_oct[o];
-                queue[base + pos] = id[e];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     __shared__ int s_stack[TR_STACK_WORDS];
@@ -617,7 +482,7 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(Sce
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < ((n + 63u) & ~63u); qi += gridDim.x * KB) {
         if (qi >= n) continue;
         const f4 o = pb.sh_org_tmax[qi], d = pb.sh_dir_id[qi], c = pb.sh_contrib[qi];
-        const float vis = trace_shadow_any<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
+        const float vis = trace_shadow4<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, s_stack + threadIdx.x, st, overflow);
         rays++;
         if (vis == 0.0f) continue;
         const uint id = __float_as_uint(d.w);
@@ -799,11 +664,8 @@ PtStage::~PtStage() {
 void PtStage::free_buffers() {
     PathBuffers& pb = impl->pb;
     void* ptrs[] = {pb.org_pdf, pb.dir_reg, pb.atten_alpha, pb.diffuse, pb.reflection, pb.plobes, pb.first_mat, pb.first_emis, pb.rng, pb.misc, pb.hit,
-                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.surf, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
+                    pb.sum_color, pb.sum_diffuse, pb.sum_reflection, pb.sh_org_tmax, pb.sh_dir_id, pb.sh_contrib, pb.sh_lobes, pb.sh_cweight, pb.queue[0], pb.queue[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-#if TR_OCC_CACHE
-    if (pb.occ) (void)hipFree(pb.occ);
-#endif
     uint *counters = pb.counters, *bounce = pb.bounce;
     int* qspill = pb.qspill;
     pb = PathBuffers{};
@@ -827,9 +689,6 @@ int PtStage::ensure_buffers(size_t n, bool lobe_sums) {
     HIPCHK(hipMalloc(&pb.misc, n * 16)); HIPCHK(hipMalloc(&pb.hit, n * 16)); HIPCHK(hipMalloc(&pb.sum_color, n * 16));
     HIPCHK(hipMalloc(&pb.sh_org_tmax, n * 16)); HIPCHK(hipMalloc(&pb.sh_dir_id, n * 16)); HIPCHK(hipMalloc(&pb.sh_contrib, n * 16));
     HIPCHK(hipMalloc(&pb.sh_lobes, n * 8));
-#if TR_OCC_CACHE
-    HIPCHK(hipMalloc(&pb.occ, n * 4));
-#endif
     if (lobe_sums) { HIPCHK(hipMalloc(&pb.sum_diffuse, n * 16)); HIPCHK(hipMalloc(&pb.sum_reflection, n * 16)); }
     HIPCHK(hipMalloc(&pb.queue[0], n * 4)); HIPCHK(hipMalloc(&pb.queue[1], n * 4));
     impl->capacity = n;
@@ -895,13 +754,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     P.fused_resolve = opt.samples_per_pass == 1;
     P.T = targets;
     const bool timing = detailed_timing != 0;
-    static const bool split = getenv("TRHIP_SHADE_SPLIT") && atoi(getenv("TRHIP_SHADE_SPLIT")) != 0;   // k_surface + k_shade<.., true>
     // A frame of several one-sample passes can keep whole samples in flight instead of slices of one (see "sample lanes" below):
     // every lane then needs path state for all n paths.
     static const bool sample_lanes_enabled = !(getenv("TRHIP_SAMPLE_LANES") && atoi(getenv("TRHIP_SAMPLE_LANES")) == 0);
     const int passes_total = opt.samples_per_pixel / opt.samples_per_pass;
     const int sample_lane_count = std::min(passes_total, PT_LANES);
-    const bool sample_lanes = sample_lanes_enabled && !direct && !timing && !split && lanes == 0 && opt.samples_per_pass == 1 && passes_total >= 2 &&
+    const bool sample_lanes = sample_lanes_enabled && !direct && !timing && lanes == 0 && opt.samples_per_pass == 1 && passes_total >= 2 &&
                               n * (size_t)sample_lane_count * 224u <= ((size_t)8 << 30);
     if (int rc = ensure_buffers(sample_lanes ? n * (size_t)sample_lane_count : n, targets.diffuse || targets.reflection)) return rc;
     PathBuffers& pb = impl->pb;
@@ -916,8 +774,6 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // ... which exist twice: at IEEE fp32 here and, the default, at the accuracy Vulkan asks of the reference's GLSL (shade_fast.hip)
     static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
     const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;
-    const bool top = TR_BVH4 && sv.treetop != nullptr;   // trace blocks keep the top of the tree in LDS
-    if (split && !direct && !pb.surf) HIPCHK(hipMalloc(&pb.surf, impl->capacity * 5 * 16));
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
     // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
     // want different resources.  Two ways to fill the gaps, both bit-neutral:
@@ -1000,8 +856,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             LP.rng_sample = shard_sample_base + shard_sample_stride * LP.previous_samples;
             timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
             timed(T_CLOSEST, stream, [&] {
-                auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
-                                : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>);
+                auto kc = count ? k_trace_closest<true, false> : k_trace_closest<false, false>;
                 hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, 0, (const uint*)nullptr, lb.bounce);
             });
             for (int smp = 0; smp < opt.samples_per_pass; ++smp) {
@@ -1066,9 +921,6 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             const size_t o = (size_t)lane * n;
             lb.org_pdf += o; lb.dir_reg += o; lb.atten_alpha += o; lb.diffuse += o; lb.reflection += o; lb.plobes += o; lb.first_mat += o; lb.first_emis += o;
             lb.rng += o; lb.misc += o; lb.hit += o;
-#if TR_OCC_CACHE
-            lb.occ += o;
-#endif
         }
         c.blocks_all = (c.LP.n_ids + KB - 1) / KB;
         // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
@@ -1102,19 +954,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     uint* bc = lb.bounce + BC_STRIDE * bounce;
                     if (fused && bounce > 0) {
                         // closest(b) together with shadow(b - 1): one launch, one tail
-                        hipLaunchKernelGGL(top ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
+                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
-                            // TRHIP_PACKET=1: the primary rays of a frame travel together (8 x 8 pixel tiles per wave): one walk per wave
-                            static const bool packet = getenv("TRHIP_PACKET") && atoi(getenv("TRHIP_PACKET")) != 0;
-                            if (packet && bounce == 0 && !top) {
-                                if (count) hipLaunchKernelGGL(k_trace_primary<true>, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bc);
-                                else hipLaunchKernelGGL(k_trace_primary<false>, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bc);
-                                return;
-                            }
-                            auto kc = count ? (top ? k_trace_closest<true, false, true> : k_trace_closest<true, false, false>)
-                                            : (timing ? (top ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)
-                                                      : (top ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>));
+                            auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
                             hipLaunchKernelGGL(kc, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
                         });
                     }
@@ -1125,28 +968,16 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 2048u;
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
                         static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
-                        const bool last = last_variant && bounce == opt.max_bounces - 1 && !split;
-                        if (cli_set && shade_fast && !split) launch_shade_fast(count, last, blocks_s, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else if (split) {
-                            hipLaunchKernelGGL(k_surface, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, q, bc);
-                            if (count) hipLaunchKernelGGL((k_shade<true, true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else hipLaunchKernelGGL((k_shade<false, true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        }
+                        const bool last = last_variant && bounce == opt.max_bounces - 1;
+                        if (cli_set && shade_fast) launch_shade_fast(count, last, blocks_s, ls, sv, LP, lb, bounce, q, bc, qn);
                         else if (last) {
-                            if (count) hipLaunchKernelGGL((k_shade<true, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else if (cli_set) hipLaunchKernelGGL((k_shade<false, true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                            else hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                         }
-                        else if (count) hipLaunchKernelGGL((k_shade<true, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else hipLaunchKernelGGL((k_shade<false, false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        static const int reorder = getenv("TRHIP_REORDER") ? atoi(getenv("TRHIP_REORDER")) : 0;
-                        if (reorder > 0 && bounce < opt.max_bounces - 1) {
-                            const uint rb = std::max(1u, std::min(blocks_all / (uint)reorder, 2048u));
-                            if (reorder >= 16) hipLaunchKernelGGL(k_reorder_queue<16>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
-                            else if (reorder >= 4) hipLaunchKernelGGL(k_reorder_queue<4>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
-                            else hipLaunchKernelGGL(k_reorder_queue<1>, dim3(rb), dim3(KB), 0, ls, lb, bc + BC_STRIDE + BC_QUEUE, qn);
-                        }
+                        else if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        else hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
@@ -1158,7 +989,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                             ss = impl->side;
                         }
                         timed(T_SHADOW, ss, [&] {
-                            auto ks = count ? (top ? k_trace_shadow<true, true> : k_trace_shadow<true, false>) : (top ? k_trace_shadow<false, true> : k_trace_shadow<false, false>);
+                            auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
                             // on the side stream the launch runs next to closest(b + 1) of the same lane: its quad tails spill into
                             // the second region, not into the slices the closest-hit waves are using
                             PathBuffers sb = lb;

@@ -36,11 +36,7 @@ struct PathBuffers {
     // per lane and bounce b (BC_STRIDE words apart): live paths entering b, shadow rays of b, work cursors of the closest-hit /
     // shadow kernel of b (BC_*).  Zeroed by k_raygen; nothing has to be rotated between bounces.
     uint* bounce;
-    f4* surf;         // TRHIP_SHADE_SPLIT: 5 f4 per path, what k_surface hands to k_shade (see SurfRecord below); null otherwise
     int* qspill;      // deep stack entries of the quad-cooperative tail of the closest-hit waves (trace_quad.h): 16 * TR_QSPILL words per wave of a launch
-#if TR_OCC_CACHE
-    uint* occ;        // experiment: leaf slot of the opaque triangle that occluded the path's previous shadow ray, ~0 for none
-#endif
     uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
 };
 
@@ -243,37 +239,9 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
     else l.transmission = 0;
 }
 
-// The split form of a bounce (TRHIP_SHADE_SPLIT=1): k_surface does the gathers of get_intersection_info for surface hits -
-// indices, three vertices, the instance record, up to four texture taps - at high occupancy and leaves what evaluate_ray
-// needs of the result in five float4 per path; k_shade<.., true> reads that record instead of calling shade_surface.
-//   0: pos.xyz, tri_light_pdf   1: hard_normal.xyz, metallic   2: mapped_normal.xyz, roughness
-//   3: albedo.rgb, transmittance   4: emission.rgb, +-material ior (negative: the ray is inside, ior_in = ior, ior_out = 1)
-TR_DEV void store_surface(f4* surf, size_t n, uint id, const SurfacePoint& v, const SampledMaterial& m) {
-    surf[id] = F4(v.pos, v.tri_light_pdf);
-    surf[n + id] = F4(v.hard_normal, m.metallic);
-    surf[2 * n + id] = F4(v.mapped_normal, m.roughness);
-    surf[3 * n + id] = F4(F3(m.albedo), m.transmittance);
-    surf[4 * n + id] = F4(m.emission, m.ior_in != 1.0f || m.ior_out == 1.0f ? -m.ior_in : m.ior_out);
-}
-TR_DEV void load_surface(const f4* surf, size_t n, uint id, SurfacePoint& v, SampledMaterial& m) {
-    const f4 a = surf[id], b = surf[n + id], c = surf[2 * n + id], d = surf[3 * n + id], e = surf[4 * n + id];
-    v.pos = F3(a); v.tri_light_pdf = a.w;
-    v.hard_normal = F3(b); m.metallic = b.w;
-    v.mapped_normal = F3(c); v.smooth_normal = F3(c); m.roughness = c.w;
-    m.albedo = F4(F3(d), 1.0f); m.transmittance = d.w;
-    m.emission = F3(e);
-    if (__float_as_uint(e.w) >> 31) { m.ior_in = -e.w; m.ior_out = 1.0f; }
-    else { m.ior_in = 1.0f; m.ior_out = e.w; }
-    const float f0 = (m.ior_out - m.ior_in) / (m.ior_out + m.ior_in);      // as shade_surface ends (scene.glsl:150-151)
-    m.f0 = f0 * f0;
-}
-
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
 #ifndef TR_SHADE_WAVES
 #define TR_SHADE_WAVES 3
-#endif
-#ifndef TR_SHADE2_WAVES
-#define TR_SHADE2_WAVES 4      // waves per SIMD asked for the half of the split bounce that does no gathering
 #endif
 #ifndef TR_SHADE_LAST_WAVES
 #define TR_SHADE_LAST_WAVES 5   // the last bounce only collects emission: no light or BSDF sampling, no queue appends
@@ -298,8 +266,8 @@ static bool is_cli_default_set(const trhip_pt_options& o) {
            o.use_white_albedo_on_first_bounce == 0 && o.transparent_background == 0 && o.pre_transformed_vertices == 0;
 }
 
-template <bool COUNT, bool SPLIT, bool LAST, bool CLI = false>
-__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2_WAVES : TR_SHADE_WAVES)) void k_shade(SceneView sv, PtParams P_, PathBuffers pb, int bounce, const uint* queue,
+template <bool COUNT, bool LAST, bool CLI = false>
+__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P_, PathBuffers pb, int bounce, const uint* queue,
                                               uint* bc, uint* next_queue) {
     PtParams P = P_;
     if (CLI) pin_cli_defaults(P);
@@ -350,8 +318,7 @@ __global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : (SPLIT ? TR_SHADE2
             if (h.x >= 0) {
                 surface = true;
                 if (COUNT) surf++;
-                if (SPLIT) load_surface(pb.surf, P.n_launch, id, v, mat);
-                else shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, CLI);
+                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, CLI);
                 mat.albedo.w = 1.0f;
                 if (P.nee_tri) {
                     tri_pdf = v.tri_light_pdf;

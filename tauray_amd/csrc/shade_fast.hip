@@ -21,11 +21,11 @@ namespace tr {
 void launch_shade_fast(bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
                        const uint* queue, uint* bc, uint* next_queue) {
     if (last) {
-        if (count) hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
-        else hipLaunchKernelGGL((k_shade<false, false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        if (count) hipLaunchKernelGGL((k_shade<true, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        else hipLaunchKernelGGL((k_shade<false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
     } else {
-        if (count) hipLaunchKernelGGL((k_shade<true, false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
-        else hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        if (count) hipLaunchKernelGGL((k_shade<true, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
     }
 }
 

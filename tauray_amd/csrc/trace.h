@@ -21,9 +21,6 @@ namespace tr {
                            // thin end of a wave, 16 after it; re-measured on the static-build tree: 12 / 16 / 24 / 32 = 3.89 / 3.85 /
                            // 3.81 / 3.79 ms per frame, and 3 / 5 / 6 eighths of the live lanes instead of half: 3.84 / 3.84 / 3.88
 #endif
-#ifndef TR_OCC_CACHE
-#define TR_OCC_CACHE 0     // 1: a shadow ray tests the opaque triangle that occluded the path's previous shadow ray before it walks the tree
-#endif
 #ifndef TR_VOTE_SHADOW_WAVE
 #define TR_VOTE_SHADOW_WAVE 16   // the same vote in the per-lane loop of trace_shadow_wave4 (0: none); 8 / 16 measured: -1 ... -2 % shadow time
 #endif
@@ -103,24 +100,6 @@ TR_DEV bool tri_intersect(const RayPre& r, f3 v0, f3 v1, f3 v2, float tmin, floa
     return true;
 }
 
-// Conservative slab test; returns entry distance in tnear.
-TR_DEV bool box_intersect(const RayPre& r, const float* lo, const float* hi, float tmin, float tmax, float& tnear) {
-    float tx0 = (lo[0] - r.org.x) * r.inv_dir.x, tx1 = (hi[0] - r.org.x) * r.inv_dir.x;
-    float ty0 = (lo[1] - r.org.y) * r.inv_dir.y, ty1 = (hi[1] - r.org.y) * r.inv_dir.y;
-    float tz0 = (lo[2] - r.org.z) * r.inv_dir.z, tz1 = (hi[2] - r.org.z) * r.inv_dir.z;
-    // near / far by the direction's sign, not by comparing: 0 * inf = NaN (origin on a plane of an axis the ray does not move
-    // along) must leave the axis unconstrained, and min / max would order a NaN against -inf the wrong way round
-    const bool sx = r.nox & 16u, sy = r.noy & 16u, sz = r.noz & 16u;
-    float nx = sx ? tx1 : tx0, fx = sx ? tx0 : tx1;
-    float ny = sy ? ty1 : ty0, fy = sy ? ty0 : ty1;
-    float nz = sz ? tz1 : tz0, fz = sz ? tz0 : tz1;
-    // fminf/fmaxf below drop NaNs
-    float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-    float t1 = fminf(fminf(fminf(fx, fy), fz), tmax) * TR_SLAB_PAD;
-    tnear = t0;
-    return t0 <= t1;
-}
-
 // Per-lane traversal stack: first TR_LDS_STACK entries in LDS, the rest in a private spill array.
 // `sp` must stay in a VGPR and the LDS access must stay a ds_read/ds_write: the spill array is therefore a separate
 // local (a struct member array drags the whole struct, sp included, into scratch) and pop() reads LDS
@@ -187,146 +166,6 @@ TR_DEV float alpha_cutoff_hash(uint seed, int instance_id, int primitive_id) {
     return (float)pcg(h) * 2.3283064365386963e-10f;
 }
 
-// Closest hit over triangles (+ sphere lights).  ALPHA_MODE 0: stochastic alpha keyed by `seed`
-// (shader/rt_common.rahit:15-24); 1: fixed cutoff 1e-4 (shader/rt_feature.rahit:17).
-template <int ALPHA_MODE, bool COUNT>
-TR_DEV void trace_closest(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                          int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
-    hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
-    float best_t = tmax;
-    bool found = false;
-    uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
-    RayPre r = make_ray(org, dir);
-    // A ray with a non-finite origin/direction or a zero direction is outside traceRayEXT's contract; the reference
-    // produces one when a refraction sample fails at bounce 0 (ggx.glsl:343-348 sets out_dir = vec3(0)).  It is defined
-    // here as a miss; without this guard a zero direction passes the slab test of every box on its positive side.
-    const bool finite_ray = ray_is_finite(org, dir);
-    if (sv.tri_count > 0 && finite_ray) {
-        LaneStack stk;
-        int spill[TR_SPILL_STACK];
-        stk.init(lds_stack);
-        int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
-        while (true) {
-#if TR_VOTE > 0
-            // wave vote: run the (expensive) triangle branch only when enough lanes hold a leaf; leaf lanes wait otherwise
-            const bool at_leaf = node < 0;
-            const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
-            const bool leaf_phase = n_leaf >= TR_VOTE || n_leaf == n_all;
-            if (at_leaf != leaf_phase) continue;
-#endif
-            if (node >= 0) {
-                const BvhNode n = sv.nodes[node];
-                if (COUNT) st.nodes++;
-                float t0, t1;
-                bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, best_t, t0);
-                bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, best_t, t1);
-                if (h0 && h1) {
-                    bool first0 = t0 <= t1;
-                    stk.push(spill, first0 ? n.child1 : n.child0);
-                    if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
-                    node = first0 ? n.child0 : n.child1;
-                    continue;
-                } else if (h0) { node = n.child0; continue; }
-                else if (h1) { node = n.child1; continue; }
-            } else {
-                const TriRecord tr = sv.tris[~node];
-                if (COUNT) st.tris++;
-                float t, bu, bv;
-                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-                if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) {
-                    const uint inst = tr.inst_flags & 0x7FFFFFFFu;
-                    const bool closer = t < best_t ||
-                        (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
-                    if (closer && t < tmax) {
-                        bool accept = true;
-                        if (tr.inst_flags & 0x80000000u) {
-                            if (COUNT) st.alpha++;
-                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
-                            float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
-                            accept = !(a <= cutoff);   // is_material_skippable (shader/rt.glsl:136-144)
-                        }
-                        if (accept) {
-                            best_t = t; found = true; best_inst = inst; best_prim = tr.prim;
-                            hit.instance_id = (int)inst; hit.primitive_id = (int)tr.prim; hit.u = bu; hit.v = bv;
-                        }
-                    }
-                }
-            }
-            if (stk.sp == 0) break;
-            node = stk.pop(spill);
-        }
-        overflow += stk.overflow;
-    }
-    if (include_lights && finite_ray) {
-        // rt_common_point_light.rint:11-17 / .rchit:10-15, shader/rt_common.glsl:36-51
-        for (uint i = 0; i < sv.point_light_count; ++i) {
-            const PointLight& pl = sv.point_lights[i];
-            float radius = pl.radius;
-            if (radius == 0.0f) continue;
-            f3 oc = org - pl.pos;
-            float a = dot(dir, dir);
-            float b = 2.0f * dot(oc, dir);
-            float c = dot(oc, oc) - radius * radius;
-            float disc = b * b - 4.0f * a * c;
-            if (disc < 0) continue;
-            float h = (-b - sqrtf(disc)) / (2.0f * a);
-            if (h > 0 && h > tmin && h < best_t) {
-                best_t = h; found = true;
-                hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = h; hit.v = 0;
-            }
-        }
-    }
-    hit.t = found ? best_t : -1.0f;
-}
-
-// shadow_ray (shader/path_tracer.glsl:35-52) + rt_common_shadow.rahit/.rchit: product of (1 - alpha)
-// over non-opaque hits, 0 on the first opaque hit; lights are excluded (mask 0xFD).
-template <bool COUNT>
-TR_DEV float trace_shadow(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st,
-                          int& overflow) {
-    float visibility = 1.0f;
-    if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
-    RayPre r = make_ray(org, dir);
-    LaneStack stk;
-    int spill[TR_SPILL_STACK];
-    stk.init(lds_stack);
-    int node = sv.node_count > 0 ? 0 : -1;
-    while (true) {
-#ifdef TR_VOTE_SHADOW
-        const bool at_leaf = node < 0;
-        const int n_leaf = __popcll(__ballot(at_leaf)), n_all = __popcll(__ballot(true));
-        const bool leaf_phase = n_leaf >= TR_VOTE_SHADOW || n_leaf == n_all;
-        if (at_leaf != leaf_phase) continue;
-#endif
-        if (node >= 0) {
-            const BvhNode n = sv.nodes[node];
-            if (COUNT) st.nodes++;
-            float t0, t1;
-            bool h0 = box_intersect(r, n.lo0, n.hi0, tmin, tmax, t0);
-            bool h1 = box_intersect(r, n.lo1, n.hi1, tmin, tmax, t1);
-            if (h0 && h1) { stk.push(spill, n.child1); node = n.child0; continue; }
-            else if (h0) { node = n.child0; continue; }
-            else if (h1) { node = n.child1; continue; }
-        } else {
-            const TriRecord tr = sv.tris[~node];
-            if (COUNT) st.tris++;
-            float t, bu, bv;
-            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
-                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
-                if (COUNT) st.alpha++;
-                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
-                visibility *= 1.0f - alpha;
-                if (visibility == 0.0f) break;
-            }
-        }
-        if (stk.sp == 0) break;
-        node = stk.pop(spill);
-    }
-    overflow += stk.overflow;
-    return visibility;
-}
-
 // =====================================================================================================================
 // 4-wide fp32 BVH: half the dependent node fetches of the binary tree for about the same box-test arithmetic.
 struct Hit4 { float t[4]; int c[4]; };
@@ -336,89 +175,10 @@ struct Hit4 { float t[4]; int c[4]; };
 // one compare.  NaNs (0 * inf: origin on a plane of an axis the ray does not move along) are dropped by min / max, i.e.
 // that axis does not constrain the interval.  Empty slots hold an inverted infinite box: their near distance is +inf (or
 // their far distance -inf) for every ray, so they never pass and need no test of their own.
-template <bool TOP>
-TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* top, int node, float tmin, float tmax, Hit4& h) {
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h) {
     f4 nxv, fxv, nyv, fyv, nzv, fzv;
     int c0, c1, c2, c3;
-    if (TOP && (node & TR_TOP_FLAG)) {
-        // a treetop slot: the seven rows come out of LDS (plane-major, 16 bytes per slot: conflict-free for any mix of slots)
-        const char* lb = reinterpret_cast<const char*>(top);
-        const uint s = ((uint)node & 0xFFu) << 4;
-        // opaque copies: the six plane offsets are loop invariants the compiler would otherwise keep in six registers
-        // (and spill, in the fused kernel); a multiply-add per plane and visit is cheaper
-        uint nox = r.nox, noy = r.noy, noz = r.noz;
-        asm volatile("" : "+v"(nox), "+v"(noy), "+v"(noz));
-        uint ax = nox * TR_TOP_SLOTS + s, ay = noy * TR_TOP_SLOTS + s, az = noz * TR_TOP_SLOTS + s;
-        uint bx = (nox ^ 16u) * TR_TOP_SLOTS + s, by = (noy ^ 16u) * TR_TOP_SLOTS + s, bz = (noz ^ 16u) * TR_TOP_SLOTS + s;
-        nxv = *reinterpret_cast<const f4*>(lb + ax); fxv = *reinterpret_cast<const f4*>(lb + bx);
-        nyv = *reinterpret_cast<const f4*>(lb + ay); fyv = *reinterpret_cast<const f4*>(lb + by);
-        nzv = *reinterpret_cast<const f4*>(lb + az); fzv = *reinterpret_cast<const f4*>(lb + bz);
-        const int4 ch = *reinterpret_cast<const int4*>(lb + 96u * TR_TOP_SLOTS + s);
-        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
-        // pins the LDS reads: merged with the other branch they would become flat loads through a selected pointer
-        asm volatile("" : "+v"(nxv.x), "+v"(fxv.x), "+v"(nyv.x), "+v"(fyv.x), "+v"(nzv.x), "+v"(fzv.x), "+v"(c0));
-    }
-#if TR_QNODES == 2
-    else {
-        // 64-byte quantised node, decode folded into the slab test: t = q * (scale / d) + (origin - o) / d per plane, one conversion
-        // and one multiply-add where the fp32 node has a subtraction and a multiplication.  scale / d is exact (a power of two);
-        // (origin - o) / d carries two roundings relative to its own size, so it is moved outwards by 2^-22 of its size - the
-        // box the test sees contains the exact quantised box, which contains the fp32 box (k_quantize4 checks that in double).
-        const char* base = reinterpret_cast<const char*>(nodes);
-        const uint t = (uint)node << 6;
-        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
-        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 16);
-        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
-        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
-        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
-        const float ax = __uint_as_float((hd.w & 0xFFu) << 23) * r.inv_dir.x, ay = __uint_as_float((hd.w & 0xFF00u) << 15) * r.inv_dir.y,
-                    az = __uint_as_float((hd.w & 0xFF0000u) << 7) * r.inv_dir.z;
-        const float bx = (__uint_as_float(hd.x) - r.org.x) * r.inv_dir.x, by = (__uint_as_float(hd.y) - r.org.y) * r.inv_dir.y,
-                    bz = (__uint_as_float(hd.z) - r.org.z) * r.inv_dir.z;
-        const float K = 2.384185791015625e-07f;      // 2^-22
-        const float bnx = __builtin_fmaf(-K, __builtin_fabsf(bx), bx), bfx = __builtin_fmaf(K, __builtin_fabsf(bx), bx);
-        const float bny = __builtin_fmaf(-K, __builtin_fabsf(by), by), bfy = __builtin_fmaf(K, __builtin_fabsf(by), by);
-        const float bnz = __builtin_fmaf(-K, __builtin_fabsf(bz), bz), bfz = __builtin_fmaf(K, __builtin_fabsf(bz), bz);
-        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
-        const uint qnx = gx ? p0.y : p0.x, qfx = gx ? p0.x : p0.y, qny = gy ? p0.w : p0.z, qfy = gy ? p0.z : p0.w, qnz = gz ? p1.y : p1.x, qfz = gz ? p1.x : p1.y;
-#define TR_QB(w, k) (float)(((w) >> (8 * (k))) & 0xFFu)
-#define TR_QSLAB(k) { \
-        const float tx0 = __builtin_fmaf(TR_QB(qnx, k), ax, bnx), tx1 = __builtin_fmaf(TR_QB(qfx, k), ax, bfx); \
-        const float ty0 = __builtin_fmaf(TR_QB(qny, k), ay, bny), ty1 = __builtin_fmaf(TR_QB(qfy, k), ay, bfy); \
-        const float tz0 = __builtin_fmaf(TR_QB(qnz, k), az, bnz), tz1 = __builtin_fmaf(TR_QB(qfz, k), az, bfz); \
-        const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin)); \
-        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD; \
-        h.t[k] = t0 <= t1 ? t0 : __builtin_huge_valf(); }
-        TR_QSLAB(0) TR_QSLAB(1) TR_QSLAB(2) TR_QSLAB(3)
-        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-        h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
-        return;
-    }
-#elif TR_QNODES
-    else {
-        // 64-byte quantised node (common.h Bvh4NodeQ): header, children, 6 x 4 plane bytes in four loads; planes reconstructed as
-        // origin + q * scale (one rounding, the same the builder's conservative choice of q assumed)
-        const char* base = reinterpret_cast<const char*>(nodes);
-        const uint t = (uint)node << 6;
-        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
-        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 16);
-        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
-        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
-        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
-        const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
-        const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
-        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
-        const uint qnx = gx ? p0.y : p0.x, qfx = gx ? p0.x : p0.y, qny = gy ? p0.w : p0.z, qfy = gy ? p0.z : p0.w, qnz = gz ? p1.y : p1.x, qfz = gz ? p1.x : p1.y;
-#define TR_QP(w, k, s, o) __builtin_fmaf((float)(((w) >> (8 * (k))) & 0xFFu), s, o)
-        nxv = f4{TR_QP(qnx, 0, sx, ox), TR_QP(qnx, 1, sx, ox), TR_QP(qnx, 2, sx, ox), TR_QP(qnx, 3, sx, ox)};
-        fxv = f4{TR_QP(qfx, 0, sx, ox), TR_QP(qfx, 1, sx, ox), TR_QP(qfx, 2, sx, ox), TR_QP(qfx, 3, sx, ox)};
-        nyv = f4{TR_QP(qny, 0, sy, oy), TR_QP(qny, 1, sy, oy), TR_QP(qny, 2, sy, oy), TR_QP(qny, 3, sy, oy)};
-        fyv = f4{TR_QP(qfy, 0, sy, oy), TR_QP(qfy, 1, sy, oy), TR_QP(qfy, 2, sy, oy), TR_QP(qfy, 3, sy, oy)};
-        nzv = f4{TR_QP(qnz, 0, sz, oz), TR_QP(qnz, 1, sz, oz), TR_QP(qnz, 2, sz, oz), TR_QP(qnz, 3, sz, oz)};
-        fzv = f4{TR_QP(qfz, 0, sz, oz), TR_QP(qfz, 1, sz, oz), TR_QP(qfz, 2, sz, oz), TR_QP(qfz, 3, sz, oz)};
-    }
-#else
-    else {
+    {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = (uint)node << 7;
         uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
@@ -431,7 +191,6 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
         const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
         c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
     }
-#endif
     const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
     const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
 #pragma unroll
@@ -449,56 +208,15 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, const float* 
     h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
 }
 
-#if TR_BVH8
-// Eight children of node `node`: entry distances (huge = missed) and references.  TR_BVH8 = 1: two fp32 halves (lines 2n, 2n + 1);
-// TR_BVH8 = 2: one quantised line (common.h Bvh8NodeQ).
-template <bool TOP>
-TR_DEV void box8_intersect(const RayPre& r, const SceneView& sv, const float* top, int node, float tmin, float tmax, float* ht, int* hc) {
-#if TR_BVH8 == 2
-    // the quantised line: planes reconstructed first (origin + q * scale, one rounding - what k_quantize8 checked), then the fp32 slab test.
-    // (The decode folded into the slab test, as TR_QNODES = 2 has it, was tried here too: its NaNs for rays that start on a plane of the
-    // node frame make some shadow rays of the path tracer visit whole subtrees - 1.8 s per frame - although every frame stays the same bits.)
-    const char* base = reinterpret_cast<const char*>(sv.nodesq);
-    const uint t = (uint)node << 7;
-    const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
-    const int4 ca = *reinterpret_cast<const int4*>(base + (size_t)t + 16), cb = *reinterpret_cast<const int4*>(base + (size_t)t + 32);
-    const uint4 px = *reinterpret_cast<const uint4*>(base + (size_t)t + 48), py = *reinterpret_cast<const uint4*>(base + (size_t)t + 64),
-                pz = *reinterpret_cast<const uint4*>(base + (size_t)t + 80);
-    const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
-    const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
-    const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;      // near plane = hi
-    const uint qnx[2] = {gx ? px.z : px.x, gx ? px.w : px.y}, qfx[2] = {gx ? px.x : px.z, gx ? px.y : px.w};
-    const uint qny[2] = {gy ? py.z : py.x, gy ? py.w : py.y}, qfy[2] = {gy ? py.x : py.z, gy ? py.y : py.w};
-    const uint qnz[2] = {gz ? pz.z : pz.x, gz ? pz.w : pz.y}, qfz[2] = {gz ? pz.x : pz.z, gz ? pz.y : pz.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int w = k >> 2, sh = 8 * (k & 3);
-        const float tx0 = (__builtin_fmaf((float)((qnx[w] >> sh) & 0xFFu), sx, ox) - r.org.x) * r.inv_dir.x, tx1 = (__builtin_fmaf((float)((qfx[w] >> sh) & 0xFFu), sx, ox) - r.org.x) * r.inv_dir.x;
-        const float ty0 = (__builtin_fmaf((float)((qny[w] >> sh) & 0xFFu), sy, oy) - r.org.y) * r.inv_dir.y, ty1 = (__builtin_fmaf((float)((qfy[w] >> sh) & 0xFFu), sy, oy) - r.org.y) * r.inv_dir.y;
-        const float tz0 = (__builtin_fmaf((float)((qnz[w] >> sh) & 0xFFu), sz, oz) - r.org.z) * r.inv_dir.z, tz1 = (__builtin_fmaf((float)((qfz[w] >> sh) & 0xFFu), sz, oz) - r.org.z) * r.inv_dir.z;
-        const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin));
-        const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
-        ht[k] = t0 <= t1 ? t0 : __builtin_huge_valf();
-    }
-    int c0 = ca.x, c1 = ca.y, c2 = ca.z, c3 = ca.w, c4 = cb.x, c5 = cb.y, c6 = cb.z, c7 = cb.w;
-    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));
-    hc[0] = c0; hc[1] = c1; hc[2] = c2; hc[3] = c3; hc[4] = c4; hc[5] = c5; hc[6] = c6; hc[7] = c7;
-#else
-    Hit4 h0, h1;
-    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, 2 * node, tmin, tmax, h0);
-    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, 2 * node + 1, tmin, tmax, h1);
-    for (int k = 0; k < 4; ++k) { ht[k] = h0.t[k]; hc[k] = h0.c[k]; ht[4 + k] = h1.t[k]; hc[4 + k] = h1.c[k]; }
-#endif
-}
-#endif
 
 #define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
                        h.t[a] = sw ? tb : ta; h.t[b] = sw ? ta : tb; h.c[a] = sw ? cb : ca; h.c[b] = sw ? ca : cb; }
 
-// `top`: the block's LDS copy of the treetop (TOP = true; the traversal then starts at treetop slot 0) or unused.
-template <int ALPHA_MODE, bool COUNT, bool TOP = false>
+// Closest hit over triangles (+ sphere lights), one ray per lane.  ALPHA_MODE 0: stochastic alpha keyed by `seed`
+// (shader/rt_common.rahit:15-24); 1: fixed cutoff 1e-4 (shader/rt_feature.rahit:17).
+template <int ALPHA_MODE, bool COUNT>
 TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                           int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow, const float* top = nullptr) {
+                           int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow) {
     hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
     float best_t = tmax;
     bool found = false;
@@ -509,7 +227,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
         LaneStack stk;
         int spill[TR_SPILL_STACK];
         stk.init(lds_stack);
-        int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+        int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
         while (true) {
 #if TR_VOTE > 0
             const bool at_leaf = node < 0;
@@ -524,45 +242,9 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     else st.ph_tri++;
                 }
             }
-#if TR_BVH8
-            if (node >= 0) {
-                float ht[8];
-                int hc[8];
-                box8_intersect<TOP>(r, sv, top, node, tmin, best_t, ht, hc);
-                if (COUNT) st.nodes++;
-#if defined(TR_BVH8_NEAREST_ONLY)
-                // no sort: the nearest child is entered, the others are pushed in slot order
-                float bt = __builtin_huge_valf(); int bc = 0x7FFFFFFF;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (ht[k] < __builtin_huge_valf()) {
-                        const bool nearer = ht[k] < bt;
-                        const int out = nearer ? bc : hc[k];
-                        if (nearer) { bt = ht[k]; bc = hc[k]; }
-                        if (out != 0x7FFFFFFF) stk.push(spill, out);
-                    }
-                }
-                if (bc != 0x7FFFFFFF) { if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp); node = bc; continue; }
-            } else {
-#else
-#define TR_CE8(a, b) { const bool sw = ht[b] < ht[a]; const float ta = ht[a], tb = ht[b]; const int ca = hc[a], cb = hc[b]; \
-                       ht[a] = sw ? tb : ta; ht[b] = sw ? ta : tb; hc[a] = sw ? cb : ca; hc[b] = sw ? ca : cb; }
-                TR_CE8(0, 1) TR_CE8(2, 3) TR_CE8(4, 5) TR_CE8(6, 7) TR_CE8(0, 2) TR_CE8(1, 3) TR_CE8(4, 6) TR_CE8(5, 7) TR_CE8(1, 2) TR_CE8(5, 6)
-                TR_CE8(0, 4) TR_CE8(3, 7) TR_CE8(1, 5) TR_CE8(2, 6) TR_CE8(1, 4) TR_CE8(3, 6) TR_CE8(2, 4) TR_CE8(3, 5) TR_CE8(3, 4)
-#undef TR_CE8
-                if (ht[0] < __builtin_huge_valf()) {
-#pragma unroll
-                    for (int k = 7; k >= 1; --k) if (ht[k] < __builtin_huge_valf()) stk.push(spill, hc[k]);
-                    if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
-                    node = hc[0];
-                    continue;
-                }
-            } else {
-#endif
-#else
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, best_t, h);
+                box4_intersect(r, sv.nodes4, node, tmin, best_t, h);
                 if (COUNT) st.nodes++;
                 TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                 if (h.t[0] < __builtin_huge_valf()) {
@@ -574,7 +256,6 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     continue;
                 }
             } else {
-#endif
                 const TriRecord tr = sv.tris[~node];
                 if (COUNT) st.tris++;
                 float t, bu, bv;
@@ -624,36 +305,23 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     hit.t = found ? best_t : -1.0f;
 }
 
-template <bool COUNT, bool TOP = false>
-TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow,
-                           const float* top = nullptr) {
+// shadow_ray (shader/path_tracer.glsl:35-52) + rt_common_shadow.rahit/.rchit: product of (1 - alpha)
+// over non-opaque hits, 0 on the first opaque hit; lights are excluded (mask 0xFD).
+template <bool COUNT>
+TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow) {
     float visibility = 1.0f;
     if (sv.tri_count == 0 || !ray_is_finite(org, dir)) return visibility;
     RayPre r = make_ray(org, dir);
     LaneStack stk;
     int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
-    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+    int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
     while (true) {
         if (node >= 0) {
             int next = 0x7FFFFFFF;
-#if TR_BVH8
-            {
-                float ht[8];
-                int hc[8];
-                box8_intersect<TOP>(r, sv, top, node, tmin, tmax, ht, hc);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (ht[k] < __builtin_huge_valf()) {
-                        if (next == 0x7FFFFFFF) next = hc[k];
-                        else stk.push(spill, hc[k]);
-                    }
-                }
-            }
-#else
             {
                 Hit4 h;
-                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
+                box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (h.t[k] < __builtin_huge_valf()) {
@@ -662,7 +330,6 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                     }
                 }
             }
-#endif
             if (COUNT) st.nodes++;
             if (next != 0x7FFFFFFF) { node = next; continue; }
         } else {
@@ -687,26 +354,5 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
 
 // LDS words per block for the per-lane stacks
 #define TR_STACK_WORDS (TR_LDS_STACK * TR_BLOCK)
-
-template <int ALPHA_MODE, bool COUNT, bool TOP = false>
-TR_DEV void trace_closest_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                              int* lds_stack, HitRecord& hit, TraceStats& st, int& overflow, const float* top = nullptr) {
-    if (TR_BVH4) trace_closest4<ALPHA_MODE, COUNT, TOP>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow, top);
-    else trace_closest<ALPHA_MODE, COUNT>(sv, org, dir, tmin, tmax, include_lights, seed, lds_stack, hit, st, overflow);
-}
-template <bool COUNT, bool TOP = false>
-TR_DEV float trace_shadow_any(const SceneView& sv, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, TraceStats& st, int& overflow,
-                              const float* top = nullptr) {
-    if (TR_BVH4) return trace_shadow4<COUNT, TOP>(sv, org, dir, tmin, tmax, lds_stack, st, overflow, top);
-    return trace_shadow<COUNT>(sv, org, dir, tmin, tmax, lds_stack, st, overflow);
-}
-
-// Copies the scene's treetop into the block's LDS (every thread of the block; ends with a barrier).
-TR_DEV void load_treetop(const SceneView& sv, float* s_top) {
-    const f4* src = sv.treetop;
-    f4* dst = reinterpret_cast<f4*>(s_top);
-    for (uint i = threadIdx.x; i < 7u * TR_TOP_SLOTS; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-}
 
 }  // namespace tr

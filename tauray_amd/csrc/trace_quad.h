@@ -25,13 +25,6 @@ namespace tr {
 #define TR_QSPILL TR_SPILL_STACK   // stack entries per quad beyond the LDS part: the per-lane loop's depth (deepest stack seen on the bench scenes: 26)
 static_assert(TR_QUAD_SWITCH <= 16, "a wave has sixteen quads");
 
-// Stack-top prefetch (experiment, TR_PREFETCH > 0): when a node phase pushes children, the one that ends up on top of the stack -
-// the next node this ray pops - is requested right away with a fire-and-forget load (global_load_lds into a per-wave dump area:
-// no destination register, nothing waits for it; one dump area per block), so that the pop finds its line in L1 / L2 instead of paying the trip to the
-// Infinity Cache behind the current node's.  1: closest-hit per-lane loop, 2: + shadow per-lane loop.
-#ifndef TR_PREFETCH
-#define TR_PREFETCH 0
-#endif
 #define TR_OWNER_WORDS 16     // LDS words per wave behind QuadCtx::owner_tab
 
 struct QuadCtx {
@@ -50,15 +43,6 @@ TR_DEV float qrot2f(float v) { return __int_as_float(qrot2(__float_as_int(v))); 
 TR_DEV int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 TR_DEV float bpermf(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
 
-TR_DEV void prefetch_ref(const SceneView& sv, int c) {
-#if TR_PREFETCH
-    __shared__ int s_dump[64];      // one dump area per block at a link-time address: M0 is a constant, no register is involved
-    const char* p = c >= 0 ? reinterpret_cast<const char*>(sv.nodes4) + ((size_t)(uint)c << 7) : reinterpret_cast<const char*>(sv.tris) + (size_t)(uint)(~c) * 48u;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(p)),
-                                     reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_dump[0]))), 4, 0, 0);
-#endif
-}
-
 TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its other lanes afterwards (no other wave is involved)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -75,37 +59,10 @@ struct QuadRay {
 };
 
 // Box of child q of `node` against the quad's ray; returns the child reference, `hit` and the entry distance.
-template <bool TOP>
-TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* top, int node, int q, float tmax, bool& hit, float& t0) {
+TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0) {
     float nx, fx, ny, fy, nz, fz;
     int c;
-    if (TOP && (node & TR_TOP_FLAG)) {
-        const char* lb = reinterpret_cast<const char*>(top);
-        const uint s = (((uint)node & 0xFFu) << 4) + ((uint)q << 2);
-        nx = *reinterpret_cast<const float*>(lb + r.nox * TR_TOP_SLOTS + s); fx = *reinterpret_cast<const float*>(lb + (r.nox ^ 16u) * TR_TOP_SLOTS + s);
-        ny = *reinterpret_cast<const float*>(lb + r.noy * TR_TOP_SLOTS + s); fy = *reinterpret_cast<const float*>(lb + (r.noy ^ 16u) * TR_TOP_SLOTS + s);
-        nz = *reinterpret_cast<const float*>(lb + r.noz * TR_TOP_SLOTS + s); fz = *reinterpret_cast<const float*>(lb + (r.noz ^ 16u) * TR_TOP_SLOTS + s);
-        c = *reinterpret_cast<const int*>(lb + 96u * TR_TOP_SLOTS + s);
-        asm volatile("" : "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz), "+v"(c));
-    }
-#if TR_QNODES == 1
-    else {
-        const char* base = reinterpret_cast<const char*>(nodes);
-        const uint t = (uint)node << 6;
-        const uint4 hd = *reinterpret_cast<const uint4*>(base + (size_t)t);
-        c = *reinterpret_cast<const int*>(base + (size_t)t + 16 + ((uint)q << 2));
-        const uint4 p0 = *reinterpret_cast<const uint4*>(base + (size_t)t + 32);
-        const uint2 p1 = *reinterpret_cast<const uint2*>(base + (size_t)t + 48);
-        const float ox = __uint_as_float(hd.x), oy = __uint_as_float(hd.y), oz = __uint_as_float(hd.z);
-        const float sx = __uint_as_float((hd.w & 0xFFu) << 23), sy = __uint_as_float((hd.w & 0xFF00u) << 15), sz = __uint_as_float((hd.w & 0xFF0000u) << 7);
-        const bool gx = r.nox & 16u, gy = r.noy & 16u, gz = r.noz & 16u;
-        const uint sh = (uint)q << 3;
-        nx = __builtin_fmaf((float)(((gx ? p0.y : p0.x) >> sh) & 0xFFu), sx, ox); fx = __builtin_fmaf((float)(((gx ? p0.x : p0.y) >> sh) & 0xFFu), sx, ox);
-        ny = __builtin_fmaf((float)(((gy ? p0.w : p0.z) >> sh) & 0xFFu), sy, oy); fy = __builtin_fmaf((float)(((gy ? p0.z : p0.w) >> sh) & 0xFFu), sy, oy);
-        nz = __builtin_fmaf((float)(((gz ? p1.y : p1.x) >> sh) & 0xFFu), sz, oz); fz = __builtin_fmaf((float)(((gz ? p1.x : p1.y) >> sh) & 0xFFu), sz, oz);
-    }
-#else
-    else {
+    {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = ((uint)node << 7) | ((uint)q << 2);
         uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
@@ -115,7 +72,6 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, const float* 
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
         c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
     }
-#endif
     // the arithmetic of box4_intersect for one child
     const float tx0 = (nx - r.org.x) * r.inv_dir.x, tx1 = (fx - r.org.x) * r.inv_dir.x;
     const float ty0 = (ny - r.org.y) * r.inv_dir.y, ty1 = (fy - r.org.y) * r.inv_dir.y;
@@ -228,9 +184,9 @@ TR_DEV void quad_inherited_leaf(int q, int& pend, QuadStack& qs, int& qnode, boo
 
 // Closest hit for the rays of one wave.  Every lane of the wave calls this (`valid` = the lane has a ray); parameters and
 // result as trace_closest4.
-template <int ALPHA_MODE, bool COUNT, bool TOP>
+template <int ALPHA_MODE, bool COUNT>
 TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir, float tmin, float tmax, bool include_lights, uint seed,
-                                int* lds_stack, const QuadCtx& qc, const float* top, HitRecord& hit, TraceStats& st, int& overflow) {
+                                int* lds_stack, const QuadCtx& qc, HitRecord& hit, TraceStats& st, int& overflow) {
     hit.instance_id = -1; hit.primitive_id = -1; hit.u = 0; hit.v = 0; hit.t = -1.0f;
     float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
     uint best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;   // none found yet
@@ -240,7 +196,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     LaneStack stk;
     int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
-    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+    int node = sv.node_count > 0 ? 0 : -1;
 
     // candidate of a triangle test against the lane's best so far (shader/rt_common.rahit:15-24 for non-opaque geometry)
     auto consider = [&](const TriRecord& tr, float t, float bu, float bv) {
@@ -282,17 +238,13 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 bool descend = false;
                 if (!at_leaf) {
                     Hit4 h;
-                    box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, best_t, h);
+                    box4_intersect(r, sv.nodes4, node, tmin, best_t, h);
                     if (COUNT) st.nodes++;
                     TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                     if (h.t[0] < __builtin_huge_valf()) {
                         if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
                         if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
-                        if (h.t[1] < __builtin_huge_valf()) { stk.push(spill, h.c[1]); if (TR_PREFETCH == 1 || TR_PREFETCH == 2) prefetch_ref(sv, h.c[1]); }
-                        if (TR_PREFETCH == 3) {      // the triangle records of the leaf children this phase found: they wait for the wave's next triangle phase
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) if (h.t[k] < __builtin_huge_valf() && h.c[k] < 0) prefetch_ref(sv, h.c[k]);
-                        }
+                        if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
                         if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                         node = h.c[0];
                         descend = true;
@@ -366,7 +318,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, TR_QUAD_NODES_OF(sv), top, qnode, q, qbest, hitb, t0);
+                const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
@@ -424,16 +376,16 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
 
 // Any-hit visibility for the shadow rays of one wave (trace_shadow4 with the quad-cooperative tail).  Every lane of the wave
 // calls this; returns the product of (1 - alpha) over the non-opaque hits, 0 after an opaque one.
-template <bool COUNT, bool TOP>
+template <bool COUNT>
 TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir, float tmin, float tmax, int* lds_stack, const QuadCtx& qc,
-                                const float* top, TraceStats& st, int& overflow, uint* occluder = nullptr) {
+                                TraceStats& st, int& overflow) {
     float visibility = 1.0f;
     bool live = valid && sv.tri_count > 0 && ray_is_finite(org, dir);
     RayPre r = make_ray(org, dir);
     LaneStack stk;
     int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
-    int node = sv.node_count > 0 ? (TOP ? TR_TOP_FLAG : 0) : -1;
+    int node = sv.node_count > 0 ? 0 : -1;
     while (true) {
         if (__popcll(__ballot(live)) <= TR_QUAD_SWITCH) break;
 #if TR_VOTE_SHADOW_WAVE > 0
@@ -451,17 +403,16 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             bool descend = false;
             if (node >= 0) {
                 Hit4 h;
-                box4_intersect<TOP>(r, TR_NODES_OF(sv), top, node, tmin, tmax, h);
+                box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
                 if (COUNT) st.nodes++;
-                int next = 0x7FFFFFFF, last = 0x7FFFFFFF;
+                int next = 0x7FFFFFFF;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (h.t[k] < __builtin_huge_valf()) {
                         if (next == 0x7FFFFFFF) next = h.c[k];
-                        else { stk.push(spill, h.c[k]); last = h.c[k]; }
+                        else stk.push(spill, h.c[k]);
                     }
                 }
-                if (TR_PREFETCH == 2 && last != 0x7FFFFFFF) prefetch_ref(sv, last);
                 if (next != 0x7FFFFFFF) { node = next; descend = true; }
             } else {
                 const TriRecord tr = sv.tris[~node];
@@ -469,7 +420,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 float t, bu, bv;
                 f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
                 if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
-                    if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; if (TR_OCC_CACHE && occluder) *occluder = (uint)~node; }
+                    if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
                     else {
                         if (COUNT) st.alpha++;
                         const float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
@@ -495,7 +446,6 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         float lvis = q == 0 ? owner_vis : 1.0f;     // the owner's product so far rides in lane 0 of the quad
         bool qlive = deal.has_ray;
         int pend = -1;
-        int qocc = -1;
         while (true) {
             int w = pend >= 0 ? 1 : 0;
             w |= qrot1(w); w |= qrot2(w);
@@ -510,7 +460,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     float t, bu, bv;
                     f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
                     if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, qtmax, t, bu, bv)) {
-                        if (!(tr.inst_flags & 0x80000000u)) { lvis = 0.0f; if (TR_OCC_CACHE) qocc = pend; }
+                        if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
                         else {
                             if (COUNT) st.alpha++;
                             lvis *= 1.0f - candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
@@ -524,7 +474,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box<TOP>(qr, TR_QUAD_NODES_OF(sv), top, qnode, q, qtmax, hitb, t0);
+                const int c = quad_child_box(qr, sv.nodes4, qnode, q, qtmax, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
@@ -539,12 +489,6 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         const float rv = bpermf(back, v);
         const int ro = bperm(back, qo);
         if (live) { visibility = rv; overflow += ro; }
-        if (TR_OCC_CACHE) {      // the opaque occluder one of the quad's lanes found (any of them, if several did in the same phase)
-            int m = qocc;
-            m = max(m, qrot1(m)); m = max(m, qrot2(m));
-            const int rocc = bperm(back, m);
-            if (live && occluder && rocc >= 0) *occluder = (uint)rocc;
-        }
     }
     overflow += stk.overflow;
     return visibility;

@@ -9,9 +9,7 @@ import sys, random
 random.seed(int(sys.argv[2]))
 for _ in range(int(sys.argv[1])):
     e = {"TRHIP_BUILDER": random.choice(["lbvh", "ploc", "ploc"]), "TRHIP_PLOC_RADIUS": random.choice(["4", "16", "64"]), "TRHIP_BVH_OPT": random.choice(["0", "2", "8"]),
-         "TRHIP_COLLAPSE": random.choice(["greedy", "cost"]), "TRHIP_NODE_LAYOUT": random.choice(["build", "dfs"]), "TRHIP_TREETOP": random.choice(["0", "0", "1"])}
-    if random.random() < 0.6:
-        e["TRHIP_PRESPLIT"] = random.choice(["5", "30", "100"])
+         "TRHIP_COLLAPSE": random.choice(["greedy", "cost"]), "TRHIP_NODE_LAYOUT": random.choice(["build", "dfs"])}
     print(" ".join(f"{k}={v}" for k, v in e.items()))
 PY
 while read -r combo; do
