@@ -71,7 +71,12 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--spp", type=int, default=1)
-    ap.add_argument("--sampler", type=int, default=0)
+    ap.add_argument("--sampler", type=int, default=0, help="0 uniform-random, 1 sobol-owen, 2 sobol-z2, 3 sobol-z3")
+    ap.add_argument("--preset", default=None, choices=["quality", "reference", "accumulation"],
+                    help="the path-tracer options of one of the reference's presets (data/presets/*.cfg: film, ray depth, regularisation, "
+                         "triangle-light mode), one sample per pixel and frame unless --spp says otherwise")
+    ap.add_argument("--general-kernels", action="store_true", help="no shading program compiled for the option set (trhip_pt_set_specialization 0): A/B")
+    ap.add_argument("--ieee-shading", action="store_true", help="shading kernels at IEEE fp32 (trhip_pt_set_shading_arithmetic 1): A/B")
     ap.add_argument("--views", type=int, default=1, help="camera-grid viewports per frame (45 = the 5x9 light field of config 5)")
     ap.add_argument("--shard", default="pixels", choices=["pixels", "views", "samples"],
                     help="what N GPUs divide: scanlines of one frame (default, the reference's strategy), viewports, or samples")
@@ -120,6 +125,23 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def stage_options(args, scene, R):
+    """The path tracer's options of this run: the command-line set of the reference with --bounces / --spp / --sampler, or one of
+    the reference's presets (tauray_amd/presets.py), which brings its own ray depth."""
+    kw = dict(max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
+    if args.preset:
+        from tauray_amd.presets import REFERENCE_PRESETS
+        kw.update(REFERENCE_PRESETS[args.preset])
+        kw["samples_per_pixel"] = args.spp
+        args.bounces = kw["max_bounces"]
+    if args.general_kernels:
+        os.environ["TRHIP_SPECIALIZE"] = "0"
+    if args.ieee_shading:
+        os.environ["TRHIP_SHADE_FAST"] = "0"
+    args.option_kw = kw
+    return R.options_for_scene(scene, **kw)
+
+
 def pmc_child(args):
     """What a counter pass profiles: the launches the roofline times - one lane, unfused, every kernel owning the chip
     (trhip_pt_set_profiling detailed timing: k_trace_closest<false, true, ..>), two frames per launch like the timed-alone run."""
@@ -129,7 +151,7 @@ def pmc_child(args):
     W, H = args.width, args.height
     scene = scenes.WORKLOADS[args.workload](W, H)
     ctx = R.Context(0)
-    opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
+    opt = stage_options(args, scene, R)
     B = max(args.frames_per_launch, 1)
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, frames_in_flight=1, frames_per_launch=B)
     rr.set_profiling(False, True)
@@ -157,7 +179,8 @@ def run_pmc_passes(args, B, dump_dir=None):
     tmp = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height),
-             "--bounces", str(args.bounces), "--spp", str(args.spp), "--sampler", str(args.sampler), "--steps", "4", "--frames-per-launch", str(B)]
+             "--bounces", str(args.bounces), "--spp", str(args.spp), "--sampler", str(args.sampler), "--steps", "4", "--frames-per-launch", str(B)] + \
+            (["--preset", args.preset] if args.preset else []) + (["--general-kernels"] if args.general_kernels else []) + (["--ieee-shading"] if args.ieee_shading else [])
     for name, counters in PMC_PASSES.items():
         d = os.path.join(tmp, name)
         cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
@@ -321,7 +344,7 @@ def main():
         gw = 9 if args.views == 45 else args.views
         scene.cameras = generate_camera_grid(scene.cameras[0], gw, args.views // gw, 0.02, 0.02, 5.0)
     ctx = R.Context(local_rank)
-    opt = R.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, samples_per_pass=1, sampler=args.sampler)
+    opt = stage_options(args, scene, R)
     strips = world > 1 and args.shard == "pixels" and args.strategy != "scanline"
     strategy = DISTRIBUTION_SHUFFLED_STRIPS if strips else DISTRIBUTION_SCANLINE
     steps = max(args.steps, MIN_TIMED_FRAMES)           # frames of every timed region
@@ -452,7 +475,11 @@ def main():
         "pipelined": {"ms_per_frame": round(elapsed_p / steps_pipelined * 1e3, 4), "frames": steps_pipelined, "frames_in_flight": args.frames_in_flight,
                       "frames_per_launch": B, "unit": "Mray/s"},
         "config": {"workload": args.workload, "triangles": scene.triangle_count, "width": W, "height": H, "bounces": args.bounces,
-                   "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][args.sampler],
+                   "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][opt.sampler],
+                   "preset": args.preset, "film": ["point", "box", "blackman-harris"][opt.film], "regularization": round(opt.regularization_gamma, 3),
+                   "tri_light_mode": ["area", "solid-angle", "hybrid"][opt.tri_light_mode],
+                   "shading_program": ("general kernels" if args.general_kernels else ("command-line set, ahead of time" if (opt.sampler == 0 and opt.film == 0 and opt.regularization_gamma == 0
+                                       and opt.tri_light_mode == 1) else "compiled for the option set (hipRTC / kernel cache)")) + (", IEEE fp32" if args.ieee_shading else ", Vulkan-grade arithmetic"),
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
@@ -577,7 +604,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as OB
         osc = OB.OracleScene(scene)
-        oopt = OB.options_for_scene(scene, max_bounces=args.bounces, samples_per_pixel=args.spp, sampler=args.sampler)
+        oopt = OB.options_for_scene(scene, **args.option_kw)
         # threads: what this process may actually run on - its affinity mask, bounded by the cgroup's CPU quota - not os.cpu_count()
         affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         quota = None

@@ -256,13 +256,29 @@ typedef struct trhip_pt_targets {
 } trhip_pt_targets;
 int trhip_pt_render_targets(trhip_pt* pt, const trhip_pt_targets* targets, uint32_t target_w, uint32_t target_h, uint32_t viewports, void* stream);
 /* Arithmetic of the shading kernel.  The reference's GLSL runs at the accuracy Vulkan asks of an implementation (SPIR-V
- * precision requirements: `/` 2.5 ULP, inversesqrt 2 ULP, sin / cos 2^-11 absolute, pow through exp2 and log2), and so does the
- * shading kernel of the reference's command-line option set here by default (csrc/shade_fast.hip: v_rcp / v_rsq / v_sqrt /
+ * precision requirements: `/` 2.5 ULP, inversesqrt 2 ULP, sin / cos 2^-11 absolute, pow through exp2 and log2), and so do the
+ * shading kernels here by default (csrc/shade_fast.hip, csrc/shade_spec.hip: v_rcp / v_rsq / v_sqrt /
  * v_sin / v_cos / v_exp / v_log).  ieee != 0: every shading kernel of this stage computes in IEEE fp32 with the C library's
  * sin / cos / pow, expression by expression like the CPU oracle - slower (1.22 instead of 0.97 ms per 1080p frame of the
  * million-triangle bench scene), for comparisons that want the last bit.  Ray traversal and the ray-triangle test are IEEE
  * fp32 in either mode: hits do not depend on it.  The environment variable TRHIP_SHADE_FAST=0 makes ieee the default. */
 int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee);
+/* Shading program of the stage.  The reference compiles a stage's options into its pipeline as #defines when the stage is built
+ * (src/path_tracer_stage.cc:30-116, shaderc at run time through src/shader_source.cc).  Here the ray generation and shading
+ * kernels exist ahead of time for the command-line option set and in a general form that reads every option as data; a stage
+ * with any other option set gets a program compiled for it the first time it renders (csrc/shade_spec.hip through hipRTC: the
+ * sampler, film filter, MIS rule, bounce and triangle-light modes, the light classes in use and the on / off state of roulette,
+ * clamping, regularisation, depth of field ... become constants; a few seconds once, then the kernel cache -
+ * trhip_kernel_cache_dir - serves it).  Same bits as the general kernels of the same arithmetic, fewer instructions.
+ * enable: 1 = specialise (the default unless TRHIP_SPECIALIZE=0), 0 = always the general kernels.  If no program can be built
+ * (no libhiprtc) the stage renders with the general kernels and says so once on stderr. */
+int trhip_pt_set_specialization(trhip_pt* pt, int enable);
+/* Compiles the shading programs of an option set into the kernel cache ahead of time, so that the first frame does not wait for
+ * the compiler: both programs (ray generation, shading) for `arch` (NULL = "gfx950"); shade_tris = the scene will have whole-triangle
+ * index spans (what trhip_scene_upload derives ShadeTri records from - true for every glTF file), ieee / count_work as in
+ * trhip_pt_set_shading_arithmetic / trhip_pt_set_profiling.  Needs no GPU and no device handle. */
+int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch);
+const char* trhip_kernel_cache_dir(void);   /* TRHIP_KERNEL_CACHE, else kernel_cache/ next to libtrhip.so, else ~/.cache/trhip; "" = none writable */
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */
 int trhip_pt_reset_counters(trhip_pt* pt);

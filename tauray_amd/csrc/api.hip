@@ -9,6 +9,7 @@
 #include "pt.h"
 #include "trace.h"
 #include "trace_quad.h"
+#include "specialize.h"
 #include "../../include/tauray_image.hh"
 #include "../../include/tauray_exr.hh"
 
@@ -668,6 +669,25 @@ int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee) {
     if (!pt) return set_error("null trhip_pt");
     pt->stage->ieee_shading = ieee ? 1 : 0;
     return 0;
+}
+int trhip_pt_set_specialization(trhip_pt* pt, int enable) {
+    if (!pt) return set_error("null trhip_pt");
+    pt->stage->specialize = enable ? 1 : 0;
+    return 0;
+}
+int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch) {
+    if (!opt) return set_error("trhip_pt_precompile: null options");
+    if (is_cli_default_set(*opt) && shade_tris) return 0;      // the ahead-of-time instances of libtrhip.so
+    SpecRequest rq{*opt, shade_tris != 0 && !opt->pre_transformed_vertices, ieee != 0, count_work != 0, false};
+    std::string why;
+    if (spec_precompile(rq, arch, &why)) return set_error("trhip_pt_precompile: " + why);
+    rq.raygen = true;
+    if (spec_precompile(rq, arch, &why)) return set_error("trhip_pt_precompile: " + why);
+    return 0;
+}
+const char* trhip_kernel_cache_dir(void) {
+    static const std::string dir = spec_cache_dir();
+    return dir.c_str();
 }
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
     if (!pt) return set_error("null trhip_pt");

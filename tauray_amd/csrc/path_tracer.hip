@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pt_kernels.h"
+#include "specialize.h"
 
 namespace tr {
 
@@ -26,45 +27,6 @@ namespace {
 #ifndef TR_SHADOW_WAVES
 #define TR_SHADOW_WAVES 8
 #endif
-
-// ---------------------------------------------------------------------------------------------------
-// path_tracer.rgen:88-101 + get_world_camera_ray (path_tracer.glsl:504-533)
-__global__ __launch_bounds__(KB) void k_raygen(SceneView sv, PtParams P, PathBuffers pb) {
-    if (blockIdx.x == 0) for (uint k = threadIdx.x; k < P.bounce_words; k += KB) pb.bounce[k] = 0;   // queue lengths and work cursors of this sample
-    uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_ids) return;
-    i += P.id_offset;
-    uint lx, ly, lz;
-    launch_coord(P.L, i, lx, ly, lz);
-    int px, py;
-    bool valid = get_pixel_pos(P.L, lx, ly, px, py);
-    u4 misc = {0, 0, i, valid ? 0u : 1u};
-    if (P.sample_in_pass == 0 && !P.fused_resolve) {
-        pb.sum_color[i] = F4(0, 0, 0, 1);
-        if (pb.sum_diffuse) { pb.sum_diffuse[i] = F4(0); pb.sum_reflection[i] = F4(0); }
-    }
-    if (!valid) { pb.misc[i] = misc; return; }
-    LocalSampler ls = init_local_sampler(u4{(uint)px, (uint)py, global_viewport(P, lz), P.rng_sample}, sample_counter_of(P, lz),
-                                         P.rng_seed, P.opt.sampler);
-    f2 cam_offset = F2(0.0f);
-    if (P.opt.film != 0) {   // control.antialiasing == 1
-        f4 r = u4_to_unit(pcg4d(ls.rs));   // generate_film_sample
-        if (P.opt.film == 1) cam_offset = F2(r.x, r.y) * 2.0f - 1.0f;
-        else cam_offset = sample_blackman_harris_concentric_disk(F2(r.x, r.y)) * 2.0f;
-        cam_offset = cam_offset * (2.0f * P.opt.film_radius);
-    }
-    f2 dof_u = F2(0.5f);
-    if (P.opt.depth_of_field) { f4 r = u4_to_unit(pcg4d(ls.rs)); dof_u = F2(r.x, r.y); }
-    f3 origin, dir;
-    get_screen_camera_ray(P.L, px, py, sv.cameras[global_viewport(P, lz)], P.opt.projection, P.opt.depth_of_field != 0, cam_offset, dof_u, origin, dir);
-    misc.x = pcg4d(ls.rs).x;      // payload.random_seed = pcg4d(lsampler.rs.seed).x  (path_tracer.glsl:384)
-    misc.y = ls.sobol_index;
-    pb.org_pdf[i] = F4(origin, 0.0f);            // bsdf_pdf = 0
-    pb.dir_reg[i] = F4(dir, 1.0f);               // regularization = 1
-    pb.atten_alpha[i] = F4(1, 1, 1, 1);          // attenuation = 1
-    pb.rng[i] = ls.rs;
-    pb.misc[i] = misc;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // The closest-hit rays of queue slots base .. base + 63 (path_tracer.glsl:387-403), one wave: trace, store the hit records of
@@ -600,8 +562,9 @@ uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strat
 
 }  // namespace
 
-void launch_shade_fast(bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
-                       const uint* queue, uint* bc, uint* next_queue);     // shade_fast.hip
+// shade_fast.hip: the ahead-of-time k_shade instances (command-line option set or general) at the accuracy Vulkan asks of the reference's GLSL
+void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
+                       const uint* queue, uint* bc, uint* next_queue);
 
 void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/distribution_strategy.cc:33-61
     if (d.strategy == 0) { w = d.size_x; h = d.size_y; }
@@ -769,11 +732,53 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         sv.vertices = scene->world_vertices; sv.spans = scene->world_spans;
     }
     const bool count = count_work != 0;
+    // Which shading program renders this stage.  The kernels exist in two arithmetics - IEEE fp32 (path_tracer.hip) and, the default,
+    // the accuracy Vulkan asks of the reference's GLSL (shade_fast.hip; trhip_pt_set_shading_arithmetic) - and, in each, as
+    //  * the ahead-of-time instances of the command-line option set (SpecCli; TRHIP_SHADE_CLI=0 switches them off),
+    //  * an instance compiled for this stage's option set the first time it renders (shade_spec.hip through specialize.cc: hipRTC,
+    //    or the kernel cache; trhip_pt_set_specialization / TRHIP_SPECIALIZE=0 switch that off),
+    //  * the general instances, which read every option from the parameter block - what renders when neither of the above applies.
+    // All three render the same bits in the same arithmetic.
     static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
-    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr;     // k_shade<.., CLI>: reads the ShadeTri records
-    // ... which exist twice: at IEEE fp32 here and, the default, at the accuracy Vulkan asks of the reference's GLSL (shade_fast.hip)
+    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr;     // k_shade<.., SpecCli>: reads the ShadeTri records
     static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
     const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;
+    static const bool specialize_env = !(getenv("TRHIP_SPECIALIZE") && atoi(getenv("TRHIP_SPECIALIZE")) == 0);
+    const SpecKernels *spec_shade = nullptr, *spec_raygen = nullptr;
+    if (!cli_set && !direct && (specialize < 0 ? specialize_env : specialize != 0)) {
+        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, false};
+        std::string why;
+        spec_shade = spec_kernels(rq, &why);
+        if (spec_shade) { rq.raygen = true; spec_raygen = spec_kernels(rq, &why); }
+        if (!spec_shade || !spec_raygen) {
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "[trhip] no specialised shading program for {%s}: %s - rendering with the general kernels\n", spec_key(rq).c_str(), why.c_str());
+            warned = true;
+            spec_shade = nullptr; spec_raygen = nullptr;
+        }
+    }
+    auto launch_raygen = [&](uint blocks, hipStream_t on, const PtParams& LP, const PathBuffers& lb) {
+        if (spec_raygen) {
+            SceneView a0 = sv; PtParams a1 = LP; PathBuffers a2 = lb;
+            void* args[] = {&a0, &a1, &a2};
+            (void)hipModuleLaunchKernel(spec_raygen->raygen, blocks, 1, 1, KB, 1, 1, 0, on, args, nullptr);
+        } else hipLaunchKernelGGL(k_raygen<SpecGeneral>, dim3(blocks), dim3(KB), 0, on, sv, LP, lb);
+    };
+    auto launch_shade = [&](bool count, bool last, uint blocks, hipStream_t on, const PtParams& LP, const PathBuffers& lb, int bounce, const uint* q, uint* bc, uint* qn) {
+        if (spec_shade) {
+            SceneView a0 = sv; PtParams a1 = LP; PathBuffers a2 = lb;
+            void* args[] = {&a0, &a1, &a2, &bounce, &q, &bc, &qn};
+            (void)hipModuleLaunchKernel(last ? spec_shade->shade_last : spec_shade->shade, blocks, 1, 1, KB, 1, 1, 0, on, args, nullptr);
+        } else if (shade_fast) launch_shade_fast(cli_set, count, last, blocks, on, sv, LP, lb, bounce, q, bc, qn);
+        else if (last) {
+            if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+            else if (cli_set) hipLaunchKernelGGL((k_shade<false, true, SpecCli>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+            else hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+        }
+        else if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+        else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, SpecCli>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+        else hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(KB), 0, on, sv, LP, lb, bounce, q, bc, qn);
+    };
     // Concurrency inside a frame.  The trace kernels are persistent and leave the chip under-filled while their last
     // waves finish, the bounce loop is a chain of dependent launches, and trace (VALU-bound) and shade (latency-bound)
     // want different resources.  Two ways to fill the gaps, both bit-neutral:
@@ -854,7 +859,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
             LP.sample_in_pass = 0;
             LP.rng_sample = shard_sample_base + shard_sample_stride * LP.previous_samples;
-            timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
+            timed(T_RAYGEN, stream, [&] { hipLaunchKernelGGL(k_raygen<SpecGeneral>, dim3(blocks_all), dim3(KB), 0, stream, sv, LP, lb); });
             timed(T_CLOSEST, stream, [&] {
                 auto kc = count ? k_trace_closest<true, false> : k_trace_closest<false, false>;
                 hipLaunchKernelGGL(kc, dim3(blocks_q), dim3(KB), 0, stream, sv, LP, lb, 0, (const uint*)nullptr, lb.bounce);
@@ -945,7 +950,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                 LP.sample_in_pass = (uint)s;
                 LP.rng_sample = shard_sample_base + shard_sample_stride * (LP.previous_samples + LP.sample_in_pass);
                 if (only == -2 || only == -1) timed(T_RAYGEN, ls, [&] {
-                    hipLaunchKernelGGL(k_raygen, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);
+                    launch_raygen(blocks_all, ls, LP, lb);
                 });
                 for (int bounce = 0; bounce < opt.max_bounces; ++bounce) {
                     if (only != -2 && only != bounce) continue;
@@ -969,15 +974,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
                         static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
                         const bool last = last_variant && bounce == opt.max_bounces - 1;
-                        if (cli_set && shade_fast) launch_shade_fast(count, last, blocks_s, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else if (last) {
-                            if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else if (cli_set) hipLaunchKernelGGL((k_shade<false, true, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                            else hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        }
-                        else if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else if (cli_set) hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
-                        else hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks_s), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, qn);
+                        launch_shade(count, last, blocks_s, ls, LP, lb, bounce, q, bc, qn);
                     });
                     if (bounce == 0 && first_hit_targets && s == opt.samples_per_pass - 1 && LP.samples_accumulated + LP.previous_samples == 0)
                         hipLaunchKernelGGL(k_first_hit_gbuffer, dim3(blocks_all), dim3(KB), 0, ls, sv, LP, lb);

@@ -1,484 +1,9 @@
-// Device code the bounce kernels share: path state, launch parameters, queue appends, light sampling and k_shade itself.
-// Included by path_tracer.hip (IEEE arithmetic, -ffp-contract=off) and by shade_fast.hip, which compiles the k_shade instances
-// of the reference's command-line option set a second time with the arithmetic a Vulkan implementation is allowed
-// (2.5-ulp division, native sqrt / sin / cos / exp2 / log2, contraction): see shade_fast.hip.
+// Device code of the frame kernels, for the ahead-of-time translation units (path_tracer.hip: IEEE arithmetic, -ffp-contract=off;
+// shade_fast.hip: the shading kernels a second time with the arithmetic a Vulkan implementation is allowed).  The traversal lives in
+// trace.h / trace_quad.h, the shading kernels in shade_kernel.h, the state they share in pt_state.h.
 #pragma once
 #include "pt.h"
 #include "trace.h"
 #include "trace_quad.h"
-
-namespace tr {
-
-constexpr int KB = TR_BLOCK;
-
-struct PathBuffers {
-    f4* org_pdf;      // origin.xyz, bsdf_pdf
-    f4* dir_reg;      // direction.xyz, regularization
-    f4* atten_alpha;  // attenuation.rgb, first-hit albedo.a
-    f4* diffuse;      // demodulated diffuse light of the current sample (path_tracer.glsl:376), a = 1/length at bounce 1
-    f4* reflection;   // demodulated reflected light, same layout
-    f2* plobes;       // primary_lobes as add_demodulated_color uses them: (diffuse + transmission, dielectric + metallic reflection)
-    f4* first_mat;    // first_hit_material: albedo.rgb, metallic
-    f4* first_emis;   // first_hit_material.emission (= bounce-0 light), albedo.a
-    u4* rng;          // random_sampler.seed
-    u4* misc;         // payload.random_seed, sobol_index, launch linear id, flags (bit0 = dead)
-    int4* hit;        // instance, primitive, bary.u bits, bary.v bits (u carries t for sphere lights)
-    f4* sum_color;    // sum over the samples of one pass (+ alpha of the last sample)
-    f4* sum_diffuse;  // only allocated when the diffuse / reflection targets are requested
-    f4* sum_reflection;
-    // shadow rays of the current bounce (compact)
-    f4* sh_org_tmax;  // origin.xyz, tmax
-    f4* sh_dir_id;    // direction.xyz, path id bits
-    f4* sh_contrib;   // rgb radiance if visible, luminance for the indirect clamp
-    f2* sh_lobes;     // lobe weights the contribution is demodulated with
-    f4* sh_cweight;   // direct_stage only: modulate_bsdf(first hit, lobes), the weight of the sample in the colour target
-    uint* queue[2];
-    // per lane and bounce b (BC_STRIDE words apart): live paths entering b, shadow rays of b, work cursors of the closest-hit /
-    // shadow kernel of b (BC_*).  Zeroed by k_raygen; nothing has to be rotated between bounces.
-    uint* bounce;
-    int* qspill;      // deep stack entries of the quad-cooperative tail of the closest-hit waves (trace_quad.h): 16 * TR_QSPILL words per wave of a launch
-    uint* counters;   // per lane: statistics (CNT_*): overflow flag, ray / node / triangle / alpha / surface counts, debug slots
-};
-
-// Every counter of PathBuffers::bounce sits in its own 256 bytes: k_shade appends to the shadow queue and to the next
-// bounce's queue with one atomic per wave each, and two hot words in one cache line serialise in the same L2 channel
-// (measured: 0.83 ms instead of 0.56 ms for one k_shade launch of 2 M paths).
-enum { BC_QUEUE = 0, BC_SHADOW = 64, BC_CUR_CLOSEST = 128, BC_CUR_SHADOW = 192, BC_STRIDE = 256 };
-enum { CNT_OVERFLOW = 2, CNT_CLOSEST = 4, CNT_SHADOWRAYS = 6, CNT_NODES = 8, CNT_TRIS = 10, CNT_ALPHA = 12, CNT_SURF = 14, CNT_MAXVIS = 16, CNT_DBG = 17,
-       CNT_MAXSP = 30, CNT_CNODES = 32, CNT_PH_NODE = 34, CNT_PH_TRI = 36, CNT_PH_NODE16 = 38, CNT_PH_NODE8 = 40, CNT_LV_NODE16 = 42, CNT_PH_QNODE = 44, CNT_PH_QTRI = 46, CNT_PH_HIST = 48, CNT_WORDS = 64 };   // statistics of a lane; queue lengths and work cursors live in PathBuffers::bounce
-
-struct PtParams {
-    trhip_pt_options opt;
-    LaunchCtx L;
-    uint viewports;
-    uint n_launch;                // launch_w * launch_h * viewports
-    uint id_offset, n_ids;        // the slice of path ids this launch group (lane) works on
-    uint max_sobol_bounces;
-    uint sample_counter, rng_seed;
-    uint previous_samples;        // control.previous_samples of the pass
-    uint sample_in_pass;
-    uint rng_sample;              // index of this sample in the pixel's sequence: sample_base + sample_stride * (previous_samples + sample_in_pass)
-    uint vp_base, vp_stride;      // local layer l renders viewport vp_base + l * vp_stride (trhip_pt_set_shard)
-    uint frame_views;             // trhip_pt_set_frame_batch: layers per frame; layer l belongs to frame l / frame_views of the launch
-    uint frame_counter_step;      // ... whose sample counter is sample_counter + that * frame_counter_step
-    uint samples_accumulated;
-    uint target_w, target_h;
-    float prob_point, prob_tri, prob_dir, prob_env;   // get_nee_sampling_probabilities, scene constants
-    int nee_point, nee_tri, nee_dir, nee_env;
-    int count_work;
-    uint bounce_words;            // size of PathBuffers::bounce for one lane
-    int fused_resolve;            // samples_per_pass == 1: k_resolve forms the sample's colour itself
-    trhip_pt_targets T;           // device images; null = target not requested
-};
-
-
-namespace {
-
-TR_DEV void add64(uint* counters, int idx, uint v) {
-    if (v) atomicAdd(reinterpret_cast<unsigned long long*>(counters + idx), (unsigned long long)v);
-}
-
-// wave-aggregated append: one atomic per wave, slots handed out in lane order
-TR_DEV uint wave_append(uint* counter, bool pred) {
-    unsigned long long mask = __ballot(pred);
-    uint n = __popcll(mask);
-    uint base = 0;
-    int lane = threadIdx.x & 63;
-    int leader = __ffsll((long long)mask) - 1;
-    if (pred && lane == leader) base = atomicAdd(counter, n);
-    base = __shfl(base, leader < 0 ? 0 : leader);
-    uint rank = __popcll(mask & ((1ull << lane) - 1ull));
-    return base + rank;
-}
-
-// Two appends per block iteration with one atomic each per *block*: 2 M paths are 32 k waves, and 32 k atomics on one word
-// take longer than a shade launch should (the word's L2 channel handles them one by one).  Every thread of the block
-// must call this (three __syncthreads).  Slots keep thread order within the block.
-TR_DEV void block_append2(uint* counter_a, bool pred_a, uint& slot_a, uint* counter_b, bool pred_b, uint& slot_b) {
-    __shared__ uint s_cnt[2][KB / 64];
-    __shared__ uint s_base[2];
-    const unsigned long long ma = __ballot(pred_a), mb = __ballot(pred_b);
-    const uint lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[0][wave] = (uint)__popcll(ma); s_cnt[1][wave] = (uint)__popcll(mb); }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        uint total = 0;
-        for (int w = 0; w < KB / 64; ++w) total += s_cnt[threadIdx.x][w];
-        s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? counter_a : counter_b, total) : 0u;
-    }
-    __syncthreads();
-    uint off_a = s_base[0], off_b = s_base[1];
-    for (uint w = 0; w < wave; ++w) { off_a += s_cnt[0][w]; off_b += s_cnt[1][w]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    slot_a = off_a + (uint)__popcll(ma & below);
-    slot_b = off_b + (uint)__popcll(mb & below);
-    __syncthreads();   // s_cnt / s_base are reused by the next iteration
-}
-
-// A launch can hold several consecutive frames (trhip_pt_set_frame_batch): its layers are frame-major, frame_views per frame.
-TR_DEV uint global_viewport(const PtParams& P, uint lz) { return P.vp_base + (lz % P.frame_views) * P.vp_stride; }
-TR_DEV uint sample_counter_of(const PtParams& P, uint lz) { return P.sample_counter + (lz / P.frame_views) * P.frame_counter_step; }
-
-// ---------------------------------------------------------------------------------------------------
-// MIS (path_tracer.glsl:54-89)
-TR_DEV float bsdf_mis_pdf(const SceneView& sv, const PtParams& P, float pl_pdf, float dl_pdf, float tri_pdf, float env_pdf, float bsdf_pdf) {
-    if (bsdf_pdf == 0.0f) return 1.0f;
-    float avg_nee_pdf =
-        dl_pdf * P.prob_dir / (float)max(sv.directional_light_count, 1u) +
-        tri_pdf * P.prob_tri / (float)max(sv.tri_light_count, 1u) +
-        env_pdf * P.prob_env +
-        pl_pdf * P.prob_point / (float)max(sv.point_light_count, 1u);
-    if (P.opt.mis_mode == 2) return (avg_nee_pdf * avg_nee_pdf + bsdf_pdf * bsdf_pdf) / bsdf_pdf;
-    if (P.opt.mis_mode == 1) return avg_nee_pdf + bsdf_pdf;
-    return avg_nee_pdf > 0 ? __builtin_huge_valf() : bsdf_pdf;
-}
-TR_DEV float nee_mis_pdf(const PtParams& P, float nee_pdf, float bsdf_pdf) {
-    if (nee_pdf <= 0.0f) return -nee_pdf;
-    if (P.opt.mis_mode == 2) return (nee_pdf * nee_pdf + bsdf_pdf * bsdf_pdf) / nee_pdf;
-    if (P.opt.mis_mode == 1) return nee_pdf + bsdf_pdf;
-    return nee_pdf;
-}
-TR_DEV float clamp_contribution_mul(const PtParams& P, f3 contrib) {   // path_tracer.glsl:356-365
-    if (P.opt.indirect_clamping > 0.0f) {
-        float m = rgb_to_luminance(contrib);
-        if (m > P.opt.indirect_clamping) return P.opt.indirect_clamping / m;
-    }
-    return 1;
-}
-
-// sample_environment_map (rt.glsl:251-285)
-TR_DEV f3 sample_environment_map(const SceneView& sv, u4 rnd, f3& dir, float& length, float& pdf) {
-    f3 color = F3(sv.environment_factor);
-    if (sv.environment_proj >= 0) {
-        uint sx = sv.env_w, sy = sv.env_h;
-        const uint pixel_count = sx * sy;
-        uint ipx = clampu(rnd.x / (0xFFFFFFFFu / sx), 0u, sx - 1u), ipy = clampu(rnd.y / (0xFFFFFFFFu / sy), 0u, sy - 1u);
-        int i = (int)(ipx + ipy * sx);
-        AliasEntry at = sv.alias_table[i];
-        pdf = at.pdf;
-        if (rnd.z > at.probability) { i = (int)at.alias_id; pdf = at.alias_pdf; }
-        int ppx = (int)((uint)i % sx), ppy = (int)((uint)i / sx);
-        f2 off = F2((float)(uint)(rnd.x * pixel_count), (float)(uint)(rnd.y * pixel_count)) * TR_INV_UINT32_MAX;
-        f2 uv = (F2((float)ppx, (float)ppy) + off) / F2((float)sx, (float)sy);
-        dir = uv_to_latlong_direction(uv);
-        color = color * F3(sample_envmap(sv, uv));
-    } else {
-        pdf = 1.0f / (4.0f * TR_PI);
-        dir = sample_sphere(F2((float)rnd.x, (float)rnd.y) * TR_INV_UINT32_MAX);
-    }
-    length = __builtin_huge_valf();
-    return color;
-}
-TR_DEV float sample_environment_map_pdf(const SceneView& sv, f3 dir) {   // rt.glsl:287-299
-    if (sv.environment_proj >= 0) {
-        uint i = (uint)latlong_direction_to_pixel_id(dir, (int)sv.env_w, (int)sv.env_h);
-        uint n = sv.env_w * sv.env_h;
-        if (i >= n) i = n - 1;   // the GLSL read is out of bounds for the last half texel row/column
-        return sv.alias_table[i].pdf;
-    }
-    return 1.0f / (4.0f * TR_PI);
-}
-
-// sample_explicit_light (path_tracer.glsl:203-289)
-TR_DEV f3 sample_explicit_light(const SceneView& sv, const PtParams& P, u4 rnd, f3 pos, f3& out_dir, float& out_length, float& pdf) {
-    f4 u = u4_to_unit(rnd);
-    if (P.nee_point && (u.w -= P.prob_point) < 0) {
-        const int light_count = (int)sv.point_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);   // random_sample_point_light
-        float weight = (float)max(light_count, 1);
-        const PointLight pl = sv.point_lights[light_index];
-        f3 color;
-        sample_point_light(pl, F2(u.x, u.y), pos, out_dir, out_length, color, pdf);
-        pdf *= P.prob_point / weight;
-        return color;
-    }
-    if (P.nee_tri && (u.w -= P.prob_tri) < 0) {
-        const int light_count = (int)sv.tri_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
-        const TriLight tl = sv.tri_lights[light_index];
-        f3 A = tl.pos[0] - pos, B = tl.pos[1] - pos, C = tl.pos[2] - pos;
-        f3 color = r9g9b9e5_to_rgb(tl.emission_factor);
-        float tri_pdf = 0.0f;
-        out_dir = sample_triangle_light(P.opt.tri_light_mode, F2(u.x, u.y), A, B, C, tri_pdf);
-        out_length = ray_plane_intersection_dist(out_dir, A, B, C);
-        if (isinf(tri_pdf) || tri_pdf <= 0 || out_length <= P.opt.min_ray_dist || any_nan(out_dir)) {
-            pdf = 1.0f; out_dir = F3(0);
-            return F3(0);
-        }
-        if (tl.emission_tex_id >= 0) {
-            f3 bary = get_barycentric_coords(out_dir * out_length, A, B, C);
-            f2 uv = bary.x * unpack_half2x16(tl.uv[0]) + bary.y * unpack_half2x16(tl.uv[1]) + bary.z * unpack_half2x16(tl.uv[2]);
-            color = color * F3(sample_texture(sv, tl.emission_tex_id, uv));
-        }
-        out_length -= P.opt.min_ray_dist;
-        pdf = P.prob_tri * tri_pdf / light_count;
-        return color;
-    }
-    if (P.nee_env && (u.w -= P.prob_env) < 0) {
-        f3 color = sample_environment_map(sv, rnd, out_dir, out_length, pdf);
-        pdf *= P.prob_env;
-        return color;
-    }
-    if (P.nee_dir && (u.w -= P.prob_dir) < 0) {
-        const int light_count = (int)sv.directional_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
-        const DirectionalLight dl = sv.directional_lights[light_index];
-        out_length = __builtin_huge_valf();
-        out_dir = sample_cone(F2(u.x, u.y), -dl.dir, dl.dir_cutoff);   // sample_directional_light (light.glsl:119-129)
-        pdf = dl.dir_cutoff >= 1.0f ? -1.0f : 1.0f / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
-        f3 color = pdf > 0 ? dl.color * pdf : dl.color;
-        pdf *= P.prob_dir / light_count;
-        return color;
-    }
-    out_dir = F3(0); out_length = 0; pdf = 1.0f;
-    return F3(0);
-}
-
-TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lobes& l) {   // path_tracer.glsl:291-300
-    if (dot(geometric_normal, sample_dir) < 0) { l.diffuse = 0; l.dielectric_reflection = 0; l.metallic_reflection = 0; }
-    else l.transmission = 0;
-}
-
-// One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
-#ifndef TR_SHADE_WAVES
-#define TR_SHADE_WAVES 3
-#endif
-#ifndef TR_SHADE_LAST_WAVES
-#define TR_SHADE_LAST_WAVES 5   // the last bounce only collects emission: no light or BSDF sampling, no queue appends
-#endif
-// LAST: the instance for bounce == max_bounces - 1, where every path is terminal (path_tracer.glsl:445): compiled without the
-// NEE / BSDF half of the loop body and without the block-wide appends (and their barriers).
-// CLI: the instance for the option set of the reference's command line (uniform-random sampler, point film,
-// power MIS, material bounces, solid-angle triangle lights, no roulette / clamping / regularisation / depth of field / hidden
-// lights / white first-bounce albedo / transparent background / pre-transformed vertices) - what every BASELINE config renders
-// with.  The reference compiles its options into the pipeline as #defines (src/path_tracer_stage.cc:30-116); here the options
-// are data, and this instance pins them to constants so that the compiler drops the other samplers, bounce modes, light modes
-// and their registers.  PtStage::render picks it when the stage's options are that set.
-TR_DEV void pin_cli_defaults(PtParams& P) {
-    P.opt.sampler = 0; P.opt.film = 0; P.opt.mis_mode = 2; P.opt.bounce_mode = 2; P.opt.tri_light_mode = 1;
-    P.opt.russian_roulette_delta = 0.0f; P.opt.indirect_clamping = 0.0f; P.opt.regularization_gamma = 0.0f;
-    P.opt.depth_of_field = 0; P.opt.hide_lights = 0; P.opt.use_white_albedo_on_first_bounce = 0; P.opt.transparent_background = 0;
-    P.opt.pre_transformed_vertices = 0;
-}
-static bool is_cli_default_set(const trhip_pt_options& o) {
-    return o.sampler == 0 && o.film == 0 && o.mis_mode == 2 && o.bounce_mode == 2 && o.tri_light_mode == 1 && o.russian_roulette_delta == 0.0f &&
-           o.indirect_clamping == 0.0f && o.regularization_gamma == 0.0f && o.depth_of_field == 0 && o.hide_lights == 0 &&
-           o.use_white_albedo_on_first_bounce == 0 && o.transparent_background == 0 && o.pre_transformed_vertices == 0;
-}
-
-template <bool COUNT, bool LAST, bool CLI = false>
-__global__ __launch_bounds__(KB, LAST ? TR_SHADE_LAST_WAVES : TR_SHADE_WAVES) void k_shade(SceneView sv, PtParams P_, PathBuffers pb, int bounce, const uint* queue,
-                                              uint* bc, uint* next_queue) {
-    PtParams P = P_;
-    if (CLI) pin_cli_defaults(P);
-    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
-    const uint n_round = LAST ? n : ((n + (uint)KB - 1u) & ~((uint)KB - 1u));   // whole blocks take part in the appends
-    uint surf = 0;
-    for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
-        bool active = qi < n;
-        uint id = 0;
-        u4 misc = {0, 0, 0, 1};
-        if (active) {
-            id = queue ? queue[qi] : qi + P.id_offset;
-            // PathBuffers::misc is written by k_raygen only.  What this kernel wants from it on a queue-driven bounce of the
-            // command-line option set - the path's launch id - is the path id itself (the Sobol index is for the Sobol samplers, the
-            // dead flag for bounce 0, where the ids are all launch ids): 16 bytes per path and bounce not read
-            if (CLI && queue) misc = u4{0u, 0u, id, 0u};
-            else { misc = pb.misc[id]; active = !(misc.w & 1u); }
-        }
-        bool alive = false;        // continues to the next bounce
-        bool want_shadow = false;
-        f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
-        f2 sh_w = F2(0.0f);
-        float sh_tmax = 0, sh_lum = 0;
-        if (active) {
-            const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id], a4 = pb.atten_alpha[id];
-            const int4 h = pb.hit[id];
-            f3 pos = F3(o4), view = F3(d4);
-            float bsdf_pdf = o4.w, regularization = d4.w;
-            f3 attenuation = F3(a4);
-            // demodulated light of this sample: known to be zero before bounce 0, otherwise fetched only by the paths that add to
-            // it in this kernel (emitters, envmap/light hits, NEE samples too dim for a shadow ray)
-            f4 dif = F4(0), ref = F4(0);
-            bool have = bounce == 0;
-            f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
-            u4 rs = pb.rng[id];
-            // (payload.random_seed advances once per closest-hit trace: closest_lane derives the seed of its bounce from the one k_raygen
-            // stored, so no kernel rewrites misc)
-
-            // ---- get_intersection_info (path_tracer.glsl:91-201)
-            SampledMaterial mat;
-            mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
-            mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
-            SurfacePoint v;
-            v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
-            float pl_pdf = 0, dl_pdf = 0, tri_pdf = 0, env_pdf = 0;
-            f3 light = F3(0);
-            bool surface = false;
-            if (h.x >= 0) {
-                surface = true;
-                if (COUNT) surf++;
-                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, CLI);
-                mat.albedo.w = 1.0f;
-                if (P.nee_tri) {
-                    tri_pdf = v.tri_light_pdf;
-                    light = mat.emission;
-                    mat.emission = F3(0);
-                }
-            } else if (h.y >= 0) {
-                const PointLight pl = sv.point_lights[h.y];
-                f3 c = get_spotlight_intensity(pl, view) * pl.color / (pl.radius * pl.radius * TR_PI);
-                if (P.nee_point) { light = c; pl_pdf = sample_point_light_pdf(pl, pos); }
-                else mat.emission = c;
-                v.pos = pos + __int_as_float(h.z) * view;
-                v.mapped_normal = normalize(v.pos - pl.pos);
-                mat.albedo = F4(0, 0, 0, 1);
-            } else {
-                f4 c = sv.environment_factor;
-                if (sv.environment_proj >= 0) {
-                    f2 uv;
-                    uv.y = asinf(-view.y) / TR_PI + 0.5f;
-                    uv.x = atan2f(view.z, view.x) / (2 * TR_PI) + 0.5f;
-                    f4 t = sample_envmap(sv, uv);
-                    c.x *= t.x; c.y *= t.y; c.z *= t.z;
-                }
-                for (uint i = 0; i < sv.directional_light_count; ++i) {
-                    const DirectionalLight dl = sv.directional_lights[i];
-                    if (dl.dir_cutoff >= 1.0f) continue;
-                    float visible = stepf(dl.dir_cutoff, dot(view, -dl.dir));
-                    f3 dc = visible * dl.color / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
-                    if (P.nee_dir) { light += dc; dl_pdf += visible * sample_directional_light_pdf(dl); }
-                    else mat.emission += dc;
-                }
-                v.pos = pos;
-                v.mapped_normal = -view;
-                mat.albedo = F4(0);
-                if (P.nee_env) {
-                    light += F3(c);
-                    env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
-                } else mat.emission += F3(c);
-            }
-            const bool terminal = LAST || !surface || bounce == P.opt.max_bounces - 1;
-
-            // ---- emission with MIS (path_tracer.glsl:413-435)
-            float mis_pdf = bsdf_mis_pdf(sv, P, pl_pdf, dl_pdf, tri_pdf, env_pdf, bsdf_pdf);
-            float mis_weight = 1.0f;
-            if (bsdf_pdf != 0) { attenuation = attenuation / bsdf_pdf; mis_weight = bsdf_pdf / mis_pdf; }
-            light = attenuation * mis_weight * (mat.emission + light);
-            if (bounce != 0) light *= clamp_contribution_mul(P, light);
-
-            // add_demodulated_color(primary_lobes, light, diffuse, reflection) (path_tracer.glsl:435, material.glsl:66-73)
-            if (bounce == 0 || light.x != 0.0f || light.y != 0.0f || light.z != 0.0f) {
-                if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
-                dif.x += light.x * pl.x; dif.y += light.y * pl.x; dif.z += light.z * pl.x;
-                ref.x += light.x * pl.y; ref.y += light.y * pl.y; ref.z += light.z * pl.y;
-            }
-            if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
-                pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
-                pb.first_emis[id] = F4(light, mat.albedo.w);
-            }
-
-            if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
-                if (bsdf_pdf != 0.0f) regularization *= fmax2(1 - P.opt.regularization_gamma / tpow(bsdf_pdf, 0.25f), 0.0f);
-                mat.roughness = 1.0f - ((1.0f - mat.roughness) * regularization);
-            }
-
-            if (!terminal) {
-                const m3 tbn = create_tangent_space(v.mapped_normal);
-                const f3 shading_view = view_to_tangent_space(view, tbn);
-                u4 coord = {0, 0, 0, 0};   // only the Sobol-Owen sampler hashes the launch coordinate again (uniform branch)
-                if (P.opt.sampler == SAMPLER_SOBOL_OWEN) {
-                    uint lx, ly, lz;
-                    launch_coord(P.L, misc.z, lx, ly, lz);
-                    int px = 0, py = 0;
-                    get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + sample_counter_of(P, lz)};
-                }
-                // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
-                const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
-                                     (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
-                u4 rnd = ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u, P.opt.sampler, P.max_sobol_bounces);
-                Lobes lobes = {0, 0, 0, 0};
-                if (any_nee) {
-                    f3 out_dir;
-                    float out_length = 0.0f, light_pdf;
-                    f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
-                    f3 shading_light = mulT(out_dir, tbn);
-                    float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
-                    correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
-                    bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
-                    contrib = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
-                    f3 radiance = attenuation * contrib;
-                    float clamp_lum = 0.0f;   // > 0: indirect clamping applies to (radiance * visibility)
-                    if (bounce != 0) {
-                        radiance *= modulate_bsdf(mat, lobes);
-                        if (P.opt.indirect_clamping > 0.0f) clamp_lum = rgb_to_luminance(radiance);
-                    } else {
-                        // primary_lobes = lobes (path_tracer.glsl:466)
-                        pl = F2(lobes.diffuse + lobes.transmission, lobes.dielectric_reflection + lobes.metallic_reflection);
-                    }
-                    if (cast) {
-                        // contrib *= shadow_ray(...) happens in k_trace_shadow, including the clamp on the occluded value
-                        want_shadow = true;
-                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = radiance; sh_lum = clamp_lum; sh_w = pl;
-                    } else {
-                        float mul = (clamp_lum > P.opt.indirect_clamping && clamp_lum > 0.0f) ? P.opt.indirect_clamping / clamp_lum : 1.0f;
-                        if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
-                        const f3 r = radiance * mul;
-                        dif.x += r.x * pl.x; dif.y += r.y * pl.x; dif.z += r.z * pl.x;
-                        ref.x += r.x * pl.y; ref.y += r.y * pl.y; ref.z += r.z * pl.y;
-                    }
-                }
-                if (bounce == 1) {   // diffuse.a = reflection.a = 1 / length(v.pos - pos) (path_tracer.glsl:470-471)
-                    const float inv_len = 1.0f / length(v.pos - pos);
-                    if (have) { dif.w = inv_len; ref.w = inv_len; }
-                    else { pb.diffuse[id].w = inv_len; pb.reflection[id].w = inv_len; }
-                }
-                // ---- BSDF sampling (path_tracer.glsl:475-497)
-                Lobes bl = {0, 0, 0, 0};
-                f4 ray_sample = u4_to_unit(ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u + 1u, P.opt.sampler, P.max_sobol_bounces));
-                f3 new_dir;
-                material_bsdf_sample(P.opt.bounce_mode, ray_sample, shading_view, mat, new_dir, bl, bsdf_pdf);
-                view = mul(tbn, new_dir);
-                correct_lobes_for_normal_map(v.hard_normal, view, bl);
-                if (bounce != 0) attenuation *= modulate_bsdf(mat, bl);
-                else pl = F2(bl.diffuse + bl.transmission, bl.dielectric_reflection + bl.metallic_reflection);   // primary_lobes = lobes
-                pos = v.pos;
-                alive = true;
-                if (P.opt.russian_roulette_delta > 0) {   // USE_RUSSIAN_ROULETTE: the survivor weight is never applied
-                    float qi_ = fmin2(1.0f, 1.0f / P.opt.russian_roulette_delta);
-                    if (ray_sample.w > qi_) alive = false;
-                }
-                if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
-            }
-            // ---- write back
-            if (have) { pb.diffuse[id] = dif; pb.reflection[id] = ref; }
-            if (alive) {
-                pb.org_pdf[id] = F4(pos, bsdf_pdf);
-                pb.dir_reg[id] = F4(view, regularization);
-                pb.atten_alpha[id] = F4(attenuation, 0);
-                if (bounce == 0) pb.plobes[id] = pl;
-                pb.rng[id] = rs;
-            }
-        }
-        // ---- queue compaction (wave ballots)
-        if (LAST) continue;     // nothing survives the last bounce
-        uint sslot, nslot;
-        block_append2(&bc[BC_SHADOW], want_shadow, sslot, &bc[BC_STRIDE + BC_QUEUE], alive, nslot);
-        if (want_shadow) {
-            pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
-            pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
-            pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
-            pb.sh_lobes[sslot] = sh_w;
-        }
-        if (alive) next_queue[nslot] = id;
-    }
-    if (COUNT && P.count_work) {
-        for (int off = 32; off > 0; off >>= 1) surf += __shfl_xor(surf, off);
-        if ((threadIdx.x & 63) == 0) add64(pb.counters, CNT_SURF, surf);
-    }
-}
-
-}  // namespace
-
-}  // namespace tr
+#include "pt_state.h"
+#include "shade_kernel.h"

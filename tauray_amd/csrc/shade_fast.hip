@@ -18,15 +18,18 @@
 
 namespace tr {
 
-void launch_shade_fast(bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
+void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
                        const uint* queue, uint* bc, uint* next_queue) {
-    if (last) {
-        if (count) hipLaunchKernelGGL((k_shade<true, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
-        else hipLaunchKernelGGL((k_shade<false, true, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+    // (counting + command-line set: the general counting instance, as in the IEEE build)
+#define TR_LAUNCH(...) hipLaunchKernelGGL((k_shade<__VA_ARGS__>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue)
+    if (cli) {
+        if (last) { if (count) TR_LAUNCH(true, true, SpecCli); else TR_LAUNCH(false, true, SpecCli); }
+        else { if (count) TR_LAUNCH(true, false, SpecCli); else TR_LAUNCH(false, false, SpecCli); }
     } else {
-        if (count) hipLaunchKernelGGL((k_shade<true, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
-        else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bounce, queue, bc, next_queue);
+        if (last) { if (count) TR_LAUNCH(true, true, SpecGeneral); else TR_LAUNCH(false, true, SpecGeneral); }
+        else { if (count) TR_LAUNCH(true, false, SpecGeneral); else TR_LAUNCH(false, false, SpecGeneral); }
     }
+#undef TR_LAUNCH
 }
 
 }  // namespace tr

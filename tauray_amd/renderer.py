@@ -391,6 +391,11 @@ class PathTracerStage:
         for the command-line option set (False, the default unless TRHIP_SHADE_FAST=0): include/trhip.h."""
         check(_lib.lib().trhip_pt_set_shading_arithmetic(self.h, int(bool(ieee))))
 
+    def set_specialization(self, enable: bool):
+        """A shading program compiled for this stage's option set the first time it renders (True, the default unless TRHIP_SPECIALIZE=0)
+        or always the general kernels (False): include/trhip.h trhip_pt_set_specialization."""
+        check(_lib.lib().trhip_pt_set_specialization(self.h, int(bool(enable))))
+
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 

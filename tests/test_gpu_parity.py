@@ -34,14 +34,18 @@ def _dup(size):
     return DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True)
 
 
-def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, ieee=None, **kw):
-    """`ieee`: True = the shading kernel at IEEE fp32 (trhip_pt_set_shading_arithmetic), None = the stage's default."""
+def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, ieee=None, specialize=None, **kw):
+    """`ieee`: True = the shading kernels at IEEE fp32 (trhip_pt_set_shading_arithmetic), None = the stage's default (the accuracy
+    Vulkan asks of the reference's GLSL); `specialize`: False = the general kernels, None = the stage's default (a program compiled
+    for the option set, from the kernel cache __graft_entry__.build() filled or through hipRTC)."""
     from tauray_amd.distribution import get_distribution_target_size
     d = dist or _dup(size)
     opt = R.options_for_scene(scene, **kw)
     pt = R.PathTracerStage(ctx, ss, opt, d)
     if ieee is not None:
         pt.set_shading_arithmetic(ieee)
+    if specialize is not None:
+        pt.set_specialization(specialize)
     tw, th = get_distribution_target_size(d)
     color = ctx.alloc(viewports * tw * th * 16).zero()
     for _ in range(frames):
@@ -53,23 +57,42 @@ def _render_hip(R, ctx, ss, scene, size, frames=1, viewports=1, dist=None, ieee=
     return img
 
 
-def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION):
+def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION, strict=False):
+    """`strict` (frames rendered with IEEE shading arithmetic, which follows the oracle expression by expression): the image mean is
+    taken over the whole image.  Otherwise (the default arithmetic) it is taken over the pixels inside the tolerance, capped - and
+    what the excluded pixels hold is bounded on its own."""
     assert np.isfinite(img).all(), f"{what}: non-finite output"
-    rel = np.abs(img[..., :3] - ref[..., :3]) / (np.abs(ref[..., :3]) + 1e-2)
+    err = np.abs(img[..., :3] - ref[..., :3])
+    rel = err / (np.abs(ref[..., :3]) + 1e-2)
     off = rel.max(-1) > REL_TOL
     bad = float(off.mean())
     assert bad <= max_bad, f"{what}: {bad:.4%} pixels differ by more than {REL_TOL}"
-    # The image mean catches a small bias everywhere, which the per-pixel tolerance would let through.  It is taken over the pixels
-    # inside the tolerance, with values capped at a hundred times the frame's mean: one pixel can hold a highlight thousands of
-    # times the mean (a sphere light in a near-mirror panel: GGX's D at small roughness amplifies an ulp of n.h to 1-2 %, 7193 vs
-    # 7338 or 15632 vs 15772 in frames of mean 2.4-3.0 - found by tools/fuzz_campaign.sh, profiles/r3/fuzz_campaign.txt; bit-equal
-    # to the oracle under IEEE shading arithmetic) and would decide the statistic alone
-    good = ~off
-    cap = 100.0 * max(float(np.abs(ref[..., :3]).mean()), 1e-6)
-    a, b = np.minimum(img[..., :3][good], cap), np.minimum(ref[..., :3][good], cap)
-    mean_err = abs(float(a.mean()) - float(b.mean())) / max(float(b.mean()), 1e-6)
-    assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
+    total = max(float(np.abs(ref[..., :3]).sum()), 1e-6)
+    if strict:
+        # the image mean catches a small bias everywhere, which the per-pixel tolerance would let through
+        mean_err = abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) / max(float(ref[..., :3].mean()), 1e-6)
+        assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
+    else:
+        # The mean is taken over the pixels inside the tolerance, with values capped at a hundred times the frame's mean: one pixel
+        # can hold a highlight thousands of times the mean (a sphere light in a near-mirror panel: GGX's D at small roughness
+        # amplifies an ulp of n.h to 1-2 %, 7193 vs 7338 or 15632 vs 15772 in frames of mean 2.4-3.0 - found by
+        # tools/fuzz_campaign.sh, profiles/r3/fuzz_campaign.txt; bit-equal to the oracle under IEEE shading arithmetic) and would
+        # decide the statistic alone ...
+        good = ~off
+        cap = 100.0 * max(float(np.abs(ref[..., :3]).mean()), 1e-6)
+        a, b = np.minimum(img[..., :3][good], cap), np.minimum(ref[..., :3][good], cap)
+        mean_err = abs(float(a.mean()) - float(b.mean())) / max(float(b.mean()), 1e-6)
+        assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
+        # ... and the error the excluded pixels carry is bounded against the light in the frame (those highlight pixels: 2e-3)
+        excluded = float(err[off].sum()) / total
+        assert excluded < 2e-2, f"{what}: the pixels outside the tolerance differ by {excluded:.3e} of the frame's light"
     assert np.array_equal(img[..., 3], ref[..., 3]), f"{what}: alpha differs"
+
+
+def _compare_both(R, ctx, ss, scene, size, ref, what, max_bad=MAX_BAD_FRACTION, max_bad_default=None, **kw):
+    """The HIP path against the oracle's frame in both shading arithmetics: IEEE fp32 (strict comparison) and the default."""
+    _compare(_render_hip(R, ctx, ss, scene, size, ieee=True, **kw), ref, what + " [IEEE shading]", max_bad=max_bad, strict=True)
+    _compare(_render_hip(R, ctx, ss, scene, size, **kw), ref, what + " [default shading arithmetic]", max_bad=max_bad_default or max_bad)
 
 
 @pytest.fixture(scope="module")
@@ -196,30 +219,7 @@ def test_degenerate_rays_are_cheap_misses(R, ctx, glb128):
     assert np.array_equal(glb128.trace_shadow(rays), np.array([1, 1, 1, 1, 0, 1], dtype=np.float32))
 
 
-OPTION_SETS = {
-    "cli-defaults-8-bounces": dict(),
-    "4-bounces": dict(max_bounces=4),
-    "1-bounce": dict(max_bounces=1),
-    "sobol-owen": dict(max_bounces=4, sampler=1),
-    "sobol-z2": dict(max_bounces=4, sampler=2),
-    "sobol-z3": dict(max_bounces=4, sampler=3, samples_per_pixel=2),
-    "box-film": dict(max_bounces=3, film=1),
-    "blackman-harris": dict(max_bounces=3, film=2, film_radius=1.0),
-    "mis-balance": dict(max_bounces=3, mis_mode=1),
-    "mis-off": dict(max_bounces=3, mis_mode=0),
-    "bounce-hemisphere": dict(max_bounces=3, bounce_mode=0),
-    "bounce-cosine": dict(max_bounces=3, bounce_mode=1),
-    "tri-area": dict(max_bounces=3, tri_light_mode=0),
-    "tri-hybrid": dict(max_bounces=3, tri_light_mode=2),
-    "regularization+clamp": dict(max_bounces=5, regularization_gamma=0.2, indirect_clamping=4.0),
-    "russian-roulette": dict(max_bounces=6, russian_roulette_delta=2.0),
-    "hide-lights-seed": dict(max_bounces=3, hide_lights=1, rng_seed=1234),
-    "no-nee": dict(max_bounces=3, nee_point=0.0, nee_directional=0.0, nee_triangles=0.0),
-    "nee-weights": dict(max_bounces=3, nee_point=3.0, nee_directional=0.5, nee_triangles=2.0),
-    "white-albedo-transparent": dict(max_bounces=3, use_white_albedo_on_first_bounce=1, transparent_background=1),
-    "4spp-2-per-pass": dict(max_bounces=3, samples_per_pixel=4, samples_per_pass=2),
-    "dof": dict(max_bounces=2, depth_of_field=1),
-}
+from tauray_amd.presets import NAMED_OPTION_SETS as OPTION_SETS      # noqa: E402  (the sets __graft_entry__.build() compiles programs for)
 
 
 @pytest.mark.parametrize("name", list(OPTION_SETS))
@@ -233,9 +233,13 @@ def test_path_tracer_matches_oracle(R, ctx, glb128, test_glb_128, oracle, oracle
     else:
         osc = oracle_scene_128
     try:
-        img = _render_hip(R, ctx, glb128, scene, (128, 128), **kw)
         ref = osc.render_pt(oracle.options_for_scene(scene, **kw), 128, 128)
-        _compare(img, ref, name)
+        _compare_both(R, ctx, glb128, scene, (128, 128), ref, name, **kw)
+        if name in ("sobol-owen", "blackman-harris", "tri-hybrid", "regularization+clamp", "no-nee", "dof"):
+            # the program compiled for the option set renders the bits of the general kernels, in either arithmetic
+            for ieee in (True, None):
+                assert np.array_equal(_render_hip(R, ctx, glb128, scene, (128, 128), ieee=ieee, **kw),
+                                      _render_hip(R, ctx, glb128, scene, (128, 128), ieee=ieee, specialize=False, **kw)), f"{name}: specialised != general (ieee={ieee})"
     finally:
         if name == "dof":
             scene.cameras[0].focus = (1.0, 0.0, 0.0, 0.0)
@@ -1723,7 +1727,11 @@ def test_random_option_combinations(R, ctx, oracle):
             samples_per_pass=per_pass, samples_per_pixel=per_pass * int(rng.integers(1, 3)), depth_of_field=int(rng.integers(0, 2)),
             pre_transformed_vertices=int(rng.integers(0, 2)), rng_seed=int(rng.choice([0, 0, 77])))
         frames = int(rng.integers(1, 3))
-        img = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, **kw)
+        # every sixth draw through a shading program compiled for it on the spot (hipRTC, 2-3 s each); the others through the general
+        # kernels, which take any option set as data - the same bits (test_specialization.py), without the compiler in the loop.
+        # Both in the default arithmetic; the strict comparison at IEEE fp32 follows below.
+        spec = None if k % 6 == 0 else False
+        img = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, specialize=spec, **kw)
         opt = oracle.options_for_scene(sc, **kw)
         ref = None
         for f in range(frames):
@@ -1734,11 +1742,14 @@ def test_random_option_combinations(R, ctx, oracle):
             # suite's seed, a handful in a thousand (tools/fuzz_campaign.sh) - and the HIP path must produce it in the same pixels
             # when it computes in the oracle's arithmetic; the other pixels are compared as usual
             assert nf.mean() < 1e-3, f"draw {k}: the oracle produced {int(nf.sum())} non-finite pixels with {kw}"
-            strict = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, ieee=True, **kw)
+        strict = _render_hip(R, ctx, ss, sc, (96, 96), frames=frames, ieee=True, specialize=False, **kw)
+        if nf.any():
             assert np.array_equal(~np.isfinite(strict).all(-1), nf), f"draw {k}: non-finite pixels differ from the oracle's with {kw}"
             img = np.where(nf[..., None], np.float32(0), img)
+            strict = np.where(nf[..., None], np.float32(0), strict)
             ref = np.where(nf[..., None], np.float32(0), ref)
-        _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s)")
+        _compare(strict, ref, f"draw {k}: {kw}, {frames} frame(s) [IEEE shading]", strict=True)
+        _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s) [default shading arithmetic]")
 
 
 @pytest.mark.gpu

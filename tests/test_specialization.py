@@ -1,0 +1,161 @@
+"""Shading programs compiled for one option set (csrc/shade_spec.hip through csrc/specialize.cc): what the reference does with its
+options as #defines when it builds a stage's pipeline (src/path_tracer_stage.cc:30-116).  CPU part: the compiler path needs no GPU
+(trhip_pt_precompile), the kernel cache is keyed by option set, arithmetic and sources.  GPU part: a specialised program renders the
+bits of the general kernels in the same arithmetic - whole frames, every sampler / film / MIS / bounce / light mode, counters too."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+_PRECOMPILE = r"""
+import ctypes as C, sys, time, json
+sys.path.insert(0, sys.argv[1])
+from tauray_amd import _lib
+from tauray_amd.renderer import make_options
+L = _lib.lib()
+out = {"dir": L.trhip_kernel_cache_dir().decode(), "times": []}
+for kw in json.loads(sys.argv[2]):
+    ieee = kw.pop("_ieee", 0)
+    o = make_options(**kw)
+    t = time.perf_counter()
+    rc = L.trhip_pt_precompile(C.byref(o), 1, ieee, 0, None)
+    out["times"].append([rc, time.perf_counter() - t])
+print(json.dumps(out))
+"""
+
+
+def _run_precompile(cache_dir, sets):
+    import json
+    env = dict(os.environ, TRHIP_KERNEL_CACHE=str(cache_dir))
+    r = subprocess.run([sys.executable, "-c", _PRECOMPILE, ROOT, json.dumps(sets)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_precompile_needs_no_gpu_and_fills_the_cache(tmp_path):
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    sets = [dict(sampler=1), dict(sampler=1, _ieee=1), dict(sampler=1, film=2), dict()]
+    first = _run_precompile(cache, sets)
+    assert first["dir"] == str(cache) and all(rc == 0 for rc, _ in first["times"])
+    files = sorted(os.listdir(cache))
+    # two programs (ray generation, shading) per new option set; the ray-generation program does not depend on the arithmetic, and the
+    # command-line set (the last one) is served by the ahead-of-time instances of libtrhip.so: nothing to compile
+    assert len(files) == 2 + 1 + 2 and all(f.startswith("spec_") and f.endswith(".hsaco") for f in files)
+    assert all(open(cache / f, "rb").read(4) == b"\x7fELF" for f in files)
+    assert first["times"][3][1] < 0.05
+    second = _run_precompile(cache, sets)      # another process: everything comes from the cache
+    assert sorted(os.listdir(cache)) == files and all(t < 0.2 for _, t in second["times"])
+
+
+def test_build_warmed_the_cache_for_the_named_option_sets():
+    """__graft_entry__.build() compiles the programs of the reference's presets and of the sets the tests and the bench render."""
+    from tauray_amd import _lib, presets
+    d = _lib.lib().trhip_kernel_cache_dir().decode()
+    assert d and os.path.isdir(d), "run __graft_entry__.build()"
+    t = time.perf_counter()
+    for kw, ieee, count in presets.warm_up_jobs()[:6]:
+        assert presets.precompile(kw, True, ieee, count) < 0.5, f"{kw} was not in {d}: run __graft_entry__.build()"
+    assert time.perf_counter() - t < 3.0
+
+
+def test_reference_presets_are_what_the_cfg_files_say():
+    """tauray_amd/presets.py against data/presets/*.cfg of the reference (restated here: the reference is not on the GPU box)."""
+    from tauray_amd.presets import REFERENCE_PRESETS as P
+    # quality.cfg: film blackman-harris, max-ray-depth 4, samples-per-pixel 4096, sampler uniform-random, regularization 0.1
+    assert P["quality"] == dict(film=2, max_bounces=4, samples_per_pixel=4096, sampler=0, regularization_gamma=0.1)
+    # reference.cfg: film blackman-harris, max-ray-depth 8, samples-per-pixel 16384, sampler uniform-random, tri-light-mode hybrid
+    assert P["reference"] == dict(film=2, max_bounces=8, samples_per_pixel=16384, sampler=0, tri_light_mode=2)
+    # accumulation.cfg: film blackman-harris, max-ray-depth 5, sampler uniform-random, samples-per-pixel 1, regularization 0.2
+    assert P["accumulation"] == dict(film=2, max_bounces=5, samples_per_pixel=1, sampler=0, regularization_gamma=0.2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def R():
+    from tauray_amd import renderer
+    return renderer
+
+
+def _frame(R, ctx, ss, scene, size, specialize, ieee, count=False, **kw):
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, **kw), DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True))
+    pt.set_specialization(specialize)
+    pt.set_shading_arithmetic(ieee)
+    if count:
+        pt.set_profiling(True, False)
+    buf = ctx.alloc(size[0] * size[1] * 16).zero()
+    pt.run(buf)
+    img = buf.download((size[1], size[0], 4))
+    c = pt.counters()
+    pt.close()
+    return img, c
+
+
+@pytest.mark.gpu
+def test_specialised_programs_render_the_bits_of_the_general_kernels(R):
+    """Every axis a program pins, one at a time and together, in both arithmetics, on the bench scene's little sister (textures, a sun,
+    an environment map, emissive triangles) at a size that takes the four-lane schedule; counting instances report the same work."""
+    from tauray_amd import scenes
+    from tauray_amd.presets import REFERENCE_PRESETS
+    W, H = 960, 540
+    scene = scenes.sponza_class(seed=3, target_tris=40000, width=W, height=H)
+    ctx = R.Context(0)
+    ss = R.SceneStage(ctx, scene)
+    sets = [dict(max_bounces=4, sampler=1), dict(max_bounces=4, sampler=2), dict(max_bounces=4, sampler=3, film=1),
+            dict(REFERENCE_PRESETS["quality"], samples_per_pixel=1), dict(REFERENCE_PRESETS["reference"], samples_per_pixel=1),
+            dict(max_bounces=3, mis_mode=0, bounce_mode=0, tri_light_mode=0, nee_envmap=0.0),
+            dict(max_bounces=5, mis_mode=1, bounce_mode=1, russian_roulette_delta=1.5, indirect_clamping=5.0, hide_lights=1, use_white_albedo_on_first_bounce=1,
+                 transparent_background=1, depth_of_field=1, pre_transformed_vertices=1, samples_per_pixel=2)]
+    for kw in sets:
+        for ieee in (True, False):
+            spec, cs = _frame(R, ctx, ss, scene, (W, H), True, ieee, **kw)
+            gen, cg = _frame(R, ctx, ss, scene, (W, H), False, ieee, **kw)
+            assert np.isfinite(gen[..., :3]).mean() > 0.999 and np.nanmean(gen[..., :3]) > 1e-3
+            assert np.array_equal(spec, gen, equal_nan=True), f"{kw}, ieee={ieee}: {int((spec != gen).any(-1).sum())} pixels differ"
+            assert cs["closest_rays"] == cg["closest_rays"] and cs["shadow_rays"] == cg["shadow_rays"]
+    kw = sets[0]
+    spec, cs = _frame(R, ctx, ss, scene, (W, H), True, False, count=True, **kw)
+    gen, cg = _frame(R, ctx, ss, scene, (W, H), False, False, count=True, **kw)
+    assert np.array_equal(spec, gen) and cs == cg and cs["surface_hits"] > 0
+
+
+@pytest.mark.gpu
+def test_a_new_option_set_is_compiled_when_it_first_renders(R, tmp_path):
+    """A stage whose option set is in no cache: the first frame compiles (hipRTC), the next process finds the program in the cache."""
+    script = tmp_path / "first_frame.py"
+    script.write_text(r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from tauray_amd import renderer as R, scenes
+from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+sc = scenes.test_glb(96, 96)
+ctx = R.Context(0)
+ss = R.SceneStage(ctx, sc)
+pt = R.PathTracerStage(ctx, ss, R.options_for_scene(sc, max_bounces=3, sampler=2, film=1, mis_mode=1, tri_light_mode=2), DistributionParams((96, 96), DISTRIBUTION_DUPLICATE, 0, 1, True))
+buf = ctx.alloc(96 * 96 * 16).zero()
+t = time.perf_counter()
+pt.run(buf)
+img = buf.download((96, 96, 4))
+print("FIRST", time.perf_counter() - t)
+np.save(sys.argv[2], img)
+""")
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, TRHIP_KERNEL_CACHE=str(cache), TRHIP_DEBUG="1")
+    runs = []
+    for k in range(2):
+        out = str(tmp_path / f"f{k}.npy")
+        r = subprocess.run([sys.executable, str(script), ROOT, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append((float(r.stdout.split("FIRST")[1].split()[0]), r.stderr, np.load(out)))
+    assert "compiled through hipRTC" in runs[0][1] and "from the kernel cache" in runs[1][1] and "compiled through hipRTC" not in runs[1][1]
+    assert len(os.listdir(cache)) == 2 and np.array_equal(runs[0][2], runs[1][2]) and np.isfinite(runs[0][2]).all()
+    assert runs[1][0] < runs[0][0]
