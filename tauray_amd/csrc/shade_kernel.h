@@ -187,6 +187,196 @@ struct SpecMacros {
     }
 };
 #endif
+// What one bounce of one path leaves for the kernel that called it: whether the path goes on, and its shadow ray if it cast one
+// (contrib *= shadow_ray(...) happens in the trace kernel, including the clamp on the occluded value).
+struct ShadeOut {
+    bool alive = false;          // continues to the next bounce
+    bool want_shadow = false;
+    f3 sh_o = {0, 0, 0}, sh_d = {0, 0, 0}, sh_c = {0, 0, 0};
+    f2 sh_w = {0, 0};
+    float sh_tmax = 0, sh_lum = 0;
+};
+
+// One bounce of evaluate_ray (path_tracer.glsl:385-498) for path `id`: reads the path's state and hit record, adds emission (with
+// MIS) to the sample's demodulated sums, samples a light (the shadow ray goes to `o`) and the BSDF, writes the next ray back.
+// P: the launch parameters with the option set already pinned (S::pin).
+template <bool COUNT, bool LAST, typename S>
+TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, uint id, u4 misc, ShadeOut& o, uint& surf) {
+    bool& alive = o.alive;
+    bool& want_shadow = o.want_shadow;
+    f3 &sh_o = o.sh_o, &sh_d = o.sh_d, &sh_c = o.sh_c;
+    f2& sh_w = o.sh_w;
+    float &sh_tmax = o.sh_tmax, &sh_lum = o.sh_lum;
+        const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id], a4 = pb.atten_alpha[id];
+        const int4 h = pb.hit[id];
+        f3 pos = F3(o4), view = F3(d4);
+        float bsdf_pdf = o4.w, regularization = d4.w;
+        f3 attenuation = F3(a4);
+        // demodulated light of this sample: known to be zero before bounce 0, otherwise fetched only by the paths that add to
+        // it in this kernel (emitters, envmap/light hits, NEE samples too dim for a shadow ray)
+        f4 dif = F4(0), ref = F4(0);
+        bool have = bounce == 0;
+        f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
+        u4 rs = pb.rng[id];
+        // (payload.random_seed advances once per closest-hit trace: closest_lane derives the seed of its bounce from the one k_raygen
+        // stored, so no kernel rewrites misc)
+
+        // ---- get_intersection_info (path_tracer.glsl:91-201)
+        SampledMaterial mat;
+        mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
+        mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
+        SurfacePoint v;
+        v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
+        float pl_pdf = 0, dl_pdf = 0, tri_pdf = 0, env_pdf = 0;
+        f3 light = F3(0);
+        bool surface = false;
+        if (h.x >= 0) {
+            surface = true;
+            if (COUNT) surf++;
+            shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, S::shade_tris);
+            mat.albedo.w = 1.0f;
+            if (P.nee_tri) {
+                tri_pdf = v.tri_light_pdf;
+                light = mat.emission;
+                mat.emission = F3(0);
+            }
+        } else if (h.y >= 0) {
+            const PointLight pl = sv.point_lights[h.y];
+            f3 c = get_spotlight_intensity(pl, view) * pl.color / (pl.radius * pl.radius * TR_PI);
+            if (P.nee_point) { light = c; pl_pdf = sample_point_light_pdf(pl, pos); }
+            else mat.emission = c;
+            v.pos = pos + __int_as_float(h.z) * view;
+            v.mapped_normal = normalize(v.pos - pl.pos);
+            mat.albedo = F4(0, 0, 0, 1);
+        } else {
+            f4 c = sv.environment_factor;
+            if (sv.environment_proj >= 0) {
+                f2 uv;
+                uv.y = asinf(-view.y) / TR_PI + 0.5f;
+                uv.x = atan2f(view.z, view.x) / (2 * TR_PI) + 0.5f;
+                f4 t = sample_envmap(sv, uv);
+                c.x *= t.x; c.y *= t.y; c.z *= t.z;
+            }
+            for (uint i = 0; i < sv.directional_light_count; ++i) {
+                const DirectionalLight dl = sv.directional_lights[i];
+                if (dl.dir_cutoff >= 1.0f) continue;
+                float visible = stepf(dl.dir_cutoff, dot(view, -dl.dir));
+                f3 dc = visible * dl.color / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
+                if (P.nee_dir) { light += dc; dl_pdf += visible * sample_directional_light_pdf(dl); }
+                else mat.emission += dc;
+            }
+            v.pos = pos;
+            v.mapped_normal = -view;
+            mat.albedo = F4(0);
+            if (P.nee_env) {
+                light += F3(c);
+                env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
+            } else mat.emission += F3(c);
+        }
+        const bool terminal = LAST || !surface || bounce == P.opt.max_bounces - 1;
+
+        // ---- emission with MIS (path_tracer.glsl:413-435)
+        float mis_pdf = bsdf_mis_pdf(sv, P, pl_pdf, dl_pdf, tri_pdf, env_pdf, bsdf_pdf);
+        float mis_weight = 1.0f;
+        if (bsdf_pdf != 0) { attenuation = attenuation / bsdf_pdf; mis_weight = bsdf_pdf / mis_pdf; }
+        light = attenuation * mis_weight * (mat.emission + light);
+        if (bounce != 0) light *= clamp_contribution_mul(P, light);
+
+        // add_demodulated_color(primary_lobes, light, diffuse, reflection) (path_tracer.glsl:435, material.glsl:66-73)
+        if (bounce == 0 || light.x != 0.0f || light.y != 0.0f || light.z != 0.0f) {
+            if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
+            dif.x += light.x * pl.x; dif.y += light.y * pl.x; dif.z += light.z * pl.x;
+            ref.x += light.x * pl.y; ref.y += light.y * pl.y; ref.z += light.z * pl.y;
+        }
+        if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
+            pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
+            pb.first_emis[id] = F4(light, mat.albedo.w);
+        }
+
+        if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
+            if (bsdf_pdf != 0.0f) regularization *= fmax2(1 - P.opt.regularization_gamma / tpow(bsdf_pdf, 0.25f), 0.0f);
+            mat.roughness = 1.0f - ((1.0f - mat.roughness) * regularization);
+        }
+
+        if (!terminal) {
+            const m3 tbn = create_tangent_space(v.mapped_normal);
+            const f3 shading_view = view_to_tangent_space(view, tbn);
+            u4 coord = {0, 0, 0, 0};   // only the Sobol-Owen sampler hashes the launch coordinate again (uniform branch)
+            if (P.opt.sampler == SAMPLER_SOBOL_OWEN) {
+                uint lx, ly, lz;
+                launch_coord(P.L, misc.z, lx, ly, lz);
+                int px = 0, py = 0;
+                get_pixel_pos(P.L, lx, ly, px, py);
+                coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + sample_counter_of(P, lz)};
+            }
+            // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
+            const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
+                                 (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
+            u4 rnd = ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u, P.opt.sampler, P.max_sobol_bounces);
+            Lobes lobes = {0, 0, 0, 0};
+            if (any_nee) {
+                f3 out_dir;
+                float out_length = 0.0f, light_pdf;
+                f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
+                f3 shading_light = mulT(out_dir, tbn);
+                float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
+                correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
+                bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
+                contrib = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
+                f3 radiance = attenuation * contrib;
+                float clamp_lum = 0.0f;   // > 0: indirect clamping applies to (radiance * visibility)
+                if (bounce != 0) {
+                    radiance *= modulate_bsdf(mat, lobes);
+                    if (P.opt.indirect_clamping > 0.0f) clamp_lum = rgb_to_luminance(radiance);
+                } else {
+                    // primary_lobes = lobes (path_tracer.glsl:466)
+                    pl = F2(lobes.diffuse + lobes.transmission, lobes.dielectric_reflection + lobes.metallic_reflection);
+                }
+                if (cast) {
+                    // contrib *= shadow_ray(...) happens in k_trace_shadow, including the clamp on the occluded value
+                    want_shadow = true;
+                    sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = radiance; sh_lum = clamp_lum; sh_w = pl;
+                } else {
+                    float mul = (clamp_lum > P.opt.indirect_clamping && clamp_lum > 0.0f) ? P.opt.indirect_clamping / clamp_lum : 1.0f;
+                    if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
+                    const f3 r = radiance * mul;
+                    dif.x += r.x * pl.x; dif.y += r.y * pl.x; dif.z += r.z * pl.x;
+                    ref.x += r.x * pl.y; ref.y += r.y * pl.y; ref.z += r.z * pl.y;
+                }
+            }
+            if (bounce == 1) {   // diffuse.a = reflection.a = 1 / length(v.pos - pos) (path_tracer.glsl:470-471)
+                const float inv_len = 1.0f / length(v.pos - pos);
+                if (have) { dif.w = inv_len; ref.w = inv_len; }
+                else { pb.diffuse[id].w = inv_len; pb.reflection[id].w = inv_len; }
+            }
+            // ---- BSDF sampling (path_tracer.glsl:475-497)
+            Lobes bl = {0, 0, 0, 0};
+            f4 ray_sample = u4_to_unit(ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u + 1u, P.opt.sampler, P.max_sobol_bounces));
+            f3 new_dir;
+            material_bsdf_sample(P.opt.bounce_mode, ray_sample, shading_view, mat, new_dir, bl, bsdf_pdf);
+            view = mul(tbn, new_dir);
+            correct_lobes_for_normal_map(v.hard_normal, view, bl);
+            if (bounce != 0) attenuation *= modulate_bsdf(mat, bl);
+            else pl = F2(bl.diffuse + bl.transmission, bl.dielectric_reflection + bl.metallic_reflection);   // primary_lobes = lobes
+            pos = v.pos;
+            alive = true;
+            if (P.opt.russian_roulette_delta > 0) {   // USE_RUSSIAN_ROULETTE: the survivor weight is never applied
+                float qi_ = fmin2(1.0f, 1.0f / P.opt.russian_roulette_delta);
+                if (ray_sample.w > qi_) alive = false;
+            }
+            if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
+        }
+        // ---- write back
+        if (have) { pb.diffuse[id] = dif; pb.reflection[id] = ref; }
+        if (alive) {
+            pb.org_pdf[id] = F4(pos, bsdf_pdf);
+            pb.dir_reg[id] = F4(view, regularization);
+            pb.atten_alpha[id] = F4(attenuation, 0);
+            if (bounce == 0) pb.plobes[id] = pl;
+            pb.rng[id] = rs;
+        }
+}
+
 template <bool COUNT, bool LAST, typename S>
 TR_DEV void shade_bounce(const SceneView& sv, const PtParams& P_, const PathBuffers& pb, int bounce, const uint* queue, uint* bc, uint* next_queue) {
     PtParams P = P_;
@@ -208,190 +398,18 @@ TR_DEV void shade_bounce(const SceneView& sv, const PtParams& P_, const PathBuff
             if (!misc_needed && queue) misc = u4{0u, 0u, id, 0u};
             else { misc = pb.misc[id]; active = !(misc.w & 1u); }
         }
-        bool alive = false;        // continues to the next bounce
-        bool want_shadow = false;
-        f3 sh_o = F3(0), sh_d = F3(0), sh_c = F3(0);
-        f2 sh_w = F2(0.0f);
-        float sh_tmax = 0, sh_lum = 0;
-        if (active) {
-            const f4 o4 = pb.org_pdf[id], d4 = pb.dir_reg[id], a4 = pb.atten_alpha[id];
-            const int4 h = pb.hit[id];
-            f3 pos = F3(o4), view = F3(d4);
-            float bsdf_pdf = o4.w, regularization = d4.w;
-            f3 attenuation = F3(a4);
-            // demodulated light of this sample: known to be zero before bounce 0, otherwise fetched only by the paths that add to
-            // it in this kernel (emitters, envmap/light hits, NEE samples too dim for a shadow ray)
-            f4 dif = F4(0), ref = F4(0);
-            bool have = bounce == 0;
-            f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
-            u4 rs = pb.rng[id];
-            // (payload.random_seed advances once per closest-hit trace: closest_lane derives the seed of its bounce from the one k_raygen
-            // stored, so no kernel rewrites misc)
-
-            // ---- get_intersection_info (path_tracer.glsl:91-201)
-            SampledMaterial mat;
-            mat.albedo = F4(0); mat.metallic = 1; mat.roughness = 0; mat.emission = F3(0);
-            mat.transmittance = 0; mat.ior_in = 1; mat.ior_out = 1; mat.f0 = 0;
-            SurfacePoint v;
-            v.pos = pos; v.hard_normal = F3(0); v.smooth_normal = F3(0); v.mapped_normal = F3(0); v.tri_light_pdf = 0;
-            float pl_pdf = 0, dl_pdf = 0, tri_pdf = 0, env_pdf = 0;
-            f3 light = F3(0);
-            bool surface = false;
-            if (h.x >= 0) {
-                surface = true;
-                if (COUNT) surf++;
-                shade_surface(sv, h.x, h.y, __int_as_float(h.z), __int_as_float(h.w), view, pos, P.nee_tri != 0, P.opt.tri_light_mode, P.opt.pre_transformed_vertices != 0, v, mat, S::shade_tris);
-                mat.albedo.w = 1.0f;
-                if (P.nee_tri) {
-                    tri_pdf = v.tri_light_pdf;
-                    light = mat.emission;
-                    mat.emission = F3(0);
-                }
-            } else if (h.y >= 0) {
-                const PointLight pl = sv.point_lights[h.y];
-                f3 c = get_spotlight_intensity(pl, view) * pl.color / (pl.radius * pl.radius * TR_PI);
-                if (P.nee_point) { light = c; pl_pdf = sample_point_light_pdf(pl, pos); }
-                else mat.emission = c;
-                v.pos = pos + __int_as_float(h.z) * view;
-                v.mapped_normal = normalize(v.pos - pl.pos);
-                mat.albedo = F4(0, 0, 0, 1);
-            } else {
-                f4 c = sv.environment_factor;
-                if (sv.environment_proj >= 0) {
-                    f2 uv;
-                    uv.y = asinf(-view.y) / TR_PI + 0.5f;
-                    uv.x = atan2f(view.z, view.x) / (2 * TR_PI) + 0.5f;
-                    f4 t = sample_envmap(sv, uv);
-                    c.x *= t.x; c.y *= t.y; c.z *= t.z;
-                }
-                for (uint i = 0; i < sv.directional_light_count; ++i) {
-                    const DirectionalLight dl = sv.directional_lights[i];
-                    if (dl.dir_cutoff >= 1.0f) continue;
-                    float visible = stepf(dl.dir_cutoff, dot(view, -dl.dir));
-                    f3 dc = visible * dl.color / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
-                    if (P.nee_dir) { light += dc; dl_pdf += visible * sample_directional_light_pdf(dl); }
-                    else mat.emission += dc;
-                }
-                v.pos = pos;
-                v.mapped_normal = -view;
-                mat.albedo = F4(0);
-                if (P.nee_env) {
-                    light += F3(c);
-                    env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
-                } else mat.emission += F3(c);
-            }
-            const bool terminal = LAST || !surface || bounce == P.opt.max_bounces - 1;
-
-            // ---- emission with MIS (path_tracer.glsl:413-435)
-            float mis_pdf = bsdf_mis_pdf(sv, P, pl_pdf, dl_pdf, tri_pdf, env_pdf, bsdf_pdf);
-            float mis_weight = 1.0f;
-            if (bsdf_pdf != 0) { attenuation = attenuation / bsdf_pdf; mis_weight = bsdf_pdf / mis_pdf; }
-            light = attenuation * mis_weight * (mat.emission + light);
-            if (bounce != 0) light *= clamp_contribution_mul(P, light);
-
-            // add_demodulated_color(primary_lobes, light, diffuse, reflection) (path_tracer.glsl:435, material.glsl:66-73)
-            if (bounce == 0 || light.x != 0.0f || light.y != 0.0f || light.z != 0.0f) {
-                if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
-                dif.x += light.x * pl.x; dif.y += light.y * pl.x; dif.z += light.z * pl.x;
-                ref.x += light.x * pl.y; ref.y += light.y * pl.y; ref.z += light.z * pl.y;
-            }
-            if (bounce == 0) {   // first_hit_vertex / first_hit_material (path_tracer.glsl:437-442)
-                pb.first_mat[id] = F4(F3(mat.albedo), mat.metallic);
-                pb.first_emis[id] = F4(light, mat.albedo.w);
-            }
-
-            if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
-                if (bsdf_pdf != 0.0f) regularization *= fmax2(1 - P.opt.regularization_gamma / tpow(bsdf_pdf, 0.25f), 0.0f);
-                mat.roughness = 1.0f - ((1.0f - mat.roughness) * regularization);
-            }
-
-            if (!terminal) {
-                const m3 tbn = create_tangent_space(v.mapped_normal);
-                const f3 shading_view = view_to_tangent_space(view, tbn);
-                u4 coord = {0, 0, 0, 0};   // only the Sobol-Owen sampler hashes the launch coordinate again (uniform branch)
-                if (P.opt.sampler == SAMPLER_SOBOL_OWEN) {
-                    uint lx, ly, lz;
-                    launch_coord(P.L, misc.z, lx, ly, lz);
-                    int px = 0, py = 0;
-                    get_pixel_pos(P.L, lx, ly, px, py);
-                    coord = u4{(uint)px, (uint)py, global_viewport(P, lz) + P.rng_seed, P.rng_sample + sample_counter_of(P, lz)};
-                }
-                // ---- next_event_estimation (path_tracer.glsl:302-344, 449-472)
-                const bool any_nee = (P.nee_point && sv.point_light_count > 0) || (P.nee_dir && sv.directional_light_count > 0) ||
-                                     (P.nee_tri && sv.tri_light_count > 0) || (P.nee_env && sv.environment_proj >= 0);
-                u4 rnd = ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u, P.opt.sampler, P.max_sobol_bounces);
-                Lobes lobes = {0, 0, 0, 0};
-                if (any_nee) {
-                    f3 out_dir;
-                    float out_length = 0.0f, light_pdf;
-                    f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
-                    f3 shading_light = mulT(out_dir, tbn);
-                    float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
-                    correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
-                    bool cast = contrib.x > 0.0001f || contrib.y > 0.0001f || contrib.z > 0.0001f;
-                    contrib = contrib / nee_mis_pdf(P, light_pdf, nee_bsdf_pdf);
-                    f3 radiance = attenuation * contrib;
-                    float clamp_lum = 0.0f;   // > 0: indirect clamping applies to (radiance * visibility)
-                    if (bounce != 0) {
-                        radiance *= modulate_bsdf(mat, lobes);
-                        if (P.opt.indirect_clamping > 0.0f) clamp_lum = rgb_to_luminance(radiance);
-                    } else {
-                        // primary_lobes = lobes (path_tracer.glsl:466)
-                        pl = F2(lobes.diffuse + lobes.transmission, lobes.dielectric_reflection + lobes.metallic_reflection);
-                    }
-                    if (cast) {
-                        // contrib *= shadow_ray(...) happens in k_trace_shadow, including the clamp on the occluded value
-                        want_shadow = true;
-                        sh_o = v.pos; sh_d = out_dir; sh_tmax = out_length; sh_c = radiance; sh_lum = clamp_lum; sh_w = pl;
-                    } else {
-                        float mul = (clamp_lum > P.opt.indirect_clamping && clamp_lum > 0.0f) ? P.opt.indirect_clamping / clamp_lum : 1.0f;
-                        if (!have) { dif = pb.diffuse[id]; ref = pb.reflection[id]; have = true; }
-                        const f3 r = radiance * mul;
-                        dif.x += r.x * pl.x; dif.y += r.y * pl.x; dif.z += r.z * pl.x;
-                        ref.x += r.x * pl.y; ref.y += r.y * pl.y; ref.z += r.z * pl.y;
-                    }
-                }
-                if (bounce == 1) {   // diffuse.a = reflection.a = 1 / length(v.pos - pos) (path_tracer.glsl:470-471)
-                    const float inv_len = 1.0f / length(v.pos - pos);
-                    if (have) { dif.w = inv_len; ref.w = inv_len; }
-                    else { pb.diffuse[id].w = inv_len; pb.reflection[id].w = inv_len; }
-                }
-                // ---- BSDF sampling (path_tracer.glsl:475-497)
-                Lobes bl = {0, 0, 0, 0};
-                f4 ray_sample = u4_to_unit(ray_sample_uint(rs, coord, misc.y, (uint)bounce * 2u + 1u, P.opt.sampler, P.max_sobol_bounces));
-                f3 new_dir;
-                material_bsdf_sample(P.opt.bounce_mode, ray_sample, shading_view, mat, new_dir, bl, bsdf_pdf);
-                view = mul(tbn, new_dir);
-                correct_lobes_for_normal_map(v.hard_normal, view, bl);
-                if (bounce != 0) attenuation *= modulate_bsdf(mat, bl);
-                else pl = F2(bl.diffuse + bl.transmission, bl.dielectric_reflection + bl.metallic_reflection);   // primary_lobes = lobes
-                pos = v.pos;
-                alive = true;
-                if (P.opt.russian_roulette_delta > 0) {   // USE_RUSSIAN_ROULETTE: the survivor weight is never applied
-                    float qi_ = fmin2(1.0f, 1.0f / P.opt.russian_roulette_delta);
-                    if (ray_sample.w > qi_) alive = false;
-                }
-                if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
-            }
-            // ---- write back
-            if (have) { pb.diffuse[id] = dif; pb.reflection[id] = ref; }
-            if (alive) {
-                pb.org_pdf[id] = F4(pos, bsdf_pdf);
-                pb.dir_reg[id] = F4(view, regularization);
-                pb.atten_alpha[id] = F4(attenuation, 0);
-                if (bounce == 0) pb.plobes[id] = pl;
-                pb.rng[id] = rs;
-            }
-        }
+        ShadeOut o;
+        if (active) shade_path<COUNT, LAST, S>(sv, P, pb, bounce, id, misc, o, surf);
+        const bool alive = o.alive, want_shadow = o.want_shadow;
         // ---- queue compaction (wave ballots)
         if (LAST) continue;     // nothing survives the last bounce
         uint sslot, nslot;
         block_append2(&bc[BC_SHADOW], want_shadow, sslot, &bc[BC_STRIDE + BC_QUEUE], alive, nslot);
         if (want_shadow) {
-            pb.sh_org_tmax[sslot] = F4(sh_o, sh_tmax);
-            pb.sh_dir_id[sslot] = F4(sh_d, __uint_as_float(id));
-            pb.sh_contrib[sslot] = F4(sh_c, sh_lum);
-            pb.sh_lobes[sslot] = sh_w;
+            pb.sh_org_tmax[sslot] = F4(o.sh_o, o.sh_tmax);
+            pb.sh_dir_id[sslot] = F4(o.sh_d, __uint_as_float(id));
+            pb.sh_contrib[sslot] = F4(o.sh_c, o.sh_lum);
+            pb.sh_lobes[sslot] = o.sh_w;
         }
         if (alive) next_queue[nslot] = id;
     }

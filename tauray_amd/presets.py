@@ -87,11 +87,16 @@ def warm_up_jobs():
     return jobs
 
 
-def warm_kernel_cache(workers=None, verbose=False):
-    """Compiles the shading programs of every named option set into the kernel cache (trhip_kernel_cache_dir) in parallel processes."""
+def warm_kernel_cache(workers=None, verbose=False, clean=False):
+    """Compiles the shading programs of every named option set into the kernel cache (trhip_kernel_cache_dir) in parallel processes.
+    clean: programs of earlier builds (other sources, other hashes) are removed first."""
     import concurrent.futures as F
+    import glob
     import time
     jobs = warm_up_jobs()
+    if clean:
+        for f in glob.glob(os.path.join(_lib.lib().trhip_kernel_cache_dir().decode(), "spec_*.hsaco")):
+            os.remove(f)
     t0 = time.perf_counter()
     workers = workers or min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 8)
     with F.ProcessPoolExecutor(max_workers=workers) as ex:

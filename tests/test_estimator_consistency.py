@@ -1,0 +1,307 @@
+"""Tests of the HIP path tracer that do not go through the CPU oracle.
+
+Parity with the oracle says that the HIP kernels and the oracle agree; both restate the reference's shaders, so a pdf or a weight
+both got wrong the same way passes every parity test.  What catches that is the mathematics itself:
+
+* closed forms - a lit plane whose radiance is one evaluation of the BSDF, and a furnace (a closed box of emitters) whose second
+  bounce is the directional albedo of the material, obtained here by quadrature of the BSDF and never by sampling;
+* estimator consistency - the converged mean must not depend on how the integral is sampled: triangle lights by area, by solid angle or
+  hybrid (shader/light.glsl:39-179), MIS off / balance / power (shader/path_tracer.glsl:54-89), next-event estimation on or off per light
+  class (shader/path_tracer.glsl:203-289), BSDF sampling by hemisphere / cosine / material lobes (shader/ggx.glsl:512-552), pseudo-random
+  or one of the three Sobol samplers (shader/sampling.glsl).
+
+Bounds are set from the measured Monte-Carlo noise: every configuration is rendered as K independent batches, the standard error
+of a mean is the spread of its batches, and two configurations must agree within z standard errors (image mean) and in all but a
+few 32 x 32 pixel blocks, plus a floor of 0.2 % of the mean: the reference's integrator has small biases of its own that depend on
+the estimator (a light sample whose contribution is below 1e-4 is added without a shadow ray, shader/path_tracer.glsl:320-327; light
+samples closer than min_ray_dist are dropped) - 4e-4 ... 7e-4 between the MIS heuristics in the room below, which 3 000 samples per
+pixel resolve.  A pdf or weight that is wrong shows up in per cent.  Options that are biased by design stay out (roulette without
+survivor weight, clamping, regularisation)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    from tauray_amd import renderer
+    return renderer
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    return R.Context(0)
+
+
+def _dup(size):
+    from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+    return DistributionParams(tuple(size), DISTRIBUTION_DUPLICATE, 0, 1, True)
+
+
+def _quad(S, p0, eu, ev):
+    """Four vertices of the parallelogram p0 + s eu + t ev, normal eu x ev, two triangles."""
+    v = np.zeros(4, dtype=S.VERTEX)
+    p0, eu, ev = (np.asarray(a, dtype=np.float64) for a in (p0, eu, ev))
+    v["pos"] = [p0, p0 + eu, p0 + eu + ev, p0 + ev]
+    n = np.cross(eu, ev)
+    v["normal"] = n / np.linalg.norm(n)
+    v["tangent"] = tuple(eu / np.linalg.norm(eu)) + (1.0,)
+    v["uv"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    return v, [0, 1, 2, 0, 2, 3]
+
+
+def _scene(S, quads, cameras, **kw):
+    """quads: [(vertices, indices, material)], every one an instance with the identity transform."""
+    insts, verts, spans, idx = [], [], [], []
+    for v, i, m in quads:
+        spans.append((sum(len(x) for x in verts), len(v), len(idx), len(i) // 3))
+        insts.append(S.make_instance(np.eye(4), m))
+        verts.append(v)
+        idx += i
+    return S.SceneDesc(instances=np.concatenate(insts), spans=np.array(spans, dtype=S.MESH_SPAN), vertices=np.concatenate(verts),
+                       indices=np.array(idx, dtype=np.uint32), cameras=cameras, **kw).finalize(True)
+
+
+def _ortho_camera(S, eye, target, half, up=(0, 1, 0)):
+    """Orthographic camera at `eye` looking at `target` (camera space: -z forward), seeing [-half, half]^2."""
+    eye, target, up = (np.asarray(a, dtype=np.float64) for a in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, up)
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = r, u, -f, eye
+    cam = S.Camera(projection=S.PROJ_ORTHOGRAPHIC)
+    # an orthographic ray starts at NDC depth 0 (shader/camera.glsl get_camera_ray), the middle of the clip range: a range that is
+    # symmetric about the camera puts the origins on the camera plane
+    cam.ortho = (-half, half, -half, half, -50.0, 50.0)
+    cam.transform = m
+    return cam
+
+
+# ---- the material model in double precision (shader/ggx.glsl:36-49, 101-147): one evaluation, no sampling
+def _bsdf_lobes(cos_v_vec, l, roughness, ior=1.45):
+    """(diffuse lobe without albedo, dielectric reflection lobe) of a non-metallic opaque surface for unit vectors v, l in the
+    tangent frame (z = normal), cosine of the light included - what material_bsdf_pdf leaves in `lobes`."""
+    v = np.asarray(cos_v_vec, dtype=np.float64)
+    l = np.asarray(l, dtype=np.float64)
+    h = v + l
+    h = h / np.linalg.norm(h, axis=-1, keepdims=True)
+    cos_d = np.sum(v * h, -1)
+    cos_l, cos_v, cos_h = l[..., 2], v[..., 2], h[..., 2]
+    f0 = ((ior - 1.0) / (ior + 1.0)) ** 2
+    fresnel = f0 + (1.0 - f0) * np.maximum(1.0 - cos_d, 0.0) ** 5
+    a2 = roughness * roughness
+    dist = a2 / (math.pi * (cos_h * cos_h * (a2 - 1.0) + 1.0) ** 2)
+    geom = 0.5 / (np.abs(cos_l) * np.sqrt(a2 + (1 - a2) * cos_v * cos_v) + np.abs(cos_v) * np.sqrt(a2 + (1 - a2) * cos_l * cos_l))
+    cl = np.maximum(cos_l, 0.0)
+    return (1.0 - fresnel) * cl / math.pi, fresnel * geom * dist * cl
+
+
+def _directional_albedo(v, roughness, n=1200):
+    """integral of the two lobes over the hemisphere of light directions: midpoint rule in (cos theta, phi)"""
+    mu = (np.arange(n) + 0.5) / n
+    phi = (np.arange(2 * n) + 0.5) / (2 * n) * 2 * math.pi
+    mu, phi = np.meshgrid(mu, phi, indexing="ij")
+    s = np.sqrt(1 - mu * mu)
+    l = np.stack([s * np.cos(phi), s * np.sin(phi), mu], -1)
+    d, r = _bsdf_lobes(np.broadcast_to(np.asarray(v, dtype=np.float64), l.shape), l, roughness)
+    w = (1.0 / n) * (2 * math.pi / (2 * n))
+    return float(d.sum() * w), float(r.sum() * w)
+
+
+def _render(R, ctx, ss, scene, size, ieee=None, **kw):
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, **kw), _dup(size))
+    if ieee is not None:
+        pt.set_shading_arithmetic(ieee)
+    buf = ctx.alloc(size[0] * size[1] * 16).zero()
+    pt.run(buf)
+    img = buf.download((size[1], size[0], 4))
+    assert pt.counters()["stack_overflows"] == 0
+    pt.close()
+    return img
+
+
+def _batches(R, ctx, ss, scene, size, K, spp, **kw):
+    """K independent estimates of the frame, `spp` samples per pixel each (consecutive sample ranges of the pixel's sequence)."""
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, samples_per_pixel=spp, samples_per_pass=1, **kw), _dup(size))
+    buf = ctx.alloc(size[0] * size[1] * 16).zero()
+    out = np.zeros((K, size[1], size[0], 3), dtype=np.float64)
+    for k in range(K):
+        pt.reset_accumulated_samples()      # a new frame of the same accumulation-free sequence: the sample counter moves on
+        pt.run(buf)
+        out[k] = buf.download((size[1], size[0], 4))[..., :3]
+    assert pt.counters()["stack_overflows"] == 0
+    pt.close()
+    assert np.isfinite(out).all(), f"{kw}: non-finite radiance"
+    return out
+
+
+def _blocks(b, size=32):
+    K, H, W, C = b.shape
+    return b.reshape(K, H // size, size, W // size, size, C).mean((2, 4))
+
+
+BIAS_FLOOR = 2e-3      # relative; see the module docstring
+
+
+def _assert_same_mean(a, b, what, z_image=4.0, z_block=5.0, max_block_outliers=0.02):
+    """Two sets of batches estimate the same image: the image means agree within z_image standard errors (per channel) and the block
+    means within z_block standard errors in all but a few blocks (a block that holds a firefly of one estimator has a standard error
+    its handful of batches under-estimates)."""
+    K = a.shape[0]
+    ma, mb = a.mean((1, 2)), b.mean((1, 2))                       # (K, 3) image means per batch
+    se = np.sqrt(ma.var(0, ddof=1) / K + mb.var(0, ddof=1) / b.shape[0])
+    diff = ma.mean(0) - mb.mean(0)
+    rel = np.abs(diff) / np.maximum(ma.mean(0), 1e-9)
+    assert (np.abs(diff) <= z_image * se + BIAS_FLOOR * ma.mean(0)).all(), \
+        f"{what}: image means differ by {diff / np.maximum(se, 1e-30)} standard errors ({rel} relative; means {ma.mean(0)} vs {mb.mean(0)})"
+    ba, bb = _blocks(a), _blocks(b)
+    bse = np.sqrt(ba.var(0, ddof=1) / K + bb.var(0, ddof=1) / b.shape[0]) + BIAS_FLOOR * ba.mean(0) / z_block + 1e-12
+    z = np.abs(ba.mean(0) - bb.mean(0)) / bse
+    frac = float((z > z_block).mean())
+    assert frac <= max_block_outliers, f"{what}: {frac:.2%} of the blocks differ by more than {z_block} standard errors (largest {z.max():.1f})"
+    return rel.max(), float(np.abs(diff / np.maximum(se, 1e-30)).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_lit_plane_is_one_evaluation_of_the_bsdf(R, ctx):
+    """A plane under a directional light of angle 0, seen by an orthographic camera, black environment: the first hit's next-event
+    sample is the only light there is, it is deterministic (one delta light), and the pixel is
+        colour * (albedo * (1 - F) cos_l / pi + F G D cos_l)
+    - shader/path_tracer.glsl:302-344 (NEE), shader/light.glsl:119-129 (the delta light's colour is its irradiance), shader/ggx.glsl:123-147,
+    shader/material.glsl:57-73 (demodulation and re-modulation cancel for a dielectric).  Every pixel, both arithmetics, four geometries."""
+    from tauray_amd import scene as S
+    albedo = np.array([0.8, 0.5, 0.3])
+    colour = np.array([2.0, 1.5, 1.0])
+    for roughness, view_from, light_to in ((1.0, (0, 0, 5), (0, 0, -1)), (0.6, (2.5, 0.5, 4.0), (0.3, -0.2, -1.0)), (0.3, (0, 3.0, 3.0), (0.0, 1.0, -1.05)),
+                                           (0.9, (-3.0, -1.0, 2.0), (-0.6, 0.5, -0.7))):
+        v, i = _quad(S, (-20, -20, 0), (40, 0, 0), (0, 40, 0))
+        cam = _ortho_camera(S, view_from, (0, 0, 0), 0.5, up=(0, 1, 0) if abs(view_from[1]) < 2 else (0, 0, 1))
+        d = np.asarray(light_to, dtype=np.float64)
+        d /= np.linalg.norm(d)
+        sc = _scene(S, [(v, i, S.make_material(albedo=tuple(albedo) + (1,), metallic=0.0, roughness=roughness))], [cam],
+                    directional_lights=S.make_directional_light(tuple(colour), tuple(d), 0.0))
+        ss = R.SceneStage(ctx, sc)
+        vdir = np.asarray(view_from, dtype=np.float64)
+        vdir /= np.linalg.norm(vdir)
+        # the stored light direction is a float32 vector: evaluate with what the kernel sees
+        l = -np.asarray(sc.directional_lights["dir"][0], dtype=np.float64)
+        dif, spec = _bsdf_lobes(vdir, l, roughness)
+        want = colour * (albedo * dif + spec)
+        for ieee, tol in ((True, 2e-5), (None, 2e-3)):
+            img = _render(R, ctx, ss, sc, (32, 32), ieee=ieee, max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC)
+            got = img[..., :3].astype(np.float64)
+            assert np.abs(got / want - 1).max() < tol, f"roughness {roughness}, view {view_from}, ieee {ieee}: {got[0, 0]} instead of {want}"
+            assert (img[..., 3] == 1).all()
+
+
+def _furnace(S, emission, albedo, roughness):
+    """The unit-ish box [-1, 1]^3, every wall an emitter facing inwards, an orthographic camera inside looking at the back wall."""
+    m = S.make_material(albedo=tuple(albedo) + (1,), metallic=0.0, roughness=roughness, emission=tuple(emission))
+    walls = [((-1, -1, -1), (2, 0, 0), (0, 2, 0)),      # back, normal +z
+             ((-1, -1, 1), (0, 2, 0), (2, 0, 0)),       # front, normal -z
+             ((-1, -1, -1), (0, 2, 0), (0, 0, 2)),      # left, normal +x
+             ((1, -1, -1), (0, 0, 2), (0, 2, 0)),       # right, normal -x
+             ((-1, -1, -1), (0, 0, 2), (2, 0, 0)),      # floor, normal +y
+             ((-1, 1, -1), (2, 0, 0), (0, 0, 2))]       # ceiling, normal -y
+    quads = [(*_quad(S, *w), m) for w in walls]
+    cam = _ortho_camera(S, (0, 0, 0.5), (0, 0, -1), 0.4)
+    return _scene(S, quads, [cam])
+
+
+def test_furnace_second_bounce_is_the_directional_albedo(R, ctx):
+    """Inside a closed box whose walls all emit Le, with two bounces, a pixel that looks at a wall along its normal holds
+        Le * (2 + albedo * rho_d + rho_s)
+    whichever way the second segment is sampled: 2 Le is the wall's own emission (counted twice for a directly visible dielectric
+    emitter - the checkout's behaviour), rho_d / rho_s the directional albedos of the diffuse and the reflection
+    lobe at normal incidence, computed here by quadrature of shader/ggx.glsl:123-147.  Next-event estimation of the twelve wall
+    triangles in three sampling modes, MIS off / balance / power, no NEE at all, three BSDF sampling modes, four samplers."""
+    from tauray_amd import scene as S
+    Le = np.array([1.0, 0.7, 0.4])
+    albedo = np.array([0.7, 0.8, 0.9])
+    for roughness in (1.0, 0.4):
+        rho_d, rho_s = _directional_albedo((0, 0, 1), roughness)
+        want = Le * (2.0 + albedo * rho_d + rho_s)
+        sc = _furnace(S, Le, albedo, roughness)
+        ss = R.SceneStage(ctx, sc)
+        assert ss.tri_lights().shape[0] == 12
+        modes = [dict(), dict(tri_light_mode=0), dict(tri_light_mode=2), dict(mis_mode=1), dict(mis_mode=0), dict(nee_triangles=0.0),
+                 dict(nee_triangles=0.0, bounce_mode=1), dict(nee_triangles=0.0, bounce_mode=0), dict(bounce_mode=1, mis_mode=1, tri_light_mode=0),
+                 dict(bounce_mode=0, tri_light_mode=2), dict(sampler=1), dict(sampler=2), dict(sampler=3, mis_mode=1)]
+        for kw in modes if roughness == 1.0 else modes[:6]:
+            b = _batches(R, ctx, ss, sc, (64, 64), 12, 64, max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC, **kw)
+            per_batch = b.mean((1, 2))
+            mean, se = per_batch.mean(0), per_batch.std(0, ddof=1) / math.sqrt(len(per_batch))
+            assert (np.abs(mean - want) <= 4 * se + BIAS_FLOOR * want).all(), \
+                f"roughness {roughness}, {kw}: {mean} +- {se} instead of {want} ({(mean - want) / want} relative, {(mean - want) / np.maximum(se, 1e-12)} standard errors)"
+            assert (se < 0.02 * want).all(), f"roughness {roughness}, {kw}: the estimate is too noisy to say anything ({se / want})"
+
+
+def _room(S):
+    """A room with everything at once: an emissive ceiling panel and a small emissive quad (triangle lights), a sphere light, a sun
+    through the open front, a uniform environment, a rough floor, a glossy and a metallic block face - and no glass (refraction keeps
+    the estimators consistent as well, but a path through two interfaces converges too slowly for a two-second test)."""
+    grey = S.make_material(albedo=(0.7, 0.7, 0.7, 1), metallic=0.0, roughness=0.9)
+    red = S.make_material(albedo=(0.8, 0.2, 0.15, 1), metallic=0.0, roughness=0.6)
+    glossy = S.make_material(albedo=(0.3, 0.5, 0.8, 1), metallic=0.0, roughness=0.25)
+    metal = S.make_material(albedo=(0.9, 0.7, 0.3, 1), metallic=1.0, roughness=0.35)
+    lamp = S.make_material(albedo=(0, 0, 0, 1), metallic=0.0, roughness=1.0, emission=(6.0, 5.5, 5.0), double_sided=True)
+    glow = S.make_material(albedo=(0.2, 0.2, 0.2, 1), metallic=0.0, roughness=1.0, emission=(1.0, 2.0, 4.0), double_sided=True)
+    quads = [(*_quad(S, (-2, -1, -2), (4, 0, 0), (0, 0, 4)), grey),          # floor (normal +y ... eu x ev = (4,0,0) x (0,0,4) = -y: fixed below)
+             (*_quad(S, (-2, -1, -2), (4, 0, 0), (0, 3, 0)), grey),          # back wall, normal +z
+             (*_quad(S, (-2, -1, -2), (0, 3, 0), (0, 0, 4)), red),           # left wall, normal +x
+             (*_quad(S, (2, -1, -2), (0, 0, 4), (0, 3, 0)), grey),           # right wall, normal -x
+             (*_quad(S, (-2, 2, -2), (4, 0, 0), (0, 0, 4)), grey),           # ceiling, normal -y
+             (*_quad(S, (-0.6, 1.98, -0.9), (1.2, 0, 0), (0, 0, 0.8)), lamp),
+             (*_quad(S, (-1.6, -0.6, -1.9), (0.5, 0, 0), (0, 0.5, 0)), glow),
+             (*_quad(S, (0.3, -1, -0.8), (0.9, 0, 0.3), (0, 1.2, 0)), glossy),
+             (*_quad(S, (-1.3, -1, -0.2), (0.8, 0, -0.4), (0, 0.9, 0)), metal)]
+    v, i, m = quads[0]
+    quads[0] = (*_quad(S, (-2, -1, -2), (0, 0, 4), (4, 0, 0)), grey)          # floor with its normal up
+    cam = S.Camera(fov=60, aspect=1.0)
+    cam.transform = S.trs_matrix((0.0, 0.4, 3.6))
+    return _scene(S, quads, [cam], point_lights=S.make_point_light((8, 7, 6), (1.2, 1.2, 0.6), 0.15),
+                  directional_lights=S.make_directional_light((1.5, 1.4, 1.2), (-0.2, -0.5, -1.0), 3.0),
+                  envmap=np.ones((2, 4, 4), dtype=np.float32), environment_factor=(0.25, 0.3, 0.4, 1.0))
+
+
+def test_the_converged_image_does_not_depend_on_the_estimator(R, ctx):
+    """One room, 4 bounces, 16 batches of 192 samples per pixel at 128 x 128 per configuration (3 072 spp): every way of sampling the
+    same integrand against the reference's command-line configuration."""
+    from tauray_amd import scene as S
+    sc = _room(S)
+    ss = R.SceneStage(ctx, sc)
+    size, K, spp = (128, 128), 16, 192
+    base = _batches(R, ctx, ss, sc, size, K, spp, max_bounces=4)
+    assert base.mean() > 0.05
+    variants = {
+        "triangle lights by area": dict(tri_light_mode=0), "triangle lights hybrid": dict(tri_light_mode=2),
+        "MIS balance heuristic": dict(mis_mode=1), "MIS off": dict(mis_mode=0),
+        "no NEE of triangle lights": dict(nee_triangles=0.0), "no NEE of the environment": dict(nee_envmap=0.0), "no NEE of the sun": dict(nee_directional=0.0),
+        "NEE weights 3 : 0.5 : 2 : 0.25": dict(nee_point=3.0, nee_directional=0.5, nee_triangles=2.0, nee_envmap=0.25),
+        "cosine-hemisphere bounces": dict(bounce_mode=1), "hemisphere bounces, balance MIS": dict(bounce_mode=0, mis_mode=1),
+        "Sobol-Owen sampler": dict(sampler=1), "Sobol Z2 sampler": dict(sampler=2), "Sobol Z3 sampler": dict(sampler=3),
+        "box film": dict(film=1, film_radius=0.5),
+        "another seed": dict(rng_seed=12345),
+    }
+    report = {}
+    for name, kw in variants.items():
+        b = _batches(R, ctx, ss, sc, size, K, spp, max_bounces=4, **kw)
+        # a film filter blurs edges: the block statistic is for estimators of the same per-pixel integrand
+        report[name] = _assert_same_mean(base, b, name, max_block_outliers=0.02 if "film" not in name else 0.1)
+    # the test has teeth: a light class that is neither sampled nor hit (a sphere light needs NEE or a lucky BSDF sample; a
+    # point light of radius 0 can only be sampled) changes the image by far more than the noise
+    sc2 = _room(S)
+    sc2.point_lights["radius"] = 0.0
+    ss2 = R.SceneStage(ctx, sc2)
+    with_light = _batches(R, ctx, ss2, sc2, size, 8, spp, max_bounces=4)
+    without = _batches(R, ctx, ss2, sc2, size, 8, spp, max_bounces=4, nee_point=0.0)
+    with pytest.raises(AssertionError):
+        _assert_same_mean(with_light, without, "negative control")
+    print("estimator consistency (largest relative difference of a channel mean, in standard errors):",
+          {k: (round(float(v[0]), 5), round(v[1], 2)) for k, v in report.items()})

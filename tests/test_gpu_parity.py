@@ -236,10 +236,15 @@ def test_path_tracer_matches_oracle(R, ctx, glb128, test_glb_128, oracle, oracle
         ref = osc.render_pt(oracle.options_for_scene(scene, **kw), 128, 128)
         _compare_both(R, ctx, glb128, scene, (128, 128), ref, name, **kw)
         if name in ("sobol-owen", "blackman-harris", "tri-hybrid", "regularization+clamp", "no-nee", "dof"):
-            # the program compiled for the option set renders the bits of the general kernels, in either arithmetic
-            for ieee in (True, None):
-                assert np.array_equal(_render_hip(R, ctx, glb128, scene, (128, 128), ieee=ieee, **kw),
-                                      _render_hip(R, ctx, glb128, scene, (128, 128), ieee=ieee, specialize=False, **kw)), f"{name}: specialised != general (ieee={ieee})"
+            # the program compiled for the option set against the general kernels, which take the set as data: the same bits at IEEE
+            # fp32; at the default arithmetic every instance is an implementation of its own within Vulkan's accuracy (which of
+            # 1 / sqrt(x) becomes v_rsq_f32 and which v_rcp_f32(v_sqrt_f32) depends on the code around it): equal to a few ulps per
+            # operation, i.e. to the comparator's tolerance with nearly every pixel inside 1e-4
+            a, b = (_render_hip(R, ctx, glb128, scene, (128, 128), ieee=True, specialize=sp, **kw) for sp in (None, False))
+            assert np.array_equal(a, b), f"{name}: specialised != general at IEEE fp32"
+            a, b = (_render_hip(R, ctx, glb128, scene, (128, 128), specialize=sp, **kw) for sp in (None, False))
+            _compare(a, b, f"{name}: specialised vs general kernels, default arithmetic")
+            assert (np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6).all(-1).mean() > 0.98
     finally:
         if name == "dof":
             scene.cameras[0].focus = (1.0, 0.0, 0.0, 0.0)
@@ -2331,14 +2336,19 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     variants = {"default": {}, "one_lane_unfused": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0"}, "no_overlap": {"TRHIP_LANES": "1", "TRHIP_FUSED": "0", "TRHIP_OVERLAP": "0"},
                 "two_lanes": {"TRHIP_LANES": "2"}, "small_grids": {"TRHIP_GRID_BLOCKS": "300", "TRHIP_SHADE_BLOCKS": "100"},
                 "general_last_bounce": {"TRHIP_SHADE_LAST": "0"},
-                "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"}, "generic_shade": {"TRHIP_SHADE_CLI": "0"},
+                "lbvh": {"TRHIP_BUILDER": "lbvh"}, "unoptimised_tree": {"TRHIP_BVH_OPT": "0"}, "greedy_collapse": {"TRHIP_COLLAPSE": "greedy"},
+                # no ahead-of-time instance of the command-line set: a program compiled for it (hipRTC / kernel cache), or the general kernels
+                "compiled_shade": {"TRHIP_SHADE_CLI": "0"}, "general_shade": {"TRHIP_SHADE_CLI": "0", "TRHIP_SPECIALIZE": "0"},
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
                 "no_triangle_records": {"TRHIP_NO_SHADE_TRIS": "1"},      # no ShadeTri records: the general k_shade with indexed vertex fetches (IEEE fp32)
                 "lanes_enqueued_in_turn": {"TRHIP_ENQUEUE": "step"}, "lanes_enqueued_a_step_apart": {"TRHIP_ENQUEUE": "skew1"},      # instead of lane after lane (the first frame of a stage)
                 "ploc_grid_rounds": {"TRHIP_PLOC_NO_TAIL": "1"},      # every clustering round as grid launches (csrc/bvh_build.hip k_ploc_tail otherwise)
                 # the shading kernels of the command-line option set exist at IEEE fp32 too (TRHIP_SHADE_FAST=0; csrc/shade_fast.hip)
-                "ieee_shade": {"TRHIP_SHADE_FAST": "0"}, "ieee_generic_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0"},
+                "ieee_shade": {"TRHIP_SHADE_FAST": "0"}, "ieee_compiled_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0"},
+                "ieee_general_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0", "TRHIP_SPECIALIZE": "0"},
+                "ieee_no_triangle_records": {"TRHIP_SHADE_FAST": "0", "TRHIP_NO_SHADE_TRIS": "1"},
                 "ieee_general_last_bounce": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_LAST": "0"}}
+    other_instances = ("compiled_shade", "general_shade", "no_triangle_records")
     # TRHIP_FUZZ_SWITCH_COMBOS=N (with TRHIP_FUZZ_SEED): N random combinations of the switches that keep the default arithmetic, by hand
     rng = np.random.default_rng(int(os.environ.get("TRHIP_FUZZ_SEED", "1")))
     for k in range(int(os.environ.get("TRHIP_FUZZ_SWITCH_COMBOS", "0"))):
@@ -2353,7 +2363,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_SHADE_FAST", "TRHIP_PLOC_NO_TAIL", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_SHADE_FAST", "TRHIP_SPECIALIZE", "TRHIP_PLOC_NO_TAIL", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
@@ -2365,6 +2375,12 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     # schedule, tree and kernel instance renders the same bits (the general k_shade only exists at IEEE fp32)
     ieee = frames["ieee_shade"]
     for tag, f in frames.items():
-        base = ieee if tag in ("ieee_shade", "ieee_generic_shade", "ieee_general_last_bounce", "generic_shade", "no_triangle_records") else ref
+        if tag in other_instances:
+            # another instance of k_shade at the default arithmetic: an implementation of its own within Vulkan's accuracy (see
+            # test_path_tracer_matches_oracle) - close, not the same bits
+            _compare(f[None], ref[None], f"{tag} vs the default frame")
+            assert (np.abs(f - ref) <= 1e-4 * np.abs(ref) + 1e-6).all(-1).mean() > 0.98, tag
+            continue
+        base = ieee if tag.startswith("ieee_") else ref
         assert np.array_equal(f, base), f"{tag}: {int((f != base).any(-1).sum())} pixels differ from the {'IEEE' if base is ieee else 'default'} frame"
     _compare(ref[None], ieee[None], "default shading arithmetic vs IEEE fp32")
