@@ -43,6 +43,39 @@ int trhip_gather_partials(trhip_comm* comm, int root, const void* send_dev, size
  * `root` (recv_dev may equal send_dev; it is ignored on the other ranks).  ncclReduce(sum). */
 int trhip_reduce_samples(trhip_comm* comm, int root, const void* send_dev, void* recv_dev, size_t float_count, void* stream);
 
+
+/* ---- The same gather on the copy engines: no kernel of a library runs on either side.
+ *
+ * trhip_gather_partials is an RCCL send / receive pair per peer: RCCL moves the bytes with kernels of its own, which need CUs on
+ * both devices - on the display rank, next to persistent trace kernels that fill the chip.  trhip_ipc moves them the way the
+ * single-process host does (trhip_copy_peer = hipMemcpyPeerAsync, tauray_hip.hh) and the way the reference's device_transfer
+ * does in spirit (src/device_transfer.cc:140-290: plain copies paced by semaphores), across process boundaries: the display rank
+ * owns one receive arena (slots x peers x slot_bytes of device memory) and exports it with hipIpcGetMemHandle; every other rank
+ * maps it (hipIpcOpenMemHandle) and writes its partial frame there with hipMemcpyAsync on its own stream - a DMA over its xGMI
+ * link to the display device, no CU involved.  Ordering travels in 8-byte tags: behind its copy a sender writes the frame's
+ * number into the display rank's tag block, the display rank's stream waits for the tags of all peers (one wave of a one-block
+ * kernel that polls, the only device code of the exchange) before whatever consumes the frames; when the consumer is enqueued the
+ * display rank releases the slot by writing a tag into every sender's block, which a sender's stream waits for before it
+ * overwrites that slot `slots` frames later.  Nothing synchronises with the host.
+ *
+ * Set-up: every rank creates its end, exports TRHIP_IPC_EXPORT_BYTES bytes, the caller gathers the blobs of all ranks by its own
+ * means (as with the communicator id) and hands them, rank-major, to trhip_ipc_connect.  Ranks may share a device (the two-process
+ * test on one GPU), not a process (an IPC handle cannot be opened by the process that made it). */
+#define TRHIP_IPC_EXPORT_BYTES 256
+typedef struct trhip_ipc trhip_ipc;
+/* slot_bytes: the largest partial frame a peer will send (get_distribution_target_max_size x layers x 16); slots: frames that may
+ * be in flight between a sender and the display rank (the renderer's frame slots). */
+int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot_bytes, int slots, trhip_ipc** out);
+int trhip_ipc_export(trhip_ipc* ipc, void* blob_out);
+int trhip_ipc_connect(trhip_ipc* ipc, const void* blobs_of_all_ranks);
+/* One frame.  Not the root: waits (on `stream`) until the slot of this frame has been released, copies send_bytes bytes from
+ * send_dev into it, posts the arrival tag.  Root: waits (on `stream`) for the arrival tags of every peer r with recv_bytes[r] > 0
+ * and returns where their partial frames are in recv_dev_out[r] (pointers into the arena, valid until trhip_ipc_release). */
+int trhip_ipc_gather_partials(trhip_ipc* ipc, const void* send_dev, size_t send_bytes, void** recv_dev_out, const size_t* recv_bytes, void* stream);
+/* Root, after the consumers of the frame just gathered have been enqueued on `stream`: the slot may be overwritten once they are done. */
+int trhip_ipc_release(trhip_ipc* ipc, void* stream);
+void trhip_ipc_destroy(trhip_ipc* ipc);
+
 #ifdef __cplusplus
 }
 #endif

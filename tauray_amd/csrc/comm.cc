@@ -15,9 +15,12 @@ struct trhip_comm {
     int device = 0, nranks = 1, rank = 0;
 };
 
+std::string& trhip_comm_error_slot() {      // one message slot for the RCCL exchange here and the copy-engine exchange of comm_ipc.hip
+    thread_local std::string e;
+    return e;
+}
 namespace {
-thread_local std::string g_error;
-int fail(const std::string& m) { g_error = m; return 1; }
+int fail(const std::string& m) { trhip_comm_error_slot() = m; return 1; }
 }  // namespace
 
 #define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + ncclGetErrorString(r_)); } while (0)
@@ -25,7 +28,7 @@ int fail(const std::string& m) { g_error = m; return 1; }
 
 extern "C" {
 
-const char* trhip_comm_last_error(void) { return g_error.c_str(); }
+const char* trhip_comm_last_error(void) { return trhip_comm_error_slot().c_str(); }
 
 int trhip_comm_unique_id(void* id_out) {
     if (!id_out) return fail("trhip_comm_unique_id: null out");

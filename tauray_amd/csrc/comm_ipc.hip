@@ -1,0 +1,212 @@
+// The copy-engine exchange of include/trhip_comm.h (trhip_ipc_*): partial frames travel by hipMemcpyAsync into IPC-mapped memory
+// of the display rank, ordering by 8-byte tags.  Part of libtrhip_comm.so.  Replaces src/device_transfer.cc:140-290 for one
+// process per GPU when the RCCL kernels of trhip_gather_partials are not wanted on the devices.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/trhip_comm.h"
+
+namespace {
+
+int ipc_fail(const std::string& m);
+
+// One lane per tag: polls until the tag has reached `want` (tags only grow).  System-scope acquire loads: the tag is written by
+// another device's DMA engine (or another process's copy), and what it announces - the partial frame - was written before it.
+// Gives up after ~10 s of wall clock (a peer that died) and says so in *timed_out; the caller's consumers then read what is there.
+__global__ void k_wait_tags(const unsigned long long* tags, int n, int stride, const unsigned char* wanted, unsigned long long want, int* timed_out) {
+    const int i = threadIdx.x;
+    if (i >= n || !wanted[i]) return;
+    const unsigned long long* p = tags + (size_t)i * stride;
+    const unsigned long long t0 = wall_clock64();       // 100 MHz
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 1000000000ull) { *timed_out = 1; return; }
+    }
+}
+
+struct Blob {      // what a rank tells the others (TRHIP_IPC_EXPORT_BYTES)
+    char magic[8];
+    int rank, root, nranks, slots;
+    unsigned long long slot_bytes;
+    int has_arena, pad;
+    hipIpcMemHandle_t arena;      // root: the receive arena
+    hipIpcMemHandle_t tags;       // root: arrival tags [nranks][slots]; others: release tags [slots]
+};
+static_assert(sizeof(Blob) <= TRHIP_IPC_EXPORT_BYTES, "trhip_comm.h: export size");
+
+constexpr int TAG_RING = 1024;      // tag values wait in pinned host memory for their copy: at most this many gathers enqueued ahead of the device
+
+}  // namespace
+
+struct trhip_ipc {
+    int device = 0, nranks = 1, rank = 0, root = 0, slots = 1;
+    size_t slot_bytes = 0;
+    unsigned long long frame = 0;            // gathers so far
+    bool connected = false;
+    // own allocations
+    void* arena = nullptr;                    // root
+    unsigned long long* tags = nullptr;       // root: [nranks][slots] arrival tags; others: [slots] release tags
+    int* timed_out = nullptr;
+    unsigned char* wanted_dev = nullptr;
+    unsigned long long* tag_values = nullptr; // pinned ring: sources of the tag copies
+    // mapped from the other side
+    void* root_arena = nullptr;               // non-root
+    unsigned long long* root_tags = nullptr;  // non-root
+    std::vector<unsigned long long*> peer_tags;   // root: release tags of every peer
+    std::vector<unsigned char> wanted_host;
+};
+
+std::string& trhip_comm_error_slot();      // comm.cc: what trhip_comm_last_error() returns
+namespace {
+int ipc_fail(const std::string& m) { trhip_comm_error_slot() = m; return 1; }
+#define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return ipc_fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+}  // namespace
+
+extern "C" {
+
+int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot_bytes, int slots, trhip_ipc** out) {
+    if (!out) return ipc_fail("trhip_ipc_create: null out");
+    if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || root < 0 || root >= nranks) return ipc_fail("trhip_ipc_create: rank out of range (at most 64 ranks)");
+    if (slots < 1 || slots > 16 || slot_bytes == 0) return ipc_fail("trhip_ipc_create: 1 ... 16 slots of at least one byte");
+    ICHK(hipSetDevice(hip_device));
+    trhip_ipc* c = new trhip_ipc();
+    c->device = hip_device; c->nranks = nranks; c->rank = rank; c->root = root; c->slots = slots;
+    c->slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+    const size_t n_tags = rank == root ? (size_t)nranks * slots : (size_t)slots;
+    hipError_t e = hipSuccess;
+    if (rank == root) e = hipMalloc(&c->arena, (size_t)nranks * slots * c->slot_bytes);
+    if (e == hipSuccess) e = hipMalloc(&c->tags, n_tags * 8);
+    if (e == hipSuccess) e = hipMemset(c->tags, 0, n_tags * 8);
+    if (e == hipSuccess) e = hipMalloc(&c->timed_out, 4);
+    if (e == hipSuccess) e = hipMemset(c->timed_out, 0, 4);
+    if (e == hipSuccess) e = hipMalloc(&c->wanted_dev, 64 * (size_t)slots);
+    if (e == hipSuccess) e = hipHostMalloc(&c->tag_values, TAG_RING * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { trhip_ipc_destroy(c); return ipc_fail(std::string("trhip_ipc_create: ") + hipGetErrorString(e)); }
+    c->wanted_host.assign(64, 0);
+    *out = c;
+    return 0;
+}
+
+int trhip_ipc_export(trhip_ipc* c, void* blob_out) {
+    if (!c || !blob_out) return ipc_fail("trhip_ipc_export: null argument");
+    ICHK(hipSetDevice(c->device));
+    Blob b;
+    memset(&b, 0, sizeof(b));
+    memcpy(b.magic, "TRHIPIPC", 8);
+    b.rank = c->rank; b.root = c->root; b.nranks = c->nranks; b.slots = c->slots; b.slot_bytes = c->slot_bytes; b.has_arena = c->arena != nullptr;
+    if (c->arena) ICHK(hipIpcGetMemHandle(&b.arena, c->arena));
+    ICHK(hipIpcGetMemHandle(&b.tags, c->tags));
+    memset(blob_out, 0, TRHIP_IPC_EXPORT_BYTES);
+    memcpy(blob_out, &b, sizeof(b));
+    return 0;
+}
+
+int trhip_ipc_connect(trhip_ipc* c, const void* blobs) {
+    if (!c || !blobs) return ipc_fail("trhip_ipc_connect: null argument");
+    if (c->connected) return ipc_fail("trhip_ipc_connect: already connected");
+    ICHK(hipSetDevice(c->device));
+    const char* base = static_cast<const char*>(blobs);
+    std::vector<Blob> all((size_t)c->nranks);
+    for (int r = 0; r < c->nranks; ++r) {
+        memcpy(&all[(size_t)r], base + (size_t)r * TRHIP_IPC_EXPORT_BYTES, sizeof(Blob));
+        const Blob& b = all[(size_t)r];
+        if (memcmp(b.magic, "TRHIPIPC", 8) != 0 || b.rank != r || b.root != c->root || b.nranks != c->nranks || b.slots != c->slots || b.slot_bytes != c->slot_bytes)
+            return ipc_fail("trhip_ipc_connect: the blob of rank " + std::to_string(r) + " does not belong to this exchange (rank order, root, slots or slot size differ)");
+    }
+    if (c->rank == c->root) {
+        c->peer_tags.assign((size_t)c->nranks, nullptr);
+        for (int r = 0; r < c->nranks; ++r) {
+            if (r == c->root) continue;
+            void* p = nullptr;
+            ICHK(hipIpcOpenMemHandle(&p, all[(size_t)r].tags, hipIpcMemLazyEnablePeerAccess));
+            c->peer_tags[(size_t)r] = static_cast<unsigned long long*>(p);
+        }
+    } else {
+        const Blob& rb = all[(size_t)c->root];
+        if (!rb.has_arena) return ipc_fail("trhip_ipc_connect: the root exported no arena");
+        ICHK(hipIpcOpenMemHandle(&c->root_arena, rb.arena, hipIpcMemLazyEnablePeerAccess));
+        void* p = nullptr;
+        ICHK(hipIpcOpenMemHandle(&p, rb.tags, hipIpcMemLazyEnablePeerAccess));
+        c->root_tags = static_cast<unsigned long long*>(p);
+    }
+    c->connected = true;
+    return 0;
+}
+
+int trhip_ipc_gather_partials(trhip_ipc* c, const void* send_dev, size_t send_bytes, void** recv_dev_out, const size_t* recv_bytes, void* stream) {
+    if (!c) return ipc_fail("trhip_ipc_gather_partials: null exchange");
+    if (c->nranks == 1) return 0;
+    if (!c->connected) return ipc_fail("trhip_ipc_gather_partials: call trhip_ipc_connect first");
+    ICHK(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long f = c->frame++;
+    const int slot = (int)(f % (unsigned long long)c->slots);
+    const unsigned long long use = f / (unsigned long long)c->slots + 1;      // the slot's use count with this frame: its tag value
+    unsigned long long* val = c->tag_values + (f % TAG_RING);
+    if (c->rank != c->root) {
+        if (send_bytes > c->slot_bytes) return ipc_fail("trhip_ipc_gather_partials: the partial frame is larger than a slot");
+        if (send_bytes == 0) return 0;      // (a rank whose share is empty sends nothing and is not waited for: recv_bytes[r] = 0 on the root)
+        if (!send_dev) return ipc_fail("trhip_ipc_gather_partials: null send buffer");
+        if (use > 1) {      // the slot's previous frame has to be consumed: release tag >= use - 1
+            c->wanted_host[0] = 1;
+            ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), 1, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, 1, 1, c->wanted_dev + 64 * slot, use - 1, c->timed_out);
+        }
+        char* dst = static_cast<char*>(c->root_arena) + ((size_t)slot * c->nranks + (size_t)c->rank) * c->slot_bytes;
+        ICHK(hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, s));
+        *val = use;
+        ICHK(hipMemcpyAsync(c->root_tags + (size_t)c->rank * c->slots + slot, val, 8, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    if (!recv_dev_out || !recv_bytes) return ipc_fail("trhip_ipc_gather_partials: the root needs the receive arrays");
+    bool any = false;
+    for (int r = 0; r < c->nranks; ++r) {
+        const bool w = r != c->root && recv_bytes[r] > 0;
+        if (w && recv_bytes[r] > c->slot_bytes) return ipc_fail("trhip_ipc_gather_partials: a partial frame is larger than a slot");
+        c->wanted_host[(size_t)r] = w ? 1 : 0;
+        recv_dev_out[r] = w ? static_cast<char*>(c->arena) + ((size_t)slot * c->nranks + (size_t)r) * c->slot_bytes : nullptr;
+        any |= w;
+    }
+    if (any) {
+        ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), (size_t)c->nranks, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, c->nranks, c->slots, c->wanted_dev + 64 * slot, use, c->timed_out);
+    }
+    ICHK(hipGetLastError());
+    return 0;
+}
+
+int trhip_ipc_release(trhip_ipc* c, void* stream) {
+    if (!c) return ipc_fail("trhip_ipc_release: null exchange");
+    if (c->nranks == 1 || c->rank != c->root) return 0;
+    if (c->frame == 0) return ipc_fail("trhip_ipc_release: nothing gathered yet");
+    ICHK(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long f = c->frame - 1;
+    const int slot = (int)(f % (unsigned long long)c->slots);
+    unsigned long long* val = c->tag_values + (f % TAG_RING);
+    *val = f / (unsigned long long)c->slots + 1;
+    for (int r = 0; r < c->nranks; ++r)
+        if (r != c->root && c->peer_tags[(size_t)r]) ICHK(hipMemcpyAsync(c->peer_tags[(size_t)r] + slot, val, 8, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+void trhip_ipc_destroy(trhip_ipc* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->root_arena) (void)hipIpcCloseMemHandle(c->root_arena);
+    if (c->root_tags) (void)hipIpcCloseMemHandle(c->root_tags);
+    for (unsigned long long* p : c->peer_tags) if (p) (void)hipIpcCloseMemHandle(p);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->tags) (void)hipFree(c->tags);
+    if (c->timed_out) (void)hipFree(c->timed_out);
+    if (c->wanted_dev) (void)hipFree(c->wanted_dev);
+    if (c->tag_values) (void)hipHostFree(c->tag_values);
+    delete c;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pt_kernels.h"
+#include "resolve_kernel.h"
 #include "specialize.h"
 
 namespace tr {
@@ -27,116 +28,6 @@ namespace {
 #ifndef TR_SHADOW_WAVES
 #define TR_SHADOW_WAVES 8
 #endif
-
-// ---------------------------------------------------------------------------------------------------
-// The closest-hit rays of queue slots base .. base + 63 (path_tracer.glsl:387-403), one wave: trace, store the hit records of
-// the paths.  Every lane of the wave calls this; the traversal re-deals the last rays of the chunk over quads (trace_quad.h).
-template <bool COUNT>
-TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, const uint* queue, uint qi, uint n, int* lds_stack,
-                         const QuadCtx& qc, TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
-    bool valid = qi < n;
-    uint id = 0;
-    u4 misc = {0, 0, 0, 1};
-    f4 o = F4(0), d = F4(0);
-    // the ray is fetched together with the path's flags, not behind them: one round trip less before the traversal starts, and a
-    // queue holds live paths only (the flag matters at bounce 0, where the ids are all launch ids)
-    if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
-    // payload.random_seed of this trace: k_raygen stored the seed of bounce 0, every closest-hit trace advances it once
-    // (path_tracer.glsl:387-403; DESIGN.md on the any-hit hash)
-    for (int b = 0; b < bounce; ++b) pcg(misc.x);
-    HitRecord hit;
-    const bool include_lights = !(P.opt.hide_lights && bounce == 0);
-    const uint before = st.nodes;
-#if TR_QUAD_SWITCH > 0
-    trace_closest_wave4<0, COUNT>(sv, valid, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights, misc.x,
-                                  lds_stack, qc, hit, st, overflow);
-#else
-    if (valid) trace_closest4<0, COUNT>(sv, F3(o), F3(d), bounce == 0 ? 0.0f : P.opt.min_ray_dist, __builtin_huge_valf(), include_lights,
-                                        misc.x, lds_stack, hit, st, overflow);
-#endif
-    if (COUNT) st.cnodes += st.nodes - before;      // every lane: in the quad tail lane 0 of a quad counts for the quad's ray
-    if (!valid) return;
-    if (COUNT) {
-        const uint vis = st.nodes - before;
-        max_vis = max(max_vis, vis);
-        if (vis > 100000u && vis > atomicMax(&pb.counters[CNT_MAXVIS], vis)) {   // debugging aid: remember a pathological ray
-            float* dbg = reinterpret_cast<float*>(pb.counters + CNT_DBG);
-            dbg[0] = o.x; dbg[1] = o.y; dbg[2] = o.z; dbg[3] = d.x; dbg[4] = d.y; dbg[5] = d.z; dbg[6] = (float)bounce; dbg[7] = (float)id;
-            dbg[8] = o.w; dbg[9] = d.w;
-        }
-    }
-    pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
-    rays++;
-}
-
-// LDS and global scratch of a wave's quad tail
-TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb) {
-    QuadCtx qc;
-    const uint wave = threadIdx.x >> 6;
-    qc.wave_stack = s_stack + (threadIdx.x & ~63u);
-    qc.owner_tab = s_owner + wave * TR_OWNER_WORDS;
-    qc.spill = pb.qspill + ((size_t)blockIdx.x * (KB / 64) + wave) * (16u * TR_QSPILL);
-    return qc;
-}
-
-// The shadow rays of slots base .. base + 63 of the bounce's shadow queue, one wave: contrib *= shadow_ray(...)
-// (path_tracer.glsl:35-52, 462-463) and add_demodulated_color of the result.  Every lane of the wave calls this.
-template <bool COUNT>
-TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, const QuadCtx& qc,
-                        TraceStats& st, int& overflow, uint& rays) {
-    const bool valid = qi < n;
-    f4 o = F4(0), d = F4(0), c = F4(0);
-    if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; c = pb.sh_contrib[qi]; }
-#if TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
-    float vis = trace_shadow_wave4<COUNT>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, st, overflow);
-#else
-    float vis = 1.0f;
-    if (valid) vis = trace_shadow4<COUNT>(sv, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, st, overflow);
-#endif
-    if (!valid) return;
-    const uint id = __float_as_uint(d.w);
-    if (vis != 0.0f) {
-        // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
-        float m = c.w * vis;
-        if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
-        const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
-        const f2 w = pb.sh_lobes[qi];
-        // add_demodulated_color; a zero weight adds exactly nothing, so that target is left alone
-        if (w.x != 0.0f) { f4 d4 = pb.diffuse[id]; d4.x += radiance.x * w.x; d4.y += radiance.y * w.x; d4.z += radiance.z * w.x; pb.diffuse[id] = d4; }
-        if (w.y != 0.0f) { f4 r4 = pb.reflection[id]; r4.x += radiance.x * w.y; r4.y += radiance.y * w.y; r4.z += radiance.z * w.y; pb.reflection[id] = r4; }
-    }
-    rays++;
-}
-
-template <bool COUNT>
-TR_DEV void flush_trace_counters(const PtParams& P, const PathBuffers& pb, int overflow, int overflow_tag, uint closest_rays, uint shadow_rays,
-                                 TraceStats st, uint max_vis) {
-    if (overflow) { pb.counters[CNT_OVERFLOW] = 1; pb.counters[CNT_DBG + 12] = (uint)overflow_tag; }
-    if (!P.count_work) return;
-    for (int off = 32; off > 0; off >>= 1) {
-        closest_rays += __shfl_xor(closest_rays, off); shadow_rays += __shfl_xor(shadow_rays, off);
-        if (COUNT) {
-            st.nodes += __shfl_xor(st.nodes, off); st.tris += __shfl_xor(st.tris, off); st.alpha += __shfl_xor(st.alpha, off);
-            st.ph_node += __shfl_xor(st.ph_node, off); st.ph_tri += __shfl_xor(st.ph_tri, off); st.ph_node16 += __shfl_xor(st.ph_node16, off);
-            st.ph_node8 += __shfl_xor(st.ph_node8, off); st.lv_node16 += __shfl_xor(st.lv_node16, off);
-            st.ph_qnode += __shfl_xor(st.ph_qnode, off); st.ph_qtri += __shfl_xor(st.ph_qtri, off); st.cnodes += __shfl_xor(st.cnodes, off);
-            for (int b = 0; b < 8; ++b) st.ph_hist[b] += __shfl_xor(st.ph_hist[b], off);
-            st.maxsp = max(st.maxsp, (uint)__shfl_xor(st.maxsp, off)); max_vis = max(max_vis, (uint)__shfl_xor(max_vis, off));
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        add64(pb.counters, CNT_CLOSEST, closest_rays);
-        add64(pb.counters, CNT_SHADOWRAYS, shadow_rays);
-        if (COUNT) {
-            add64(pb.counters, CNT_NODES, st.nodes); add64(pb.counters, CNT_TRIS, st.tris); add64(pb.counters, CNT_ALPHA, st.alpha);
-            add64(pb.counters, CNT_PH_NODE, st.ph_node); add64(pb.counters, CNT_PH_TRI, st.ph_tri); add64(pb.counters, CNT_PH_NODE16, st.ph_node16);
-            add64(pb.counters, CNT_PH_NODE8, st.ph_node8); add64(pb.counters, CNT_LV_NODE16, st.lv_node16);
-            add64(pb.counters, CNT_PH_QNODE, st.ph_qnode); add64(pb.counters, CNT_PH_QTRI, st.ph_qtri); add64(pb.counters, CNT_CNODES, st.cnodes);
-            for (int b = 0; b < 8; ++b) add64(pb.counters, CNT_PH_HIST + 2 * b, st.ph_hist[b]);
-            atomicMax(&pb.counters[CNT_MAXSP], st.maxsp); atomicMax(&pb.counters[CNT_MAXVIS], max_vis);
-        }
-    }
-}
 
 // Persistent waves: each wave takes its first 64 rays by wave id (no atomic: avoids a burst of ~7000 dequeues on one word
 // at kernel start) and later chunks from a device-side cursor, which starts past the statically assigned range.
@@ -486,72 +377,6 @@ __global__ __launch_bounds__(KB) void k_resolve_direct(PtParams P, PathBuffers p
     if (P.T.reflection) accumulate(P.T.reflection, pb.reflection[i]);
 }
 
-// end of one sample (path_tracer.rgen:105-118): sum_color += first_hit_material.emission + modulate_color(first_hit_material,
-// diffuse, reflection) with material.glsl:57-65; sum_diffuse / sum_reflection when those targets exist
-TR_DEV f4 sample_color(const PtParams& P, f4 d, f4 r, f4 fm, f4 fe) {   // rgb = emission + modulate_color(...), a = first-hit alpha
-    const f3 albedo = P.opt.use_white_albedo_on_first_bounce ? F3(1) : F3(fm);
-    const float metallic = fm.w;
-    const float approx_fresnel = 0.02f;
-    const f3 dd = F3(d) * albedo * (1 - metallic);
-    const f3 rr = F3(r) * mix3(F3(approx_fresnel), albedo, metallic) / mixf(approx_fresnel, 1.0f, metallic);
-    return F4(F3(fe) + (dd + rr), fe.w);
-}
-
-__global__ __launch_bounds__(KB) void k_accumulate_sample(PtParams P, PathBuffers pb) {
-    uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_ids) return;
-    i += P.id_offset;
-    u4 misc = pb.misc[i];
-    if (misc.w & 1u) return;
-    const f4 s = pb.sum_color[i], d = pb.diffuse[i], r = pb.reflection[i];
-    const f4 c = sample_color(P, d, r, pb.first_mat[i], pb.first_emis[i]);
-    pb.sum_color[i] = F4(s.x + c.x, s.y + c.y, s.z + c.z, c.w);
-    if (pb.sum_diffuse) {
-        const f4 sd = pb.sum_diffuse[i], sr = pb.sum_reflection[i];
-        pb.sum_diffuse[i] = F4(sd.x + d.x, sd.y + d.y, sd.z + d.z, sd.w + d.w);
-        pb.sum_reflection[i] = F4(sr.x + r.x, sr.y + r.y, sr.z + r.z, sr.w + r.w);
-    }
-}
-
-// write_all_outputs (path_tracer.glsl:535-576) + accumulate_gbuffer_{color,diffuse,reflection} (gbuffer.glsl:18-28,68-78,118-128)
-__global__ __launch_bounds__(KB) void k_resolve(PtParams P, PathBuffers pb) {
-    uint i = blockIdx.x * KB + threadIdx.x;
-    if (i >= P.n_ids) return;
-    i += P.id_offset;
-    uint lx, ly, lz;
-    launch_coord(P.L, i, lx, ly, lz);
-    int wx, wy;
-    if (!get_write_pixel_pos(P.L, lx, ly, wx, wy)) return;
-    if ((uint)wx >= P.target_w || (uint)wy >= P.target_h) return;
-    const float spp = (float)P.opt.samples_per_pass;
-    const size_t idx = ((size_t)lz * P.target_h + (uint)wy) * P.target_w + (uint)wx;
-    const uint prev_samples = P.samples_accumulated + P.previous_samples;
-    const float keep = prev_samples != 0 ? (float)prev_samples / (float)((uint)P.opt.samples_per_pass + prev_samples) : 0.0f;
-    auto accumulate = [&](void* image, f4 value) {
-        f4* target = reinterpret_cast<f4*>(image);
-        if (prev_samples != 0) value = mix4(value, target[idx], keep);
-        target[idx] = value;
-    };
-    if (P.fused_resolve) {
-        // one sample per pass: the sums are the sample itself (0 + x and x / 1 are exact), k_accumulate_sample is not launched.
-        // A launch id whose pixel is invalid never gets here: get_write_pixel_pos fails with get_pixel_pos.
-        const f4 d = pb.diffuse[i], r = pb.reflection[i];
-        if (P.T.color) {
-            const f4 c = sample_color(P, d, r, pb.first_mat[i], pb.first_emis[i]);
-            accumulate(P.T.color, F4(c.x, c.y, c.z, P.opt.transparent_background ? c.w : 1.0f));
-        }
-        if (P.T.diffuse) accumulate(P.T.diffuse, d);
-        if (P.T.reflection) accumulate(P.T.reflection, r);
-        return;
-    }
-    if (P.T.color) {
-        const f4 s = pb.sum_color[i];
-        accumulate(P.T.color, F4(s.x / spp, s.y / spp, s.z / spp, P.opt.transparent_background ? s.w : 1.0f));
-    }
-    if (P.T.diffuse) { const f4 s = pb.sum_diffuse[i]; accumulate(P.T.diffuse, F4(s.x / spp, s.y / spp, s.z / spp, s.w / spp)); }
-    if (P.T.reflection) { const f4 s = pb.sum_reflection[i]; accumulate(P.T.reflection, F4(s.x / spp, s.y / spp, s.z / spp, s.w / spp)); }
-}
-
 uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strategy.cc:62-69
     uint n = sx * sy, b = 31;
     while ((n >> b) < 128 && b > 0) b--;
@@ -565,6 +390,7 @@ uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strat
 // shade_fast.hip: the ahead-of-time k_shade instances (command-line option set or general) at the accuracy Vulkan asks of the reference's GLSL
 void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
                        const uint* queue, uint* bc, uint* next_queue);
+void launch_frame_fast(bool cli, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint* bc);
 
 void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/distribution_strategy.cc:33-61
     if (d.strategy == 0) { w = d.size_x; h = d.size_y; }
@@ -746,10 +572,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     static const bool specialize_env = !(getenv("TRHIP_SPECIALIZE") && atoi(getenv("TRHIP_SPECIALIZE")) == 0);
     const SpecKernels *spec_shade = nullptr, *spec_raygen = nullptr;
     if (!cli_set && !direct && (specialize < 0 ? specialize_env : specialize != 0)) {
-        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, false};
+        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, SPEC_SHADE};
         std::string why;
         spec_shade = spec_kernels(rq, &why);
-        if (spec_shade) { rq.raygen = true; spec_raygen = spec_kernels(rq, &why); }
+        if (spec_shade) { rq.program = SPEC_RAYGEN; spec_raygen = spec_kernels(rq, &why); }
         if (!spec_shade || !spec_raygen) {
             static bool warned = false;
             if (!warned) fprintf(stderr, "[trhip] no specialised shading program for {%s}: %s - rendering with the general kernels\n", spec_key(rq).c_str(), why.c_str());
@@ -884,6 +710,55 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         frame_counter++;
         accumulated_samples += (uint)opt.samples_per_pixel;
         return 0;
+    }
+    // The resident schedule (frame_kernel.h): a launch whose paths all fit on the device at once is rendered by one kernel that keeps
+    // every path in its wave through all bounces, between the ray-generation launch and the resolve.  What a small frame - the strip
+    // one GPU of eight renders - costs under the queue schedule is latency: ten dependent launches, each as long as its longest ray.
+    {
+        static const int resident_env = getenv("TRHIP_RESIDENT") ? atoi(getenv("TRHIP_RESIDENT")) : -1;
+        const size_t resident_capacity = (size_t)n_cu * 4u * TR_FRAME_WAVES * 64u;      // four SIMDs per CU
+        bool resident = !timing && !count && !first_hit_targets && !sample_lanes && schedule != 1 && resident_env != 0 &&
+                        (schedule == 2 || resident_env == 1 || n <= resident_capacity);
+        const SpecKernels* spec_frame = nullptr;
+        if (resident && spec_shade) {
+            SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, false, SPEC_FRAME};
+            std::string why;
+            spec_frame = spec_kernels(rq, &why);
+            if (!spec_frame) resident = false;
+        }
+        if (resident) {
+            PtParams LP = P;
+            PathBuffers lb = pb;
+            const uint blocks_all = (LP.n_ids + KB - 1) / KB;
+            const uint blocks_f = std::min(blocks_all, n_cu * (uint)TR_FRAME_WAVES);
+            if (int rc = ensure_qspill(impl->pb, impl->qspill_lane_words, impl->qspill_regions, 1, blocks_f)) return rc;
+            lb.qspill = impl->pb.qspill;
+            const int passes = opt.samples_per_pixel / opt.samples_per_pass;
+            for (int pass = 0; pass < passes; ++pass) {
+                LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
+                for (int s = 0; s < opt.samples_per_pass; ++s) {
+                    LP.sample_in_pass = (uint)s;
+                    LP.rng_sample = shard_sample_base + shard_sample_stride * (LP.previous_samples + LP.sample_in_pass);
+                    launch_raygen(blocks_all, stream, LP, lb);
+                    if (spec_frame) {
+                        SceneView a0 = sv; PtParams a1 = LP; PathBuffers a2 = lb; uint* a3 = lb.bounce;
+                        void* args[] = {&a0, &a1, &a2, &a3};
+                        (void)hipModuleLaunchKernel(spec_frame->frame, blocks_f, 1, 1, KB, 1, 1, 0, stream, args, nullptr);
+                    } else if (shade_fast) launch_frame_fast(cli_set, blocks_f, stream, sv, LP, lb, lb.bounce);
+                    else if (cli_set) hipLaunchKernelGGL((k_frame_resident<false, SpecCli>), dim3(blocks_f), dim3(KB), 0, stream, sv, LP, lb, lb.bounce);
+                    else hipLaunchKernelGGL((k_frame_resident<false, SpecGeneral>), dim3(blocks_f), dim3(KB), 0, stream, sv, LP, lb, lb.bounce);
+                    if (!LP.fused_resolve) hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, LP, lb);
+                }
+                hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, LP, lb);
+            }
+            HIPCHK(hipEventRecord(ev[1], stream));
+            HIPCHK(hipGetLastError());
+            timing_pending = true;
+            impl->frames++;
+            frame_counter += frame_batch;
+            accumulated_samples += (uint)opt.samples_per_pixel;
+            return 0;
+        }
     }
     for (int l = 2; l < n_lanes; ++l) if (!impl->lane_stream[l]) {
         HIPCHK(hipStreamCreateWithFlags(&impl->lane_stream[l], hipStreamNonBlocking));

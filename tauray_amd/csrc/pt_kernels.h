@@ -7,3 +7,5 @@
 #include "trace_quad.h"
 #include "pt_state.h"
 #include "shade_kernel.h"
+#include "trace_lanes.h"
+#include "frame_kernel.h"

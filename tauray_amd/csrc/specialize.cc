@@ -40,8 +40,8 @@ std::vector<std::string> spec_flags(const SpecRequest& r, const std::string& arc
     const trhip_pt_options& o = r.opt;
     std::vector<std::string> f = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off"};
     auto d = [&](const char* name, int v) { f.push_back(std::string("-DTR_SPEC_") + name + "=" + std::to_string(v)); };
-    d("PROGRAM", r.raygen ? 1 : 0);
-    if (r.raygen) {   // what k_raygen reads: sampler (its Sobol index), film filter, depth of field, projection
+    d("PROGRAM", r.program);
+    if (r.program == SPEC_RAYGEN) {   // what k_raygen reads: sampler (its Sobol index), film filter, depth of field, projection
         d("SAMPLER", o.sampler); d("FILM", o.film); d("PROJECTION", o.projection); d("DOF", o.depth_of_field != 0);
         for (const char* unused : {"MIS", "BOUNCE_MODE", "TRI_LIGHT_MODE", "ROULETTE", "CLAMPING", "REGULARIZATION", "HIDE_LIGHTS", "WHITE_ALBEDO", "TRANSPARENT",
                                    "PRE_TRANSFORMED", "NEE_POINT", "NEE_TRI", "NEE_DIR", "NEE_ENV", "SHADE_TRIS", "COUNT"}) d(unused, 0);
@@ -148,7 +148,7 @@ std::map<std::string, std::string> g_failed; // requests that could not be built
 std::string spec_key(const SpecRequest& r) {
     std::string s;
     for (const std::string& f : spec_flags(r, "")) if (f.rfind("-DTR_SPEC_", 0) == 0) s += f.substr(10) + " ";
-    s += (r.ieee || r.raygen) ? "ieee" : "vulkan-grade";
+    s += (r.ieee || r.program == SPEC_RAYGEN) ? "ieee" : "vulkan-grade";
     return s;
 }
 
@@ -196,9 +196,10 @@ const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
     Loaded l;
     bool ok = code_object(r, arch, code, &compiled, &err) == 0;
     if (ok && hipModuleLoadData(&l.module, code.data()) != hipSuccess) { ok = false; err = "hipModuleLoadData failed for " + spec_key(r); (void)hipGetLastError(); }
-    if (ok && (r.raygen ? hipModuleGetFunction(&l.k.raygen, l.module, "trhip_spec_raygen") != hipSuccess
-                        : (hipModuleGetFunction(&l.k.shade, l.module, "trhip_spec_shade") != hipSuccess ||
-                           hipModuleGetFunction(&l.k.shade_last, l.module, "trhip_spec_shade_last") != hipSuccess))) {
+    if (ok && (r.program == SPEC_RAYGEN ? hipModuleGetFunction(&l.k.raygen, l.module, "trhip_spec_raygen") != hipSuccess
+               : r.program == SPEC_FRAME ? hipModuleGetFunction(&l.k.frame, l.module, "trhip_spec_frame") != hipSuccess
+                                         : (hipModuleGetFunction(&l.k.shade, l.module, "trhip_spec_shade") != hipSuccess ||
+                                            hipModuleGetFunction(&l.k.shade_last, l.module, "trhip_spec_shade_last") != hipSuccess))) {
         ok = false; err = "the specialised program lacks a kernel"; (void)hipGetLastError();
     }
     if (!ok) { g_failed[key] = err; if (why) *why = err; return nullptr; }

@@ -25,7 +25,7 @@ for kw in json.loads(sys.argv[2]):
     ieee = kw.pop("_ieee", 0)
     o = make_options(**kw)
     t = time.perf_counter()
-    rc = L.trhip_pt_precompile(C.byref(o), 1, ieee, 0, None)
+    rc = L.trhip_pt_precompile(C.byref(o), 1, ieee, 0, 0, None)
     out["times"].append([rc, time.perf_counter() - t])
 print(json.dumps(out))
 """
@@ -133,7 +133,10 @@ def test_specialised_programs_render_the_bits_of_the_general_kernels(R):
     kw = sets[0]
     spec, cs = _frame(R, ctx, ss, scene, (W, H), True, True, count=True, **kw)
     gen, cg = _frame(R, ctx, ss, scene, (W, H), False, True, count=True, **kw)
-    assert np.array_equal(spec, gen) and cs == cg and cs["surface_hits"] > 0
+    # (node visits and triangle tests are not compared: the quad tail of a trace wave starts when at most sixteen of its rays are left,
+    # i.e. they depend on which rays share a wave, which is the order the queue appends happened to land in)
+    assert np.array_equal(spec, gen) and cs["surface_hits"] > 0
+    assert all(cs[k] == cg[k] for k in ("closest_rays", "shadow_rays", "surface_hits", "alpha_tests"))
 
 
 @pytest.mark.gpu
