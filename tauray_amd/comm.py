@@ -26,7 +26,14 @@ SYMBOLS = {
     "trhip_comm_size": (_i, [_vp]),
     "trhip_gather_partials": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _vp]),
     "trhip_reduce_samples": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "trhip_ipc_create": (_i, [_i, _i, _i, _i, _sz, _i, C.POINTER(_vp)]),
+    "trhip_ipc_export": (_i, [_vp, _vp]),
+    "trhip_ipc_connect": (_i, [_vp, _vp]),
+    "trhip_ipc_gather_partials": (_i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _vp]),
+    "trhip_ipc_release": (_i, [_vp, _vp]),
+    "trhip_ipc_destroy": (None, [_vp]),
 }
+IPC_EXPORT_BYTES = 256
 _LIB = None
 
 
@@ -127,3 +134,84 @@ class NativeExchange:
             ptrs[r], sizes[r], out[r] = box[0].data_ptr(), nbytes, box[0]
         self.comm.gather_partials(0, None, 0, ptrs, sizes)
         return out
+
+
+class Ipc:
+    """One rank's end of the copy-engine exchange (trhip_ipc_*, include/trhip_comm.h).  `allgather(blob) -> [blob of rank 0, ...]`
+    is the caller's transport for the set-up (torch.distributed.all_gather_object, a pipe, files)."""
+
+    def __init__(self, hip_device: int, nranks: int, rank: int, slot_bytes: int, slots: int, allgather, root: int = 0):
+        h = C.c_void_p()
+        _check(lib().trhip_ipc_create(hip_device, nranks, rank, root, slot_bytes, slots, C.byref(h)))
+        self.h, self.rank, self.nranks, self.root, self.slot_bytes, self.slots = h.value, rank, nranks, root, slot_bytes, slots
+        blob = C.create_string_buffer(IPC_EXPORT_BYTES)
+        _check(lib().trhip_ipc_export(self.h, blob))
+        blobs = allgather(blob.raw)
+        assert len(blobs) == nranks and all(len(b) == IPC_EXPORT_BYTES for b in blobs)
+        _check(lib().trhip_ipc_connect(self.h, C.create_string_buffer(b"".join(blobs), IPC_EXPORT_BYTES * nranks)))
+
+    def send(self, send_ptr, send_bytes: int, stream=None):
+        _check(lib().trhip_ipc_gather_partials(self.h, send_ptr, send_bytes, None, None, stream))
+
+    def receive(self, recv_bytes, stream=None):
+        """Root: {peer: device pointer of its partial frame}; the pointers stay valid until release()."""
+        ptrs = (C.c_void_p * self.nranks)()
+        sizes = (C.c_size_t * self.nranks)(*recv_bytes)
+        _check(lib().trhip_ipc_gather_partials(self.h, None, 0, ptrs, sizes, stream))
+        return {r: ptrs[r] for r in range(self.nranks) if ptrs[r]}
+
+    def release(self, stream=None):
+        _check(lib().trhip_ipc_release(self.h, stream))
+
+    def close(self):
+        if self.h:
+            lib().trhip_ipc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _ArenaView:
+    """A partial frame inside the display rank's receive arena, as the stitch takes it."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def data_ptr(self):
+        return self.ptr
+
+
+class IpcExchange:
+    """RtRenderer(exchange=...) over the copy engines: the partial frames of a pixel-sharded job are written by their ranks into the
+    display rank's IPC-mapped receive arena (hipMemcpyAsync - a DMA over the sender's xGMI link, no kernel on either device), tags
+    order them (trhip_ipc_*).  The arena slot of a frame is released when the next frame is gathered: by then the renderer has
+    enqueued the stitch that reads it, in front of the release on the same stream."""
+
+    def __init__(self, ipc: Ipc):
+        self.ipc = ipc
+        self.pending_release = False
+
+    def attach(self, rank: int, ctx):
+        if rank != self.ipc.rank:
+            raise ValueError("IpcExchange: the exchange end belongs to another rank")
+
+    def gather_to_display(self, color, dists: List[DistributionParams], rank: int, world_size: int, viewports: int, recv_buffers, ctx):
+        if world_size == 1:
+            return {}
+        if rank != 0:
+            shape = partial_shape(dists[rank], viewports)
+            self.ipc.send(_ptr(color), shape[0] * shape[1] * shape[2] * 16)
+            return {}
+        if self.pending_release:
+            self.ipc.release()      # the previous frame's stitch sits in front of this on the stream
+        sizes = [0] * world_size
+        for r in range(1, world_size):
+            shape = partial_shape(dists[r], viewports)
+            sizes[r] = shape[0] * shape[1] * shape[2] * 16
+        ptrs = self.ipc.receive(sizes)
+        self.pending_release = True
+        return {r: _ArenaView(p) for r, p in ptrs.items()}

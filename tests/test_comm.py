@@ -17,7 +17,7 @@ def test_comm_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trhip_comm.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(trhip_[a-z_0-9]+)\s*\(", text)))
     L = comm.lib()
-    assert len(names) == 8 and sorted(comm.SYMBOLS) == names
+    assert len(names) == 14 and sorted(comm.SYMBOLS) == names
     for n in names:
         assert hasattr(L, n), f"libtrhip_comm.so does not export {n}"
     # linked against RCCL, not against the path-tracing library
@@ -52,3 +52,90 @@ def test_one_rank_communicator():
     assert ex.gather_to_display(src, [], 0, 1, 1, {}, ctx) == {}
     c.close()
     ctx.destroy_stream(st)
+
+
+_IPC_RANK = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+rank, world, workdir, frames, slots = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+import numpy as np
+from tauray_amd import comm, renderer as R, scenes
+from tauray_amd.distribution import DISTRIBUTION_SHUFFLED_STRIPS, get_distribution_target_max_size
+
+
+def allgather(blob):      # the caller's transport for the set-up: files in a directory both processes see
+    open(os.path.join(workdir, f"blob{rank}.tmp"), "wb").write(blob)
+    os.rename(os.path.join(workdir, f"blob{rank}.tmp"), os.path.join(workdir, f"blob{rank}"))
+    out, t0 = [], time.time()
+    for r in range(world):
+        path = os.path.join(workdir, f"blob{r}")
+        while not os.path.exists(path):
+            assert time.time() - t0 < 120, "the other rank never showed up"
+            time.sleep(0.01)
+        out.append(open(path, "rb").read())
+    return out
+
+
+W, H = 256, 192
+scene = scenes.test_glb(W, H)
+ctx = R.Context(0)      # every rank on device 0: two processes, one GPU
+opt = R.options_for_scene(scene, max_bounces=3)
+ipc = comm.Ipc(0, world, rank, W * H * 16, slots, allgather)
+rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS, rank=rank, world_size=world, exchange=comm.IpcExchange(ipc), frames_in_flight=slots)
+out = []
+for f in range(frames):
+    rr.render()
+    if rank == 0 and (f % slots == slots - 1 or f == frames - 1):      # the display rank looks at its frames now and then; the others never wait
+        rr.sync()
+    if rank == 0:
+        out.append(rr.download("display").copy()) if slots == 1 else None
+rr.sync()
+if rank == 0:
+    np.save(os.path.join(workdir, "last.npy"), rr.download("display"))
+    if out:
+        np.save(os.path.join(workdir, "all.npy"), np.stack(out))
+open(os.path.join(workdir, f"done{rank}"), "w").write("ok")
+t0 = time.time()
+while not all(os.path.exists(os.path.join(workdir, f"done{r}")) for r in range(world)):      # nobody unmaps while the other still copies
+    assert time.time() - t0 < 120
+    time.sleep(0.01)
+rr.close()
+ipc.close()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,slots", [(2, 1), (3, 2)])
+def test_processes_exchange_frames_through_the_copy_engines(tmp_path, world, slots):
+    """trhip_ipc_* (include/trhip_comm.h) with real processes: `world` processes share the one GPU, each renders its shuffled-strip share
+    of every frame, the partial frames travel into the display process's IPC-mapped arena by hipMemcpyAsync, tags order them, the display
+    process stitches and tonemaps.  Bytes move between address spaces; every display frame is the single-process frame bit for bit."""
+    import subprocess
+    import sys
+    from tauray_amd import renderer as R, scenes
+    frames = 6
+    script = tmp_path / "rank.py"
+    script.write_text(_IPC_RANK)
+    work = tmp_path / "work"
+    work.mkdir()
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), str(work), str(frames), str(slots)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    # the same frames from one process
+    W, H = 256, 192
+    scene = scenes.test_glb(W, H)
+    ctx = R.Context(0)
+    rr = R.RtRenderer(ctx, scene, R.options_for_scene(scene, max_bounces=3), (W, H))
+    ref = []
+    for f in range(frames):
+        rr.render()
+        rr.sync()
+        ref.append(rr.download("display").copy())
+    rr.close()
+    last = np.load(work / "last.npy")
+    assert np.isfinite(last).all() and last[..., :3].mean() > 1e-3 and np.array_equal(last, ref[-1])
+    if slots == 1:
+        got = np.load(work / "all.npy")
+        assert all(np.array_equal(got[f], ref[f]) for f in range(frames))
