@@ -274,18 +274,10 @@ int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee);
  * (no libhiprtc) the stage renders with the general kernels and says so once on stderr. */
 int trhip_pt_set_specialization(trhip_pt* pt, int enable);
 /* Compiles the programs of an option set into the kernel cache ahead of time, so that the first frame does not wait for
- * the compiler: ray generation, shading and - small_frames != 0 - the resident-paths kernel small frames render with
- * (trhip_pt_set_schedule), for `arch` (NULL = "gfx950"); shade_tris = the scene will have whole-triangle
+ * the compiler: ray generation and shading, for `arch` (NULL = "gfx950"); shade_tris = the scene will have whole-triangle
  * index spans (what trhip_scene_upload derives ShadeTri records from - true for every glTF file), ieee / count_work as in
  * trhip_pt_set_shading_arithmetic / trhip_pt_set_profiling.  Needs no GPU and no device handle. */
-int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, int small_frames, const char* arch);
-/* Schedule of a frame.  0 (default) = the stage chooses: the queue schedule - per bounce a trace launch and a shade launch over
- * compacted queues, the frame cut into lanes - or, for a launch whose paths all fit on the device at once (262 144 on 256 CUs:
- * the strip one GPU of eight renders of a 1080p frame) and that writes no first-hit targets, the resident schedule: one kernel
- * keeps every path in its wave from the camera ray to the last bounce, so the frame lasts as long as its slowest wave instead of
- * the sum over the bounces of each bounce's slowest ray (csrc/frame_kernel.h).  1 = always the queue schedule, 2 = the resident
- * schedule whenever it applies, whatever the size.  Same bits either way.  TRHIP_RESIDENT=0|1 overrides the default. */
-int trhip_pt_set_schedule(trhip_pt* pt, int schedule);
+int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch);
 const char* trhip_kernel_cache_dir(void);   /* TRHIP_KERNEL_CACHE, else kernel_cache/ next to libtrhip.so, else ~/.cache/trhip; "" = none writable */
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */

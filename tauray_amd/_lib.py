@@ -116,8 +116,7 @@ SYMBOLS = {
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
     "trhip_pt_set_shading_arithmetic": (_i, [_vp, C.c_int]),
     "trhip_pt_set_specialization": (_i, [_vp, C.c_int]),
-    "trhip_pt_precompile": (_i, [C.POINTER(PtOptionsC), C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]),
-    "trhip_pt_set_schedule": (_i, [_vp, C.c_int]),
+    "trhip_pt_precompile": (_i, [C.POINTER(PtOptionsC), C.c_int, C.c_int, C.c_int, C.c_char_p]),
     "trhip_kernel_cache_dir": (C.c_char_p, []),
     "trhip_pt_set_shard": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "trhip_scene_set_skin": (_i, [_vp, _u32, _vp, _vp, _u32]),

@@ -675,19 +675,12 @@ int trhip_pt_set_specialization(trhip_pt* pt, int enable) {
     pt->stage->specialize = enable ? 1 : 0;
     return 0;
 }
-int trhip_pt_set_schedule(trhip_pt* pt, int schedule) {
-    if (!pt) return set_error("null trhip_pt");
-    if (schedule < 0 || schedule > 2) return set_error("trhip_pt_set_schedule: 0 = automatic, 1 = queues, 2 = resident paths");
-    pt->stage->schedule = schedule;
-    return 0;
-}
-int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, int small_frames, const char* arch) {
+int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch) {
     if (!opt) return set_error("trhip_pt_precompile: null options");
     if (is_cli_default_set(*opt) && shade_tris) return 0;      // the ahead-of-time instances of libtrhip.so
     SpecRequest rq{*opt, shade_tris != 0 && !opt->pre_transformed_vertices, ieee != 0, count_work != 0, SPEC_SHADE};
     std::string why;
-    for (int program : {SPEC_SHADE, SPEC_RAYGEN, SPEC_FRAME}) {
-        if (program == SPEC_FRAME && (count_work || !small_frames)) continue;      // the resident-paths kernel has no counting instance
+    for (int program : {SPEC_SHADE, SPEC_RAYGEN}) {
         rq.program = program;
         if (spec_precompile(rq, arch, &why)) return set_error("trhip_pt_precompile: " + why);
     }

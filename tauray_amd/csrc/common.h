@@ -101,20 +101,6 @@ TR_HD float tpow(float x, float y) { return powf(x, y); }
 TR_HD float tpow_ge0(float x, float y) { return powf(x, y); }
 #endif
 
-// Division and square root that are correctly rounded whatever the translation unit's flags say.  The geometry code (ray set-up, the
-// triangle test, the sphere lights: trace.h, trace_quad.h) is IEEE fp32 everywhere - hits are bit-equal to the oracle's and do not
-// depend on the kernel that finds them - but the kernel that keeps a small frame's paths resident (frame_kernel.h) is compiled together
-// with the shading code, i.e. also with -fno-hip-fp32-correctly-rounded-divide-sqrt.  There the operation goes through fp64: the
-// quotient (root) of two floats rounded to 53 bits and then to 24 is the correctly rounded float (53 >= 2 * 24 + 2: double rounding
-// is innocuous for +, -, *, /, sqrt).  In the IEEE translation units these are the plain operators.
-#if defined(TR_SHADE_NATIVE_MATH) && defined(__HIP_DEVICE_COMPILE__)
-TR_DEV float div_rn(float a, float b) { return (float)((double)a / (double)b); }
-TR_DEV float sqrt_rn(float x) { return (float)__builtin_sqrt((double)x); }
-#else
-TR_HD float div_rn(float a, float b) { return a / b; }
-TR_HD float sqrt_rn(float x) { return sqrtf(x); }
-#endif
-
 // column-major matrices, as glm / GLSL
 struct m3 { f3 c[3]; };
 struct m4 { f4 c[4]; };

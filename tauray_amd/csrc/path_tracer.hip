@@ -390,7 +390,6 @@ uint calculate_shuffled_strips_b(uint sx, uint sy) {   // src/distribution_strat
 // shade_fast.hip: the ahead-of-time k_shade instances (command-line option set or general) at the accuracy Vulkan asks of the reference's GLSL
 void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce,
                        const uint* queue, uint* bc, uint* next_queue);
-void launch_frame_fast(bool cli, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint* bc);
 
 void get_ray_count(const trhip_distribution& d, uint& w, uint& h) {   // src/distribution_strategy.cc:33-61
     if (d.strategy == 0) { w = d.size_x; h = d.size_y; }
@@ -710,55 +709,6 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         frame_counter++;
         accumulated_samples += (uint)opt.samples_per_pixel;
         return 0;
-    }
-    // The resident schedule (frame_kernel.h): a launch whose paths all fit on the device at once is rendered by one kernel that keeps
-    // every path in its wave through all bounces, between the ray-generation launch and the resolve.  What a small frame - the strip
-    // one GPU of eight renders - costs under the queue schedule is latency: ten dependent launches, each as long as its longest ray.
-    {
-        static const int resident_env = getenv("TRHIP_RESIDENT") ? atoi(getenv("TRHIP_RESIDENT")) : -1;
-        const size_t resident_capacity = (size_t)n_cu * 4u * TR_FRAME_WAVES * 64u;      // four SIMDs per CU
-        bool resident = !timing && !count && !first_hit_targets && !sample_lanes && schedule != 1 && resident_env != 0 &&
-                        (schedule == 2 || resident_env == 1 || n <= resident_capacity);
-        const SpecKernels* spec_frame = nullptr;
-        if (resident && spec_shade) {
-            SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, false, SPEC_FRAME};
-            std::string why;
-            spec_frame = spec_kernels(rq, &why);
-            if (!spec_frame) resident = false;
-        }
-        if (resident) {
-            PtParams LP = P;
-            PathBuffers lb = pb;
-            const uint blocks_all = (LP.n_ids + KB - 1) / KB;
-            const uint blocks_f = std::min(blocks_all, n_cu * (uint)TR_FRAME_WAVES);
-            if (int rc = ensure_qspill(impl->pb, impl->qspill_lane_words, impl->qspill_regions, 1, blocks_f)) return rc;
-            lb.qspill = impl->pb.qspill;
-            const int passes = opt.samples_per_pixel / opt.samples_per_pass;
-            for (int pass = 0; pass < passes; ++pass) {
-                LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
-                for (int s = 0; s < opt.samples_per_pass; ++s) {
-                    LP.sample_in_pass = (uint)s;
-                    LP.rng_sample = shard_sample_base + shard_sample_stride * (LP.previous_samples + LP.sample_in_pass);
-                    launch_raygen(blocks_all, stream, LP, lb);
-                    if (spec_frame) {
-                        SceneView a0 = sv; PtParams a1 = LP; PathBuffers a2 = lb; uint* a3 = lb.bounce;
-                        void* args[] = {&a0, &a1, &a2, &a3};
-                        (void)hipModuleLaunchKernel(spec_frame->frame, blocks_f, 1, 1, KB, 1, 1, 0, stream, args, nullptr);
-                    } else if (shade_fast) launch_frame_fast(cli_set, blocks_f, stream, sv, LP, lb, lb.bounce);
-                    else if (cli_set) hipLaunchKernelGGL((k_frame_resident<false, SpecCli>), dim3(blocks_f), dim3(KB), 0, stream, sv, LP, lb, lb.bounce);
-                    else hipLaunchKernelGGL((k_frame_resident<false, SpecGeneral>), dim3(blocks_f), dim3(KB), 0, stream, sv, LP, lb, lb.bounce);
-                    if (!LP.fused_resolve) hipLaunchKernelGGL(k_accumulate_sample, dim3(blocks_all), dim3(KB), 0, stream, LP, lb);
-                }
-                hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, stream, LP, lb);
-            }
-            HIPCHK(hipEventRecord(ev[1], stream));
-            HIPCHK(hipGetLastError());
-            timing_pending = true;
-            impl->frames++;
-            frame_counter += frame_batch;
-            accumulated_samples += (uint)opt.samples_per_pixel;
-            return 0;
-        }
     }
     for (int l = 2; l < n_lanes; ++l) if (!impl->lane_stream[l]) {
         HIPCHK(hipStreamCreateWithFlags(&impl->lane_stream[l], hipStreamNonBlocking));

@@ -29,7 +29,6 @@ public:
     uint frame_batch = 1;            // trhip_pt_set_frame_batch: consecutive frames per render() call
     int ieee_shading = -1;           // trhip_pt_set_shading_arithmetic: 1 = k_shade at IEEE fp32 for every option set, 0 = Vulkan-grade arithmetic for the command-line set, -1 = TRHIP_SHADE_FAST decides
     int specialize = -1;             // trhip_pt_set_specialization: 1 = a shading program compiled for this stage's option set (hipRTC / kernel cache), 0 = the general kernels, -1 = TRHIP_SPECIALIZE decides (default on)
-    int schedule = 0;                // trhip_pt_set_schedule: 0 = automatic, 1 = queue schedule, 2 = resident paths whenever possible
     bool direct = false;             // direct_stage instead of path_tracer_stage (trhip_direct_create)
     hipStream_t last_stream = nullptr;
 

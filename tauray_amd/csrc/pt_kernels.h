@@ -8,4 +8,3 @@
 #include "pt_state.h"
 #include "shade_kernel.h"
 #include "trace_lanes.h"
-#include "frame_kernel.h"

@@ -32,10 +32,4 @@ void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t
 #undef TR_LAUNCH
 }
 
-// the resident-paths kernel (frame_kernel.h) with this translation unit's shading arithmetic; its traversal stays IEEE fp32 (div_rn)
-void launch_frame_fast(bool cli, uint blocks, hipStream_t stream, const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint* bc) {
-    if (cli) hipLaunchKernelGGL((k_frame_resident<false, SpecCli>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bc);
-    else hipLaunchKernelGGL((k_frame_resident<false, SpecGeneral>), dim3(blocks), dim3(KB), 0, stream, sv, P, pb, bc);
-}
-
 }  // namespace tr

@@ -7,9 +7,6 @@
 // -fno-hip-fp32-correctly-rounded-divide-sqrt - what Vulkan asks of the reference's GLSL (shade_fast.hip).
 // An instance renders the same bits as the general kernel of the same arithmetic (tests/test_specialization.py).
 #include "shade_kernel.h"
-#if TR_SPEC_PROGRAM == 2
-#include "frame_kernel.h"
-#endif
 
 #ifndef TR_SPEC_COUNT
 #define TR_SPEC_COUNT 0
@@ -21,13 +18,6 @@ namespace tr {
 // Ray generation is a program of its own: it is compiled at IEEE fp32 whatever the arithmetic of the shading kernels (camera rays,
 // like the traversal, are bit-equal to the oracle's in both modes).
 extern "C" __global__ __launch_bounds__(KB) void trhip_spec_raygen(SceneView sv, PtParams P, PathBuffers pb) { raygen_paths<SpecMacros>(sv, P, pb); }
-#elif TR_SPEC_PROGRAM == 2
-// The kernel that keeps a small frame's paths resident through all their bounces (frame_kernel.h), with this option set's shading code.
-extern "C" __global__ __launch_bounds__(KB, TR_FRAME_WAVES) void trhip_spec_frame(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
-    __shared__ int s_stack[TR_STACK_WORDS];
-    __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    frame_resident<false, SpecMacros>(sv, P, pb, bc, s_stack, s_owner);
-}
 #else
 extern "C" __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void trhip_spec_shade(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue, uint* bc,
                                                                                   uint* next_queue) {

@@ -197,9 +197,8 @@ const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
     bool ok = code_object(r, arch, code, &compiled, &err) == 0;
     if (ok && hipModuleLoadData(&l.module, code.data()) != hipSuccess) { ok = false; err = "hipModuleLoadData failed for " + spec_key(r); (void)hipGetLastError(); }
     if (ok && (r.program == SPEC_RAYGEN ? hipModuleGetFunction(&l.k.raygen, l.module, "trhip_spec_raygen") != hipSuccess
-               : r.program == SPEC_FRAME ? hipModuleGetFunction(&l.k.frame, l.module, "trhip_spec_frame") != hipSuccess
-                                         : (hipModuleGetFunction(&l.k.shade, l.module, "trhip_spec_shade") != hipSuccess ||
-                                            hipModuleGetFunction(&l.k.shade_last, l.module, "trhip_spec_shade_last") != hipSuccess))) {
+                                        : (hipModuleGetFunction(&l.k.shade, l.module, "trhip_spec_shade") != hipSuccess ||
+                                           hipModuleGetFunction(&l.k.shade_last, l.module, "trhip_spec_shade_last") != hipSuccess))) {
         ok = false; err = "the specialised program lacks a kernel"; (void)hipGetLastError();
     }
     if (!ok) { g_failed[key] = err; if (why) *why = err; return nullptr; }

@@ -15,9 +15,9 @@ struct SpecRequest {
     bool ieee;                 // IEEE fp32 without contraction (true) or the accuracy Vulkan asks of the reference's GLSL (shade_fast.hip)
     bool count;                // the counting instances (trhip_pt_set_profiling: count_work)
     int program;               // SPEC_SHADE: trhip_spec_shade + trhip_spec_shade_last; SPEC_RAYGEN: trhip_spec_raygen (always IEEE fp32; `ieee`, `count`
-                               // and the shading options are ignored); SPEC_FRAME: trhip_spec_frame, the resident-paths kernel (frame_kernel.h)
+                               // and the shading options are ignored)
 };
-enum { SPEC_SHADE = 0, SPEC_RAYGEN = 1, SPEC_FRAME = 2 };
+enum { SPEC_SHADE = 0, SPEC_RAYGEN = 1 };
 
 // the option set of the reference's command line, which has ahead-of-time instances (SpecCli, shade_kernel.h)
 inline bool is_cli_default_set(const trhip_pt_options& o) {
@@ -26,7 +26,7 @@ inline bool is_cli_default_set(const trhip_pt_options& o) {
            o.use_white_albedo_on_first_bounce == 0 && o.transparent_background == 0 && o.pre_transformed_vertices == 0;
 }
 
-struct SpecKernels { hipFunction_t raygen = nullptr, shade = nullptr, shade_last = nullptr, frame = nullptr; };
+struct SpecKernels { hipFunction_t raygen = nullptr, shade = nullptr, shade_last = nullptr; };
 
 // The pinned fields as text: what tells two instances apart (and, with the sources and the flags, names the cache file).
 std::string spec_key(const SpecRequest& r);

@@ -52,10 +52,10 @@ TR_DEV RayPre make_ray(f3 org, f3 dir) {
     int ky = kx + 1; if (ky == 3) ky = 0;
     if (comp(dir, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = div_rn(comp(dir, kx), comp(dir, kz));
-    r.Sy = div_rn(comp(dir, ky), comp(dir, kz));
-    r.Sz = div_rn(1.0f, comp(dir, kz));
-    r.inv_dir = F3(div_rn(1.0f, dir.x), div_rn(1.0f, dir.y), div_rn(1.0f, dir.z));
+    r.Sx = comp(dir, kx) / comp(dir, kz);
+    r.Sy = comp(dir, ky) / comp(dir, kz);
+    r.Sz = 1.0f / comp(dir, kz);
+    r.inv_dir = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     r.nox = (__float_as_uint(r.inv_dir.x) >> 31) << 4;
     r.noy = ((__float_as_uint(r.inv_dir.y) >> 31) << 4) | 32u;
     r.noz = ((__float_as_uint(r.inv_dir.z) >> 31) << 4) | 64u;
@@ -93,7 +93,7 @@ TR_DEV bool tri_intersect(const RayPre& r, f3 v0, f3 v1, f3 v2, float tmin, floa
     if (det == 0.0f) return false;
     const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
     const float T = U * Az + V * Bz + W * Cz;
-    const float rcp = div_rn(1.0f, det);
+    const float rcp = 1.0f / det;
     const float tt = T * rcp;
     if (!(tt > tmin && tt < tmax)) return false;
     t = tt; bu = V * rcp; bv = W * rcp;
@@ -295,7 +295,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             float c = dot(oc, oc) - radius * radius;
             float disc = b * b - 4.0f * a * c;
             if (disc < 0) continue;
-            float hh = div_rn(-b - sqrt_rn(disc), 2.0f * a);
+            float hh = (-b - sqrtf(disc)) / (2.0f * a);
             if (hh > 0 && hh > tmin && hh < best_t) {
                 best_t = hh; found = true;
                 hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = hh; hit.v = 0;

@@ -1,6 +1,5 @@
 // One wave's share of a trace launch: the closest-hit rays / shadow rays of 64 queue slots, and the counters a launch keeps.
-// Shared by the queue kernels (path_tracer.hip: k_trace_closest, k_trace_shadow, k_trace_fused) and by the kernel that keeps a
-// small frame's paths resident from ray generation to resolve (frame_kernel.h).  Device-only, free of host headers.
+// What the queue kernels of path_tracer.hip (k_trace_closest, k_trace_shadow, k_trace_fused) are made of.  Device-only, free of host headers.
 #pragma once
 #include "trace.h"
 #include "trace_quad.h"
@@ -15,8 +14,8 @@ namespace {
 // the paths.  Every lane of the wave calls this; the traversal re-deals the last rays of the chunk over quads (trace_quad.h).
 template <bool COUNT>
 TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, int bounce, const uint* queue, uint qi, uint n, int* lds_stack,
-                         const QuadCtx& qc, TraceStats& st, int& overflow, uint& max_vis, uint& rays, bool live = true) {
-    bool valid = qi < n && live;
+                         const QuadCtx& qc, TraceStats& st, int& overflow, uint& max_vis, uint& rays) {
+    bool valid = qi < n;
     uint id = 0;
     u4 misc = {0, 0, 0, 1};
     f4 o = F4(0), d = F4(0);
@@ -77,7 +76,7 @@ TR_DEV void shadow_ray(const SceneView& sv, const PtParams& P, const PathBuffers
     if (vis != 0.0f) {
         // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
         float m = c.w * vis;
-        if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= div_rn(P.opt.indirect_clamping, m);
+        if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
         const f3 radiance = F3(c.x * vis, c.y * vis, c.z * vis);
         const f2 w = lobes();
         // add_demodulated_color; a zero weight adds exactly nothing, so that target is left alone

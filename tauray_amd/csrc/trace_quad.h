@@ -361,7 +361,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             float c = dot(oc, oc) - radius * radius;
             float disc = b * b - 4.0f * a * c;
             if (disc < 0) continue;
-            float hh = div_rn(-b - sqrt_rn(disc), 2.0f * a);
+            float hh = (-b - sqrtf(disc)) / (2.0f * a);
             if (hh > 0 && hh > tmin && hh < best_t) {
                 best_t = hh; found = true;
                 hit.instance_id = -1; hit.primitive_id = (int)i; hit.u = hh; hit.v = 0;

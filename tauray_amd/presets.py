@@ -54,12 +54,12 @@ def scene_classes():
     return out
 
 
-def precompile(kw, shade_tris=True, ieee=False, count_work=False, arch=None, small_frames=True):
-    """One option set into the kernel cache (ray generation, shading and - small_frames - the resident-paths kernel); returns the seconds it took."""
+def precompile(kw, shade_tris=True, ieee=False, count_work=False, arch=None):
+    """One option set into the kernel cache (ray generation and shading programs); returns the seconds it took."""
     import time
     o = make_options(**kw)
     t = time.perf_counter()
-    _lib.check(_lib.lib().trhip_pt_precompile(C.byref(o), int(shade_tris), int(ieee), int(count_work), int(small_frames), arch.encode() if arch else None))
+    _lib.check(_lib.lib().trhip_pt_precompile(C.byref(o), int(shade_tris), int(ieee), int(count_work), arch.encode() if arch else None))
     return time.perf_counter() - t
 
 

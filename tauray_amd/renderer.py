@@ -396,10 +396,6 @@ class PathTracerStage:
         or always the general kernels (False): include/trhip.h trhip_pt_set_specialization."""
         check(_lib.lib().trhip_pt_set_specialization(self.h, int(bool(enable))))
 
-    def set_schedule(self, schedule: int):
-        """0 = the stage chooses, 1 = the queue schedule, 2 = resident paths whenever they apply (trhip_pt_set_schedule, include/trhip.h)."""
-        check(_lib.lib().trhip_pt_set_schedule(self.h, int(schedule)))
-
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 

@@ -2342,7 +2342,6 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                 "optimised_lbvh": {"TRHIP_BUILDER": "lbvh", "TRHIP_BVH_OPT": "24", "TRHIP_BVH_OPT_MOD": "3"},
                 "no_triangle_records": {"TRHIP_NO_SHADE_TRIS": "1"},      # no ShadeTri records: the general k_shade with indexed vertex fetches (IEEE fp32)
                 "lanes_enqueued_in_turn": {"TRHIP_ENQUEUE": "step"}, "lanes_enqueued_a_step_apart": {"TRHIP_ENQUEUE": "skew1"},      # instead of lane after lane (the first frame of a stage)
-                "resident_paths": {"TRHIP_RESIDENT": "1"},      # csrc/frame_kernel.h at a size where the waves take several chunks each
                 "ploc_grid_rounds": {"TRHIP_PLOC_NO_TAIL": "1"},      # every clustering round as grid launches (csrc/bvh_build.hip k_ploc_tail otherwise)
                 # the shading kernels of the command-line option set exist at IEEE fp32 too (TRHIP_SHADE_FAST=0; csrc/shade_fast.hip)
                 "ieee_shade": {"TRHIP_SHADE_FAST": "0"}, "ieee_compiled_shade": {"TRHIP_SHADE_FAST": "0", "TRHIP_SHADE_CLI": "0"},
@@ -2364,7 +2363,7 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
     for tag, env in variants.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
-        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_SHADE_FAST", "TRHIP_SPECIALIZE", "TRHIP_RESIDENT", "TRHIP_PLOC_NO_TAIL", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
+        for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_SHADE_FAST", "TRHIP_SPECIALIZE", "TRHIP_PLOC_NO_TAIL", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
             e.pop(k, None)
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)

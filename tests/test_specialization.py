@@ -25,7 +25,7 @@ for kw in json.loads(sys.argv[2]):
     ieee = kw.pop("_ieee", 0)
     o = make_options(**kw)
     t = time.perf_counter()
-    rc = L.trhip_pt_precompile(C.byref(o), 1, ieee, 0, 0, None)
+    rc = L.trhip_pt_precompile(C.byref(o), 1, ieee, 0, None)
     out["times"].append([rc, time.perf_counter() - t])
 print(json.dumps(out))
 """
