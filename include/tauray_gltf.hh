@@ -286,7 +286,7 @@ inline camera_data pack_camera(gltf_camera& c, double aspect)
 }
 
 struct mesh_span { uint32_t vertex_offset, vertex_count, index_offset, triangle_count; };
-struct texture_info { uint32_t width, height, texel_offset, pad; };
+struct texture_info { uint32_t width, height, texel_offset, format; };      // offset in 4-byte words; format 0 = RGBA8, 1 = RGBA16 (include/trhip.h)
 #pragma pack(pop)
 static_assert(sizeof(vertex) == 48 && sizeof(material) == 80 && sizeof(instance) == 288 && sizeof(camera_data) == 320, "layout");
 static_assert(sizeof(directional_light) == 32 && sizeof(point_light) == 64, "layout");
@@ -661,14 +661,15 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     auto list = [&](const char* key) -> const json& { return j.has(key) ? j.at(key) : empty; };
 
     // The reference loads images flipped (stbi flag) and flips them back (src/gltf.cc:525,557): row 0 = top row of the file.
-    struct texture { uint32_t w, h; std::vector<uint8_t> rgba; };
+    // A PNG of 16 bits per sample stays RGBA16, as the reference keeps it (R16G16B16A16Unorm, src/gltf.cc:548-556).
+    struct texture { uint32_t w, h; bool wide; std::vector<uint8_t> rgba; std::vector<uint16_t> rgba16; };
     std::vector<texture> textures;
     for(const json& img: list("images").arr)
     {
         const std::vector<uint8_t> file = g.image(img);      // PNG or JPEG by signature
         image::decoded d = image::decode(file.data(), file.size());
         texture t;
-        t.w = d.w; t.h = d.h; t.rgba = std::move(d.rgba);
+        t.w = d.w; t.h = d.h; t.wide = d.bits == 16; t.rgba = std::move(d.rgba); t.rgba16 = std::move(d.rgba16);
         textures.push_back(std::move(t));
     }
 
@@ -985,7 +986,14 @@ inline scene_data load_glb(const std::string& path, uint32_t width, uint32_t hei
     std::vector<bool> opaque;
     for(const texture& t: textures)
     {
-        infos.push_back(texture_info{t.w, t.h, (uint32_t)(s.texels.size() / 4), 0});
+        infos.push_back(texture_info{t.w, t.h, (uint32_t)(s.texels.size() / 4), t.wide ? 1u : 0u});
+        if(t.wide)
+        {
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(t.rgba16.data());
+            s.texels.insert(s.texels.end(), b, b + t.rgba16.size() * 2);
+            opaque.push_back(false);      // check_opaque looks at 8-bit images only
+            continue;
+        }
         s.texels.insert(s.texels.end(), t.rgba.begin(), t.rgba.end());
         bool op = true;
         for(size_t i = 3; i < t.rgba.size(); i += 4) if(t.rgba[i] != 255) { op = false; break; }

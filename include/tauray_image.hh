@@ -4,7 +4,7 @@
 // The reference decodes glTF images with stb_image through tinygltf (src/gltf.cc:520-576; external/stb_image.h is vendored there
 // and is not used here): PNG in every colour type and bit depth, interlaced or not, and JPEG.  This header reads
 //   * PNG: grey, grey + alpha, RGB, RGBA and palette images of 1 / 2 / 4 / 8 / 16 bits per sample, tRNS transparency, Adam7
-//     interlacing.  16-bit samples become 8-bit ones by rounding v * 255 / 65535 (the reference keeps them as R16G16B16A16Unorm
+//     interlacing.  16-bit samples are kept (decoded::rgba16) and also rounded to 8 bits, v * 255 / 65535 (the reference keeps them as R16G16B16A16Unorm
 //     textures: at most half an 8-bit step apart, the texel store here is RGBA8);
 //   * JPEG: baseline, extended-sequential and progressive Huffman files (SOF0 / SOF1 / SOF2, 8 bits per sample; scans of all or of
 //     single components), grey or YCbCr (or RGB when an Adobe marker says so), any sampling factors, restart intervals.  Chroma planes subsampled by two are interpolated linearly
@@ -28,7 +28,10 @@ namespace tr
 namespace image
 {
 
-struct decoded { uint32_t w = 0, h = 0; int channels_in_file = 0; std::vector<uint8_t> rgba; };
+// rgba: 8 bits per sample, always.  bits = 16 (a PNG of 16 bits per sample): rgba16 holds the same image at its own precision - what the
+// reference keeps as R16G16B16A16Unorm (src/gltf.cc:548-556; stb_image expands grey / RGB to RGBA with alpha 65535) - and rgba its
+// rounding to 8 bits for callers that want bytes.
+struct decoded { uint32_t w = 0, h = 0; int channels_in_file = 0; int bits = 8; std::vector<uint8_t> rgba; std::vector<uint16_t> rgba16; };
 
 //---------------------------------------------------------------------------------------------------------------------
 // PNG
@@ -132,6 +135,29 @@ inline decoded decode_png(const uint8_t* data, size_t size)
     auto to8 = [&](uint16_t v) -> uint8_t { return depth == 8 ? (uint8_t)v : (uint8_t)((uint32_t(v) * 255u + (uint32_t)maxv / 2u) / (uint32_t)maxv); };
     out.rgba.resize(w * h * 4);
     out.channels_in_file = ctype == 3 ? (trns.empty() ? 3 : 4) : ch + ((ctype == 0 || ctype == 2) && !trns.empty() ? 1 : 0);
+    if(depth == 16)
+    {   // the samples as they are (ctype 3 has no 16-bit form)
+        out.bits = 16;
+        out.rgba16.resize(w * h * 4);
+        for(size_t i = 0; i < w * h; ++i)
+        {
+            const uint16_t* s = px.data() + i * (size_t)ch;
+            uint16_t* d = out.rgba16.data() + i * 4;
+            if(ch <= 2)
+            {
+                d[0] = d[1] = d[2] = s[0];
+                d[3] = ch == 2 ? s[1] : 65535;
+                if(ch == 1 && trns.size() >= 2 && s[0] == (uint16_t)((trns[0] << 8) | trns[1])) d[3] = 0;
+            }
+            else
+            {
+                d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+                d[3] = ch == 4 ? s[3] : 65535;
+                if(ch == 3 && trns.size() >= 6 && s[0] == (uint16_t)((trns[0] << 8) | trns[1]) && s[1] == (uint16_t)((trns[2] << 8) | trns[3]) &&
+                   s[2] == (uint16_t)((trns[4] << 8) | trns[5])) d[3] = 0;
+            }
+        }
+    }
     for(size_t i = 0; i < w * h; ++i)
     {
         const uint16_t* s = px.data() + i * (size_t)ch;

@@ -57,6 +57,10 @@ int trhip_copy_peer(trhip_device* dst_dev, void* dst, trhip_device* src_dev, con
  * Python mirror calls this entry point, so both flatten a scene to the same bytes).  *rgba_out is released with
  * trhip_image_free.  channels_in_file: 1 grey, 2 grey + alpha, 3 RGB, 4 RGBA. */
 int trhip_image_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels_in_file, uint8_t** rgba_out);
+/* The same file as the texels a scene stores: RGBA8 (*bits = 8), or - a PNG of 16 bits per sample - RGBA16 in host byte order
+ * (*bits = 16, 8 bytes per texel): the reference keeps such an image as R16G16B16A16Unorm (src/gltf.cc:548-556).  Released with
+ * trhip_image_free. */
+int trhip_image_decode_texels(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels_in_file, uint32_t* bits, uint8_t** texels_out);
 void trhip_image_free(uint8_t* rgba);
 
 /* OpenEXR files (include/tauray_exr.hh; what tinyexr is to the reference).  trhip_exr_decode = read_exr of src/texture.cc:70-163:
@@ -82,9 +86,9 @@ typedef struct trhip_scene_desc {
     uint32_t point_light_count;
     const void* directional_lights;   /* 32 B (shader/light.glsl:7-13) */
     uint32_t directional_light_count;
-    const void* texture_infos;        /* u32x4 per texture: width, height, texel_offset (in texels), pad */
+    const void* texture_infos;        /* u32x4 per texture: width, height, texel_offset (in 4-byte words of `texels`), format (0 = RGBA8, 1 = RGBA16) */
     uint32_t texture_count;
-    const uint8_t* texels;            /* RGBA8, row 0 first */
+    const uint8_t* texels;            /* RGBA8 (4 bytes per texel) or RGBA16 (8 bytes, host byte order) by the texture's format, row 0 first */
     const float* envmap;              /* RGBA32F lat-long, or NULL (then environment_factor is ignored, proj = -1) */
     uint32_t envmap_width, envmap_height;
     const void* alias_table;          /* 16 B entries (src/environment_map.hh:37-43), one per envmap texel */

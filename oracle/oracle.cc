@@ -64,7 +64,7 @@ struct camera_data {                                                            
     mat4 view, view_inverse, view_proj, proj_inverse; vec4 origin, dof_params, projection_info, pan;
 };
 struct mesh_span { uint vertex_offset, vertex_count, index_offset, triangle_count; };
-struct texture_info { uint width, height, texel_offset, pad; };
+struct texture_info { uint width, height, texel_offset, format; };      // format 1: RGBA16 texels (R16G16B16A16Unorm, src/gltf.cc:548-556), two 4-byte words each
 #pragma pack(pop)
 static_assert(sizeof(vertex) == 48 && sizeof(material) == 80 && sizeof(instance) == 288, "layout");
 static_assert(sizeof(directional_light) == 32 && sizeof(point_light) == 64 && sizeof(tri_light) == 64, "layout");
@@ -619,6 +619,10 @@ vec4 sample_texture(const oracle_scene& s, int tex_id, vec2 uv) {
     int x1 = wrap_repeat((int)fx0 + 1, w), y1 = wrap_repeat((int)fy0 + 1, h);
     const uint8_t* base = s.texels.data() + (size_t)ti.texel_offset * 4;
     auto fetch = [&](int xx, int yy) {
+        if (ti.format == 1) {
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(base) + ((size_t)yy * w + xx) * 4;
+            return V4(q[0], q[1], q[2], q[3]) * (1.0f / 65535.0f);
+        }
         const uint8_t* p = base + ((size_t)yy * w + xx) * 4;
         return V4(p[0], p[1], p[2], p[3]) * (1.0f / 255.0f);
     };
@@ -1863,7 +1867,7 @@ oracle_scene* oracle_scene_create(const oracle_scene_desc* d) {
                                  (const directional_light*)d->directional_lights + d->directional_light_count);
     s->tex_infos.assign((const texture_info*)d->texture_infos, (const texture_info*)d->texture_infos + d->texture_count);
     size_t texel_count = 0;
-    for (auto& ti : s->tex_infos) texel_count = std::max(texel_count, (size_t)ti.texel_offset + (size_t)ti.width * ti.height);
+    for (auto& ti : s->tex_infos) texel_count = std::max(texel_count, (size_t)ti.texel_offset + (size_t)ti.width * ti.height * (ti.format == 1 ? 2u : 1u));
     s->texels.assign(d->texels, d->texels + texel_count * 4);
     // scene_metadata (src/scene_stage.cc:1341-1352): the factor is the environment map's; without a map it is zero, proj -1
     s->environment_factor = V4(0.0f);

@@ -92,6 +92,7 @@ SYMBOLS = {
     "trhip_device_destroy": (None, [_vp]),
     "trhip_last_error": (C.c_char_p, []),
     "trhip_malloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "trhip_image_decode_texels": (_i, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]),
     "trhip_free": (_i, [_vp, _vp]),
     "trhip_upload": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "trhip_download": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),

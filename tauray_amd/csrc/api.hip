@@ -282,6 +282,20 @@ int trhip_image_decode(const void* data, size_t bytes, uint32_t* width, uint32_t
     } catch (const std::exception& e) { return set_error(e.what()); }
     return 0;
 }
+int trhip_image_decode_texels(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels_in_file, uint32_t* bits, uint8_t** texels_out) {
+    if (!data || !width || !height || !bits || !texels_out) return set_error("trhip_image_decode_texels: null argument");
+    try {
+        tr::image::decoded d = tr::image::decode(static_cast<const uint8_t*>(data), bytes);
+        const bool wide = d.bits == 16;
+        const size_t n = wide ? d.rgba16.size() * 2 : d.rgba.size();
+        uint8_t* p = static_cast<uint8_t*>(malloc(n ? n : 1));
+        if (!p) return set_error("trhip_image_decode_texels: out of memory");
+        memcpy(p, wide ? static_cast<const void*>(d.rgba16.data()) : static_cast<const void*>(d.rgba.data()), n);
+        *width = d.w; *height = d.h; *bits = (uint32_t)d.bits; *texels_out = p;
+        if (channels_in_file) *channels_in_file = (uint32_t)d.channels_in_file;
+    } catch (const std::exception& e) { return set_error(e.what()); }
+    return 0;
+}
 void trhip_image_free(uint8_t* rgba) { free(rgba); }
 
 int trhip_exr_decode(const void* data, size_t bytes, uint32_t* width, uint32_t* height, uint32_t* channels, float** pixels_out) {
@@ -439,7 +453,8 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     const TextureInfo* ti = (const TextureInfo*)d->texture_infos;
     for (uint i = 0; i < d->texture_count; ++i) {
         if (ti[i].width == 0 || ti[i].height == 0) return set_error("trhip_scene_upload: empty texture");
-        texel_count = std::max(texel_count, (size_t)ti[i].texel_offset + (size_t)ti[i].width * ti[i].height);
+        if (ti[i].format != TEXTURE_FORMAT_RGBA8 && ti[i].format != TEXTURE_FORMAT_RGBA16) return set_error("trhip_scene_upload: unknown texture format");
+        texel_count = std::max(texel_count, (size_t)ti[i].texel_offset + (size_t)ti[i].width * ti[i].height * (ti[i].format == TEXTURE_FORMAT_RGBA16 ? 2u : 1u));
     }
     if (upload_array(s.texels, d->texels, texel_count * 4)) return 1;
     if (upload_array(s.cameras, d->cameras, d->camera_count)) return 1;

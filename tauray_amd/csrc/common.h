@@ -138,7 +138,10 @@ struct MeshSpan { uint vertex_offset, vertex_count, index_offset, triangle_count
 // built at upload and after skinning (csrc/bvh_build.hip build_shade_tris), absent when the spans do not allow that index.
 struct ShadeTri { Vertex v[3]; };
 struct Skin { uint joints[4]; float weights[4]; };   // mesh::skin_data (src/mesh.hh:32-36), `skin` of shader/skinning.comp:10-14
-struct TextureInfo { uint width, height, texel_offset, pad; };
+// texel_offset: where the texture starts in SceneView::texels, in 4-byte words; format: TEXTURE_FORMAT_RGBA8 (one word per texel) or
+// TEXTURE_FORMAT_RGBA16 (two: what the reference stores a 16-bit PNG as, src/gltf.cc:548-556)
+struct TextureInfo { uint width, height, texel_offset, format; };
+enum { TEXTURE_FORMAT_RGBA8 = 0, TEXTURE_FORMAT_RGBA16 = 1 };
 #pragma pack(pop)
 static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288 && sizeof(ShadeTri) == 144, "layout");
 static_assert(sizeof(DirectionalLight) == 32 && sizeof(PointLight) == 64 && sizeof(TriLight) == 64, "layout");

@@ -27,15 +27,19 @@ _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 
 
 def decode_image(data: bytes) -> np.ndarray:
-    """A texture file (PNG of any colour type / bit depth / interlacing, baseline or extended-sequential JPEG) -> HxWx4 uint8,
-    row 0 = top row: what stb_image hands the reference's loader (src/gltf.cc:520-576).  One decoder for both hosts:
-    include/tauray_image.hh through trhip_image_decode, so the C++ loader flattens the same scene to the same bytes."""
+    """A texture file (PNG of any colour type / bit depth / interlacing, baseline, extended-sequential or progressive JPEG) -> HxWx4,
+    row 0 = top row: what stb_image hands the reference's loader (src/gltf.cc:520-576) - uint8, or uint16 for a PNG of 16 bits per
+    sample, which the reference keeps as R16G16B16A16Unorm.  One decoder for both hosts: include/tauray_image.hh through
+    trhip_image_decode_texels, so the C++ loader flattens the same scene to the same bytes."""
     import ctypes as C
     from . import _lib
     L = _lib.lib()
-    w, h, ch, p = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
-    _lib.check(L.trhip_image_decode(bytes(data), len(data), C.byref(w), C.byref(h), C.byref(ch), C.byref(p)))
-    out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+    w, h, ch, bits, p = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    _lib.check(L.trhip_image_decode_texels(bytes(data), len(data), C.byref(w), C.byref(h), C.byref(ch), C.byref(bits), C.byref(p)))
+    if bits.value == 16:
+        out = np.ctypeslib.as_array(p, (h.value, w.value, 8)).copy().view(np.uint16).reshape(h.value, w.value, 4)
+    else:
+        out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
     L.trhip_image_free(p)
     return out
 

@@ -52,8 +52,9 @@ CAMERA_DATA = np.dtype([
 # Per-instance geometry span inside the concatenated vertex/index arrays.
 MESH_SPAN = np.dtype([("vertex_offset", u4), ("vertex_count", u4), ("index_offset", u4), ("triangle_count", u4)])
 SKIN = np.dtype([("joints", u4, 4), ("weights", f4, 4)])   # mesh::skin_data (src/mesh.hh:32-36)
-# Texture table entry: RGBA8 texels concatenated in one byte array.
-TEXTURE_INFO = np.dtype([("width", u4), ("height", u4), ("texel_offset", u4), ("pad", u4)])
+# Texture table entry: texels concatenated in one byte array; texel_offset in 4-byte words, format 0 = RGBA8, 1 = RGBA16 (a 16-bit PNG,
+# which the reference keeps as R16G16B16A16Unorm, src/gltf.cc:548-556)
+TEXTURE_INFO = np.dtype([("width", u4), ("height", u4), ("texel_offset", u4), ("format", u4)])
 
 assert VERTEX.itemsize == 48 and MATERIAL.itemsize == 80 and INSTANCE.itemsize == 288
 assert DIRECTIONAL_LIGHT.itemsize == 32 and POINT_LIGHT.itemsize == 64 and TRI_LIGHT.itemsize == 64
@@ -312,7 +313,7 @@ class SceneDesc:
     indices: np.ndarray                        # uint32[...], per-instance, relative to the span
     point_lights: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=POINT_LIGHT))
     directional_lights: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=DIRECTIONAL_LIGHT))
-    textures: List[np.ndarray] = field(default_factory=list)   # each HxWx4 uint8, row 0 first in memory
+    textures: List[np.ndarray] = field(default_factory=list)   # each HxWx4 uint8 (or uint16: RGBA16), row 0 first in memory
     envmap: Optional[np.ndarray] = None        # HxWx4 float32 lat-long, or None
     environment_factor: tuple = (0.0, 0.0, 0.0, 0.0)
     cameras: List[Camera] = field(default_factory=list)
@@ -353,11 +354,12 @@ class SceneDesc:
         off = 0
         chunks = []
         for i, t in enumerate(self.textures):
-            t = np.ascontiguousarray(t, dtype=np.uint8)
+            wide = np.asarray(t).dtype == np.uint16
+            t = np.ascontiguousarray(t, dtype=np.uint16 if wide else np.uint8)
             assert t.ndim == 3 and t.shape[2] == 4
-            infos[i] = (t.shape[1], t.shape[0], off, 0)
-            off += t.shape[0] * t.shape[1]
-            chunks.append(t.reshape(-1))
+            infos[i] = (t.shape[1], t.shape[0], off, 1 if wide else 0)
+            off += t.shape[0] * t.shape[1] * (2 if wide else 1)
+            chunks.append(t.reshape(-1).view(np.uint8))
         texels = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
         return infos, texels
 
@@ -381,8 +383,8 @@ class SceneDesc:
 
 
 def texture_is_opaque(tex: np.ndarray) -> bool:
-    """check_opaque (src/gltf.cc:54-66)."""
-    return bool(np.all(tex[..., 3] == 255))
+    """check_opaque (src/gltf.cc:54-66): only an 8-bit image whose alpha is 255 everywhere counts as opaque."""
+    return tex.dtype == np.uint8 and bool(np.all(tex[..., 3] == 255))
 
 
 def make_instance(model: np.ndarray, material: np.ndarray, shadow_terminator_offset: float = 0.0) -> np.ndarray:

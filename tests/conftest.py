@@ -10,6 +10,22 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cpus():
+    """CPUs this process may run on: the affinity mask bounded by the cgroup's quota (a GPU box of this pool shows 256 CPUs and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# the oracle's OpenMP loops: as many threads as there are CPUs to run them (256 threads on 16 CPUs cost more than they compute)
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cpus()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

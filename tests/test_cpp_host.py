@@ -241,7 +241,10 @@ def test_cpp_glb_loader_matches_python_loader(tmp_path):
     for name in ("room_embedded.glb", "room_datauri.gltf"):
         for n in names:
             assert dumps[name][n] == dumps["room.gltf"][n], f"{name} vs room.gltf: {n}"
-    assert len(dumps["room.gltf"]["texels"]) == 4 * (64 * 48 + 20 * 12 + 32 * 32)
+    # two RGBA8 textures and the 16-bit PNG as RGBA16 (8 bytes per texel), what the reference keeps as R16G16B16A16Unorm (src/gltf.cc:548-556)
+    assert len(dumps["room.gltf"]["texels"]) == 4 * (64 * 48 + 20 * 12) + 8 * (32 * 32)
+    infos = np.frombuffer(dumps["room.gltf"]["texture_infos"], np.uint32).reshape(-1, 4)
+    assert list(infos[:, 3]) == [0, 0, 1] and list(infos[:, 2]) == [0, 64 * 48, 64 * 48 + 20 * 12]
     bad = tmp_path / "bad.glb"
     bad.write_bytes(b"not a glb file at all")
     r = subprocess.run([CLI, str(bad), f"--dump-scene={tmp_path / 'x.trsc'}"], capture_output=True, text=True)

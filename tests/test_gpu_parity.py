@@ -1758,6 +1758,47 @@ def test_random_option_combinations(R, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_sixteen_bit_textures_are_sampled_at_sixteen_bits(R, ctx, oracle):
+    """A 16-bit PNG stays RGBA16 (the reference's R16G16B16A16Unorm, src/gltf.cc:548-556; csrc/texture.h fetch_rgba16): a horizontal ramp
+    of 4096 distinct 16-bit levels over a quad comes back through the albedo feature with (nearly) as many distinct values - an RGBA8 store
+    would leave 256 -, every texel centre reads v / 65535 exactly, and the frame equals the oracle's."""
+    from tauray_amd import scene as S
+    W = 4096
+    ramp = np.zeros((2, W, 4), dtype=np.uint16)
+    ramp[..., 0] = (np.arange(W, dtype=np.uint32) * 16 + 7)[None, :]
+    ramp[..., 1] = 65535 - ramp[..., 0]
+    ramp[..., 2] = 12345
+    ramp[..., 3] = 65535
+    quad = np.zeros(4, dtype=S.VERTEX)
+    quad["pos"] = [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)]
+    quad["normal"] = (0, 0, 1)
+    quad["tangent"] = (1, 0, 0, 1)
+    quad["uv"] = [(0, 1), (1, 1), (1, 0), (0, 0)]
+    cam = S.Camera(projection=S.PROJ_ORTHOGRAPHIC)
+    cam.ortho = (-1, 1, -1, 1, -10, 10)
+    cam.transform = S.trs_matrix((0, 0, 2))
+    sc = S.SceneDesc(instances=S.make_instance(np.eye(4), S.make_material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0, albedo_tex=0)),
+                     spans=np.array([(0, 4, 0, 2)], dtype=S.MESH_SPAN), vertices=quad, indices=np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32),
+                     textures=[ramp], cameras=[cam], point_lights=S.make_point_light((5, 5, 5), (0, 0, 3), 0.0)).finalize(True)
+    infos, texels = sc.texture_table()
+    assert infos["format"][0] == 1 and len(texels) == 2 * W * 8
+    ss = R.SceneStage(ctx, sc)
+    fs = R.FeatureStage(ctx, ss, 0, _dup((W, 4)), projection=S.PROJ_ORTHOGRAPHIC)      # albedo
+    buf = ctx.alloc(W * 4 * 16).zero()
+    fs.run(buf)
+    img = buf.download((4, W, 4))
+    ref = oracle.OracleScene(sc).render_feature(0, W, 4, projection=S.PROJ_ORTHOGRAPHIC)
+    assert np.abs(img - ref).max() < 1e-6
+    # texel centres: pixel x looks at texel x; sRGB decode (inverse_srgb_correction) applies to the colour channels
+    lin = lambda c: np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    want = lin(ramp[0, :, 0].astype(np.float64) / 65535.0)
+    assert np.abs(img[1, :, 0] - want).max() < 2e-6
+    assert len(np.unique(img[1, :, 0])) > 4000
+    _compare(_render_hip(R, ctx, ss, sc, (256, 64), max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC),
+             oracle.OracleScene(sc).render_pt(oracle.options_for_scene(sc, max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC), 256, 64), "16-bit albedo texture")
+
+
+@pytest.mark.gpu
 def test_scenes_without_triangle_records_render_the_same(R, ctx):
     """The command-line k_shade reads a hit's vertices from per-triangle records addressed by index_offset / 3 + primitive (csrc/common.h
     ShadeTri).  A scene whose spans do not start at whole triangles, or whose meshes share indices over different vertices, gets no

@@ -75,6 +75,16 @@ def test_png_sixteen_bit_sub_byte_and_interlaced():
     got, ch = decode(_png(w, h, 16, 0, [[g16[y].astype(">u2").tobytes() for y in range(h)]]))
     want = ((g16.astype(np.uint32) * 255 + 32767) // 65535).astype(np.uint8)
     assert ch == 1 and np.array_equal(got[..., 0], want) and np.array_equal(got[..., 2], want) and (got[..., 3] == 255).all()
+    # ... and the texels a scene stores keep all sixteen bits (trhip_image_decode_texels; the reference's R16G16B16A16Unorm, src/gltf.cc:548-556):
+    # RGBA as it is, grey expanded to (g, g, g, 65535) as stb_image does for tinygltf; an 8-bit file stays 8 bits
+    from tauray_amd.gltf import decode_image
+    t = decode_image(_png(w, h, 16, 6, rows))
+    assert t.dtype == np.uint16 and np.array_equal(t, v)
+    t = decode_image(_png(w, h, 16, 0, [[g16[y].astype(">u2").tobytes() for y in range(h)]]))
+    assert t.dtype == np.uint16 and np.array_equal(t[..., 0], g16) and np.array_equal(t[..., 1], g16) and np.array_equal(t[..., 2], g16) and (t[..., 3] == 65535).all()
+    t = decode_image(_png(w, h, 16, 2, [[v[y, :, :3].astype(">u2").tobytes() for y in range(h)]]))
+    assert t.dtype == np.uint16 and np.array_equal(t[..., :3], v[..., :3]) and (t[..., 3] == 65535).all()
+    assert decode_image(_png(w, h, 8, 6, [[(v[y] >> 8).astype(np.uint8).tobytes() for y in range(h)]])).dtype == np.uint8
     # 1, 2 and 4 bits per sample (grey): Pillow reads those too
     for depth in (1, 2, 4):
         g = rng.integers(0, 1 << depth, size=(h, w), dtype=np.uint8)

@@ -133,10 +133,10 @@ def test_specialised_programs_render_the_bits_of_the_general_kernels(R):
     kw = sets[0]
     spec, cs = _frame(R, ctx, ss, scene, (W, H), True, True, count=True, **kw)
     gen, cg = _frame(R, ctx, ss, scene, (W, H), False, True, count=True, **kw)
-    # (node visits and triangle tests are not compared: the quad tail of a trace wave starts when at most sixteen of its rays are left,
-    # i.e. they depend on which rays share a wave, which is the order the queue appends happened to land in)
+    # (node visits, triangle and alpha tests are not compared: the quad tail of a trace wave starts when at most sixteen of its rays are
+    # left, i.e. they depend on which rays share a wave, which is the order the queue appends happened to land in)
     assert np.array_equal(spec, gen) and cs["surface_hits"] > 0
-    assert all(cs[k] == cg[k] for k in ("closest_rays", "shadow_rays", "surface_hits", "alpha_tests"))
+    assert all(cs[k] == cg[k] for k in ("closest_rays", "shadow_rays", "surface_hits"))
 
 
 @pytest.mark.gpu
