@@ -91,7 +91,7 @@ def parse():
                     help="pipelined region: frame slots rendering concurrently (the reference keeps 2, src/context.hh:26); "
                          "0 = 4 (on eight hardware queues; measured best from whole frames down to 1/8 shards, tools/shard_share_probe.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch", "ipc"],
                     help="what carries the partial frames of N > 1 pixel shards to rank 0: native = libtrhip_comm.so (include/trhip_comm.h: grouped "
                          "ncclSend / ncclRecv on RCCL), torch = torch.distributed point-to-point; auto = native with the nccl backend, torch otherwise")
     ap.add_argument("--one-device", action="store_true", help="all ranks on HIP device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
@@ -315,7 +315,9 @@ def main():
     exchange, exchange_name = None, "none"
     if world > 1 and args.shard == "pixels":
         exchange_name = "torch.distributed (%s)" % args.dist_backend
-        if args.exchange == "native" or (args.exchange == "auto" and args.dist_backend == "nccl"):
+        if args.exchange == "ipc":
+            pass      # created below, once the frame batch is known
+        elif args.exchange == "native" or (args.exchange == "auto" and args.dist_backend == "nccl"):
             # creating the communicator is collective: first make sure every rank can take part (a rank that cannot load the
             # library must not leave the others waiting inside ncclCommInitRank), then every rank or none
             TC, err = None, None
@@ -358,6 +360,18 @@ def main():
         else:       # whole frames: two per launch are worth 2 % on sponza_teapots and 5 % on test.glb, more are not
             B = 2 if (world == 1 and args.views == 1 and args.spp == 1) else 1
     steps_pipelined = ((steps + B - 1) // B) * B
+    if world > 1 and args.shard == "pixels" and args.exchange == "ipc":
+        # The copy-engine exchange (include/trhip_comm.h trhip_ipc_*): partial frames are written into the display rank's IPC-mapped
+        # arena by hipMemcpyAsync - no RCCL kernel on either device - and ordered by tags.  A/B against the RCCL exchange: the display
+        # rank's phases below say whether RCCL's kernels wait behind the persistent trace kernels.
+        from tauray_amd import comm as TC
+
+        def allgather(blob):
+            out = [None] * world
+            dist.all_gather_object(out, blob)
+            return out
+        exchange = TC.IpcExchange(TC.Ipc(local_rank, world, rank, W * H * 16 * max(B, 1) * args.views, args.frames_in_flight, allgather))
+        exchange_name = "libtrhip_comm.so: trhip_ipc_gather_partials (hipMemcpyAsync into IPC-mapped memory of the display rank, tags; no RCCL kernels)"
     rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world,
                       viewports=args.views, shard=args.shard, frames_in_flight=args.frames_in_flight, frames_per_launch=B, exchange=exchange)
     # The renderer of a caller that waits for every frame: no frame slots, one frame per launch; each frame runs as four concurrent
@@ -461,6 +475,38 @@ def main():
     elapsed_p = time.perf_counter() - t0
     rays_p, elapsed_p, _ = total_rays(rr, elapsed_p)
 
+    # ---- N > 1, pixel shards: where a rank's frame goes (one frame at a time, after the timed regions).  Three loops of the same frames:
+    # the whole frame; the frame with nothing travelling (transfer.StandaloneExchange: the display rank stitches standing buffers);
+    # the path tracing of the rank's share alone.  Differences: what the stitch and the tonemap add on the display rank, and what a
+    # rank waits for the transport (on the display rank: for the last partial frame to arrive - behind RCCL's kernels or the copy
+    # engines, --exchange ipc - on the others: for their send to drain).  Every rank reports; expectations from DESIGN.md section 6.
+    phases = None
+    if world > 1 and args.shard == "pixels":
+        from tauray_amd.transfer import StandaloneExchange
+        n_ph = max(min(steps, 50), 20)
+
+        def loop_ms(body):
+            sync_all(lone)
+            t1 = time.perf_counter()
+            for _ in range(n_ph):
+                lone.reset_accumulation()
+                body()
+                lone.sync()
+            return (time.perf_counter() - t1) / n_ph * 1e3
+        full_ms = loop_ms(lone.render)
+        lone.exchange = StandaloneExchange()
+        free_ms = loop_ms(lone.render)
+        lone.exchange = exchange
+        trace_ms = loop_ms(lone.render_partial)
+        mine = {"path_tracing_ms": round(trace_ms, 4), "stitch_and_tonemap_ms": round(free_ms - trace_ms, 4), "transport_wait_ms": round(full_ms - free_ms, 4),
+                "frame_ms": round(full_ms, 4)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        phases = {"frames": n_ph, "display_rank": every[0], "other_ranks_max": {k: max(e[k] for e in every[1:]) for k in mine},
+                  "note": "one frame at a time with a host sync; transport_wait = whole frame - the same frame with nothing travelling"}
+    # what DESIGN.md section 6 expects of this run from one-GPU probes (a rank's strip one frame at a time / with frames in flight, before the transport)
+    expected = {1: (1.0, 1.0), 2: (1.84, 1.9), 4: (3.4, 3.8), 8: (4.8, 6.8)}.get(world)
+
     result = {
         "metric": "Mray/s (closest-hit + shadow rays traced) @%dx%d, %d bounces, %d spp" % (W, H, args.bounces, args.spp),
         "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -485,6 +531,9 @@ def main():
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
                    "views": args.views, "frames_in_flight": 1, "frames_per_launch": 1, "prewarm_frames": args.prewarm, "exchange": exchange_name,
                    "scene_hash": scenes.scene_hash(scene)},
+        **({"rank_phases": phases} if phases else {}),
+        **({"scaling_expected_vs_one_gpu": {"value": expected[0], "value_pipelined": expected[1],
+                                             "source": "DESIGN.md section 6: one-GPU probes of a rank's share, before the transport"}} if (expected and world > 1) else {}),
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         **({"load_balance": balance} if balance else {}),
         "rays_per_frame": rays_total // steps,
