@@ -76,22 +76,60 @@ inline std::vector<char> exchange_comm_id_through_file(const std::string& path, 
 // rank 0, after trhip_comm_create has returned (every rank has read the id by then: the call is collective)
 inline void remove_comm_id_file(const std::string& path, int rank) { if(rank == 0) std::remove(path.c_str()); }
 
+// The set-up of the copy-engine exchange (trhip_ipc_*) needs every rank's 256-byte blob on every rank: an all-gather through files
+// `prefix.ipc<rank>` for processes that share a file system, each with the job's nonce in front (as the communicator id above: a file of
+// another job is waited out; without a nonce, a file older than `stale_seconds`).  The files are small and stay behind; a rank replaces
+// its own at the start of the next job.
+inline std::vector<char> allgather_blobs_through_files(const std::string& prefix, int rank, int nranks, const std::vector<char>& blob, uint64_t nonce = 0,
+                                                       double timeout_seconds = 120.0, double stale_seconds = 60.0)
+{
+    auto path_of = [&](int r) { return prefix + ".ipc" + std::to_string(r); };
+    {
+        const std::string tmp = path_of(rank) + ".tmp";
+        std::remove(path_of(rank).c_str());
+        { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char*>(&nonce), 8); f.write(blob.data(), (std::streamsize)blob.size()); if(!f) throw std::runtime_error("cannot write " + tmp); }
+        if(std::rename(tmp.c_str(), path_of(rank).c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+    }
+    std::vector<char> all((size_t)nranks * blob.size());
+    const auto t0 = std::chrono::steady_clock::now();
+    const std::time_t wall0 = std::time(nullptr);
+    for(int r = 0; r < nranks; ++r)
+    {
+        while(true)
+        {
+            std::ifstream f(path_of(r), std::ios::binary);
+            uint64_t file_nonce = 0;
+            if(f && f.read(reinterpret_cast<char*>(&file_nonce), 8) && f.read(all.data() + (size_t)r * blob.size(), (std::streamsize)blob.size()) && file_nonce == nonce)
+            {
+                bool ours = true;
+                if(nonce == 0) { struct stat st; if(::stat(path_of(r).c_str(), &st) == 0) ours = std::difftime(wall0, st.st_mtime) <= stale_seconds; }
+                if(ours) break;
+            }
+            if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+                throw std::runtime_error("timed out waiting for rank " + std::to_string(r) + " in " + path_of(r));
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    return all;
+}
+
 template<typename Pipeline>
 class basic_process_rt_renderer
 {
 public:
     using options = typename basic_rt_renderer<Pipeline>::options;
 
-    // `rank` of `nranks` processes, this one on HIP device `hip_device`; `comm_id`: TRHIP_COMM_ID_BYTES bytes every rank holds.
+    // `rank` of `nranks` processes, this one on HIP device `hip_device`; `comm_id`: TRHIP_COMM_ID_BYTES bytes every rank holds (RCCL
+    // carries the partial frames), or nullptr: no RCCL communicator - use_copy_engine_exchange() before the first frame.
     basic_process_rt_renderer(int hip_device, int rank, int nranks, const void* comm_id, const scene_data& scene, uvec2 size, options opt)
-    : rank(rank), nranks(nranks), size(size), opt(opt), dev(hip_device), scene_update(dev)
+    : rank(rank), nranks(nranks), size(size), opt(opt), dev(hip_device), scene_update(dev), hip_device(hip_device)
     {
         if(nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("process_rt_renderer: rank out of range");
         if(nranks == 1) this->opt.distribution.strategy = DISTRIBUTION_DUPLICATE;   // src/tauray.cc:519-521
         const int n_slots = std::max(this->opt.max_frames_in_flight, 1);
         if(n_slots > 1 && this->opt.accumulate)
             throw std::runtime_error("process_rt_renderer: accumulating frames depend on each other, frames in flight must be 1");
-        check_comm(trhip_comm_create(hip_device, nranks, rank, comm_id, &comm));
+        if(comm_id) check_comm(trhip_comm_create(hip_device, nranks, rank, comm_id, &comm));
         scene_update.set_scene(scene);                                // the scene is replicated on every device (src/gpu_buffer.hh:63-116)
         layers = this->opt.active_viewport_count;
         set_dists(std::vector<double>((size_t)nranks, 1.0 / nranks));
@@ -133,7 +171,24 @@ public:
             dev.free(sl.color);
             dev.destroy_stream(sl.stream);
         }
+        if(ipc) trhip_ipc_destroy(ipc);
         trhip_comm_destroy(comm);
+    }
+
+    // The partial frames travel on the copy engines instead of through RCCL's kernels (trhip_ipc_*, include/trhip_comm.h): every rank
+    // writes its strip into the display rank's IPC-mapped arena with hipMemcpyAsync on its slot's stream, tags order it with the stitch.
+    // `allgather`: the caller's transport for the 256-byte set-up blobs (allgather_blobs_through_files, MPI ...): rank-major result.
+    // Every rank calls this once, before the first frame.
+    template<typename F>
+    void use_copy_engine_exchange(F&& allgather)
+    {
+        if(nranks == 1 || ipc) return;
+        check_comm(trhip_ipc_create(hip_device, nranks, rank, 0, size_t(size.x) * size.y * 16 * layers + 4096 * 16 * layers, (int)slots.size(), &ipc));
+        std::vector<char> blob(TRHIP_IPC_EXPORT_BYTES);
+        check_comm(trhip_ipc_export(ipc, blob.data()));
+        const std::vector<char> all = allgather(blob);
+        if(all.size() != blob.size() * (size_t)nranks) throw std::runtime_error("use_copy_engine_exchange: the all-gather returned the wrong size");
+        check_comm(trhip_ipc_connect(ipc, all.data()));
     }
 
     void reset_accumulation(bool reset_sample_counter = false)
@@ -166,8 +221,16 @@ public:
             // front of the stitch that reads it
             std::vector<size_t> bytes((size_t)nranks, 0);
             for(int r = 0; r < nranks; ++r) bytes[(size_t)r] = target_bytes(dists[(size_t)r]);
-            check_comm(trhip_gather_partials(comm, 0, sl.color, bytes[(size_t)rank], rank == 0 ? sl.partials.data() : nullptr,
-                                             rank == 0 ? bytes.data() : nullptr, sl.stream));
+            std::vector<void*> arrived;      // copy-engine exchange: where the partial frames are in the arena
+            if(ipc)
+            {
+                arrived.assign((size_t)nranks, nullptr);
+                check_comm(trhip_ipc_gather_partials(ipc, sl.color, bytes[(size_t)rank], rank == 0 ? arrived.data() : nullptr, rank == 0 ? bytes.data() : nullptr, sl.stream));
+            }
+            else if(comm)
+                check_comm(trhip_gather_partials(comm, 0, sl.color, bytes[(size_t)rank], rank == 0 ? sl.partials.data() : nullptr,
+                                                 rank == 0 ? bytes.data() : nullptr, sl.stream));
+            else throw std::runtime_error("process_rt_renderer: no exchange (a communicator id or use_copy_engine_exchange)");
             if(rank == 0)
             {
                 std::vector<trhip_distribution> ds;
@@ -177,12 +240,13 @@ public:
                 {
                     const uvec2 ts = get_distribution_target_size(dists[(size_t)r]);
                     if(ts.x == 0 || ts.y == 0) continue;
-                    ds.push_back(to_abi(dists[(size_t)r])); ps.push_back(sl.partials[(size_t)r]); ws.push_back(ts.x); hs.push_back(ts.y);
+                    ds.push_back(to_abi(dists[(size_t)r])); ps.push_back(ipc ? arrived[(size_t)r] : sl.partials[(size_t)r]); ws.push_back(ts.x); hs.push_back(ts.y);
                 }
                 if(!ds.empty())
                     check(trhip_stitch_batch(dev.h, (uint32_t)ds.size(), ds.data(), ps.data(), ws.data(), hs.data(), sl.color, (uint32_t)layers,
                                              stitch_blend_ratio, sl.stream));
                 stitch_blend_ratio = 1.0f;      // src/rt_renderer.cc:122
+                if(ipc) check_comm(trhip_ipc_release(ipc, sl.stream));      // behind the stitch: the senders may overwrite the slot
             }
         }
         if(rank == 0)
@@ -224,6 +288,8 @@ public:
     device dev;
     scene_stage scene_update;
     trhip_comm* comm = nullptr;
+    trhip_ipc* ipc = nullptr;
+    int hip_device = 0;
     std::vector<distribution_params> dists;      // every rank's share (all ranks compute all of them)
     std::vector<slot_data> slots;
     std::unique_ptr<tonemap_stage> tonemap;

@@ -14,7 +14,8 @@
 //
 // One process per GPU (include/tauray_hip_comm.hh): start N copies with --process-count=N --process-rank=0..N-1 --device=<HIP index>
 // --comm-id=<file on a shared file system> [--comm-nonce=<number every rank of this job gets, e.g. the launcher's pid>] (rank 0 writes the RCCL id
-// there under that nonce, the others wait for a file that carries it; rank 0 removes the file once the communicator exists); every rank renders its share
+// there under that nonce, the others wait for a file that carries it; rank 0 removes the file once the communicator exists); --exchange=ipc moves the
+// partial frames on the copy engines instead of through RCCL (trhip_ipc_*: the set-up blobs travel through <file>.ipc<rank>); every rank renders its share
 // of each frame, the partial frames meet on rank 0 through trhip_gather_partials, rank 0 stitches, tonemaps and saves.  With
 // --shard=views the ranks divide the viewports of a camera grid instead (viewport v on rank v mod N) and save their own views.
 #include <cstdlib>
@@ -57,6 +58,7 @@ int main(int argc, char** argv)
         int process_rank = -1, process_count = 0, process_device = 0;      // one process per GPU (see above)
         std::string comm_id_path;
         uint64_t comm_nonce = 0;
+        std::string exchange = "rccl";
         std::vector<double> workloads;      // --device-workloads=a,b,...: rt_renderer::set_device_workloads before the first frame
         rt_renderer::options opt;
         opt.distribution.strategy = DISTRIBUTION_SHUFFLED_STRIPS;      // CLI default (src/options.hh:43-49)
@@ -122,6 +124,7 @@ int main(int argc, char** argv)
             else if(starts(a, "--device=")) process_device = std::stoi(val("--device="));
             else if(starts(a, "--comm-id=")) comm_id_path = val("--comm-id=");
             else if(starts(a, "--comm-nonce=")) comm_nonce = std::stoull(val("--comm-nonce="));
+            else if(starts(a, "--exchange=")) exchange = val("--exchange=");
             else if(starts(a, "--fake-devices=")) fake_devices = std::stoi(val("--fake-devices="));
             else if(starts(a, "--rng-seed=")) opt.rng_seed = std::stoi(val("--rng-seed="));
             else if(starts(a, "--exposure=")) opt.tonemap.exposure = std::stof(val("--exposure="));
@@ -245,9 +248,12 @@ int main(int argc, char** argv)
             if(process_rank < 0 || process_rank >= process_count) throw std::runtime_error("--process-rank must be in [0, --process-count)");
             if(comm_id_path.empty()) throw std::runtime_error("--process-count needs --comm-id=<file every rank can read>");
             if(renderer != "path-tracer" || animated) throw std::runtime_error("--process-count renders still frames with the path tracer");
-            const std::vector<char> id = exchange_comm_id_through_file(comm_id_path, process_rank, comm_nonce);
-            process_rt_renderer rr(process_device, process_rank, process_count, id.data(), scene, size, opt);
-            remove_comm_id_file(comm_id_path, process_rank);   // the communicator exists on every rank: the file has done its job
+            if(exchange != "rccl" && exchange != "ipc") throw std::runtime_error("--exchange is rccl or ipc");
+            std::vector<char> id;
+            if(exchange == "rccl") id = exchange_comm_id_through_file(comm_id_path, process_rank, comm_nonce);
+            process_rt_renderer rr(process_device, process_rank, process_count, exchange == "rccl" ? id.data() : nullptr, scene, size, opt);
+            if(exchange == "rccl") remove_comm_id_file(comm_id_path, process_rank);   // the communicator exists on every rank: the file has done its job
+            else rr.use_copy_engine_exchange([&](const std::vector<char>& blob) { return allgather_blobs_through_files(comm_id_path, process_rank, process_count, blob, comm_nonce); });
             if(!workloads.empty()) rr.set_device_workloads(workloads);
             for(int f = -warmup; f < frames; ++f)
             {

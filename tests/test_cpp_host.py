@@ -536,6 +536,26 @@ def test_cpp_one_process_per_gpu_mode_with_one_rank(tmp_path, scene_dump):
 
 
 @pytest.mark.gpu
+def test_cpp_processes_exchange_frames_through_the_copy_engines(tmp_path, scene_dump):
+    """tauray_hip --process-count=2 --exchange=ipc: two processes on the one GPU, the partial frames of the second written into the first
+    one's IPC-mapped arena by hipMemcpyAsync (trhip_ipc_*, include/trhip_comm.h), frame slots included; the files are the single-process
+    renderer's byte for byte."""
+    W = H = 96
+    common = [scene_dump, f"--width={W}", f"--height={H}", "--max-ray-depth=4", "--filetype=raw", "--frames=5"]
+    ref_prefix = str(tmp_path / "ref")
+    subprocess.check_call([CLI] + common + [f"--headless={ref_prefix}"])
+    for tag, extra in (("ipc", []), ("ipc_slots", ["--frames-in-flight=2", "--distribution-strategy=shuffled-strips"])):
+        prefix, idf = str(tmp_path / tag), str(tmp_path / (tag + ".id"))
+        procs = [subprocess.Popen([CLI] + common + [f"--headless={prefix}", "--process-count=2", f"--process-rank={r}", "--device=0", f"--comm-id={idf}", "--exchange=ipc",
+                                                    f"--comm-nonce={os.getpid()}"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        for p in procs:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0, se[-2000:]
+        for f in range(5):
+            assert np.array_equal(np.fromfile(f"{prefix}{f}.raw", dtype=np.float32), np.fromfile(f"{ref_prefix}{f}.raw", dtype=np.float32)), (tag, f)
+
+
+@pytest.mark.gpu
 def test_cpp_renders_the_skinned_glb_like_the_python_mirror(tmp_path):
     """tests/golden/skinned.glb through tr::load_glb + scene_stage::set_scene (bind-pose vertices, skins, rest-pose joint
     matrices -> trhip_scene_set_skin / trhip_scene_skin before the build) against the Python mirror doing the same: the
