@@ -1783,17 +1783,21 @@ def test_sixteen_bit_textures_are_sampled_at_sixteen_bits(R, ctx, oracle):
     infos, texels = sc.texture_table()
     assert infos["format"][0] == 1 and len(texels) == 2 * W * 8
     ss = R.SceneStage(ctx, sc)
-    fs = R.FeatureStage(ctx, ss, 0, _dup((W, 4)), projection=S.PROJ_ORTHOGRAPHIC)      # albedo
-    buf = ctx.alloc(W * 4 * 16).zero()
-    fs.run(buf)
-    img = buf.download((4, W, 4))
-    ref = oracle.OracleScene(sc).render_feature(0, W, 4, projection=S.PROJ_ORTHOGRAPHIC)
+    # the path tracer's albedo target (feature_stage traces every ray from the camera origin, rt_feature.rgen:35: no use with an
+    # orthographic camera), one pixel per texel
+    kw = dict(max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC)
+    pt = R.PathTracerStage(ctx, ss, R.options_for_scene(sc, **kw), _dup((W, 4)))
+    bufs = {n: ctx.alloc(W * 4 * 16).zero() for n in ("color", "albedo")}
+    pt.run_targets(bufs)
+    img = bufs["albedo"].download((4, W, 4))
+    pt.close()
+    ref = oracle.OracleScene(sc).render_pt_targets(oracle.options_for_scene(sc, **kw), W, 4, ["color", "albedo"])["albedo"][0]
     assert np.abs(img - ref).max() < 1e-6
     # texel centres: pixel x looks at texel x; sRGB decode (inverse_srgb_correction) applies to the colour channels
     lin = lambda c: np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
     want = lin(ramp[0, :, 0].astype(np.float64) / 65535.0)
     assert np.abs(img[1, :, 0] - want).max() < 2e-6
-    assert len(np.unique(img[1, :, 0])) > 4000
+    assert len(np.unique(img[1, :, 0])) > 4000      # an RGBA8 store would leave 256 levels
     _compare(_render_hip(R, ctx, ss, sc, (256, 64), max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC),
              oracle.OracleScene(sc).render_pt(oracle.options_for_scene(sc, max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC), 256, 64), "16-bit albedo texture")
 
