@@ -454,6 +454,7 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     for (uint i = 0; i < d->texture_count; ++i) {
         if (ti[i].width == 0 || ti[i].height == 0) return set_error("trhip_scene_upload: empty texture");
         if (ti[i].format != TEXTURE_FORMAT_RGBA8 && ti[i].format != TEXTURE_FORMAT_RGBA16) return set_error("trhip_scene_upload: unknown texture format");
+        if (ti[i].format == TEXTURE_FORMAT_RGBA16) s.wide_textures = 1;
         texel_count = std::max(texel_count, (size_t)ti[i].texel_offset + (size_t)ti[i].width * ti[i].height * (ti[i].format == TEXTURE_FORMAT_RGBA16 ? 2u : 1u));
     }
     if (upload_array(s.texels, d->texels, texel_count * 4)) return 1;
@@ -693,7 +694,7 @@ int trhip_pt_set_specialization(trhip_pt* pt, int enable) {
 int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch) {
     if (!opt) return set_error("trhip_pt_precompile: null options");
     if (is_cli_default_set(*opt) && shade_tris) return 0;      // the ahead-of-time instances of libtrhip.so
-    SpecRequest rq{*opt, shade_tris != 0 && !opt->pre_transformed_vertices, ieee != 0, count_work != 0, SPEC_SHADE};
+    SpecRequest rq{*opt, shade_tris != 0 && !opt->pre_transformed_vertices, ieee != 0, count_work != 0, SPEC_SHADE, false};
     std::string why;
     for (int program : {SPEC_SHADE, SPEC_RAYGEN}) {
         rq.program = program;

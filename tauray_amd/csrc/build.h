@@ -37,6 +37,7 @@ struct DeviceScene {
     uint instance_count = 0, point_light_count = 0, directional_light_count = 0, camera_count = 0, texture_count = 0;
     uint env_w = 0, env_h = 0, tri_count = 0, vertex_count = 0, index_count = 0;
     uint gather_emissive_triangles = 0, host_tri_light_count = 0;
+    uint wide_textures = 0;              // some texture is RGBA16 (texture.h takes the one-dword path otherwise)
     // built by trhip_scene_build_accel
     BvhNode* nodes = nullptr;
     Bvh4Node* nodes4 = nullptr;
@@ -73,7 +74,7 @@ struct DeviceScene {
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
-        v.env_w = env_w; v.env_h = env_h; v.tri_count = accel_built ? tri_count : 0; v.node_count = node_count;
+        v.env_w = env_w; v.env_h = env_h; v.wide_textures = wide_textures; v.tri_count = accel_built ? tri_count : 0; v.node_count = node_count;
         return v;
     }
     void free_accel() {

@@ -205,6 +205,7 @@ struct SceneView {
     uint instance_count, point_light_count, directional_light_count, tri_light_count;
     uint env_w, env_h;
     uint tri_count, node_count;
+    uint wide_textures;          // some texture of the scene is TEXTURE_FORMAT_RGBA16
 };
 
 }  // namespace tr

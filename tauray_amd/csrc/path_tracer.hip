@@ -33,9 +33,12 @@ namespace {
 // at kernel start) and later chunks from a device-side cursor, which starts past the statically assigned range.
 // SOLO only names the instance launched while detailed timing serialises the frame, so that a profiler lists the
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
-template <bool COUNT, bool SOLO>
+// WIDE: the scene has RGBA16 textures.  The instances for scenes without (nearly all) pin SceneView::wide_textures to 0, and the
+// any-hit alpha test compiles to the one-dword fetch it always was (texture.h; profiles/r4/texture_format_ab.txt).
+template <bool COUNT, bool SOLO, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
+    if (!WIDE) sv.wide_textures = 0;
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
@@ -60,8 +63,9 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
+    if (!WIDE) sv.wide_textures = 0;
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
@@ -90,8 +94,10 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
 // state arrays), and in the lane schedule a launch lasts as long as its slowest wave: one launch with one tail instead of
 // two launches with two.  Chunk g of the launch is a closest-hit chunk while g < chunks_c (the longer rays go first), a
 // shadow chunk afterwards.
+template <bool WIDE>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
+    if (!WIDE) sv.wide_textures = 0;
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
@@ -565,13 +571,14 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     //  * the general instances, which read every option from the parameter block - what renders when neither of the above applies.
     // All three render the same bits in the same arithmetic.
     static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
-    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr;     // k_shade<.., SpecCli>: reads the ShadeTri records
+    const bool wide = scene->wide_textures != 0;      // RGBA16 textures: the kernel instances with the two-format texel fetch
+    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr && !wide;     // k_shade<.., SpecCli>: reads the ShadeTri records, RGBA8 texels
     static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
     const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;
     static const bool specialize_env = !(getenv("TRHIP_SPECIALIZE") && atoi(getenv("TRHIP_SPECIALIZE")) == 0);
     const SpecKernels *spec_shade = nullptr, *spec_raygen = nullptr;
     if (!cli_set && !direct && (specialize < 0 ? specialize_env : specialize != 0)) {
-        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, SPEC_SHADE};
+        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, SPEC_SHADE, wide};
         std::string why;
         spec_shade = spec_kernels(rq, &why);
         if (spec_shade) { rq.program = SPEC_RAYGEN; spec_raygen = spec_kernels(rq, &why); }
@@ -784,10 +791,11 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     uint* bc = lb.bounce + BC_STRIDE * bounce;
                     if (fused && bounce > 0) {
                         // closest(b) together with shadow(b - 1): one launch, one tail
-                        hipLaunchKernelGGL(k_trace_fused, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
+                        hipLaunchKernelGGL(wide ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
-                            auto kc = count ? k_trace_closest<true, false> : (timing ? k_trace_closest<false, true> : k_trace_closest<false, false>);
+                            auto kc = count ? k_trace_closest<true, false> : (timing ? (wide ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)
+                                                                                     : (wide ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>));
                             hipLaunchKernelGGL(kc, dim3(std::min(blocks_all, closest_cap)), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc);
                         });
                     }
@@ -811,7 +819,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                             ss = impl->side;
                         }
                         timed(T_SHADOW, ss, [&] {
-                            auto ks = count ? k_trace_shadow<true> : k_trace_shadow<false>;
+                            auto ks = count ? k_trace_shadow<true> : (wide ? k_trace_shadow<false, true> : k_trace_shadow<false, false>);
                             // on the side stream the launch runs next to closest(b + 1) of the same lane: its quad tails spill into
                             // the second region, not into the slices the closest-hit waves are using
                             PathBuffers sb = lb;

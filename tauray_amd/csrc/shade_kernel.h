@@ -152,13 +152,14 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
 //     white first-bounce albedo / transparent background / pre-transformed vertices) - what every BASELINE config renders with;
 //     ahead-of-time instances in path_tracer.hip and shade_fast.hip;
 //   * SpecMacros: whatever -DTR_SPEC_* say (shade_spec.hip: any other option set, compiled when a stage first needs it).
-// S::pinned: the sampler is known at compile time; S::shade_tris: surface hits read the ShadeTri records (common.h).
+// S::pinned: the sampler is known at compile time; S::shade_tris: surface hits read the ShadeTri records (common.h); S::wide_textures:
+// the scene may hold RGBA16 textures (false pins SceneView::wide_textures to 0: the one-dword texel fetch, texture.h).
 struct SpecGeneral {
-    static constexpr bool pinned = false, shade_tris = false;
+    static constexpr bool pinned = false, shade_tris = false, wide_textures = true;
     TR_DEV static void pin(PtParams&) {}
 };
 struct SpecCli {
-    static constexpr bool pinned = true, shade_tris = true;
+    static constexpr bool pinned = true, shade_tris = true, wide_textures = false;
     TR_DEV static void pin(PtParams& P) {
         P.opt.sampler = 0; P.opt.film = 0; P.opt.mis_mode = 2; P.opt.bounce_mode = 2; P.opt.tri_light_mode = 1;
         P.opt.russian_roulette_delta = 0.0f; P.opt.indirect_clamping = 0.0f; P.opt.regularization_gamma = 0.0f;
@@ -170,7 +171,7 @@ struct SpecCli {
 // One option set as macros (specialize.cc writes them from the stage's options; see spec_key there for the list).  The three
 // thresholds keep their run-time values when they are in use; only "off" (0) is pinned, which is what removes code.
 struct SpecMacros {
-    static constexpr bool pinned = true, shade_tris = TR_SPEC_SHADE_TRIS != 0;
+    static constexpr bool pinned = true, shade_tris = TR_SPEC_SHADE_TRIS != 0, wide_textures = TR_SPEC_WIDE_TEXTURES != 0;
     TR_DEV static void pin(PtParams& P) {
         P.opt.sampler = TR_SPEC_SAMPLER; P.opt.film = TR_SPEC_FILM; P.opt.mis_mode = TR_SPEC_MIS; P.opt.bounce_mode = TR_SPEC_BOUNCE_MODE;
         P.opt.tri_light_mode = TR_SPEC_TRI_LIGHT_MODE; P.opt.projection = TR_SPEC_PROJECTION;
@@ -378,9 +379,11 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
 }
 
 template <bool COUNT, bool LAST, typename S>
-TR_DEV void shade_bounce(const SceneView& sv, const PtParams& P_, const PathBuffers& pb, int bounce, const uint* queue, uint* bc, uint* next_queue) {
+TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuffers& pb, int bounce, const uint* queue, uint* bc, uint* next_queue) {
     PtParams P = P_;
     S::pin(P);
+    SceneView sv = sv_;
+    if (!S::wide_textures) sv.wide_textures = 0;
     // the Sobol index of the Z samplers lives in PathBuffers::misc
     const bool misc_needed = !S::pinned || P.opt.sampler == SAMPLER_SOBOL_Z2 || P.opt.sampler == SAMPLER_SOBOL_Z3;
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;

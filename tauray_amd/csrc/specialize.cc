@@ -44,7 +44,7 @@ std::vector<std::string> spec_flags(const SpecRequest& r, const std::string& arc
     if (r.program == SPEC_RAYGEN) {   // what k_raygen reads: sampler (its Sobol index), film filter, depth of field, projection
         d("SAMPLER", o.sampler); d("FILM", o.film); d("PROJECTION", o.projection); d("DOF", o.depth_of_field != 0);
         for (const char* unused : {"MIS", "BOUNCE_MODE", "TRI_LIGHT_MODE", "ROULETTE", "CLAMPING", "REGULARIZATION", "HIDE_LIGHTS", "WHITE_ALBEDO", "TRANSPARENT",
-                                   "PRE_TRANSFORMED", "NEE_POINT", "NEE_TRI", "NEE_DIR", "NEE_ENV", "SHADE_TRIS", "COUNT"}) d(unused, 0);
+                                   "PRE_TRANSFORMED", "NEE_POINT", "NEE_TRI", "NEE_DIR", "NEE_ENV", "SHADE_TRIS", "COUNT", "WIDE_TEXTURES"}) d(unused, 0);
         return f;
     }
     if (!r.ieee) { f.push_back("-fno-hip-fp32-correctly-rounded-divide-sqrt"); f.push_back("-DTR_SHADE_NATIVE_MATH=1"); }
@@ -54,7 +54,7 @@ std::vector<std::string> spec_flags(const SpecRequest& r, const std::string& arc
     d("DOF", o.depth_of_field != 0); d("HIDE_LIGHTS", o.hide_lights != 0); d("WHITE_ALBEDO", o.use_white_albedo_on_first_bounce != 0);
     d("TRANSPARENT", o.transparent_background != 0); d("PRE_TRANSFORMED", o.pre_transformed_vertices != 0);
     d("NEE_POINT", o.nee_point > 0.0f); d("NEE_TRI", o.nee_triangles > 0.0f); d("NEE_DIR", o.nee_directional > 0.0f); d("NEE_ENV", o.nee_envmap > 0.0f);
-    d("SHADE_TRIS", r.shade_tris); d("COUNT", r.count);
+    d("SHADE_TRIS", r.shade_tris); d("COUNT", r.count); d("WIDE_TEXTURES", r.wide_textures);
     return f;
 }
 

@@ -16,6 +16,7 @@ struct SpecRequest {
     bool count;                // the counting instances (trhip_pt_set_profiling: count_work)
     int program;               // SPEC_SHADE: trhip_spec_shade + trhip_spec_shade_last; SPEC_RAYGEN: trhip_spec_raygen (always IEEE fp32; `ieee`, `count`
                                // and the shading options are ignored)
+    bool wide_textures;        // the scene holds RGBA16 textures (the two-format texel fetch, csrc/texture.h)
 };
 enum { SPEC_SHADE = 0, SPEC_RAYGEN = 1 };
 

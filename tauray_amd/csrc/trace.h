@@ -154,7 +154,7 @@ TR_DEV float candidate_alpha(const SceneView& sv, int inst, int prim, float bu, 
     const Material& mat = sv.instances[inst].mat;
     float alpha = mat.albedo_factor.w;
     int tex = mat.albedo_tex_id;
-    if (tex >= 0) alpha *= sample_texture(sv, tex, candidate_uv(sv, inst, prim, bu, bv)).w;
+    if (tex >= 0) alpha *= sample_texture_alpha(sv, tex, candidate_uv(sv, inst, prim, bu, bv));
     return alpha;
 }
 
