@@ -200,6 +200,8 @@ def run_pmc_passes(args, B, dump_dir=None):
             kn = r["Kernel_Name"]
             m = re.search(r"(k_[a-z_0-9]+)<", kn)
             key = m.group(1) if m and m.group(1) in HOT_KERNELS else None
+            if key is None and kn.startswith("trhip_spec_shade"):      # the shading program compiled for the option set (csrc/shade_spec.hip)
+                key = "k_shade"
             if key is None:
                 continue
             if key == "k_trace_closest" and "<false, true" not in kn:      # the timed-alone instance only

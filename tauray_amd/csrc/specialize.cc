@@ -83,15 +83,34 @@ bool dir_usable(const std::string& d) {
     return access(d.c_str(), W_OK | X_OK) == 0;
 }
 
+// A cache file is the code object followed by a 24-byte trailer (magic, length, FNV-1a of the code): a file cut short by a full disk
+// or overwritten by something else is not handed to the loader, it counts as absent and is compiled again.
+constexpr char k_trailer_magic[8] = {'T', 'R', 'H', 'S', 'A', 'C', 'O', '1'};
+constexpr size_t k_trailer_bytes = 24;
+
+void append_trailer(std::vector<char>& file) {
+    const uint64_t n = file.size(), h = fnv1a(0xCBF29CE484222325ull, file.data(), file.size());
+    file.insert(file.end(), k_trailer_magic, k_trailer_magic + 8);
+    file.insert(file.end(), reinterpret_cast<const char*>(&n), reinterpret_cast<const char*>(&n) + 8);
+    file.insert(file.end(), reinterpret_cast<const char*>(&h), reinterpret_cast<const char*>(&h) + 8);
+}
+
 bool read_file(const std::string& path, std::vector<char>& out) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
     f.seekg(0, std::ios::end);
     const std::streamoff n = f.tellg();
-    if (n <= 0) return false;
+    if (n <= (std::streamoff)k_trailer_bytes) return false;
     out.resize((size_t)n);
     f.seekg(0);
-    return (bool)f.read(out.data(), n);
+    if (!f.read(out.data(), n)) return false;
+    const size_t code = (size_t)n - k_trailer_bytes;
+    uint64_t len = 0, h = 0;
+    memcpy(&len, out.data() + code + 8, 8);
+    memcpy(&h, out.data() + code + 16, 8);
+    if (memcmp(out.data() + code, k_trailer_magic, 8) != 0 || len != code || h != fnv1a(0xCBF29CE484222325ull, out.data(), code)) return false;
+    out.resize(code);
+    return true;
 }
 
 int compile(const SpecRequest& r, const std::string& arch, std::vector<char>& code, std::string* why) {
@@ -132,10 +151,18 @@ int code_object(const SpecRequest& r, const std::string& arch, std::vector<char>
     if (compiled) *compiled = true;
     if (!path.empty()) {
         const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        { std::ofstream f(tmp, std::ios::binary); f.write(code.data(), (std::streamsize)code.size()); }
-        if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+        std::vector<char> file = code;
+        append_trailer(file);
+        bool written = false;
+        { std::ofstream f(tmp, std::ios::binary); f.write(file.data(), (std::streamsize)file.size()); f.flush(); written = (bool)f; }
+        if (!written || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
     }
     return 0;
+}
+
+bool drop_cached(const SpecRequest& r, const std::string& arch) {
+    const std::string dir = spec_cache_dir();
+    return !dir.empty() && remove((dir + "/" + cache_name(r, arch)).c_str()) == 0;
 }
 
 struct Loaded { hipModule_t module = nullptr; SpecKernels k; };
@@ -195,7 +222,17 @@ const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
     bool compiled = false;
     Loaded l;
     bool ok = code_object(r, arch, code, &compiled, &err) == 0;
-    if (ok && hipModuleLoadData(&l.module, code.data()) != hipSuccess) { ok = false; err = "hipModuleLoadData failed for " + spec_key(r); (void)hipGetLastError(); }
+    if (ok && hipModuleLoadData(&l.module, code.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        l.module = nullptr;
+        // a cache file that does not load (truncated by a full disk, written by another compiler): compiled again, once
+        if (!compiled && drop_cached(r, arch) && code_object(r, arch, code, &compiled, &err) == 0 && compiled &&
+            hipModuleLoadData(&l.module, code.data()) == hipSuccess) {
+            fprintf(stderr, "[trhip] the kernel cache held a program that does not load for {%s}: compiled again\n", spec_key(r).c_str());
+        } else {
+            ok = false; err = "hipModuleLoadData failed for " + spec_key(r); (void)hipGetLastError();
+        }
+    }
     if (ok && (r.program == SPEC_RAYGEN ? hipModuleGetFunction(&l.k.raygen, l.module, "trhip_spec_raygen") != hipSuccess
                                         : (hipModuleGetFunction(&l.k.shade, l.module, "trhip_spec_shade") != hipSuccess ||
                                            hipModuleGetFunction(&l.k.shade_last, l.module, "trhip_spec_shade_last") != hipSuccess))) {

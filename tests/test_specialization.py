@@ -55,6 +55,30 @@ def test_precompile_needs_no_gpu_and_fills_the_cache(tmp_path):
     assert sorted(os.listdir(cache)) == files and all(t < 0.2 for _, t in second["times"])
 
 
+def test_concurrent_first_compilations_do_not_share_files(tmp_path):
+    """Eight ranks whose first frame compiles the same program at the same moment (one process per GPU, an empty cache).  hipRTC
+    materialises every embedded header under one temporary directory per compilation - as long as no header name leaves it: a name
+    with "../" in it landed in /tmp/include/, shared by all processes, and compilations failed on each other's half-written files."""
+    import re
+    inc = open(os.path.join(ROOT, "tauray_amd", "csrc", "rtc_sources.inc")).read()
+    names = re.findall(r'^    \{"([^"]+)",$', inc, flags=re.M)
+    assert len(names) >= 8 and all("/" not in n and ".." not in n for n in names)
+    assert all("/" not in m for m in re.findall(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', inc, flags=re.M))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    import json
+    env = dict(os.environ, TRHIP_KERNEL_CACHE=str(cache), AMD_COMGR_CACHE_DIR=str(tmp_path / "comgr"))
+    sets = json.dumps([dict(sampler=2, film=1, mis_mode=0, max_bounces=2)])
+    procs = [subprocess.Popen([sys.executable, "-c", _PRECOMPILE, ROOT, sets], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(8)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[-1500:] for _, e in outs if e][:1]
+    assert all(json.loads(o.strip().splitlines()[-1])["times"][0][0] == 0 for o, _ in outs)
+    files = sorted(os.listdir(cache))
+    assert len(files) == 2 and not [f for f in files if ".tmp" in f]
+    assert all(open(cache / f, "rb").read(4) == b"\x7fELF" and open(cache / f, "rb").read()[-24:-16] == b"TRHSACO1" for f in files)
+
+
 def test_build_warmed_the_cache_for_the_named_option_sets():
     """__graft_entry__.build() compiles the programs of the reference's presets and of the sets the tests and the bench render."""
     from tauray_amd import _lib, presets
@@ -172,3 +196,47 @@ np.save(sys.argv[2], img)
     assert "compiled through hipRTC" in runs[0][1] and "from the kernel cache" in runs[1][1] and "compiled through hipRTC" not in runs[1][1]
     assert len(os.listdir(cache)) == 2 and np.array_equal(runs[0][2], runs[1][2]) and np.isfinite(runs[0][2]).all()
     assert runs[1][0] < runs[0][0]
+
+
+@pytest.mark.gpu
+def test_a_cache_file_that_does_not_load_is_compiled_again(R, tmp_path):
+    """A truncated or foreign file under the cache's name (a full disk, another writer) fails the trailer check of csrc/specialize.cc: it is
+    not handed to the loader, the program is compiled again and the file replaced - the stage does not fall to the general kernels."""
+    script = tmp_path / "frame.py"
+    script.write_text(r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from tauray_amd import renderer as R, scenes
+from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+sc = scenes.test_glb(64, 64)
+ctx = R.Context(0)
+ss = R.SceneStage(ctx, sc)
+pt = R.PathTracerStage(ctx, ss, R.options_for_scene(sc, max_bounces=2, sampler=3, mis_mode=1), DistributionParams((64, 64), DISTRIBUTION_DUPLICATE, 0, 1, True))
+pt.set_shading_arithmetic(True)
+buf = ctx.alloc(64 * 64 * 16).zero()
+pt.run(buf)
+np.save(sys.argv[2], buf.download((64, 64, 4)))
+""")
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, TRHIP_KERNEL_CACHE=str(cache), TRHIP_DEBUG="1")
+
+    def run(k):
+        out = str(tmp_path / f"f{k}.npy")
+        r = subprocess.run([sys.executable, str(script), ROOT, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stderr, np.load(out)
+
+    first = run(0)
+    files = sorted(os.listdir(cache))
+    assert len(files) == 2 and "compiled through hipRTC" in first[0]
+    sizes = {f: os.path.getsize(cache / f) for f in files}
+    (cache / files[0]).write_bytes(b"not a code object")
+    (cache / files[1]).write_bytes((cache / files[1]).read_bytes()[: sizes[files[1]] // 2])
+    again = run(1)
+    assert again[0].count("compiled through hipRTC") == 2 and "from the kernel cache" not in again[0] and "general kernels" not in again[0], again[0][-1500:]
+    assert np.array_equal(first[1], again[1])
+    assert {f: os.path.getsize(cache / f) for f in sorted(os.listdir(cache))} == sizes
+    third = run(2)
+    assert third[0].count("from the kernel cache") == 2 and "compiled through hipRTC" not in third[0] and np.array_equal(first[1], third[1])
