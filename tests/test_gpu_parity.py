@@ -1754,7 +1754,10 @@ def test_random_option_combinations(R, ctx, oracle):
             strict = np.where(nf[..., None], np.float32(0), strict)
             ref = np.where(nf[..., None], np.float32(0), ref)
         _compare(strict, ref, f"draw {k}: {kw}, {frames} frame(s) [IEEE shading]", strict=True)
-        _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s) [default shading arithmetic]")
+        # the default arithmetic moves a bounce direction by an ulp, and a ray that grazes an edge then hits the neighbouring triangle: at
+        # 1-6 samples per pixel such a path is its pixel.  Typically 0-0.1 % of the pixels, 0.25 % in one draw of 900
+        # (profiles/r4/fuzz_campaign.txt: Sobol-Z2, depth of field, three samples per pass) - twice the bound of the strict comparison
+        _compare(img, ref, f"draw {k}: {kw}, {frames} frame(s) [default shading arithmetic]", max_bad=2 * MAX_BAD_FRACTION)
 
 
 @pytest.mark.gpu
@@ -2404,8 +2407,8 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
                             ("TRHIP_BVH_OPT", ["0", "3", "8"]), ("TRHIP_COLLAPSE", ["greedy", "cost"])):
             combo.update(pick(key, values))
         variants[f"combo{k}_" + "_".join(f"{a[6:]}{b}" for a, b in combo.items())] = combo
-    frames = {}
-    for tag, env in variants.items():
+    def render(item):
+        tag, env = item
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
         for k in ("TRHIP_LANES", "TRHIP_FUSED", "TRHIP_OVERLAP", "TRHIP_GRID_BLOCKS", "TRHIP_SHADE_BLOCKS", "TRHIP_SHADE_LAST", "TRHIP_BUILDER", "TRHIP_BVH_OPT", "TRHIP_BVH_OPT_MOD", "TRHIP_COLLAPSE", "TRHIP_SHADE_CLI", "TRHIP_SHADE_FAST", "TRHIP_SPECIALIZE", "TRHIP_PLOC_NO_TAIL", "TRHIP_NO_SHADE_TRIS", "TRHIP_ENQUEUE"):
@@ -2413,7 +2416,13 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
         e.update(env)
         r = subprocess.run([sys.executable, str(script), ROOT, out], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, f"{tag}: {r.stderr[-1500:]}"
-        frames[tag] = np.load(out)
+        return tag, np.load(out)
+
+    # a process per variant (the switches are read once per process), four at a time: most of a variant's second is the interpreter
+    # and the scene, not the frame
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        frames = dict(pool.map(render, variants.items()))
     ref = frames["default"]
     assert np.isfinite(ref).all() and ref[..., :3].mean() > 1e-3
     # two arithmetic modes of k_shade: the default (what Vulkan asks of the reference's GLSL) and IEEE fp32; within a mode every

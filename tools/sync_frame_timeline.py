@@ -8,9 +8,11 @@ import re
 import sys
 import numpy as np
 
-rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"]).group(1))
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"]).group(1), r.get("Queue_Id", "0"))
         for r in csv.DictReader(open(sys.argv[1])) if re.search(r"k_[a-z_0-9]+", r["Kernel_Name"])]
 rows.sort()
+all_rows = rows
+rows = [r[:3] for r in rows]
 stretches = []      # [start, end, kernel ns, {kernel: ns}]
 for s, e, k in rows:
     if stretches and s <= stretches[-1][1] + 10_000:
@@ -34,3 +36,25 @@ for _, st in sel:
     for k, v in st[3].items():
         per[k] = per.get(k, 0) + v
 print("kernel ms per frame:", {k: round(v / len(sel) / 1e6, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])})
+
+# per lane (= hardware queue): when its first kernel starts and its last one ends, as fractions of the frame's busy stretch, and how
+# many kernels run in each tenth of the frame
+lanes, tenths = {}, np.zeros(10)
+for _, st in sel:
+    f0, f1 = st[0], st[1]
+    seen = {}
+    for s0, e0, k, q in all_rows:
+        if s0 < f0 or e0 > f1:
+            continue
+        a = seen.setdefault(q, [s0, e0, 0, 0])
+        a[0] = min(a[0], s0); a[1] = max(a[1], e0); a[2] += e0 - s0; a[3] += 1
+        for t in range(10):
+            lo, hi = f0 + (f1 - f0) * t / 10, f0 + (f1 - f0) * (t + 1) / 10
+            tenths[t] += max(0.0, min(e0, hi) - max(s0, lo)) / (hi - lo)
+    for rank, (q, a) in enumerate(sorted(seen.items(), key=lambda kv: kv[1][0])):      # lanes in the order they start
+        lanes.setdefault(rank, []).append(((a[0] - f0) / (f1 - f0), (a[1] - f0) / (f1 - f0), a[2] / (a[1] - a[0]), a[3]))
+print("lanes in the order they start: first kernel starts at / last kernel ends at (fraction of the frame), busy fraction in between, launches")
+for rank, v in sorted(lanes.items()):
+    v = np.array(v)
+    print(f"  lane {rank}: {v[:, 0].mean():.3f} .. {v[:, 1].mean():.3f}   busy {v[:, 2].mean():.2f}   launches {v[:, 3].mean():.1f}")
+print("kernels running, by tenth of the frame:", " ".join(f"{x / len(sel):.2f}" for x in tenths))
