@@ -77,8 +77,17 @@ int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot
     c->slot_bytes = (slot_bytes + 255) & ~(size_t)255;
     const size_t n_tags = rank == root ? (size_t)nranks * slots : (size_t)slots;
     hipError_t e = hipSuccess;
-    if (rank == root) e = hipMalloc(&c->arena, (size_t)nranks * slots * c->slot_bytes);
-    if (e == hipSuccess) e = hipMalloc(&c->tags, n_tags * 8);
+    // What other devices write - the arena and the tags - is fine-grained device memory, as RCCL allocates the buffers its peers write:
+    // coherent for writers outside this device without relying on what an L2 does with lines of ordinary (coarse-grained) allocations
+    // between kernels.  (TRHIP_IPC_COARSE=1: plain hipMalloc, for A/B.)
+    auto shared_alloc = [](void** p, size_t bytes) {
+        static const bool coarse = getenv("TRHIP_IPC_COARSE") && atoi(getenv("TRHIP_IPC_COARSE")) != 0;
+        if (!coarse && hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        return hipMalloc(p, bytes);
+    };
+    if (rank == root) e = shared_alloc(&c->arena, (size_t)nranks * slots * c->slot_bytes);
+    if (e == hipSuccess) e = shared_alloc(reinterpret_cast<void**>(&c->tags), n_tags * 8);
     if (e == hipSuccess) e = hipMemset(c->tags, 0, n_tags * 8);
     if (e == hipSuccess) e = hipMalloc(&c->timed_out, 4);
     if (e == hipSuccess) e = hipMemset(c->timed_out, 0, 4);

@@ -17,3 +17,4 @@ for t in ("1", n):
     r = json.loads(l[-1])
     print(t, "ranks:", {k: r[k] for k in ("value", "ms_per_step", "value_pipelined", "n_gpus", "steps_effective")}, r["config"]["parallelism"], r["config"].get("exchange"), r.get("load_balance", {}).get("workloads"), r.get("rank_phases"))
 PY
+rm -f $OUT/disp1.npy $OUT/disp$N.npy      # 33 MB each: gpurun copies at most 64 MiB back
