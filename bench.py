@@ -43,6 +43,8 @@ sys.path.insert(0, ROOT)
 # Hardware queues the HIP runtime spreads streams over (default 4).  Six frame slots of a small shard want their own queue
 # each; measured neutral for full frames.  Must be set before the runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC is what the host driver of these boxes supports: RCCL and hipIpcGetMemHandle across processes fail without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 

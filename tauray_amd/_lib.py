@@ -8,6 +8,8 @@ import os
 # Hardware queues the HIP runtime spreads its streams over (default 4): frame slots beyond three only pay off with more
 # (DESIGN.md section 5).  Read by the runtime when it starts, so it has to be in the environment before the library loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Memory shared between processes (RCCL's buffers, trhip_ipc_*): the host driver of the target boxes supports dmabuf IPC only.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRHIP_LIB", os.path.join(_HERE, "libtrhip.so"))   # TRHIP_LIB: A/B builds while tuning

@@ -39,6 +39,8 @@ int main(int argc, char** argv)
     // hardware queues of the HIP runtime (default 4): more than three frame slots only pay off with more; read when the
     // runtime starts, i.e. before the first call into libtrhip
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // memory shared between processes (RCCL, the copy-engine exchange): dmabuf IPC is what the target boxes' host driver supports
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     try
     {
         std::string scene_path, prefix = "capture";
