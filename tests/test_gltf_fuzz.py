@@ -22,11 +22,14 @@ NAMES = ["instances", "spans", "vertices", "indices", "point_lights", "direction
 
 
 def _png(rgba):
+    """RGBA, 8 bits per channel for a uint8 array, 16 (big-endian samples, kept as RGBA16 texels by both loaders) for uint16."""
     h, w, _ = rgba.shape
     def chunk(tag, body):
         return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body))
-    raw = b"".join(b"\x00" + rgba[y].tobytes() for y in range(h))
-    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+    depth = 16 if rgba.dtype == np.uint16 else 8
+    rows = rgba.astype(">u2") if depth == 16 else rgba
+    raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(h))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
 
 
 class _Builder:
@@ -63,9 +66,14 @@ def _random_glb(rng):
     images, textures, materials, meshes, nodes, cameras, lights = [], [], [], [], [], [], []
     for _ in range(int(rng.integers(0, 3))):
         w, h = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-        px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
-        if rng.uniform() < 0.5:
-            px[..., 3] = 255
+        if rng.uniform() < 0.35:      # a 16-bit image: RGBA16 texels next to the RGBA8 ones of the same file
+            px = rng.integers(0, 65536, (h, w, 4)).astype(np.uint16)
+            if rng.uniform() < 0.5:
+                px[..., 3] = 65535
+        else:
+            px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+            if rng.uniform() < 0.5:
+                px[..., 3] = 255
         images.append({"bufferView": b.view(_png(px)), "mimeType": "image/png"})
         textures.append({"source": len(images) - 1})
     for _ in range(int(rng.integers(1, 4))):
