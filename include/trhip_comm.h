@@ -70,7 +70,9 @@ int trhip_ipc_export(trhip_ipc* ipc, void* blob_out);
 int trhip_ipc_connect(trhip_ipc* ipc, const void* blobs_of_all_ranks);
 /* One frame.  Not the root: waits (on `stream`) until the slot of this frame has been released, copies send_bytes bytes from
  * send_dev into it, posts the arrival tag.  Root: waits (on `stream`) for the arrival tags of every peer r with recv_bytes[r] > 0
- * and returns where their partial frames are in recv_dev_out[r] (pointers into the arena, valid until trhip_ipc_release). */
+ * and returns where their partial frames are in recv_dev_out[r] (pointers into the arena, valid until trhip_ipc_release).
+ * A device-side wait gives up after 10 s (TRHIP_IPC_TIMEOUT_MS) so that a dead peer cannot hang the device; the next call into the
+ * exchange then fails ("... gave up"): the frame behind that wait is incomplete. */
 int trhip_ipc_gather_partials(trhip_ipc* ipc, const void* send_dev, size_t send_bytes, void** recv_dev_out, const size_t* recv_bytes, void* stream);
 /* Root, after the consumers of the frame just gathered have been enqueued on `stream`: the slot may be overwritten once they are done. */
 int trhip_ipc_release(trhip_ipc* ipc, void* stream);

@@ -3,6 +3,7 @@
 // process per GPU when the RCCL kernels of trhip_gather_partials are not wanted on the devices.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,15 +16,17 @@ int ipc_fail(const std::string& m);
 
 // One lane per tag: polls until the tag has reached `want` (tags only grow).  System-scope acquire loads: the tag is written by
 // another device's DMA engine (or another process's copy), and what it announces - the partial frame - was written before it.
-// Gives up after ~10 s of wall clock (a peer that died) and says so in *timed_out; the caller's consumers then read what is there.
-__global__ void k_wait_tags(const unsigned long long* tags, int n, int stride, const unsigned char* wanted, unsigned long long want, int* timed_out) {
+// Gives up after ~10 s of wall clock (a peer that died; TRHIP_IPC_TIMEOUT_MS) and says so in *timed_out - pinned host memory, which the
+// next call into the exchange reads and turns into an error: the frame behind a wait that gave up holds whatever was in the arena.
+__global__ void k_wait_tags(const unsigned long long* tags, int n, int stride, const unsigned char* wanted, unsigned long long want, int* timed_out,
+                            unsigned long long timeout_ticks) {
     const int i = threadIdx.x;
     if (i >= n || !wanted[i]) return;
     const unsigned long long* p = tags + (size_t)i * stride;
     const unsigned long long t0 = wall_clock64();       // 100 MHz
     while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 1000000000ull) { *timed_out = 1; return; }
+        if (wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(timed_out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
     }
 }
 
@@ -49,7 +52,8 @@ struct trhip_ipc {
     // own allocations
     void* arena = nullptr;                    // root
     unsigned long long* tags = nullptr;       // root: [nranks][slots] arrival tags; others: [slots] release tags
-    int* timed_out = nullptr;
+    int* timed_out = nullptr;                 // pinned host memory: set by a wait that gave up, read by the next call
+    unsigned long long timeout_ticks = 1000000000ull;   // wall_clock64: 100 MHz
     unsigned char* wanted_dev = nullptr;
     unsigned long long* tag_values = nullptr; // pinned ring: sources of the tag copies
     // mapped from the other side
@@ -89,8 +93,9 @@ int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot
     if (rank == root) e = shared_alloc(&c->arena, (size_t)nranks * slots * c->slot_bytes);
     if (e == hipSuccess) e = shared_alloc(reinterpret_cast<void**>(&c->tags), n_tags * 8);
     if (e == hipSuccess) e = hipMemset(c->tags, 0, n_tags * 8);
-    if (e == hipSuccess) e = hipMalloc(&c->timed_out, 4);
-    if (e == hipSuccess) e = hipMemset(c->timed_out, 0, 4);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->timed_out), 4, hipHostMallocDefault);
+    if (e == hipSuccess) *c->timed_out = 0;
+    if (const char* t = getenv("TRHIP_IPC_TIMEOUT_MS")) if (atof(t) > 0) c->timeout_ticks = (unsigned long long)(atof(t) * 1e5);
     if (e == hipSuccess) e = hipMalloc(&c->wanted_dev, 64 * (size_t)slots);
     if (e == hipSuccess) e = hipHostMalloc(&c->tag_values, TAG_RING * 8, hipHostMallocDefault);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -150,6 +155,7 @@ int trhip_ipc_gather_partials(trhip_ipc* c, const void* send_dev, size_t send_by
     if (!c) return ipc_fail("trhip_ipc_gather_partials: null exchange");
     if (c->nranks == 1) return 0;
     if (!c->connected) return ipc_fail("trhip_ipc_gather_partials: call trhip_ipc_connect first");
+    if (*static_cast<volatile int*>(c->timed_out)) return ipc_fail("trhip_ipc_gather_partials: an earlier frame's wait for a peer gave up (a rank died or fell " + std::to_string(c->timeout_ticks / 100000ull) + " ms behind): that frame is incomplete");
     ICHK(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned long long f = c->frame++;
@@ -163,7 +169,7 @@ int trhip_ipc_gather_partials(trhip_ipc* c, const void* send_dev, size_t send_by
         if (use > 1) {      // the slot's previous frame has to be consumed: release tag >= use - 1
             c->wanted_host[0] = 1;
             ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), 1, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, 1, 1, c->wanted_dev + 64 * slot, use - 1, c->timed_out);
+            hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, 1, 1, c->wanted_dev + 64 * slot, use - 1, c->timed_out, c->timeout_ticks);
         }
         char* dst = static_cast<char*>(c->root_arena) + ((size_t)slot * c->nranks + (size_t)c->rank) * c->slot_bytes;
         ICHK(hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, s));
@@ -182,7 +188,7 @@ int trhip_ipc_gather_partials(trhip_ipc* c, const void* send_dev, size_t send_by
     }
     if (any) {
         ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), (size_t)c->nranks, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, c->nranks, c->slots, c->wanted_dev + 64 * slot, use, c->timed_out);
+        hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, c->nranks, c->slots, c->wanted_dev + 64 * slot, use, c->timed_out, c->timeout_ticks);
     }
     ICHK(hipGetLastError());
     return 0;
@@ -192,6 +198,7 @@ int trhip_ipc_release(trhip_ipc* c, void* stream) {
     if (!c) return ipc_fail("trhip_ipc_release: null exchange");
     if (c->nranks == 1 || c->rank != c->root) return 0;
     if (c->frame == 0) return ipc_fail("trhip_ipc_release: nothing gathered yet");
+    if (*static_cast<volatile int*>(c->timed_out)) return ipc_fail("trhip_ipc_release: a wait for a peer gave up: the frame is incomplete");
     ICHK(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned long long f = c->frame - 1;
@@ -212,7 +219,7 @@ void trhip_ipc_destroy(trhip_ipc* c) {
     for (unsigned long long* p : c->peer_tags) if (p) (void)hipIpcCloseMemHandle(p);
     if (c->arena) (void)hipFree(c->arena);
     if (c->tags) (void)hipFree(c->tags);
-    if (c->timed_out) (void)hipFree(c->timed_out);
+    if (c->timed_out) (void)hipHostFree(c->timed_out);
     if (c->wanted_dev) (void)hipFree(c->wanted_dev);
     if (c->tag_values) (void)hipHostFree(c->tag_values);
     delete c;

@@ -139,3 +139,64 @@ def test_processes_exchange_frames_through_the_copy_engines(tmp_path, world, slo
     if slots == 1:
         got = np.load(work / "all.npy")
         assert all(np.array_equal(got[f], ref[f]) for f in range(frames))
+
+
+_IPC_SILENT_PEER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+rank, workdir = int(sys.argv[2]), sys.argv[3]
+from tauray_amd import comm, renderer as R
+
+
+def allgather(blob):
+    open(os.path.join(workdir, f"blob{rank}.tmp"), "wb").write(blob)
+    os.rename(os.path.join(workdir, f"blob{rank}.tmp"), os.path.join(workdir, f"blob{rank}"))
+    out, t0 = [], time.time()
+    for r in range(2):
+        path = os.path.join(workdir, f"blob{r}")
+        while not os.path.exists(path):
+            assert time.time() - t0 < 120
+            time.sleep(0.01)
+        out.append(open(path, "rb").read())
+    return out
+
+
+ctx = R.Context(0)
+ipc = comm.Ipc(0, 2, rank, 4096, 1, allgather)
+if rank == 0:
+    ipc.receive([0, 1024])      # the display rank waits for rank 1's bytes, which never come
+    t = time.time()
+    ctx.sync()
+    waited = time.time() - t
+    try:
+        ipc.receive([0, 1024])
+        print("SECOND CALL PASSED", waited)
+    except comm.TrhipCommError as e:
+        print("SECOND CALL FAILED AFTER", waited, str(e))
+open(os.path.join(workdir, f"done{rank}"), "w").write("ok")
+t0 = time.time()
+while not all(os.path.exists(os.path.join(workdir, f"done{r}")) for r in range(2)):
+    assert time.time() - t0 < 120
+    time.sleep(0.01)
+ipc.close()
+"""
+
+
+@pytest.mark.gpu
+def test_a_peer_that_stops_sending_is_an_error_not_a_stale_frame(tmp_path):
+    """The display rank's wait for a partial frame gives up after a while (10 s; TRHIP_IPC_TIMEOUT_MS here) so that a dead peer cannot hang a
+    device for good - and the next call into the exchange says so: the frame behind that wait holds whatever was in the arena."""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(_IPC_SILENT_PEER)
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, TRHIP_IPC_TIMEOUT_MS="300")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(work)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("SECOND CALL")][0]
+    assert line.startswith("SECOND CALL FAILED AFTER") and "gave up" in line, line
+    assert 0.25 < float(line.split()[4]) < 5.0, line
