@@ -27,6 +27,7 @@ struct DeviceScene {
     uint8_t* non_opaque = nullptr;
     uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
     ShadeTri* shade_tris = nullptr;      // index_count / 3 records, or null (see common.h ShadeTri)
+    f4* shade_tangents = nullptr;        // ... and their tangents, three per record, behind the records in the same allocation
     // scene_stage's pre-transformed vertex copy (shader/pre_transform.comp): one span per instance; vertices built on first use
     std::vector<MeshSpan> host_spans, host_world_spans;
     MeshSpan* world_spans = nullptr;
@@ -70,7 +71,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.tris = tris; v.nodes4 = nodes4;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.shade_tangents = shade_tangents; v.tris = tris; v.nodes4 = nodes4;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;

@@ -571,14 +571,20 @@ __global__ __launch_bounds__(BT) void k_skinning(uint vertex_count, const Vertex
     destination[i] = dst;
 }
 
-__global__ __launch_bounds__(BT) void k_build_shade_tris(uint n_spans, const MeshSpan* spans, const Vertex* vertices, const uint* indices, ShadeTri* out) {
+__global__ __launch_bounds__(BT) void k_build_shade_tris(uint n_spans, const MeshSpan* spans, const Vertex* vertices, const uint* indices, ShadeTri* out, f4* tangents) {
     const MeshSpan sp = spans[blockIdx.y];
     const Vertex* vb = vertices + sp.vertex_offset;
     const uint* ix = indices + sp.index_offset;
     ShadeTri* o = out + sp.index_offset / 3u;
+    f4* ot = tangents + (size_t)sp.index_offset;      // three per record: index_offset / 3 * 3
     for (uint t = blockIdx.x * BT + threadIdx.x; t < sp.triangle_count; t += gridDim.x * BT) {
         ShadeTri r;
-        r.v[0] = vb[ix[3 * t]]; r.v[1] = vb[ix[3 * t + 1]]; r.v[2] = vb[ix[3 * t + 2]];
+        for (int k = 0; k < 3; ++k) {
+            const Vertex v = vb[ix[3 * t + k]];
+            r.pos[k] = v.pos; r.normal[k] = v.normal; r.uv[k] = v.uv;
+            ot[3 * t + k] = v.tangent;
+        }
+        for (float& x : r.pad) x = 0.0f;
         o[t] = r;
     }
 }
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(BT) void k_build_shade_tris(uint n_spans, const Mes
 // (none the loaders produce) simply has no records and is shaded by the general kernels.
 int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream) {
     if (instance < 0) {
-        if (ds.shade_tris) { (void)hipFree(ds.shade_tris); ds.shade_tris = nullptr; }
+        if (ds.shade_tris) { (void)hipFree(ds.shade_tris); ds.shade_tris = nullptr; ds.shade_tangents = nullptr; }
         if (ds.index_count < 3 || ds.instance_count == 0 || getenv("TRHIP_NO_SHADE_TRIS")) return 0;
         std::vector<MeshSpan> unique;
         {
@@ -608,7 +614,11 @@ int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream) {
             }
         }
         if (unique.empty()) return 0;
-        HIPCHK(hipMalloc(&ds.shade_tris, (size_t)(ds.index_count / 3u) * sizeof(ShadeTri)));
+        {   // records, then the tangents (three f4 per record) in the same allocation
+            const size_t n_rec = ds.index_count / 3u;
+            HIPCHK(hipMalloc(&ds.shade_tris, n_rec * (sizeof(ShadeTri) + 3 * sizeof(f4))));
+            ds.shade_tangents = reinterpret_cast<f4*>(ds.shade_tris + n_rec);
+        }
         MeshSpan* dev_spans = nullptr;
         HIPCHK(hipMalloc(&dev_spans, unique.size() * sizeof(MeshSpan)));
         HIPCHK(hipMemcpyAsync(dev_spans, unique.data(), unique.size() * sizeof(MeshSpan), hipMemcpyHostToDevice, stream));
@@ -616,7 +626,7 @@ int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream) {
         for (const MeshSpan& sp : unique) most = std::max(most, sp.triangle_count);
         for (size_t first = 0; first < unique.size(); first += 65535u) {
             const uint count = (uint)std::min<size_t>(65535u, unique.size() - first);
-            hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((most + BT - 1) / BT, 1024u), count), dim3(BT), 0, stream, count, dev_spans + first, ds.vertices, ds.indices, ds.shade_tris);
+            hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((most + BT - 1) / BT, 1024u), count), dim3(BT), 0, stream, count, dev_spans + first, ds.vertices, ds.indices, ds.shade_tris, ds.shade_tangents);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -627,7 +637,7 @@ int build_shade_tris(DeviceScene& ds, int instance, hipStream_t stream) {
     // one mesh again (its vertices were skinned): the span of the instance, read from the device copy of the spans
     const MeshSpan& sp = ds.host_spans[(size_t)instance];
     if (sp.triangle_count == 0) return 0;
-    hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((sp.triangle_count + BT - 1) / BT, 1024u), 1), dim3(BT), 0, stream, 1u, ds.spans + instance, ds.vertices, ds.indices, ds.shade_tris);
+    hipLaunchKernelGGL(k_build_shade_tris, dim3(std::min((sp.triangle_count + BT - 1) / BT, 1024u), 1), dim3(BT), 0, stream, 1u, ds.spans + instance, ds.vertices, ds.indices, ds.shade_tris, ds.shade_tangents);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -133,17 +133,20 @@ struct TriLight { f3 pos[3]; uint emission_factor, instance_id, primitive_id; ui
 struct AliasEntry { uint alias_id, probability; float pdf, alias_pdf; };
 struct CameraData { m4 view, view_inverse, view_proj, proj_inverse; f4 origin, dof_params, projection_info, pan; };
 struct MeshSpan { uint vertex_offset, vertex_count, index_offset, triangle_count; };
-// The three vertices of one indexed triangle side by side (144 bytes): what k_shade reads for a hit instead of three indices and three
-// 48-byte vertices from up to six cache lines.  Record index = index_offset / 3 + primitive (instances of one mesh share the records);
-// built at upload and after skinning (csrc/bvh_build.hip build_shade_tris), absent when the spans do not allow that index.
-struct ShadeTri { Vertex v[3]; };
+// The three vertices of one indexed triangle side by side: what k_shade reads for a hit instead of three indices and three 48-byte
+// vertices from up to six cache lines.  Positions, normals and texture coordinates - what every hit needs, 96 bytes - fill one 128-byte
+// record, i.e. exactly one cache line; the three tangents, which only a normal-mapped material reads, sit in an array of their own
+// (SceneView::shade_tangents, three per record).  Until round 4 a record was the three vertices whole (144 bytes from two or three
+// lines).  Record index = index_offset / 3 + primitive (instances of one mesh share the records); built at upload and after skinning
+// (csrc/bvh_build.hip build_shade_tris), absent when the spans do not allow that index.
+struct ShadeTri { f3 pos[3]; f3 normal[3]; f2 uv[3]; float pad[8]; };
 struct Skin { uint joints[4]; float weights[4]; };   // mesh::skin_data (src/mesh.hh:32-36), `skin` of shader/skinning.comp:10-14
 // texel_offset: where the texture starts in SceneView::texels, in 4-byte words; format: TEXTURE_FORMAT_RGBA8 (one word per texel) or
 // TEXTURE_FORMAT_RGBA16 (two: what the reference stores a 16-bit PNG as, src/gltf.cc:548-556)
 struct TextureInfo { uint width, height, texel_offset, format; };
 enum { TEXTURE_FORMAT_RGBA8 = 0, TEXTURE_FORMAT_RGBA16 = 1 };
 #pragma pack(pop)
-static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288 && sizeof(ShadeTri) == 144, "layout");
+static_assert(sizeof(Vertex) == 48 && sizeof(Material) == 80 && sizeof(Instance) == 288 && sizeof(ShadeTri) == 128, "layout");
 static_assert(sizeof(DirectionalLight) == 32 && sizeof(PointLight) == 64 && sizeof(TriLight) == 64, "layout");
 static_assert(sizeof(CameraData) == 320 && sizeof(AliasEntry) == 16, "layout");
 
@@ -198,6 +201,7 @@ struct SceneView {
     const MeshSpan* obj_spans;        // the uploaded model-space vertices even when `vertices` is the pre-transformed copy
     const Vertex* obj_vertices;
     const ShadeTri* shade_tris;  // null = none
+    const f4* shade_tangents;    // three per record
     const TriRecord* tris;
     const Bvh4Node* nodes4;      // the 4-wide fp32 nodes the traversal reads; node 0 is the root
     f4 environment_factor;

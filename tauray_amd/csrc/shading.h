@@ -580,38 +580,45 @@ TR_DEV f3 get_camera_projection(const CameraData& cam, int projection, f3 world_
 
 // get_interpolated_vertex + sample_material fused: fetches 3 indices, 3 x 48-byte vertices and the 288-byte
 // instance once.  `want_tri_pdf` = NEE_SAMPLE_EMISSIVE_TRIANGLES.
-// `rec` (a compile-time constant at every call): the vertices come from the triangle's ShadeTri record - the same 144 bytes, one
-// dependent fetch earlier and from two cache lines instead of up to seven.  Only without `pre` (the records hold model-space vertices).
+// `rec` (a compile-time constant at every call): the vertices come from the triangle's ShadeTri record - positions, normals and texture
+// coordinates from one cache line, one dependent fetch earlier than through the indices - and the tangents, which only a normal map
+// reads, from SceneView::shade_tangents when one is there.  Only without `pre` (the records hold model-space vertices).
 TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id, float bu, float bv, f3 view, f3 ray_origin,
                           bool want_tri_pdf, int tri_light_mode, bool pre, SurfacePoint& sp, SampledMaterial& res, bool rec = false) {
     const Instance& o = sv.instances[instance_id];
     const MeshSpan span = sv.spans[instance_id];
-    Vertex v0, v1, v2;
+    f3 q0, q1, q2, n0, n1, n2;
+    f2 t0, t1, t2;
+    f4 g0 = F4(0, 0, 0, 0), g1 = g0, g2 = g0;      // tangents: with the vertices (no records), or fetched where they are used
+    const uint record = span.index_offset / 3u + (uint)primitive_id;
     if (rec) {
-        const ShadeTri* t = sv.shade_tris + (span.index_offset / 3u + (uint)primitive_id);
-        v0 = t->v[0]; v1 = t->v[1]; v2 = t->v[2];
+        const ShadeTri* t = sv.shade_tris + record;
+        q0 = t->pos[0]; q1 = t->pos[1]; q2 = t->pos[2];
+        n0 = t->normal[0]; n1 = t->normal[1]; n2 = t->normal[2];
+        t0 = t->uv[0]; t1 = t->uv[1]; t2 = t->uv[2];
     } else {
         const uint* ix = sv.indices + span.index_offset + 3u * (uint)primitive_id;
         const Vertex* vb = sv.vertices + span.vertex_offset;
-        v0 = vb[ix[0]]; v1 = vb[ix[1]]; v2 = vb[ix[2]];
+        const Vertex v0 = vb[ix[0]], v1 = vb[ix[1]], v2 = vb[ix[2]];
+        q0 = v0.pos; q1 = v1.pos; q2 = v2.pos;
+        n0 = v0.normal; n1 = v1.normal; n2 = v2.normal;
+        t0 = v0.uv; t1 = v1.uv; t2 = v2.uv;
+        g0 = v0.tangent; g1 = v1.tangent; g2 = v2.tangent;
     }
     const m4 model = o.model;
     const m3 mn = upper3(o.model_normal);
     const f3 b = F3(1.0f - bu - bv, bu, bv);
-    f4 avg_tangent = v0.tangent * b.x + v1.tangent * b.y + v2.tangent * b.z;
-    f4 model_pos = F4(v0.pos * b.x + v1.pos * b.y + v2.pos * b.z, 1);
+    f4 model_pos = F4(q0 * b.x + q1 * b.y + q2 * b.z, 1);
     sp.pos = pre ? F3(model_pos) : F3(mul(model, model_pos));   // `pre` = PRE_TRANSFORMED_VERTICES (rt.glsl:18-22): TRANSFORM_MAT is the identity
     sp.tri_light_pdf = 0.0f;
     if (want_tri_pdf && o.light_base_id >= 0) {
-        f3 p0 = pre ? v0.pos : transform_point(model, v0.pos), p1 = pre ? v1.pos : transform_point(model, v1.pos), p2 = pre ? v2.pos : transform_point(model, v2.pos);
+        f3 p0 = pre ? q0 : transform_point(model, q0), p1 = pre ? q1 : transform_point(model, q1), p2 = pre ? q2 : transform_point(model, q2);
         sp.tri_light_pdf = sample_triangle_light_pdf(tri_light_mode, sp.pos - ray_origin, p0 - ray_origin, p1 - ray_origin, p2 - ray_origin);
     }
-    const f3 sn = v0.normal * b.x + v1.normal * b.y + v2.normal * b.z;
+    const f3 sn = n0 * b.x + n1 * b.y + n2 * b.z;
     f3 smooth_normal = normalize(pre ? sn : mul(mn, sn));
-    f3 tangent = normalize(pre ? F3(avg_tangent) : mul(mn, F3(avg_tangent)));
-    f3 bitangent = normalize(cross(smooth_normal, tangent) * avg_tangent.w);
-    f2 uv = v0.uv * b.x + v1.uv * b.y + v2.uv * b.z;
-    const f3 hn = cross(v1.pos - v0.pos, v2.pos - v0.pos);
+    f2 uv = t0 * b.x + t1 * b.y + t2 * b.z;
+    const f3 hn = cross(q1 - q0, q2 - q0);
     f3 hard_normal = normalize(pre ? hn : mul(mn, hn));
     bool back_facing = dot(hard_normal, view) > 0;
     if (back_facing) { smooth_normal = -smooth_normal; hard_normal = -hard_normal; }
@@ -634,6 +641,13 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
     res.metallic = mr.x;
     res.roughness = mr.y * mr.y;
     if (mat.normal_tex_id >= 0) {
+        // the bitangent comes from the interpolated normal BEFORE the back-face flip (the order the vertex is assembled in, and the
+        // oracle's): `front` undoes the flip, exactly
+        if (rec) { const f4* tg = sv.shade_tangents + 3u * record; g0 = tg[0]; g1 = tg[1]; g2 = tg[2]; }
+        const f4 avg_tangent = g0 * b.x + g1 * b.y + g2 * b.z;
+        const f3 front = back_facing ? -smooth_normal : smooth_normal;
+        const f3 tangent = normalize(pre ? F3(avg_tangent) : mul(mn, F3(avg_tangent)));
+        const f3 bitangent = normalize(cross(front, tangent) * avg_tangent.w);
         m3 tbn = {{tangent, bitangent, smooth_normal}};
         f4 t = sample_texture(sv, mat.normal_tex_id, uv);
         f3 ts_normal = normalize(F3(t) * 2.0f - 1.0f);
