@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd $R
-python -m pytest tests/test_gpu_parity.py tests/test_cpp_host.py -m gpu -q -x -k "switches or matches_oracle or textur or skinned or zoo or bench_scene or full_size or sixteen" 2>&1 | grep -E "passed|failed|^E  " | cut -c1-400 | head
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "soups or switches or bench_scene or full_size or shadow_queries or refit or skinned" 2>&1 | grep -E "passed|failed|^E  " | cut -c1-400 | head
 for rep in 1 2 3; do
  for w in sponza_teapots sponza_class test_glb; do
   for lib in libtrhip_head.so libtrhip.so; do
