@@ -109,9 +109,10 @@ typedef struct trhip_accel_info {
     uint32_t leaf_count;              /* leaves of the tree (= triangle_count: one triangle per leaf); node_count = leaf_count - 1 */
 } trhip_accel_info;
 
-/* Copies the scene to the device (the reference's buffers byte for byte) and derives, next to them, one 144-byte record
- * per index triangle with its three vertices side by side, which the shading kernel of the command-line option set reads instead of
- * indices + vertices (same values, fewer cache lines; rebuilt for a mesh by trhip_scene_skin).  Spans that do not start at a whole
+/* Copies the scene to the device (the reference's buffers byte for byte) and derives, next to them, one record
+ * per index triangle with its three vertices side by side (128 bytes of positions, normals and texture coordinates = one cache line, and
+ * 48 bytes of tangents apart), which the shading kernels read instead of indices + vertices (same values, fewer cache lines; rebuilt for
+ * a mesh by trhip_scene_skin).  Spans that do not start at a whole
  * triangle, or that share indices over different vertex ranges, are valid input: such a scene gets no records and the general kernels. */
 int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* desc);
 int trhip_scene_update_cameras(trhip_device* dev, const void* camera_data, uint32_t count); /* src/scene_stage.cc:1145-1174 */
