@@ -152,10 +152,14 @@ def pmc_child(args):
     from tauray_amd.distribution import DISTRIBUTION_SCANLINE
     W, H = args.width, args.height
     scene = scenes.WORKLOADS[args.workload](W, H)
+    if args.views > 1:      # the same camera grid as the timed run: the launch the counters describe is the launch the roofline times
+        from tauray_amd.scene import generate_camera_grid
+        gw = 9 if args.views == 45 else args.views
+        scene.cameras = generate_camera_grid(scene.cameras[0], gw, args.views // gw, 0.02, 0.02, 5.0)
     ctx = R.Context(0)
     opt = stage_options(args, scene, R)
     B = max(args.frames_per_launch, 1)
-    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, frames_in_flight=1, frames_per_launch=B)
+    rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SCANLINE, frames_in_flight=1, frames_per_launch=B, viewports=args.views)
     rr.set_profiling(False, True)
     for _ in range(max(args.steps // B, 1) + 1):     # the first launch is a warm-up like any other: whole frames either way
         rr.reset_accumulation()
@@ -181,7 +185,7 @@ def run_pmc_passes(args, B, dump_dir=None):
     tmp = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height),
-             "--bounces", str(args.bounces), "--spp", str(args.spp), "--sampler", str(args.sampler), "--steps", "4", "--frames-per-launch", str(B)] + \
+             "--bounces", str(args.bounces), "--spp", str(args.spp), "--sampler", str(args.sampler), "--steps", "4", "--frames-per-launch", str(B), "--views", str(args.views)] + \
             (["--preset", args.preset] if args.preset else []) + (["--general-kernels"] if args.general_kernels else []) + (["--ieee-shading"] if args.ieee_shading else [])
     for name, counters in PMC_PASSES.items():
         d = os.path.join(tmp, name)
