@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (through gpurun): bash tools/fuzz_builder_switches.sh [combos] [seed]
-# Random combinations of the acceleration-structure build switches (builder, PLOC radius, reinsertion rounds, collapse, node layout,
-# pre-splitting budget, treetop) under the triangle-soup hit-parity test and the full-size property test: hits must stay bit-equal to
-# the oracle's whatever tree is built.
+# Random combinations of the acceleration-structure build switches (builder, PLOC radius, reinsertion rounds, collapse, node layout)
+# under the triangle-soup hit-parity test and the full-size property test: hits must stay bit-equal to the oracle's whatever tree is
+# built.  (The pre-splitting budget and the treetop rode here until round 4: experiments/r4_retired_switches.patch.)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/fuzz; mkdir -p $OUT; cd $R
 python - ${1:-12} ${2:-1} > $OUT/combos.txt <<'PY'
 import sys, random
