@@ -30,7 +30,8 @@ that could bound it - vector-instruction issue (peak = a v_fma_f32 loop measured
 (fabric: Infinity Cache + HBM) bytes - from rocprofv3 counter passes this script runs itself (children of this process, each
 pass its own run with the kernel trace only; byte-per-request factors from profiles/r3/calibration.json).  `bound` is the level
 with the highest fraction, `frac` that fraction.  `algorithmic_GBps` is SURVEY.md 8(d)'s counted-work figure (cache served).
-`cpu_baseline`: the CPU oracle on the host cores.
+`cpu_baseline`: the CPU oracle on the host cores.  `parity`: frame 0 of the workload as the timed kernels render it against the oracle's
+frame 0 at the same size (share of pixels outside 1 %, error of the mean, RMS): a kernel that skipped work fails the bench's own run.
 """
 import argparse
 import json
@@ -387,6 +388,11 @@ def main():
     lone = R.RtRenderer(ctx, scene, opt, (W, H), strategy=strategy, rank=rank, world_size=world, viewports=args.views, shard=args.shard,
                         frames_in_flight=1, frames_per_launch=1, exchange=exchange)
 
+    # which kernels shade the frames: asked of the stage (trhip_pt_get_program), and - N > 1 - the same on every rank or nobody renders
+    program = lone.check_same_program() if dist is not None else lone.program()
+    if rr.program()["identity"] != program["identity"]:
+        raise RuntimeError("the two renderers of this process resolved different shading programs")
+
     def sync_all(r):
         r.sync()
         if dist is not None:
@@ -532,8 +538,10 @@ def main():
                    "spp": args.spp, "sampler": ["uniform-random", "sobol-owen", "sobol-z2", "sobol-z3"][opt.sampler],
                    "preset": args.preset, "film": ["point", "box", "blackman-harris"][opt.film], "regularization": round(opt.regularization_gamma, 3),
                    "tri_light_mode": ["area", "solid-angle", "hybrid"][opt.tri_light_mode],
-                   "shading_program": ("general kernels" if args.general_kernels else ("command-line set, ahead of time" if (opt.sampler == 0 and opt.film == 0 and opt.regularization_gamma == 0
-                                       and opt.tri_light_mode == 1) else "compiled for the option set (hipRTC / kernel cache)")) + (", IEEE fp32" if args.ieee_shading else ", Vulkan-grade arithmetic"),
+                   # what the library launched (trhip_pt_get_program), not what the options suggest
+                   "shading_program": {"general": "general kernels", "cli": "command-line set, ahead of time", "compiled": "compiled for the option set (hipRTC / kernel cache)"}[program["kind"]]
+                                      + (", IEEE fp32" if program["ieee"] else ", Vulkan-grade arithmetic"),
+                   "shading_program_identity": "%016x" % program["identity"],
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",
@@ -688,8 +696,11 @@ def main():
         osc.reset_counters()
         frames = 0
         t0 = time.perf_counter()
+        ref0 = None
         while True:
-            osc.render_pt(oopt, W, H, frame_counter=frames, threads=cores, viewports=args.views)
+            img = osc.render_pt(oopt, W, H, frame_counter=frames, threads=cores, viewports=args.views)
+            if frames == 0:
+                ref0 = img      # frame 0 of the workload as the oracle renders it: what the HIP frame of the same index is held against below
             frames += 1
             if time.perf_counter() - t0 >= args.cpu_seconds:
                 break
@@ -710,6 +721,33 @@ def main():
             "raster_fallback": ("available but not timed by this script" if (vk_icd and tauray_bin)
                                 else "unavailable: no %s on this box" % " and no ".join(([] if vk_icd else ["Vulkan ICD"]) + ([] if tauray_bin else ["Tauray binary"]))),
         }
+
+        # ---- parity of the kernels that were just timed: the HIP frame of frame index 0 against the oracle's frame 0 (same scene, camera,
+        # options, sampler state), at the full size the bench times.  The oracle is IEEE fp32; the default shading arithmetic is
+        # Vulkan-grade (2.5-ulp division, hardware square roots), so single paths may take another branch: the figures are the share of
+        # pixels outside 1 % (+ 0.01 absolute), the relative error of the image mean and the RMS difference of the radiance.
+        lone.set_profiling(False, False)
+        lone.reset_accumulation(reset_sample_counter=True)
+        lone.render()
+        sync_all(lone)
+        hip0 = lone.download("color")[:args.views]
+        a, b = hip0[..., :3].astype(np.float64), ref0[..., :3].astype(np.float64)
+        finite = bool(np.isfinite(hip0).all())
+        rel = np.abs(a - b) / (np.abs(b) + 1e-2)
+        outside = float((rel.max(-1) > 1e-2).mean())
+        mean_rel = abs(a.mean() - b.mean()) / max(b.mean(), 1e-30)
+        rms = float(np.sqrt(np.mean((a - b) ** 2)))
+        result["parity"] = {
+            "against": "oracle (CPU restatement of the reference's GLSL, IEEE fp32), frame index 0 of this workload at %dx%d" % (W, H),
+            "pixels_outside_1e-2": round(outside, 6), "mean_rel_err": float("%.3e" % mean_rel), "rms": float("%.3e" % rms),
+            "bit_identical_pixels": round(float((hip0[..., :3] == ref0[..., :3]).all(-1).mean()), 4),
+            "finite": finite,
+            "kernels": "the instances of the timed frames (no counting, no per-kernel timing), one frame with a host sync",
+            "shading_arithmetic": "IEEE fp32" if args.ieee_shading else "Vulkan-grade",
+            "pass": bool(finite and outside < 5e-3 and mean_rel < 2e-3),
+        }
+        if not result["parity"]["pass"]:
+            print("bench.py: the HIP frame deviates from the oracle's: %s" % json.dumps(result["parity"]), file=sys.stderr)
 
     if args.save_display:       # frame 0 again on every rank, outside all timing
         lone.set_profiling(False, False)

@@ -391,6 +391,9 @@ public:
     void set_frame_batch(uint32_t frames) { check(trhip_pt_set_frame_batch(pt, frames)); frame_batch = frames; }
     // slices of a frame run concurrently inside the stage: 0 = automatic, 1 = none (several frames in flight instead)
     void set_lanes(int lanes) { check(trhip_pt_set_lanes(pt, lanes)); }
+    // which shading program renders this stage (general kernels / the command-line set's ahead-of-time instances / compiled for the option
+    // set), resolved now, and its identity - what the devices of a job compare before the first frame (trhip_pt_get_program)
+    trhip_program_info program() const { trhip_program_info p; check(trhip_pt_get_program(pt, &p)); return p; }
     // view / sample shard of a multi-device job: global viewport and sample addressing
     void set_shard(uint32_t viewport_base, uint32_t viewport_stride, uint32_t sample_base = 0, uint32_t sample_stride = 1)
     {

@@ -78,12 +78,17 @@ inline void remove_comm_id_file(const std::string& path, int rank) { if(rank == 
 
 // The set-up of the copy-engine exchange (trhip_ipc_*) needs every rank's 256-byte blob on every rank: an all-gather through files
 // `prefix.ipc<rank>` for processes that share a file system, each with the job's nonce in front (as the communicator id above: a file of
-// another job is waited out; without a nonce, a file older than `stale_seconds`).  The files are small and stay behind; a rank replaces
-// its own at the start of the next job.
-inline std::vector<char> allgather_blobs_through_files(const std::string& prefix, int rank, int nranks, const std::vector<char>& blob, uint64_t nonce = 0,
-                                                       double timeout_seconds = 120.0, double stale_seconds = 60.0)
+// another job is waited out).  The nonce is required here: a blob holds a hipIpcMemHandle, and with nothing to tell jobs apart a rank
+// of a second job on the same prefix could read a peer's blob of the first job before that peer has replaced it, and map a dead or foreign
+// allocation.  A second round removes the files: every rank leaves a marker `prefix<suffix><rank>.read` once it has read all blobs, and removes
+// its own blob when every rank's marker of this job is there (the markers - nonce and nothing else - stay until the next job replaces them).
+inline std::vector<char> allgather_blobs_through_files(const std::string& prefix, int rank, int nranks, const std::vector<char>& blob, uint64_t nonce,
+                                                       double timeout_seconds = 120.0, const std::string& suffix = ".ipc")
 {
-    auto path_of = [&](int r) { return prefix + ".ipc" + std::to_string(r); };
+    if(nonce == 0) throw std::runtime_error("allgather_blobs_through_files: needs a non-zero nonce shared by the ranks of this job (--comm-nonce)");
+    auto path_of = [&](int r) { return prefix + suffix + std::to_string(r); };
+    auto marker_of = [&](int r) { return prefix + suffix + std::to_string(r) + ".read"; };
+    std::remove(marker_of(rank).c_str());
     {
         const std::string tmp = path_of(rank) + ".tmp";
         std::remove(path_of(rank).c_str());
@@ -92,7 +97,6 @@ inline std::vector<char> allgather_blobs_through_files(const std::string& prefix
     }
     std::vector<char> all((size_t)nranks * blob.size());
     const auto t0 = std::chrono::steady_clock::now();
-    const std::time_t wall0 = std::time(nullptr);
     for(int r = 0; r < nranks; ++r)
     {
         while(true)
@@ -100,15 +104,29 @@ inline std::vector<char> allgather_blobs_through_files(const std::string& prefix
             std::ifstream f(path_of(r), std::ios::binary);
             uint64_t file_nonce = 0;
             if(f && f.read(reinterpret_cast<char*>(&file_nonce), 8) && f.read(all.data() + (size_t)r * blob.size(), (std::streamsize)blob.size()) && file_nonce == nonce)
-            {
-                bool ours = true;
-                if(nonce == 0) { struct stat st; if(::stat(path_of(r).c_str(), &st) == 0) ours = std::difftime(wall0, st.st_mtime) <= stale_seconds; }
-                if(ours) break;
-            }
+                break;
             if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
                 throw std::runtime_error("timed out waiting for rank " + std::to_string(r) + " in " + path_of(r));
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
+    }
+    {   // second round: this rank has read everything; once everybody has, the blobs have done their job
+        const std::string tmp = marker_of(rank) + ".tmp";
+        { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char*>(&nonce), 8); if(!f) throw std::runtime_error("cannot write " + tmp); }
+        if(std::rename(tmp.c_str(), marker_of(rank).c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+        for(int r = 0; r < nranks; ++r)
+        {
+            while(true)
+            {
+                std::ifstream f(marker_of(r), std::ios::binary);
+                uint64_t file_nonce = 0;
+                if(f && f.read(reinterpret_cast<char*>(&file_nonce), 8) && file_nonce == nonce) break;
+                if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+                    throw std::runtime_error("timed out waiting for rank " + std::to_string(r) + " to read the blobs (" + marker_of(r) + ")");
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        }
+        std::remove(path_of(rank).c_str());
     }
     return all;
 }
@@ -189,6 +207,31 @@ public:
         const std::vector<char> all = allgather(blob);
         if(all.size() != blob.size() * (size_t)nranks) throw std::runtime_error("use_copy_engine_exchange: the all-gather returned the wrong size");
         check_comm(trhip_ipc_connect(ipc, all.data()));
+    }
+
+    // Every rank of a job has to shade with the same program: the reference compiles one pipeline per stage from the options and every
+    // device gets that one (src/path_tracer_stage.cc:30-116).  Here a rank whose run-time compilation failed, or that was started under
+    // TRHIP_SPECIALIZE=0 / another build of the library, would render its strips with other kernels - at the default arithmetic another
+    // implementation inside Vulkan's accuracy, i.e. strips that differ from their neighbours' in the last bits.
+    // `allgather`: as for use_copy_engine_exchange (blobs of 256 bytes).  Every rank calls this once, before the first frame; a mismatch throws
+    // on every rank, naming the two programs.
+    template<typename F>
+    void check_same_program(F&& allgather)
+    {
+        if(nranks == 1) return;
+        const trhip_program_info mine = slots[0].ray_tracer->program();
+        std::vector<char> blob(256, 0);
+        std::memcpy(blob.data(), &mine.identity, 8);
+        std::memcpy(blob.data() + 8, mine.key, std::min(sizeof(mine.key), blob.size() - 9));
+        const std::vector<char> all = allgather(blob);
+        if(all.size() != blob.size() * (size_t)nranks) throw std::runtime_error("check_same_program: the all-gather returned the wrong size");
+        for(int r = 0; r < nranks; ++r)
+        {
+            uint64_t id; std::memcpy(&id, all.data() + (size_t)r * blob.size(), 8);
+            if(id != mine.identity)
+                throw std::runtime_error("the ranks of this job would render with different shading programs: rank " + std::to_string(rank) + " {" + mine.key +
+                                         "} but rank " + std::to_string(r) + " {" + std::string(all.data() + (size_t)r * blob.size() + 8) + "} (same libtrhip.so, kernel cache and TRHIP_* environment on every rank?)");
+        }
     }
 
     void reset_accumulation(bool reset_sample_counter = false)

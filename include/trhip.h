@@ -283,6 +283,20 @@ int trhip_pt_set_specialization(trhip_pt* pt, int enable);
  * index spans (what trhip_scene_upload derives ShadeTri records from - true for every glTF file), ieee / count_work as in
  * trhip_pt_set_shading_arithmetic / trhip_pt_set_profiling.  Needs no GPU and no device handle. */
 int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, int count_work, const char* arch);
+/* Which shading program renders this stage, resolved now (a program for the option set is loaded from the kernel cache or compiled, as the
+ * first render would do): the reference compiles one pipeline per stage from its options (src/path_tracer_stage.cc:30-116) and every
+ * device of a job gets the same one.  Here a stage can end up on three kinds of kernels, and at the default arithmetic two kinds are two
+ * implementations inside Vulkan's accuracy, not the same bits - so the ranks of a multi-GPU job compare
+ * `identity` before the first frame (tr::process_rt_renderer, tauray_amd.renderer.RtRenderer: all-gather, mismatch = error) and
+ * bench.py records `kind` instead of inferring it from the options.
+ *   kind: 0 = the general kernels (every option read from the parameter block), 1 = the ahead-of-time instances of the reference's
+ *         command-line option set, 2 = a program compiled for this option set (hipRTC / kernel cache);
+ *   ieee: 1 = IEEE fp32 shading, 0 = Vulkan-grade arithmetic;
+ *   identity: FNV-1a over kind, arithmetic, the pinned option fields, the embedded device sources of this build of the library and,
+ *         for kind 2, the bytes of the code objects that were loaded;
+ *   key: the pinned fields as text (what TRHIP_DEBUG prints). */
+typedef struct trhip_program_info { int32_t kind, ieee; uint64_t identity; char key[240]; } trhip_program_info;
+int trhip_pt_get_program(trhip_pt* pt, trhip_program_info* out);
 const char* trhip_kernel_cache_dir(void);   /* TRHIP_KERNEL_CACHE, else kernel_cache/ next to libtrhip.so, else ~/.cache/trhip; "" = none writable */
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */

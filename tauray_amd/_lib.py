@@ -73,6 +73,11 @@ class PhaseCountersC(C.Structure):
                                                                                                  ("closest_node_visits", C.c_uint64)])
 
 
+class ProgramInfoC(C.Structure):
+    """trhip_program_info: which shading program renders a stage (kind 0 general / 1 command-line set ahead of time / 2 compiled), its arithmetic, identity."""
+    _fields_ = [("kind", C.c_int32), ("ieee", C.c_int32), ("identity", C.c_uint64), ("key", C.c_char * 240)]
+
+
 class PtTargetsC(C.Structure):
     """trhip_pt_targets: device images, None = not requested."""
     _fields_ = [(n, C.c_void_p) for n in ("color", "diffuse", "reflection", "albedo", "material", "normal", "pos", "instance_id", "screen_motion")]
@@ -138,6 +143,7 @@ SYMBOLS = {
     "trhip_pt_reset_counters": (_i, [_vp]),
     "trhip_pt_get_timings": (_i, [_vp, C.POINTER(TimingsC)]),
     "trhip_pt_get_phase_counters": (_i, [_vp, C.POINTER(PhaseCountersC)]),
+    "trhip_pt_get_program": (_i, [_vp, C.POINTER(ProgramInfoC)]),
     "trhip_calibrate_valu": (_i, [_vp, C.POINTER(C.c_float)]),
     "trhip_calibrate_l1": (_i, [_vp, C.POINTER(C.c_float)]),
     "trhip_feature_render": (_i, [_vp, _i, C.POINTER(DistributionC), _i, _u32, _f, C.POINTER(_f), _vp, _u32, _u32, _vp]),

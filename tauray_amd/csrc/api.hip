@@ -460,6 +460,15 @@ int trhip_scene_upload(trhip_device* dev, const trhip_scene_desc* d) {
     if (upload_array(s.texels, d->texels, texel_count * 4)) return 1;
     if (upload_array(s.cameras, d->cameras, d->camera_count)) return 1;
     if (upload_array(s.non_opaque, d->non_opaque, d->instance_count)) return 1;
+    {   // any-hit records: one per triangle of a non-opaque instance, laid out instance after instance (common.h AlphaTri)
+        std::vector<uint> alpha_base(d->instance_count, 0xFFFFFFFFu);
+        uint64_t n_alpha = 0;
+        for (uint i = 0; i < d->instance_count; ++i) if (d->non_opaque[i]) { alpha_base[i] = (uint)n_alpha; n_alpha += spans[i].triangle_count; }
+        if (n_alpha > 0x7FFFFFFFull) return set_error("trhip_scene_upload: more than 2^31 non-opaque triangles");
+        if (upload_array(s.alpha_base, alpha_base.data(), alpha_base.size())) return 1;
+        s.alpha_count = (uint)n_alpha;
+        if (n_alpha) HIPCHK(hipMalloc(&s.alpha_tris, (size_t)n_alpha * sizeof(AlphaTri)));
+    }
     if (upload_array(s.tri_prefix, prefix.data(), prefix.size())) return 1;
     s.environment_proj = -1;
     s.environment_factor = F4(0);
@@ -714,6 +723,7 @@ int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing) {
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_counters(out, pt->stage->last_stream); }
 int trhip_pt_reset_counters(trhip_pt* pt) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); HIPCHK(hipStreamSynchronize(pt->stage->last_stream)); return pt->stage->reset_counters(); }
 int trhip_pt_get_timings(trhip_pt* pt, trhip_timings* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_timings(out); }
+int trhip_pt_get_program(trhip_pt* pt, trhip_program_info* out) { if (!pt) return set_error("null trhip_pt"); if (!out) return set_error("trhip_pt_get_program: null out"); DEVCHK(pt->dev); return pt->stage->get_program(out); }
 int trhip_pt_get_phase_counters(trhip_pt* pt, trhip_phase_counters* out) { if (!pt) return set_error("null trhip_pt"); DEVCHK(pt->dev); return pt->stage->get_phase_counters(out, pt->stage->last_stream); }
 
 int trhip_calibrate_valu(trhip_device* dev, float* ginst_per_s) {

@@ -25,6 +25,9 @@ struct DeviceScene {
     CameraData* cameras = nullptr;
     CameraData* prev_cameras = nullptr;  // defaults to a copy of `cameras`
     uint8_t* non_opaque = nullptr;
+    uint* alpha_base = nullptr;          // per instance: first AlphaTri record of its triangles (non-opaque instances; 0xFFFFFFFF otherwise)
+    AlphaTri* alpha_tris = nullptr;      // filled by the build and the refit (k_pretransform / k_retransform)
+    uint alpha_count = 0;
     uint* tri_prefix = nullptr;          // instance_count + 1 prefix sums of triangle counts
     ShadeTri* shade_tris = nullptr;      // index_count / 3 records, or null (see common.h ShadeTri)
     f4* shade_tangents = nullptr;        // ... and their tangents, three per record, behind the records in the same allocation
@@ -71,7 +74,7 @@ struct DeviceScene {
         v.instances = instances; v.spans = spans; v.vertices = vertices; v.indices = indices;
         v.point_lights = point_lights; v.directional_lights = directional_lights; v.tri_lights = tri_lights;
         v.tex_infos = tex_infos; v.texels = texels; v.envmap = envmap; v.alias_table = alias_table;
-        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.shade_tangents = shade_tangents; v.tris = tris; v.nodes4 = nodes4;
+        v.cameras = cameras; v.prev_cameras = prev_cameras ? prev_cameras : cameras; v.obj_spans = spans; v.obj_vertices = vertices; v.shade_tris = shade_tris; v.shade_tangents = shade_tangents; v.tris = tris; v.alpha_tris = alpha_tris; v.nodes4 = nodes4;
         v.environment_factor = environment_factor; v.environment_proj = environment_proj;
         v.instance_count = instance_count; v.point_light_count = point_light_count;
         v.directional_light_count = directional_light_count; v.tri_light_count = tri_light_count;
@@ -100,7 +103,7 @@ struct DeviceScene {
         free_accel();
         free_skins();
         void* ptrs[] = {instances, spans, vertices, indices, point_lights, directional_lights, tex_infos, texels, envmap,
-                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch, shade_tris};
+                        alias_table, cameras, prev_cameras, non_opaque, tri_prefix, world_spans, world_vertices, scratch, shade_tris, alpha_base, alpha_tris};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = DeviceScene();
     }

@@ -41,9 +41,19 @@ TR_DEV void locate_triangle(const uint* tri_prefix, uint instance_count, uint gi
     prim = gid - tri_prefix[lo];
 }
 
+// TriRecord::alpha of a triangle of a non-opaque instance, and its AlphaTri record (common.h).  The material can change between a build
+// and a refit (trhip_scene_update_instances replaces the whole instance record), so both write it.
+TR_DEV uint alpha_word(const Material& mat, uint record, AlphaTri* alpha_tris, f2 uv0, f2 uv1, f2 uv2) {
+    AlphaTri a;
+    a.uv0 = uv0; a.uv1 = uv1; a.uv2 = uv2; a.factor = mat.albedo_factor.w; a.tex = mat.albedo_tex_id;
+    alpha_tris[record] = a;
+    const uint bits = __float_as_uint(a.factor);
+    return (a.tex < 0 && !(bits & 0x80000000u)) ? bits : (0x80000000u | record);
+}
+
 // world-space triangle = (model * vec4(pos, 1)).xyz in the GLSL evaluation order; also accumulates the
 // centroid bounds used to quantise Morton codes.
-__global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* tri_prefix, const uint8_t* non_opaque,
+__global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* tri_prefix, const uint8_t* non_opaque, const uint* alpha_base, AlphaTri* alpha_tris,
                                                      TriRecord* tris_unsorted, uint* cbounds /*6 flipped uints of the centroid bounds; [16..21] the same for the triangles' bounds*/) {
     float cmin[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
     float cmax[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(BT) void k_pretransform(SceneView sv, const uint* t
         t.v2[0] = p2.x; t.v2[1] = p2.y; t.v2[2] = p2.z;
         t.inst_flags = inst | (non_opaque[inst] ? 0x80000000u : 0u);
         t.prim = prim;
-        t.pad = 0;
+        t.alpha = non_opaque[inst] ? alpha_word(sv.instances[inst].mat, alpha_base[inst] + prim, alpha_tris, vb[ix[0]].uv, vb[ix[1]].uv, vb[ix[2]].uv) : 0u;
         tris_unsorted[gid] = t;
         f3 lo = min3(min3(p0, p1), p2), hi = max3(max3(p0, p1), p2);
         f3 c = (lo + hi) * 0.5f;
@@ -666,7 +676,7 @@ int skin_instance(DeviceScene& ds, uint instance, const float* joint_transforms,
 // Refit: the instance transforms changed, the tree keeps its topology (what a BLAS/TLAS *update* does in the reference,
 // src/acceleration_structure.cc:376-422).  World triangles are recomputed in place, then the child boxes of the live
 // nodes are rebuilt level by level from the deepest level up.
-__global__ __launch_bounds__(BT) void k_retransform(SceneView sv, uint n, TriRecord* tris) {
+__global__ __launch_bounds__(BT) void k_retransform(SceneView sv, uint n, TriRecord* tris, const uint* alpha_base, AlphaTri* alpha_tris) {
     uint i = blockIdx.x * BT + threadIdx.x;
     if (i >= n) return;
     TriRecord t = tris[i];
@@ -679,6 +689,7 @@ __global__ __launch_bounds__(BT) void k_retransform(SceneView sv, uint n, TriRec
     t.v0[0] = p0.x; t.v0[1] = p0.y; t.v0[2] = p0.z;
     t.v1[0] = p1.x; t.v1[1] = p1.y; t.v1[2] = p1.z;
     t.v2[0] = p2.x; t.v2[1] = p2.y; t.v2[2] = p2.z;
+    if (t.inst_flags & 0x80000000u) t.alpha = alpha_word(sv.instances[inst].mat, alpha_base[inst] + t.prim, alpha_tris, vb[ix[0]].uv, vb[ix[1]].uv, vb[ix[2]].uv);
     tris[i] = t;
 }
 
@@ -753,7 +764,7 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
             fprintf(stderr, "[trhip] 4-wide tree: %u live nodes of %u slots in %zu levels, %.3f children per node\n", ds.level_offsets.back(), n1,
                     ds.level_offsets.size() - 1, (double)(n + ds.level_offsets.back() - 1) / (double)ds.level_offsets.back());
     }
-    if (n > 0) hipLaunchKernelGGL(k_retransform, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv, n, ds.tris);
+    if (n > 0) hipLaunchKernelGGL(k_retransform, dim3((n + BT - 1) / BT), dim3(BT), 0, stream, sv, n, ds.tris, ds.alpha_base, ds.alpha_tris);
     for (size_t l = ds.level_offsets.size(); l-- > 1;) {
         const uint lo = ds.level_offsets[l - 1], cnt = ds.level_offsets[l] - lo;
         if (cnt) hipLaunchKernelGGL(k_refit_level, dim3((cnt + BT - 1) / BT), dim3(BT), 0, stream, cnt, ds.level_nodes + lo, ds.nodes4, ds.tris, ds.node_bounds);
@@ -776,6 +787,70 @@ int refit_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         info->build_ms = ms;
         for (int k = 0; k < 3; ++k) { info->bounds_min[k] = ds.bounds_lo[k]; info->bounds_max[k] = ds.bounds_hi[k]; }
     }
+    return 0;
+}
+
+// Experiment (TRHIP_TREELET=<nodes per treelet>, off by default; profiles/r5/treelet_order_ab.txt): the live 4-wide nodes laid out treelet by
+// treelet - a treelet is grown from its root by always opening the hit-likeliest (largest) child box until it holds the given number of
+// nodes, its nodes are stored side by side, the subtrees hanging off it follow depth-first - and the triangle records in the order the new
+// node array refers to them, so the leaves of a node are neighbours in memory.  Dead lines (binary nodes the collapse adopted away) drop
+// out.  A host pass over a downloaded tree: build time is not the point of the experiment.  Hits do not depend on the layout.
+static int reorder_into_treelets(DeviceScene& ds, hipStream_t stream, uint n_nodes, uint n_tris, uint treelet_nodes, bool reorder_tris) {
+    if (n_nodes == 0 || n_tris == 0) return 0;
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<Bvh4Node> nodes(n_nodes), out_nodes;
+    std::vector<TriRecord> tris(n_tris), out_tris;
+    HIPCHK(hipMemcpy(nodes.data(), ds.nodes4, (size_t)n_nodes * sizeof(Bvh4Node), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tris.data(), ds.tris, (size_t)n_tris * sizeof(TriRecord), hipMemcpyDeviceToHost));
+    std::vector<int> new_id(n_nodes, -1);
+    std::vector<uint> order;            // old node ids in their new order
+    order.reserve(n_nodes);
+    std::vector<uint> roots = {0u};     // stack of treelet roots
+    auto area = [&](const Bvh4Node& nd, int c) {
+        const float dx = nd.hix[c] - nd.lox[c], dy = nd.hiy[c] - nd.loy[c], dz = nd.hiz[c] - nd.loz[c];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<std::pair<float, uint>> heap;
+    while (!roots.empty()) {
+        const uint root = roots.back(); roots.pop_back();
+        heap.clear();
+        heap.push_back({__builtin_huge_valf(), root});
+        uint taken = 0;
+        std::vector<uint> rest;
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end());
+            const uint nd = heap.back().second; heap.pop_back();
+            if (taken >= treelet_nodes) { rest.push_back(nd); continue; }
+            new_id[nd] = (int)order.size(); order.push_back(nd); taken++;
+            for (int c = 0; c < 4; ++c) {
+                const int ch = nodes[nd].child[c];
+                if (ch >= 0 && ch != 0x7FFFFFFF) { heap.push_back({area(nodes[nd], c), (uint)ch}); std::push_heap(heap.begin(), heap.end()); }
+            }
+        }
+        // the subtrees below the treelet, the largest box last so that it is laid out next
+        for (size_t k = rest.size(); k-- > 0;) roots.push_back(rest[k]);
+    }
+    out_nodes.resize(n_nodes);
+    std::vector<int> new_tri(n_tris, -1);
+    uint next_tri = 0;
+    for (size_t k = 0; k < order.size(); ++k) {
+        Bvh4Node nd = nodes[order[k]];
+        for (int c = 0; c < 4; ++c) {
+            const int ch = nd.child[c];
+            if (ch == 0x7FFFFFFF) continue;
+            if (ch >= 0) nd.child[c] = new_id[ch];
+            else if (reorder_tris) { const uint t = (uint)~ch; if (new_tri[t] < 0) new_tri[t] = (int)next_tri++; nd.child[c] = ~new_tri[t]; }
+        }
+        out_nodes[k] = nd;
+    }
+    for (size_t k = order.size(); k < n_nodes; ++k) { out_nodes[k] = nodes[0]; }   // never referenced
+    HIPCHK(hipMemcpy(ds.nodes4, out_nodes.data(), (size_t)n_nodes * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+    if (reorder_tris) {
+        out_tris.resize(n_tris);
+        for (uint t = 0; t < n_tris; ++t) { if (new_tri[t] < 0) new_tri[t] = (int)next_tri++; out_tris[new_tri[t]] = tris[t]; }
+        HIPCHK(hipMemcpy(ds.tris, out_tris.data(), (size_t)n_tris * sizeof(TriRecord), hipMemcpyHostToDevice));
+    }
+    if (getenv("TRHIP_DEBUG")) fprintf(stderr, "[trhip] treelet layout: %zu live nodes of %u in treelets of %u, triangles %s\n", order.size(), n_nodes, treelet_nodes, reorder_tris ? "in node order" : "as built");
     return 0;
 }
 
@@ -847,7 +922,7 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
         uint* arrive = reinterpret_cast<uint*>(base + o_arrive);
         BvhNode* nodes2 = reinterpret_cast<BvhNode*>(base + o_nodes2);   // binary nodes: only the collapse input
         const uint tblocks = (n_tri + BT - 1) / BT;
-        hipLaunchKernelGGL(k_pretransform, dim3(tblocks < 1024u ? tblocks : 1024u), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, unsorted, cbounds);
+        hipLaunchKernelGGL(k_pretransform, dim3(tblocks < 1024u ? tblocks : 1024u), dim3(BT), 0, stream, sv, ds.tri_prefix, ds.non_opaque, ds.alpha_base, ds.alpha_tris, unsorted, cbounds);
         const uint blocks = (n + BT - 1) / BT;
         hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BT), 0, stream, n, unsorted, cbounds, keys, vals);
         HIPCHK(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, keys, keys_sorted, vals, vals_sorted, n, 0, 64, stream));
@@ -959,6 +1034,9 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
             }
         }
         HIPCHK(hipGetLastError());
+        if (const char* e = getenv("TRHIP_TREELET")) {
+            if (n > 2 && atoi(e) > 0) if (int rc = reorder_into_treelets(ds, stream, n - 1, n, (uint)atoi(e), !getenv("TRHIP_TREELET_KEEP_TRIS"))) return rc;
+        }
     }
     ds.leaf_count = n;
     ds.node_count = n > 1 ? n - 1 : 0;

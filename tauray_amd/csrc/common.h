@@ -175,11 +175,19 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
 
 // 48-byte world-space triangle record, stored in Morton (leaf) order.
 //   inst_flags: bits 0..30 instance id, bit 31 = non-opaque (runs the any-hit path)
+//   alpha (non-opaque triangles only): what the any-hit test needs of the material.  Bit 31 clear: the bits of the candidate's alpha
+//   itself - the material has no albedo texture, alpha = albedo_factor.a for every point of the triangle, no fetch at all.  Bit 31 set:
+//   index of the triangle's AlphaTri record.  (Round 5: the test used to walk instance -> span -> three indices -> three vertices ->
+//   texture table -> texels, four dependent round trips inside a triangle phase that every other lane of the wave waits through.)
 struct alignas(16) TriRecord {
     float v0[3], v1[3], v2[3];
-    uint inst_flags, prim, pad;
+    uint inst_flags, prim, alpha;
 };
 static_assert(sizeof(TriRecord) == 48, "tri layout");
+// One per triangle of a non-opaque instance, at alpha_base[instance] + primitive: texture coordinates of the three vertices,
+// albedo_factor.a and the albedo texture (get_interpolated_vertex_light + the alpha tap of shader/rt_common.rahit:15-24 in one 32-byte fetch).
+struct alignas(16) AlphaTri { f2 uv0, uv1, uv2; float factor; int tex; };
+static_assert(sizeof(AlphaTri) == 32, "alpha record layout");
 
 struct HitRecord { int instance_id, primitive_id; float u, v, t; };
 
@@ -203,6 +211,7 @@ struct SceneView {
     const ShadeTri* shade_tris;  // null = none
     const f4* shade_tangents;    // three per record
     const TriRecord* tris;
+    const AlphaTri* alpha_tris;  // records of the non-opaque triangles (TriRecord::alpha)
     const Bvh4Node* nodes4;      // the 4-wide fp32 nodes the traversal reads; node 0 is the root
     f4 environment_factor;
     int environment_proj;

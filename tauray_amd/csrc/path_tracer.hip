@@ -41,7 +41,8 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     if (!WIDE) sv.wide_textures = 0;
     __shared__ int s_stack[TR_STACK_WORDS];
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
-    const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
+    TL(__shared__ uint s_tl[(KB / 64) * TL_WORDS]; for (uint i = threadIdx.x; i < (KB / 64) * TL_WORDS; i += KB) s_tl[i] = 0; __syncthreads();)
+    const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb TL(, s_tl));
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     TraceStats st = {};
     uint rays = 0, max_vis = 0;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
         closest_lane<COUNT>(sv, P, pb, bounce, queue, base + (threadIdx.x & 63), n, s_stack + threadIdx.x, qc, st, overflow, max_vis, rays);
     }
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
+    TL(__syncthreads(); for (uint i = threadIdx.x; i < (KB / 64) * TL_WORDS; i += KB) if (s_tl[i]) atomicAdd(&g_timeline[i % TL_WORDS], (unsigned long long)s_tl[i]);)
 }
 
 template <bool COUNT, bool WIDE = true>
@@ -503,6 +505,50 @@ static int ensure_qspill(PathBuffers& pb, size_t& lane_words, size_t& regions_ha
     return 0;
 }
 
+PtStage::Program PtStage::choose_program() {
+    static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
+    const bool wide = scene->wide_textures != 0;      // RGBA16 textures: the kernel instances with the two-format texel fetch
+    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr && !wide;     // k_shade<.., SpecCli>: reads the ShadeTri records, RGBA8 texels
+    static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
+    const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;
+    static const bool specialize_env = !(getenv("TRHIP_SPECIALIZE") && atoi(getenv("TRHIP_SPECIALIZE")) == 0);
+    const SpecKernels *spec_shade = nullptr, *spec_raygen = nullptr;
+    std::string key;
+    if (!cli_set && !direct && (specialize < 0 ? specialize_env : specialize != 0)) {
+        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, SPEC_SHADE, wide};
+        std::string why;
+        spec_shade = spec_kernels(rq, &why);
+        if (spec_shade) { rq.program = SPEC_RAYGEN; spec_raygen = spec_kernels(rq, &why); }
+        if (!spec_shade || !spec_raygen) {
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "[trhip] no specialised shading program for {%s}: %s - rendering with the general kernels\n", spec_key(rq).c_str(), why.c_str());
+            warned = true;
+            spec_shade = nullptr; spec_raygen = nullptr;
+        }
+    }
+    return Program{cli_set, shade_fast, wide, spec_shade, spec_raygen, key};
+}
+
+// trhip_pt_get_program: the choice above with an identity the ranks of a job can compare
+int PtStage::get_program(trhip_program_info* out) {
+    memset(out, 0, sizeof(*out));
+    const Program p = choose_program();
+    out->kind = p.shade ? 2 : (p.cli_set ? 1 : 0);
+    out->ieee = p.shade_fast ? 0 : 1;
+    SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !p.shade_fast, count_work != 0, SPEC_SHADE, p.wide};
+    const std::string key = (out->kind == 2 ? "compiled: " : out->kind == 1 ? "command-line set, ahead of time: " : "general kernels: ") + spec_key(rq);
+    snprintf(out->key, sizeof(out->key), "%s", key.c_str());
+    unsigned long long h = spec_sources_hash();
+    h = spec_fnv1a(h, &out->kind, sizeof(out->kind)); h = spec_fnv1a(h, &out->ieee, sizeof(out->ieee));
+    const int dir = direct ? 1 : 0;
+    h = spec_fnv1a(h, &dir, sizeof(dir));
+    // the general kernels read the options as data: their identity is the build; the other two pin option fields
+    if (out->kind != 0) { const std::string k = spec_key(rq); h = spec_fnv1a(h, k.c_str(), k.size()); }
+    if (p.shade) { h = spec_fnv1a(h, &p.shade->code_hash, 8); h = spec_fnv1a(h, &p.raygen->code_hash, 8); }
+    out->identity = h;
+    return 0;
+}
+
 int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_h, uint viewports, hipStream_t stream) {
     if (!scene->accel_built) return set_error("trhip_pt_render: call trhip_scene_build_accel first");
     if (viewports == 0 || viewports % frame_batch != 0) return set_error("trhip_pt_render: the layers of a launch are a whole number of frames (trhip_pt_set_frame_batch)");
@@ -570,25 +616,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     //    or the kernel cache; trhip_pt_set_specialization / TRHIP_SPECIALIZE=0 switch that off),
     //  * the general instances, which read every option from the parameter block - what renders when neither of the above applies.
     // All three render the same bits in the same arithmetic.
-    static const bool cli_instances = !(getenv("TRHIP_SHADE_CLI") && atoi(getenv("TRHIP_SHADE_CLI")) == 0);
-    const bool wide = scene->wide_textures != 0;      // RGBA16 textures: the kernel instances with the two-format texel fetch
-    const bool cli_set = cli_instances && is_cli_default_set(opt) && scene->shade_tris != nullptr && !wide;     // k_shade<.., SpecCli>: reads the ShadeTri records, RGBA8 texels
-    static const bool shade_fast_env = !(getenv("TRHIP_SHADE_FAST") && atoi(getenv("TRHIP_SHADE_FAST")) == 0);
-    const bool shade_fast = ieee_shading < 0 ? shade_fast_env : ieee_shading == 0;
-    static const bool specialize_env = !(getenv("TRHIP_SPECIALIZE") && atoi(getenv("TRHIP_SPECIALIZE")) == 0);
-    const SpecKernels *spec_shade = nullptr, *spec_raygen = nullptr;
-    if (!cli_set && !direct && (specialize < 0 ? specialize_env : specialize != 0)) {
-        SpecRequest rq{opt, scene->shade_tris != nullptr && !opt.pre_transformed_vertices, !shade_fast, count_work != 0, SPEC_SHADE, wide};
-        std::string why;
-        spec_shade = spec_kernels(rq, &why);
-        if (spec_shade) { rq.program = SPEC_RAYGEN; spec_raygen = spec_kernels(rq, &why); }
-        if (!spec_shade || !spec_raygen) {
-            static bool warned = false;
-            if (!warned) fprintf(stderr, "[trhip] no specialised shading program for {%s}: %s - rendering with the general kernels\n", spec_key(rq).c_str(), why.c_str());
-            warned = true;
-            spec_shade = nullptr; spec_raygen = nullptr;
-        }
-    }
+    const Program prog = choose_program();
+    const bool wide = prog.wide, cli_set = prog.cli_set, shade_fast = prog.shade_fast;
+    const SpecKernels *spec_shade = prog.shade, *spec_raygen = prog.raygen;
     auto launch_raygen = [&](uint blocks, hipStream_t on, const PtParams& LP, const PathBuffers& lb) {
         if (spec_raygen) {
             SceneView a0 = sv; PtParams a1 = LP; PathBuffers a2 = lb;
@@ -959,3 +989,13 @@ int PtStage::get_timings(trhip_timings* out) {
 }
 
 }  // namespace tr
+
+#if TR_TIMELINE
+// Read-out of the phase timeline (trace_timeline.h); only in the variant library built with -DTR_TIMELINE=1, not part of include/trhip.h.
+extern "C" int trhip_debug_timeline(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(tr::g_timeline), sizeof(unsigned long long) * tr::TL_WORDS) != hipSuccess) return 1;
+    if (reset) { static unsigned long long zero[tr::TL_WORDS]; if (hipMemcpyToSymbol(HIP_SYMBOL(tr::g_timeline), zero, sizeof(zero)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

@@ -16,6 +16,7 @@ public:
     int reset_counters();
     int get_timings(trhip_timings* out);
     int get_phase_counters(trhip_phase_counters* out, hipStream_t stream);
+    int get_program(trhip_program_info* out);
 
     DeviceScene* scene;
     trhip_pt_options opt;
@@ -31,6 +32,10 @@ public:
     int specialize = -1;             // trhip_pt_set_specialization: 1 = a shading program compiled for this stage's option set (hipRTC / kernel cache), 0 = the general kernels, -1 = TRHIP_SPECIALIZE decides (default on)
     bool direct = false;             // direct_stage instead of path_tracer_stage (trhip_direct_create)
     hipStream_t last_stream = nullptr;
+
+    // which kernels shade this stage (render() and get_program() decide it the same way)
+    struct Program { bool cli_set, shade_fast, wide; const struct SpecKernels *shade, *raygen; std::string key; };
+    Program choose_program();
 
 private:
     struct Impl;

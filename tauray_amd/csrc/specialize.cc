@@ -172,6 +172,19 @@ std::map<std::string, std::string> g_failed; // requests that could not be built
 
 }  // namespace
 
+unsigned long long spec_fnv1a(unsigned long long h, const void* p, size_t n) { return fnv1a(h, p, n); }
+
+unsigned long long spec_sources_hash() {
+    static const unsigned long long hash = [] {
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (const auto& s : k_rtc_sources) { h = fnv1a(h, s.name, strlen(s.name) + 1); h = fnv1a(h, s.text, strlen(s.text) + 1); }
+        int major = 0, minor = 0;
+        if (hiprtcVersion(&major, &minor) == HIPRTC_SUCCESS) { h = fnv1a(h, &major, sizeof(major)); h = fnv1a(h, &minor, sizeof(minor)); }
+        return (unsigned long long)h;
+    }();
+    return hash;
+}
+
 std::string spec_key(const SpecRequest& r) {
     std::string s;
     for (const std::string& f : spec_flags(r, "")) if (f.rfind("-DTR_SPEC_", 0) == 0) s += f.substr(10) + " ";
@@ -200,7 +213,8 @@ std::string spec_cache_dir() {
 
 int spec_precompile(const SpecRequest& r, const char* arch, std::string* why) {
     std::vector<char> code;
-    return code_object(r, arch && *arch ? arch : "gfx950", code, nullptr, why);
+    std::string a = arch && *arch ? arch : "gfx950";
+    return code_object(r, a.substr(0, a.find(':')), code, nullptr, why);
 }
 
 const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
@@ -208,7 +222,11 @@ const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
     if (hipGetDevice(&dev) != hipSuccess) { if (why) *why = "no current HIP device"; return nullptr; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { if (why) *why = "hipGetDeviceProperties failed"; return nullptr; }
+    // gcnArchName is a full target id ("gfx950:sramecc+:xnack-"); trhip_pt_precompile and build() compile for the bare processor, and the
+    // cache file's name hashes the flags: with the feature suffix left on, every program warmed ahead of time missed and was compiled
+    // again through hipRTC on first render.  A code object for the bare processor loads under any setting of the features.
     std::string arch = prop.gcnArchName;
+    arch = arch.substr(0, arch.find(':'));
     if (arch.empty()) arch = "gfx950";
     std::string key = std::to_string(dev) + " " + arch;
     for (const std::string& f : spec_flags(r, arch)) key += " " + f;
@@ -239,6 +257,7 @@ const SpecKernels* spec_kernels(const SpecRequest& r, std::string* why) {
         ok = false; err = "the specialised program lacks a kernel"; (void)hipGetLastError();
     }
     if (!ok) { g_failed[key] = err; if (why) *why = err; return nullptr; }
+    l.k.code_hash = fnv1a(0xCBF29CE484222325ull, code.data(), code.size());
     if (getenv("TRHIP_DEBUG")) fprintf(stderr, "[trhip] shading program for {%s}: %s\n", spec_key(r).c_str(), compiled ? "compiled through hipRTC" : "from the kernel cache");
     return &(g_loaded[key] = l).k;
 }

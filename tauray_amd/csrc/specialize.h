@@ -27,7 +27,11 @@ inline bool is_cli_default_set(const trhip_pt_options& o) {
            o.use_white_albedo_on_first_bounce == 0 && o.transparent_background == 0 && o.pre_transformed_vertices == 0;
 }
 
-struct SpecKernels { hipFunction_t raygen = nullptr, shade = nullptr, shade_last = nullptr; };
+struct SpecKernels { hipFunction_t raygen = nullptr, shade = nullptr, shade_last = nullptr; unsigned long long code_hash = 0; /* FNV-1a of the code object that was loaded */ };
+
+// FNV-1a of the device sources embedded in this library (rtc_sources.inc) and of the hipRTC version: what tells two builds of libtrhip.so apart
+unsigned long long spec_sources_hash();
+unsigned long long spec_fnv1a(unsigned long long h, const void* p, size_t n);
 
 // The pinned fields as text: what tells two instances apart (and, with the sources and the flags, names the cache file).
 std::string spec_key(const SpecRequest& r);

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "rng.h"
 #include "texture.h"
+#include "trace_timeline.h"
 
 namespace tr {
 
@@ -139,22 +140,18 @@ struct TraceStats {
     uint cnodes;              // node visits of closest-hit rays alone (`nodes` also counts the shadow rays of a fused launch)
 };
 
-// get_interpolated_vertex_light (shader/rt.glsl:103-117): uv at a candidate hit
-TR_DEV f2 candidate_uv(const SceneView& sv, int inst, int prim, float bu, float bv) {
-    const MeshSpan sp = sv.spans[inst];
-    const uint* ix = sv.indices + sp.index_offset + 3u * (uint)prim;
-    const Vertex* vb = sv.vertices + sp.vertex_offset;
-    f2 uv0 = vb[ix[0]].uv, uv1 = vb[ix[1]].uv, uv2 = vb[ix[2]].uv;
-    float b0 = 1.0f - bu - bv;
-    return uv0 * b0 + uv1 * bu + uv2 * bv;
-}
-
-// Candidate alpha of a non-opaque triangle (albedo_factor.a * texture alpha).
-TR_DEV float candidate_alpha(const SceneView& sv, int inst, int prim, float bu, float bv) {
-    const Material& mat = sv.instances[inst].mat;
-    float alpha = mat.albedo_factor.w;
-    int tex = mat.albedo_tex_id;
-    if (tex >= 0) alpha *= sample_texture_alpha(sv, tex, candidate_uv(sv, inst, prim, bu, bv));
+// Candidate alpha of a non-opaque triangle: albedo_factor.a * texture alpha at the uv of the candidate hit
+// (get_interpolated_vertex_light, shader/rt.glsl:103-117; shader/rt_common.rahit:15-24).  `word` = TriRecord::alpha: the alpha itself for
+// an untextured material, else the triangle's AlphaTri record - one 32-byte fetch where the instance, its span, three indices and three
+// vertices used to be fetched one behind the other (same values, same expressions: common.h, bvh_build.hip alpha_word).
+TR_DEV float candidate_alpha(const SceneView& sv, uint word, float bu, float bv) {
+    if (!(word & 0x80000000u)) return __uint_as_float(word);
+    const AlphaTri a = sv.alpha_tris[word & 0x7FFFFFFFu];
+    float alpha = a.factor;
+    if (a.tex >= 0) {
+        const float b0 = 1.0f - bu - bv;
+        alpha *= sample_texture_alpha(sv, a.tex, a.uv0 * b0 + a.uv1 * bu + a.uv2 * bv);
+    }
     return alpha;
 }
 
@@ -175,7 +172,7 @@ struct Hit4 { float t[4]; int c[4]; };
 // one compare.  NaNs (0 * inf: origin on a plane of an axis the ray does not move along) are dropped by min / max, i.e.
 // that axis does not constrain the interval.  Empty slots hold an inverted infinite box: their near distance is +inf (or
 // their far distance -inf) for every ray, so they never pass and need no test of their own.
-TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h) {
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h TL(, TlPhase* tlp = nullptr)) {
     f4 nxv, fxv, nyv, fyv, nzv, fzv;
     int c0, c1, c2, c3;
     {
@@ -191,6 +188,7 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, flo
         const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
         c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
     }
+    TL(if (tlp) tlp->loads_issued();)
     const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
     const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
 #pragma unroll
@@ -268,7 +266,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                         bool accept = true;
                         if (tr.inst_flags & 0x80000000u) {
                             if (COUNT) st.alpha++;
-                            float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            float a = candidate_alpha(sv, tr.alpha, bu, bv);
                             float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
                             accept = !(a <= cutoff);
                         }
@@ -340,7 +338,7 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
                 if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
                 if (COUNT) st.alpha++;
-                float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                float alpha = candidate_alpha(sv, tr.alpha, bu, bv);
                 visibility *= 1.0f - alpha;
                 if (visibility == 0.0f) break;
             }

@@ -21,7 +21,9 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     f4 o = F4(0), d = F4(0);
     // the ray is fetched together with the path's flags, not behind them: one round trip less before the traversal starts, and a
     // queue holds live paths only (the flag matters at bounce 0, where the ids are all launch ids)
+    TL(const unsigned long long tl_chunk = tl_now();)
     if (valid) { id = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[id]; o = pb.org_pdf[id]; d = pb.dir_reg[id]; valid = !(misc.w & 1u); }
+    TL(tl_data_arrived(); tl_misc(qc.tl, 3, tl_now() - tl_chunk);)
     // payload.random_seed of this trace: k_raygen stored the seed of bounce 0, every closest-hit trace advances it once
     // (path_tracer.glsl:387-403; DESIGN.md on the any-hit hash)
     for (int b = 0; b < bounce; ++b) pcg(misc.x);
@@ -48,11 +50,13 @@ TR_DEV void closest_lane(const SceneView& sv, const PtParams& P, const PathBuffe
     }
     pb.hit[id] = make_int4(hit.instance_id, hit.primitive_id, __float_as_int(hit.u), __float_as_int(hit.v));
     rays++;
+    TL(tl_misc(qc.tl, 5, tl_now() - tl_chunk);)
 }
 
 // LDS and global scratch of a wave's quad tail
-TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb) {
+TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb TL(, uint* s_tl = nullptr)) {
     QuadCtx qc;
+    TL(qc.tl = s_tl ? s_tl + (threadIdx.x >> 6) * TL_WORDS : nullptr;)
     const uint wave = threadIdx.x >> 6;
     qc.wave_stack = s_stack + (threadIdx.x & ~63u);
     qc.owner_tab = s_owner + wave * TR_OWNER_WORDS;

@@ -31,6 +31,7 @@ struct QuadCtx {
     int* wave_stack;   // LDS: stack column of lane 0 of this wave; entry e of lane l at [e * TR_BLOCK + l]
     int* owner_tab;    // LDS: 16 words of this wave
     int* spill;        // global: 16 * TR_QSPILL words of this wave
+    TL(uint* tl;)      // LDS: TL_WORDS words of this wave (trace_timeline.h)
 };
 
 // quad permutes: lane q reads lane (q + k) & 3 of its quad
@@ -59,7 +60,7 @@ struct QuadRay {
 };
 
 // Box of child q of `node` against the quad's ray; returns the child reference, `hit` and the entry distance.
-TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0) {
+TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0 TL(, TlPhase* tlp = nullptr)) {
     float nx, fx, ny, fy, nz, fz;
     int c;
     {
@@ -72,6 +73,7 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
         c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
     }
+    TL(if (tlp) tlp->loads_issued();)
     // the arithmetic of box4_intersect for one child
     const float tx0 = (nx - r.org.x) * r.inv_dir.x, tx1 = (fx - r.org.x) * r.inv_dir.x;
     const float ty0 = (ny - r.org.y) * r.inv_dir.y, ty1 = (fy - r.org.y) * r.inv_dir.y;
@@ -197,6 +199,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     int spill[TR_SPILL_STACK];
     stk.init(lds_stack);
     int node = sv.node_count > 0 ? 0 : -1;
+    TL(const unsigned long long tl_enter = tl_now(), tl_wall0 = tl_wall();)
 
     // candidate of a triangle test against the lane's best so far (shader/rt_common.rahit:15-24 for non-opaque geometry)
     auto consider = [&](const TriRecord& tr, float t, float bu, float bv) {
@@ -206,7 +209,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             bool accept = true;
             if (tr.inst_flags & 0x80000000u) {
                 if (COUNT) st.alpha++;
-                const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                const float a = candidate_alpha(sv, tr.alpha, bu, bv);
                 const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(seed, (int)inst, (int)tr.prim) : 0.0001f;
                 accept = !(a <= cutoff);
             }
@@ -236,11 +239,13 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             }
             if (at_leaf == leaf_phase) {
                 bool descend = false;
+                TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)); tlp.begin();)
                 if (!at_leaf) {
                     Hit4 h;
-                    box4_intersect(r, sv.nodes4, node, tmin, best_t, h);
+                    box4_intersect(r, sv.nodes4, node, tmin, best_t, h TL(, &tlp));
                     if (COUNT) st.nodes++;
                     TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
+                    TL(asm volatile("" : "+v"(h.t[0]), "+v"(h.t[1]), "+v"(h.t[2]), "+v"(h.t[3]), "+v"(h.c[0]), "+v"(h.c[1]), "+v"(h.c[2]), "+v"(h.c[3])); tlp.mark_a();)
                     if (h.t[0] < __builtin_huge_valf()) {
                         if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
                         if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
@@ -251,15 +256,24 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     }
                 } else {
                     const TriRecord tr = sv.tris[~node];
+                    TL(tlp.loads_issued();)
                     if (COUNT) st.tris++;
                     float t, bu, bv;
                     f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
+#if TR_TIMELINE
+                    const bool tl_hit = tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv);
+                    tlp.mark_a();
+                    if (tl_hit) { tlp.alpha = (tr.inst_flags & 0x80000000u) != 0 && (t < best_t || t == best_t); consider(tr, t, bu, bv); }
+                    tlp.mark_b();
+#else
                     if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) consider(tr, t, bu, bv);
+#endif
                 }
                 if (!descend) {
                     if (stk.sp == 0) live = false;
                     else node = stk.pop(spill);
                 }
+                TL(tlp.end(qc.tl, leaf_phase ? TL_LT : TL_LN, tl_units, (tl_units - 1) >> 3, leaf_phase ? TL_LT_WAIT_HIST : TL_LN_WAIT_HIST);)
             }
         }
     }
@@ -272,6 +286,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
 #endif
     if (n_act > 0) {
         QuadRay qr; RayPre tr_ray; QuadStack qs; int qnode;
+        TL(const unsigned long long tl_deal = tl_now();)
         const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, tr_ray, qs, qnode);
         const int q = deal.q, src = deal.src;
         const uint qseed = (uint)bperm(src, (int)seed);
@@ -281,6 +296,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         float qbest = lt;
         bool qlive = deal.has_ray;
         int pend = -1;      // triangle this lane has to test
+        TL(tl_misc(qc.tl, 2, tl_now() - tl_deal);)
         while (true) {
             int w = pend >= 0 ? 1 : 0;
             w |= qrot1(w); w |= qrot2(w);
@@ -291,7 +307,9 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             if (COUNT && (threadIdx.x & 63) == 0) { if (tri_phase) st.ph_qtri++; else st.ph_qnode++; }
             if (tri_phase) {
                 if (pend >= 0) {
+                    TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)); tlp.begin();)
                     const TriRecord tr = sv.tris[pend];
+                    TL(tlp.loads_issued();)
                     if (COUNT) st.tris++;
                     float t, bu, bv;
                     f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
@@ -300,7 +318,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                         bool accept = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
                         if (accept && (tr.inst_flags & 0x80000000u)) {
                             if (COUNT) st.alpha++;
-                            const float a = candidate_alpha(sv, (int)inst, (int)tr.prim, bu, bv);
+                            const float a = candidate_alpha(sv, tr.alpha, bu, bv);
                             const float cutoff = ALPHA_MODE == 0 ? alpha_cutoff_hash(qseed, (int)inst, (int)tr.prim) : 0.0001f;
                             accept = !(a <= cutoff);
                         }
@@ -310,6 +328,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                         lt = accept ? t : lt; lu = accept ? bu : lu; lv = accept ? bv : lv;
                         linst = accept ? inst : linst; lprim = accept ? tr.prim : lprim;
                     }
+                    TL(tlp.end(qc.tl, TL_QT, tl_units, (tl_units - 1) >> 3, -1);)
                 }
                 pend = -1;
                 float m = lt;
@@ -318,13 +337,15 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
-                const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0);
+                TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)) >> 2; tlp.begin();)
+                const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0 TL(, &tlp));
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
                 if (hitb && c < 0) pend = ~c;
                 // order of the inner children that were hit: entry distance, ties by slot (two low mantissa bits carry the slot)
                 quad_descend(inner, inner ? ((__float_as_uint(t0) & ~3u) | (uint)q) : 0xFFFFFFFFu, c, qs, qnode, qlive);
                 if (COUNT) st.maxsp = max(st.maxsp, (uint)qs.sp);
+                TL(tlp.end(qc.tl, TL_QN, tl_units, (tl_units - 1) >> 1, TL_QN_WAIT_HIST);)
             }
         }
         // the quad's result: smallest (t, instance, primitive) of its four lanes
@@ -346,6 +367,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         if (live) { best_t = rt; best_u = ru; best_v = rv; best_inst = ri; best_prim = rp; overflow += ro; }
     }
     overflow += stk.overflow;
+    TL(tl_misc(qc.tl, 0, 1); tl_misc(qc.tl, 1, tl_now() - tl_enter); tl_misc(qc.tl, 4, tl_wall() - tl_wall0);)
 
     bool found = best_inst != 0xFFFFFFFFu;
     if (found) { hit.instance_id = (int)best_inst; hit.primitive_id = (int)best_prim; hit.u = best_u; hit.v = best_v; }
@@ -423,7 +445,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
                     else {
                         if (COUNT) st.alpha++;
-                        const float alpha = candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                        const float alpha = candidate_alpha(sv, tr.alpha, bu, bv);
                         visibility *= 1.0f - alpha;
                         if (visibility == 0.0f) live = false;
                     }
@@ -463,7 +485,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                         if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
                         else {
                             if (COUNT) st.alpha++;
-                            lvis *= 1.0f - candidate_alpha(sv, (int)(tr.inst_flags & 0x7FFFFFFFu), (int)tr.prim, bu, bv);
+                            lvis *= 1.0f - candidate_alpha(sv, tr.alpha, bu, bv);
                         }
                     }
                 }

@@ -256,6 +256,12 @@ int main(int argc, char** argv)
             process_rt_renderer rr(process_device, process_rank, process_count, exchange == "rccl" ? id.data() : nullptr, scene, size, opt);
             if(exchange == "rccl") remove_comm_id_file(comm_id_path, process_rank);   // the communicator exists on every rank: the file has done its job
             else rr.use_copy_engine_exchange([&](const std::vector<char>& blob) { return allgather_blobs_through_files(comm_id_path, process_rank, process_count, blob, comm_nonce); });
+            // all ranks shade with the same program, or none renders (needs the job's nonce like the blobs above; without one - a one-rank
+            // job, or RCCL ranks started without --comm-nonce - there is nothing to tell this job's files from another's and the check is skipped with a note)
+            if(process_count > 1 && comm_nonce != 0)
+                rr.check_same_program([&](const std::vector<char>& blob) { return allgather_blobs_through_files(comm_id_path, process_rank, process_count, blob, comm_nonce, 120.0, ".prog"); });
+            else if(process_count > 1 && process_rank == 0)
+                std::cerr << "tauray_hip: no --comm-nonce: the ranks' shading programs are not compared (trhip_pt_get_program)\n";
             if(!workloads.empty()) rr.set_device_workloads(workloads);
             for(int f = -warmup; f < frames; ++f)
             {

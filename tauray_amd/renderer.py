@@ -443,6 +443,14 @@ class PathTracerStage:
         check(_lib.lib().trhip_pt_get_timings(self.h, C.byref(t)))
         return {n: float(getattr(t, n)) for n, _ in TimingsC._fields_}
 
+    def program(self) -> dict:
+        """Which shading program renders this stage, resolved now (trhip_pt_get_program): kind ("general" | "cli" | "compiled"), ieee,
+        identity (what the ranks of a job compare), key (the pinned option fields as text)."""
+        from ._lib import ProgramInfoC
+        p = ProgramInfoC()
+        check(_lib.lib().trhip_pt_get_program(self.h, C.byref(p)))
+        return {"kind": ("general", "cli", "compiled")[p.kind], "ieee": bool(p.ieee), "identity": int(p.identity), "key": p.key.decode()}
+
     def phase_counters(self) -> dict:
         """Wave-level phase statistics of the counting trace kernels (trhip_pt_get_phase_counters)."""
         from ._lib import PhaseCountersC
@@ -670,6 +678,36 @@ class RtRenderer:
     def set_scene(self, scene: SceneDesc):
         self.sync()
         self.scene_update.set_scene(scene)
+
+    def program(self) -> dict:
+        """The shading program of this rank's stage (PathTracerStage.program)."""
+        return self.slots[0].pt.program()
+
+    def check_same_program(self, allgather=None):
+        """All ranks of a job render with the same shading program, or none renders: the reference compiles one pipeline per stage from the
+        options and every device gets it (src/path_tracer_stage.cc:30-116).  Here a rank whose run-time compilation failed ("renders with the
+        general kernels and says so"), that runs under TRHIP_SPECIALIZE=0 or loads another build of libtrhip.so would shade its strips with
+        other kernels - at the default arithmetic another implementation inside Vulkan's accuracy, i.e. strips that differ from their
+        neighbours' in the last bits.  `allgather(bytes) -> [bytes of rank 0, ...]`: the job's transport for small blobs (the one
+        comm.Ipc takes); default: torch.distributed.all_gather_object when a process group exists.  Every rank calls this before the first
+        frame (bench.py, tests/test_multi_rank_gloo.py); raises RuntimeError on every rank, naming both programs."""
+        if self.world_size == 1:
+            return self.program()
+        mine = self.program()
+        blob = mine["identity"].to_bytes(8, "little") + mine["key"].encode()
+        if allgather is None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("check_same_program: no transport (pass allgather, or initialise torch.distributed)")
+            every = [None] * self.world_size
+            dist.all_gather_object(every, blob)
+        else:
+            every = allgather(blob)
+        for r, b in enumerate(every):
+            if b[:8] != blob[:8]:
+                raise RuntimeError(f"the ranks of this job would render with different shading programs: rank {self.rank} {{{mine['key']}}} but rank {r} "
+                                   f"{{{b[8:].decode(errors='replace')}}} (same libtrhip.so, kernel cache and TRHIP_* environment on every rank?)")
+        return mine
 
     def sync(self):
         """Waits for every frame in flight."""

@@ -48,6 +48,19 @@ def _has_gpu():
         return False
 
 
+def device_count():
+    """GPUs of this node as the HIP runtime counts them (0 without a runtime or a device): tests/test_multi_device.py needs two."""
+    import ctypes
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    return 0
+
+
 def pytest_ignore_collect(collection_path, config):
     # `-m gpu` (the GPU box): the files that hold CPU tests only are not even imported - tests/test_multi_rank_gloo.py imports torch at
     # module level for its gloo jobs, which is the same minute of paging again

@@ -78,9 +78,10 @@ def allgather(blob):      # the caller's transport for the set-up: files in a di
 
 W, H = 256, 192
 scene = scenes.test_glb(W, H)
-ctx = R.Context(0)      # every rank on device 0: two processes, one GPU
+dev = rank if os.environ.get("TRHIP_TEST_DEVICE_PER_RANK") else 0      # every rank on device 0: two processes, one GPU (tests/test_multi_device.py: one each)
+ctx = R.Context(dev)
 opt = R.options_for_scene(scene, max_bounces=3)
-ipc = comm.Ipc(0, world, rank, W * H * 16, slots, allgather)
+ipc = comm.Ipc(dev, world, rank, W * H * 16, slots, allgather)
 rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS, rank=rank, world_size=world, exchange=comm.IpcExchange(ipc), frames_in_flight=slots)
 out = []
 for f in range(frames):
@@ -161,8 +162,9 @@ def allgather(blob):
     return out
 
 
-ctx = R.Context(0)
-ipc = comm.Ipc(0, 2, rank, 4096, 1, allgather)
+dev = rank if os.environ.get("TRHIP_TEST_DEVICE_PER_RANK") else 0
+ctx = R.Context(dev)
+ipc = comm.Ipc(dev, 2, rank, 4096, 1, allgather)
 if rank == 0:
     ipc.receive([0, 1024])      # the display rank waits for rank 1's bytes, which never come
     t = time.time()
@@ -200,3 +202,69 @@ def test_a_peer_that_stops_sending_is_an_error_not_a_stale_frame(tmp_path):
     line = [l for l in outs[0][0].splitlines() if l.startswith("SECOND CALL")][0]
     assert line.startswith("SECOND CALL FAILED AFTER") and "gave up" in line, line
     assert 0.25 < float(line.split()[4]) < 5.0, line
+
+
+_PROGRAM_RANK = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+rank, world, workdir = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+from tauray_amd import comm, renderer as R, scenes
+from tauray_amd.distribution import DISTRIBUTION_SHUFFLED_STRIPS
+
+
+def allgather(blob, tag=[0]):      # files in a directory both processes see; one round per call
+    tag[0] += 1
+    name = lambda r: os.path.join(workdir, f"blob{tag[0]}_{r}")
+    open(name(rank) + ".tmp", "wb").write(blob)
+    os.rename(name(rank) + ".tmp", name(rank))
+    out, t0 = [], time.time()
+    for r in range(world):
+        while not os.path.exists(name(r)):
+            assert time.time() - t0 < 120, "the other rank never showed up"
+            time.sleep(0.01)
+        out.append(open(name(r), "rb").read())
+    return out
+
+
+W, H = 96, 64
+scene = scenes.test_glb(W, H)
+ctx = R.Context(0)
+opt = R.options_for_scene(scene, max_bounces=2, sampler=2)      # not the command-line set: a program compiled for the set, or the general kernels
+ipc = comm.Ipc(0, world, rank, W * H * 16, 1, allgather)
+rr = R.RtRenderer(ctx, scene, opt, (W, H), strategy=DISTRIBUTION_SHUFFLED_STRIPS, rank=rank, world_size=world, exchange=comm.IpcExchange(ipc))
+try:
+    p = rr.check_same_program(allgather)
+    print("SAME", p["kind"], "%016x" % p["identity"])
+except RuntimeError as e:
+    print("DIFFERENT", str(e).replace("\n", " "))
+open(os.path.join(workdir, f"done{rank}"), "w").write("ok")
+t0 = time.time()
+while not all(os.path.exists(os.path.join(workdir, f"done{r}")) for r in range(world)):
+    assert time.time() - t0 < 120
+    time.sleep(0.01)
+rr.close()
+ipc.close()
+"""
+
+
+@pytest.mark.gpu
+def test_ranks_compare_their_shading_programs_before_the_first_frame(tmp_path):
+    """RtRenderer.check_same_program (trhip_pt_get_program): two ranks with the same library, cache and environment agree; with one rank
+    under TRHIP_SPECIALIZE=0 (what a failed run-time compilation amounts to: that rank would render its strips with the general kernels)
+    both ranks refuse, naming the two programs."""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(_PROGRAM_RANK)
+    lines = {}
+    for case, env1 in (("same", {}), ("one_general", {"TRHIP_SPECIALIZE": "0"})):
+        work = tmp_path / case
+        work.mkdir()
+        procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", str(work)], env=dict(os.environ, **(env1 if r == 1 else {})),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-3000:]
+        lines[case] = [[l for l in so.splitlines() if l.startswith(("SAME", "DIFFERENT"))][0] for so, _ in outs]
+    assert all(l.startswith("SAME compiled") for l in lines["same"]) and lines["same"][0] == lines["same"][1], lines["same"]
+    assert all(l.startswith("DIFFERENT") and "general kernels" in l and "compiled" in l for l in lines["one_general"]), lines["one_general"]

@@ -556,6 +556,31 @@ def test_cpp_processes_exchange_frames_through_the_copy_engines(tmp_path, scene_
 
 
 @pytest.mark.gpu
+def test_cpp_ranks_with_different_shading_programs_refuse_to_render(tmp_path, scene_dump):
+    """process_rt_renderer::check_same_program: rank 1 started under TRHIP_SHADE_CLI=0 would shade its strips with a program compiled at
+    run time where rank 0 runs the ahead-of-time instances - two implementations at the default arithmetic.  Both ranks stop before the first
+    frame and name the two programs; the blob files of the set-up are gone afterwards in the good case."""
+    W = H = 64
+    common = [scene_dump, f"--width={W}", f"--height={H}", "--max-ray-depth=3", "--filetype=raw", "--frames=1"]
+    for case, env1 in (("same", {}), ("differ", {"TRHIP_SHADE_CLI": "0"})):
+        prefix, idf = str(tmp_path / case), str(tmp_path / (case + ".id"))
+        procs = [subprocess.Popen([CLI] + common + [f"--headless={prefix}", "--process-count=2", f"--process-rank={r}", "--device=0", f"--comm-id={idf}", "--exchange=ipc",
+                                                    f"--comm-nonce={os.getpid() + 7}"], env=dict(os.environ, **(env1 if r == 1 else {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        if case == "same":
+            assert all(p.returncode == 0 for p in procs), [e[-1500:] for _, e in outs]
+            left = [f for f in os.listdir(tmp_path) if f.startswith("same.id") and not f.endswith(".read")]
+            assert left == [], left      # the ipc / prog blobs were removed once every rank had read them
+        else:
+            assert all(p.returncode != 0 for p in procs)
+            assert all("different shading programs" in e and "command-line set, ahead of time" in e and "compiled" in e for _, e in outs), [e[-800:] for _, e in outs]
+    r = subprocess.run([CLI] + common + [f"--headless={tmp_path / 'n'}", "--process-count=2", "--process-rank=0", "--device=0", f"--comm-id={tmp_path / 'n.id'}", "--exchange=ipc"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "nonce" in r.stderr      # blobs with IPC handles are never taken from a job that cannot be told apart
+
+
+@pytest.mark.gpu
 def test_cpp_renders_the_skinned_glb_like_the_python_mirror(tmp_path):
     """tests/golden/skinned.glb through tr::load_glb + scene_stage::set_scene (bind-pose vertices, skins, rest-pose joint
     matrices -> trhip_scene_set_skin / trhip_scene_skin before the build) against the Python mirror doing the same: the

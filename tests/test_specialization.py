@@ -164,6 +164,43 @@ def test_specialised_programs_render_the_bits_of_the_general_kernels(R):
 
 
 @pytest.mark.gpu
+def test_a_program_warmed_ahead_of_time_is_found_at_run_time(tmp_path):
+    """trhip_pt_precompile (what __graft_entry__.build() runs, for the bare processor name) and the stage's first render have to name the
+    same cache file.  They did not: the run-time side hashed hipDeviceProp_t::gcnArchName as it comes ("gfx950:sramecc+:xnack-"), so every
+    warmed program missed and was compiled again (round 4's advisor finding)."""
+    import json
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, TRHIP_KERNEL_CACHE=str(cache), TRHIP_DEBUG="1")
+    from tauray_amd import presets
+    kw = dict(max_bounces=3, sampler=3, film=1, mis_mode=2, tri_light_mode=1)
+    # the light classes in use are part of a program: ahead of time they are named the way options_for_scene will set them
+    warm = dict(kw, **presets.scene_classes()["test_glb"])
+    r = subprocess.run([sys.executable, "-c", _PRECOMPILE, ROOT, json.dumps([warm])], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    warmed = sorted(os.listdir(cache))
+    assert len(warmed) == 2, warmed
+    script = tmp_path / "render.py"
+    script.write_text(r"""
+import sys, json
+sys.path.insert(0, sys.argv[1])
+from tauray_amd import renderer as R, scenes
+from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE
+sc = scenes.test_glb(64, 64)
+ctx = R.Context(0)
+ss = R.SceneStage(ctx, sc)
+pt = R.PathTracerStage(ctx, ss, R.options_for_scene(sc, **json.loads(sys.argv[2])), DistributionParams((64, 64), DISTRIBUTION_DUPLICATE, 0, 1, True))
+buf = ctx.alloc(64 * 64 * 16).zero()
+pt.run(buf)
+buf.download((64, 64, 4))
+""")
+    r = subprocess.run([sys.executable, str(script), ROOT, json.dumps(kw)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("from the kernel cache") == 2 and "compiled through hipRTC" not in r.stderr, r.stderr[-1500:]
+    assert sorted(os.listdir(cache)) == warmed
+
+
+@pytest.mark.gpu
 def test_a_new_option_set_is_compiled_when_it_first_renders(R, tmp_path):
     """A stage whose option set is in no cache: the first frame compiles (hipRTC), the next process finds the program in the cache."""
     script = tmp_path / "first_frame.py"
