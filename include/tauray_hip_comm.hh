@@ -245,9 +245,12 @@ public:
         accumulated_frames = 0;
     }
 
-    void finish_frame() { if(current_slot >= 0) dev.sync(slots[(size_t)current_slot].stream); }
-    void finish_slot(int k) { dev.sync(slots[(size_t)k].stream); }
+    // (behind every wait: a frame of the copy-engine exchange whose device-side wait for a peer gave up is an error here, before the
+    // caller saves or shows it - the last frame of a job is followed by no other call into the exchange: trhip_ipc_check)
+    void finish_frame() { if(current_slot >= 0) dev.sync(slots[(size_t)current_slot].stream); check_exchange(); }
+    void finish_slot(int k) { dev.sync(slots[(size_t)k].stream); check_exchange(); }
     void finish_all() { for(slot_data& sl: slots) dev.sync(sl.stream); dev.sync(); }
+    void check_exchange() { if(ipc) check_comm(trhip_ipc_check(ipc)); }
 
     // rt_renderer::render (src/rt_renderer.cc:84-133) for this rank.  Every rank calls it once per frame, in the same order.
     void render()

@@ -76,6 +76,14 @@ int trhip_ipc_connect(trhip_ipc* ipc, const void* blobs_of_all_ranks);
 int trhip_ipc_gather_partials(trhip_ipc* ipc, const void* send_dev, size_t send_bytes, void** recv_dev_out, const size_t* recv_bytes, void* stream);
 /* Root, after the consumers of the frame just gathered have been enqueued on `stream`: the slot may be overwritten once they are done. */
 int trhip_ipc_release(trhip_ipc* ipc, void* stream);
+/* Non-zero (and the reason in trhip_comm_last_error) once a device-side wait has given up.  Every call above begins with this check; a
+ * caller that is about to use a frame - write it out, display it - calls it after synchronising the frame's stream, because the last
+ * frame of a job is followed by no other call (tr::process_rt_renderer::finish_frame, tauray_amd.comm.IpcExchange do).
+ * Contract of the calls above, for the record: the wait kernel is one wave that polls with s_sleep between system-scope loads - it holds
+ * one wave slot of the device for as long as a peer is late, at most the timeout; the host never blocks in a gather or a release unless it
+ * runs more than 1 024 of them ahead of its device (their tag values wait in a pinned ring), in which case the call waits for the oldest;
+ * a failed call leaves the frame counter where it was. */
+int trhip_ipc_check(trhip_ipc* ipc);
 void trhip_ipc_destroy(trhip_ipc* ipc);
 
 #ifdef __cplusplus

@@ -164,7 +164,14 @@ def lib():
             raise TrhipError(f"{LIB_PATH} is missing: build it with `make -C tauray_amd/csrc` (or __graft_entry__.build())")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                # the tree's own library exports everything (tests/test_abi_and_host.py); a library named by TRHIP_LIB may be an older
+                # build kept for an A/B (tools/ab_two_libs.sh): calls it does not have fail when they are made
+                if "TRHIP_LIB" not in os.environ:
+                    raise
+                continue
             fn.restype = res
             fn.argtypes = args
         _LIB = L

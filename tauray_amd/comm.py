@@ -31,6 +31,7 @@ SYMBOLS = {
     "trhip_ipc_connect": (_i, [_vp, _vp]),
     "trhip_ipc_gather_partials": (_i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _vp]),
     "trhip_ipc_release": (_i, [_vp, _vp]),
+    "trhip_ipc_check": (_i, [_vp]),
     "trhip_ipc_destroy": (None, [_vp]),
 }
 IPC_EXPORT_BYTES = 256
@@ -163,6 +164,11 @@ class Ipc:
     def release(self, stream=None):
         _check(lib().trhip_ipc_release(self.h, stream))
 
+    def check(self):
+        """Raises if a device-side wait for a peer has given up (trhip_ipc_check): call after synchronising the stream of a frame that is
+        about to be used - the last frame of a job is followed by no other call into the exchange."""
+        _check(lib().trhip_ipc_check(self.h))
+
     def close(self):
         if self.h:
             lib().trhip_ipc_destroy(self.h)
@@ -198,6 +204,10 @@ class IpcExchange:
     def attach(self, rank: int, ctx):
         if rank != self.ipc.rank:
             raise ValueError("IpcExchange: the exchange end belongs to another rank")
+
+    def check(self):
+        """RtRenderer.sync() / download() call this behind their synchronisation: a frame whose wait for a peer gave up is an error, not an image."""
+        self.ipc.check()
 
     def gather_to_display(self, color, dists: List[DistributionParams], rank: int, world_size: int, viewports: int, recv_buffers, ctx):
         if world_size == 1:

@@ -28,7 +28,8 @@ constexpr int KB = TR_BLOCK;
 // feature_stage: shader/rt_feature.rgen:21-45 + rt_feature.rchit:16-27 with FEATURE of src/feature_stage.cc:33-65
 __global__ __launch_bounds__(KB) void k_feature(SceneView sv, LaunchCtx L, int feature, int projection, uint viewport, float min_ray_dist,
                                                 f4 default_value, f4* target, uint target_w, uint target_h, uint* overflow_flag) {
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     uint i = blockIdx.x * KB + threadIdx.x;
     if (i >= L.launch_w * L.launch_h) return;
     uint lx = i % L.launch_w, ly = i / L.launch_w;
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(KB) void k_calibrate_l1(const char* base, int iters
 // which is what the frame's closest-hit kernels run.
 __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, const float* rays, const uint* seeds, int include_lights,
                                                       HitRecord* out, uint* overflow_flag, int* qspill) {
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     int* my_stack = s_stack + threadIdx.x;
     QuadCtx qc;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(KB) void k_query_closest(SceneView sv, uint n, cons
     if (overflow) *overflow_flag = 1;
 }
 __global__ __launch_bounds__(KB) void k_query_shadow(SceneView sv, uint n, const float* rays, float* out, uint* overflow_flag) {
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     int overflow = 0;
     TraceStats st = {};
     for (uint i = blockIdx.x * KB + threadIdx.x; i < n; i += gridDim.x * KB) {

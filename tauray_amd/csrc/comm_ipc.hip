@@ -40,7 +40,11 @@ struct Blob {      // what a rank tells the others (TRHIP_IPC_EXPORT_BYTES)
 };
 static_assert(sizeof(Blob) <= TRHIP_IPC_EXPORT_BYTES, "trhip_comm.h: export size");
 
-constexpr int TAG_RING = 1024;      // tag values wait in pinned host memory for their copy: at most this many gathers enqueued ahead of the device
+// What the asynchronous copies of a gather read from the host - the tag value and the mask of peers to wait for - waits in pinned rings
+// until the copy engines get to it.  A ring entry is reused TAG_RING calls later; an event recorded behind the call's last copy says
+// whether the device is done with it: a caller more than TAG_RING calls ahead of its device is held until it is (it never was: a frame
+// slot holds a handful of frames, but a ring that wraps unchecked is a contract nobody can rely on).
+constexpr int TAG_RING = 1024;
 
 }  // namespace
 
@@ -55,18 +59,30 @@ struct trhip_ipc {
     int* timed_out = nullptr;                 // pinned host memory: set by a wait that gave up, read by the next call
     unsigned long long timeout_ticks = 1000000000ull;   // wall_clock64: 100 MHz
     unsigned char* wanted_dev = nullptr;
-    unsigned long long* tag_values = nullptr; // pinned ring: sources of the tag copies
+    unsigned long long* tag_values = nullptr; // pinned ring: sources of the tag copies (gathers of a sender; releases of the root use the upper half)
+    unsigned char* wanted_ring = nullptr;     // pinned ring: 64 bytes per gather, the source of the copy into wanted_dev
+    std::vector<hipEvent_t> ring_events;      // one per ring entry, recorded behind the last copy that reads it
+    unsigned long long releases = 0;
     // mapped from the other side
     void* root_arena = nullptr;               // non-root
     unsigned long long* root_tags = nullptr;  // non-root
     std::vector<unsigned long long*> peer_tags;   // root: release tags of every peer
-    std::vector<unsigned char> wanted_host;
 };
 
 std::string& trhip_comm_error_slot();      // comm.cc: what trhip_comm_last_error() returns
 namespace {
 int ipc_fail(const std::string& m) { trhip_comm_error_slot() = m; return 1; }
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return ipc_fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+// ring entry k may be written again once the copies that read it last time have run
+int ring_acquire(trhip_ipc* c, size_t k) {
+    if (c->ring_events[k] && hipEventQuery(c->ring_events[k]) != hipSuccess) { (void)hipGetLastError(); ICHK(hipEventSynchronize(c->ring_events[k])); }
+    return 0;
+}
+int ring_release(trhip_ipc* c, size_t k, hipStream_t s) {
+    if (!c->ring_events[k]) ICHK(hipEventCreateWithFlags(&c->ring_events[k], hipEventDisableTiming));
+    ICHK(hipEventRecord(c->ring_events[k], s));
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -84,11 +100,11 @@ int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot
     // What other devices write - the arena and the tags - is fine-grained device memory, as RCCL allocates the buffers its peers write:
     // coherent for writers outside this device without relying on what an L2 does with lines of ordinary (coarse-grained) allocations
     // between kernels.  (TRHIP_IPC_COARSE=1: plain hipMalloc, for A/B.)
+    // No silent fall-back: on coarse-grained memory a polling load may be served by an L2 that never sees the peer's write - a ten-second
+    // stall and a "gave up" with nothing pointing at the allocation.  Whoever wants plain hipMalloc says so.
     auto shared_alloc = [](void** p, size_t bytes) {
         static const bool coarse = getenv("TRHIP_IPC_COARSE") && atoi(getenv("TRHIP_IPC_COARSE")) != 0;
-        if (!coarse && hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-        return hipMalloc(p, bytes);
+        return coarse ? hipMalloc(p, bytes) : hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
     };
     if (rank == root) e = shared_alloc(&c->arena, (size_t)nranks * slots * c->slot_bytes);
     if (e == hipSuccess) e = shared_alloc(reinterpret_cast<void**>(&c->tags), n_tags * 8);
@@ -97,10 +113,15 @@ int trhip_ipc_create(int hip_device, int nranks, int rank, int root, size_t slot
     if (e == hipSuccess) *c->timed_out = 0;
     if (const char* t = getenv("TRHIP_IPC_TIMEOUT_MS")) if (atof(t) > 0) c->timeout_ticks = (unsigned long long)(atof(t) * 1e5);
     if (e == hipSuccess) e = hipMalloc(&c->wanted_dev, 64 * (size_t)slots);
-    if (e == hipSuccess) e = hipHostMalloc(&c->tag_values, TAG_RING * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&c->tag_values, 2 * TAG_RING * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&c->wanted_ring, TAG_RING * 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { trhip_ipc_destroy(c); return ipc_fail(std::string("trhip_ipc_create: ") + hipGetErrorString(e)); }
-    c->wanted_host.assign(64, 0);
+    if (e != hipSuccess) {
+        const std::string what = hipGetErrorString(e);
+        trhip_ipc_destroy(c);
+        return ipc_fail("trhip_ipc_create: " + what + " (the arena and the tags are fine-grained device memory, hipExtMallocWithFlags; TRHIP_IPC_COARSE=1 takes hipMalloc instead)");
+    }
+    c->ring_events.assign(2 * TAG_RING, nullptr);
     *out = c;
     return 0;
 }
@@ -155,42 +176,64 @@ int trhip_ipc_gather_partials(trhip_ipc* c, const void* send_dev, size_t send_by
     if (!c) return ipc_fail("trhip_ipc_gather_partials: null exchange");
     if (c->nranks == 1) return 0;
     if (!c->connected) return ipc_fail("trhip_ipc_gather_partials: call trhip_ipc_connect first");
-    if (*static_cast<volatile int*>(c->timed_out)) return ipc_fail("trhip_ipc_gather_partials: an earlier frame's wait for a peer gave up (a rank died or fell " + std::to_string(c->timeout_ticks / 100000ull) + " ms behind): that frame is incomplete");
-    ICHK(hipSetDevice(c->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned long long f = c->frame++;
-    const int slot = (int)(f % (unsigned long long)c->slots);
-    const unsigned long long use = f / (unsigned long long)c->slots + 1;      // the slot's use count with this frame: its tag value
-    unsigned long long* val = c->tag_values + (f % TAG_RING);
+    if (int rc = trhip_ipc_check(c)) return rc;
+    // every argument is checked before the frame counter moves: a call that fails leaves this rank's slot and tag sequence where the
+    // other ranks expect them
     if (c->rank != c->root) {
         if (send_bytes > c->slot_bytes) return ipc_fail("trhip_ipc_gather_partials: the partial frame is larger than a slot");
+        if (send_bytes != 0 && !send_dev) return ipc_fail("trhip_ipc_gather_partials: null send buffer");
+    } else {
+        if (!recv_dev_out || !recv_bytes) return ipc_fail("trhip_ipc_gather_partials: the root needs the receive arrays");
+        for (int r = 0; r < c->nranks; ++r)
+            if (r != c->root && recv_bytes[r] > c->slot_bytes) return ipc_fail("trhip_ipc_gather_partials: a partial frame is larger than a slot");
+    }
+    ICHK(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long f = c->frame;
+    const size_t k = (size_t)(f % TAG_RING);
+    if (int rc = ring_acquire(c, k)) return rc;
+    c->frame++;
+    const int slot = (int)(f % (unsigned long long)c->slots);
+    const unsigned long long use = f / (unsigned long long)c->slots + 1;      // the slot's use count with this frame: its tag value
+    unsigned long long* val = c->tag_values + k;
+    unsigned char* wanted = c->wanted_ring + 64 * k;
+    if (c->rank != c->root) {
         if (send_bytes == 0) return 0;      // (a rank whose share is empty sends nothing and is not waited for: recv_bytes[r] = 0 on the root)
-        if (!send_dev) return ipc_fail("trhip_ipc_gather_partials: null send buffer");
         if (use > 1) {      // the slot's previous frame has to be consumed: release tag >= use - 1
-            c->wanted_host[0] = 1;
-            ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), 1, hipMemcpyHostToDevice, s));
+            wanted[0] = 1;
+            ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, wanted, 1, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, 1, 1, c->wanted_dev + 64 * slot, use - 1, c->timed_out, c->timeout_ticks);
+            ICHK(hipGetLastError());
         }
         char* dst = static_cast<char*>(c->root_arena) + ((size_t)slot * c->nranks + (size_t)c->rank) * c->slot_bytes;
         ICHK(hipMemcpyAsync(dst, send_dev, send_bytes, hipMemcpyDeviceToDevice, s));
         *val = use;
         ICHK(hipMemcpyAsync(c->root_tags + (size_t)c->rank * c->slots + slot, val, 8, hipMemcpyHostToDevice, s));
-        return 0;
+        return ring_release(c, k, s);
     }
-    if (!recv_dev_out || !recv_bytes) return ipc_fail("trhip_ipc_gather_partials: the root needs the receive arrays");
     bool any = false;
     for (int r = 0; r < c->nranks; ++r) {
         const bool w = r != c->root && recv_bytes[r] > 0;
-        if (w && recv_bytes[r] > c->slot_bytes) return ipc_fail("trhip_ipc_gather_partials: a partial frame is larger than a slot");
-        c->wanted_host[(size_t)r] = w ? 1 : 0;
+        wanted[r] = w ? 1 : 0;
         recv_dev_out[r] = w ? static_cast<char*>(c->arena) + ((size_t)slot * c->nranks + (size_t)r) * c->slot_bytes : nullptr;
         any |= w;
     }
     if (any) {
-        ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, c->wanted_host.data(), (size_t)c->nranks, hipMemcpyHostToDevice, s));
+        ICHK(hipMemcpyAsync(c->wanted_dev + 64 * slot, wanted, (size_t)c->nranks, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_wait_tags, dim3(1), dim3(64), 0, s, c->tags + slot, c->nranks, c->slots, c->wanted_dev + 64 * slot, use, c->timed_out, c->timeout_ticks);
+        ICHK(hipGetLastError());
+        return ring_release(c, k, s);
     }
-    ICHK(hipGetLastError());
+    return 0;
+}
+
+// A device-side wait that gave up reports through pinned memory; this turns it into an error.  Every call into the exchange begins with it,
+// and a caller about to use a frame (save it, show it) asks once more after synchronising that frame's stream: the last frame of a job
+// has no next call.
+int trhip_ipc_check(trhip_ipc* c) {
+    if (!c) return ipc_fail("trhip_ipc_check: null exchange");
+    if (c->timed_out && *static_cast<volatile int*>(c->timed_out))
+        return ipc_fail("trhip_ipc: a frame's wait for a peer gave up (a rank died or fell " + std::to_string(c->timeout_ticks / 100000ull) + " ms behind): that frame is incomplete");
     return 0;
 }
 
@@ -198,16 +241,19 @@ int trhip_ipc_release(trhip_ipc* c, void* stream) {
     if (!c) return ipc_fail("trhip_ipc_release: null exchange");
     if (c->nranks == 1 || c->rank != c->root) return 0;
     if (c->frame == 0) return ipc_fail("trhip_ipc_release: nothing gathered yet");
-    if (*static_cast<volatile int*>(c->timed_out)) return ipc_fail("trhip_ipc_release: a wait for a peer gave up: the frame is incomplete");
+    if (int rc = trhip_ipc_check(c)) return rc;
     ICHK(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned long long f = c->frame - 1;
     const int slot = (int)(f % (unsigned long long)c->slots);
-    unsigned long long* val = c->tag_values + (f % TAG_RING);
+    const size_t k = TAG_RING + (size_t)(c->releases % TAG_RING);      // the releases have ring entries of their own
+    if (int rc = ring_acquire(c, k)) return rc;
+    c->releases++;
+    unsigned long long* val = c->tag_values + k;
     *val = f / (unsigned long long)c->slots + 1;
     for (int r = 0; r < c->nranks; ++r)
         if (r != c->root && c->peer_tags[(size_t)r]) ICHK(hipMemcpyAsync(c->peer_tags[(size_t)r] + slot, val, 8, hipMemcpyHostToDevice, s));
-    return 0;
+    return ring_release(c, k, s);
 }
 
 void trhip_ipc_destroy(trhip_ipc* c) {
@@ -222,6 +268,8 @@ void trhip_ipc_destroy(trhip_ipc* c) {
     if (c->timed_out) (void)hipHostFree(c->timed_out);
     if (c->wanted_dev) (void)hipFree(c->wanted_dev);
     if (c->tag_values) (void)hipHostFree(c->tag_values);
+    if (c->wanted_ring) (void)hipHostFree(c->wanted_ring);
+    for (hipEvent_t e : c->ring_events) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 

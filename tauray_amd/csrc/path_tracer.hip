@@ -35,11 +35,41 @@ namespace {
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
 // WIDE: the scene has RGBA16 textures.  The instances for scenes without (nearly all) pin SceneView::wide_textures to 0, and the
 // any-hit alpha test compiles to the one-dword fetch it always was (texture.h; profiles/r4/texture_format_ab.txt).
+#if TR_RAYS2
+// Experiment: two rays per lane, four waves per SIMD (trace_rays2.h).  Same launch interface; a chunk is 128 queue slots.
+template <bool COUNT, bool SOLO, bool WIDE = true>
+__global__ __launch_bounds__(KB, 4) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue, uint* bc) {
+    if (!WIDE) sv.wide_textures = 0;
+    __shared__ int s_rows[2 * TR_STACK_WORDS];
+    int* const lds_a = s_rows + TR_STACK_ROW0 + threadIdx.x;
+    int* const lds_b = s_rows + TR_STACK_WORDS + TR_STACK_ROW0 + threadIdx.x;
+    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
+    TraceStats st = {};
+    uint rays = 0;
+    int overflow = 0;
+    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+    bool first = true;
+    while (true) {
+        uint base = 0;
+        if (first) base = wave_id * 128u;
+        else {
+            if (n <= n_waves * 128u) break;
+            if ((threadIdx.x & 63) == 0) base = n_waves * 128u + atomicAdd(&bc[BC_CUR_CLOSEST], 128u);
+            base = __shfl(base, 0);
+        }
+        first = false;
+        if (base >= n) break;
+        closest_lane2<COUNT>(sv, P, pb, bounce, queue, base, n, lds_a, lds_b, st, overflow, rays);
+    }
+    flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, 0u);
+}
+#else
 template <bool COUNT, bool SOLO, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
     if (!WIDE) sv.wide_textures = 0;
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     TL(__shared__ uint s_tl[(KB / 64) * TL_WORDS]; for (uint i = threadIdx.x; i < (KB / 64) * TL_WORDS; i += KB) s_tl[i] = 0; __syncthreads();)
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb TL(, s_tl));
@@ -64,11 +94,13 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
     TL(__syncthreads(); for (uint i = threadIdx.x; i < (KB / 64) * TL_WORDS; i += KB) if (s_tl[i]) atomicAdd(&g_timeline[i % TL_WORDS], (unsigned long long)s_tl[i]);)
 }
+#endif
 
 template <bool COUNT, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
     if (!WIDE) sv.wide_textures = 0;
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint n = bc[BC_SHADOW];
@@ -100,7 +132,8 @@ template <bool WIDE>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
     if (!WIDE) sv.wide_textures = 0;
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     __shared__ int s_owner[(KB / 64) * TR_OWNER_WORDS];
     const QuadCtx qc = make_quad_ctx(s_stack, s_owner, pb);
     const uint nc = bc[BC_QUEUE], ns = bc_prev[BC_SHADOW];
@@ -335,7 +368,8 @@ __global__ __launch_bounds__(KB, TR_SHADE_WAVES) void k_direct(SceneView sv, PtP
 
 template <bool COUNT>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow_direct(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {
-    __shared__ int s_stack[TR_STACK_WORDS];
+    __shared__ int s_stack_rows[TR_STACK_WORDS];
+    int* const s_stack = s_stack_rows + TR_STACK_ROW0;     // row -1 exists (LaneStack, trace.h)
     const uint n = bc[BC_SHADOW];
     TraceStats st = {};
     uint rays = 0;

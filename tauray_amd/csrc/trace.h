@@ -37,29 +37,35 @@ namespace tr {
 #define TR_SPILL_STACK 112
 #endif
 
+// A ray as the traversal keeps it: in the frame the watertight triangle test works in - components in the order (kx, ky, kz), kz the axis
+// the direction is largest along (Woop et al. 2013).  Round 5: the slab test does not care in which order it takes the axes (its
+// near / far planes are picked by per-lane byte offsets anyway), and the triangle test reads the vertex components it wants straight
+// from the record with per-lane offsets 4 kx / 4 ky / 4 kz - so nothing is ever picked out of a register by a run-time index, which the
+// compiler lowers to exec-mask branches: nine picks per triangle test were 150 of its 335 instructions
+// (profiles/r5/trace_phase_timeline.txt: a triangle phase spent 2 400 clocks there, twice a node phase's slab tests and sort).
 struct RayPre {
-    f3 org, dir, inv_dir;
-    int kx, ky, kz;
-    float Sx, Sy, Sz;
-    uint nox, noy, noz;   // byte offsets of the near x / y / z planes inside a Bvh4Node (far plane: offset ^ 16)
+    f3 op;                // origin in the order (kx, ky, kz)
+    f3 ip;                // 1 / direction, same order
+    float Sx, Sy;         // shear constants of the triangle test; the third one, 1 / direction[kz], is ip.z
+    uint nkx, nky, nkz;   // byte offsets of the near planes of the axes kx / ky / kz inside a Bvh4Node: 32 k + 16 (direction[k] < 0); far plane: offset ^ 16
 };
+TR_DEV uint tri_component_offset(uint nk) { return (nk >> 3) & 12u; }     // 4 k: byte offset of component k of a vertex
 
 TR_DEV RayPre make_ray(f3 org, f3 dir) {
     RayPre r;
-    r.org = org; r.dir = dir;
     float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
     int kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
     int kx = kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
     if (comp(dir, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
-    r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = comp(dir, kx) / comp(dir, kz);
-    r.Sy = comp(dir, ky) / comp(dir, kz);
-    r.Sz = 1.0f / comp(dir, kz);
-    r.inv_dir = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    r.nox = (__float_as_uint(r.inv_dir.x) >> 31) << 4;
-    r.noy = ((__float_as_uint(r.inv_dir.y) >> 31) << 4) | 32u;
-    r.noz = ((__float_as_uint(r.inv_dir.z) >> 31) << 4) | 64u;
+    const float dkx = comp(dir, kx), dky = comp(dir, ky), dkz = comp(dir, kz);
+    r.Sx = dkx / dkz;
+    r.Sy = dky / dkz;
+    r.op = F3(comp(org, kx), comp(org, ky), comp(org, kz));
+    r.ip = F3(1.0f / dkx, 1.0f / dky, 1.0f / dkz);
+    r.nkx = ((uint)kx << 5) | ((__float_as_uint(r.ip.x) >> 31) << 4);
+    r.nky = ((uint)ky << 5) | ((__float_as_uint(r.ip.y) >> 31) << 4);
+    r.nkz = ((uint)kz << 5) | ((__float_as_uint(r.ip.z) >> 31) << 4);
     return r;
 }
 
@@ -68,16 +74,28 @@ TR_DEV bool ray_is_finite(f3 o, f3 d) {
            (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f);
 }
 
-// Watertight test (Woop, Benthin, Wald 2013), no culling.  Plain IEEE fp32 without
+// What a triangle test hands back: the candidate and the words of the record behind the vertices.
+struct TriHit { float t, bu, bv; uint inst_flags, prim, alpha; };
+
+// Watertight test (Woop, Benthin, Wald 2013), no culling, of triangle record `index`.  Plain IEEE fp32 without
 // contraction: the shared-edge guarantee needs both products of each edge function
-// rounded, and the CPU oracle evaluates exactly the same expression tree.
-TR_DEV bool tri_intersect(const RayPre& r, f3 v0, f3 v1, f3 v2, float tmin, float tmax, float& t, float& bu, float& bv) {
+// rounded, and the CPU oracle evaluates exactly the same expression tree.  The nine vertex components arrive in the ray's order:
+// nine dword loads at per-lane offsets into one or two cache lines.
+TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, float tmin, float tmax, TriHit& o TL(, TlPhase* tlp = nullptr)) {
 #pragma clang fp contract(off)
-    const f3 A = v0 - r.org, B = v1 - r.org, C = v2 - r.org;
-    const float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
-    const float Ax = comp(A, r.kx) - r.Sx * Akz, Ay = comp(A, r.ky) - r.Sy * Akz;
-    const float Bx = comp(B, r.kx) - r.Sx * Bkz, By = comp(B, r.ky) - r.Sy * Bkz;
-    const float Cx = comp(C, r.kx) - r.Sx * Ckz, Cy = comp(C, r.ky) - r.Sy * Ckz;
+    const char* base = reinterpret_cast<const char*>(tris);
+    const uint rec = index * 48u;
+    const uint ox = rec + tri_component_offset(r.nkx), oy = rec + tri_component_offset(r.nky), oz = rec + tri_component_offset(r.nkz);
+    const float v0x = *reinterpret_cast<const float*>(base + (size_t)ox), v1x = *reinterpret_cast<const float*>(base + (size_t)ox + 12), v2x = *reinterpret_cast<const float*>(base + (size_t)ox + 24);
+    const float v0y = *reinterpret_cast<const float*>(base + (size_t)oy), v1y = *reinterpret_cast<const float*>(base + (size_t)oy + 12), v2y = *reinterpret_cast<const float*>(base + (size_t)oy + 24);
+    const float v0z = *reinterpret_cast<const float*>(base + (size_t)oz), v1z = *reinterpret_cast<const float*>(base + (size_t)oz + 12), v2z = *reinterpret_cast<const float*>(base + (size_t)oz + 24);
+    const uint* tail = reinterpret_cast<const uint*>(base + (size_t)rec + 36);
+    o.inst_flags = tail[0]; o.prim = tail[1]; o.alpha = tail[2];
+    TL(if (tlp) tlp->loads_issued();)
+    const float Akz = v0z - r.op.z, Bkz = v1z - r.op.z, Ckz = v2z - r.op.z;
+    const float Ax = (v0x - r.op.x) - r.Sx * Akz, Ay = (v0y - r.op.y) - r.Sy * Akz;
+    const float Bx = (v1x - r.op.x) - r.Sx * Bkz, By = (v1y - r.op.y) - r.Sy * Bkz;
+    const float Cx = (v2x - r.op.x) - r.Sx * Ckz, Cy = (v2y - r.op.y) - r.Sy * Ckz;
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -92,42 +110,91 @@ TR_DEV bool tri_intersect(const RayPre& r, f3 v0, f3 v1, f3 v2, float tmin, floa
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     const float det = U + V + W;
     if (det == 0.0f) return false;
-    const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    const float Az = r.ip.z * Akz, Bz = r.ip.z * Bkz, Cz = r.ip.z * Ckz;
     const float T = U * Az + V * Bz + W * Cz;
     const float rcp = 1.0f / det;
     const float tt = T * rcp;
     if (!(tt > tmin && tt < tmax)) return false;
-    t = tt; bu = V * rcp; bv = W * rcp;
+    o.t = tt; o.bu = V * rcp; o.bv = W * rcp;
     return true;
 }
 
-// Per-lane traversal stack: first TR_LDS_STACK entries in LDS, the rest in a private spill array.
+// Per-lane traversal stack: the top entry in a register, the next TR_LDS_STACK in LDS, the rest in a private spill array.
 // `sp` must stay in a VGPR and the LDS access must stay a ds_read/ds_write: the spill array is therefore a separate
 // local (a struct member array drags the whole struct, sp included, into scratch) and pop() reads LDS
 // unconditionally (an if/else over the two memories is if-converted into a generic pointer + flat_load).
+//
+// Round 5 (profiles/r5/trace_phase_timeline.txt): a wave gets an instruction issued every 6-7 clocks at six waves per SIMD whatever
+// its kind, and the three conditional pushes of a node phase + the pop were ~120 instructions and an LDS round trip - more clocks than
+// the four slab tests and the sort.  Now: entry sp - 1 lives in `tos`, rows 0 .. sp - 2 in memory; a node phase stores the old top and
+// up to two of the sorted children with three unconditional ds_writes (rows above the new top hold junk, which nothing reads), and a pop
+// hands out the register and refills it with a ds_read nobody waits for until the next pop or push.  Row -1 exists (the kernels
+// allocate one row more and pass the address of row 0): the store of the "old top" of an empty stack lands there.
 struct LaneStack {
-    int* lds;           // &stack[0][lane_in_block]; stride TR_BLOCK
-    int sp;
-    int overflow;       // count of dropped pushes (an int in a VGPR, not a wave-level predicate)
-    TR_DEV void init(int* base) { lds = base; sp = 0; overflow = 0; }
-    // The common case costs a compare, an address and the ds_write.  Past the end of the spill array pushes land on its last
-    // slot and are counted: the traversal still terminates (sp stays balanced) and the frame is reported as invalid.
-    TR_DEV void push(int* spill, int v) {
-        if (sp < TR_LDS_STACK) lds[sp * TR_BLOCK] = v;
+    int* lds;           // &stack[0][lane_in_block]; stride TR_BLOCK; row -1 is writable
+    int sp;             // entries, the one in `tos` included
+    int tos;
+    bool overflow;      // a store was dropped (a lane mask in scalar registers: the per-lane counter this used to be held a vector register for nothing)
+    TR_DEV void init(int* base) { lds = base; sp = 0; tos = 0; overflow = false; }
+    // row r of the memory part (r >= -1).  Past the end of the spill array stores land on its last slot and are counted: the traversal
+    // still terminates (sp stays balanced) and the frame is reported as invalid.
+    TR_DEV void store_row(int* spill, int r, int v) {
+        if (r < TR_LDS_STACK) lds[r * TR_BLOCK] = v;
         else {
-            const int k = sp - TR_LDS_STACK;
-            if (k >= TR_SPILL_STACK) overflow++;
+            const int k = r - TR_LDS_STACK;
+            if (k >= TR_SPILL_STACK) overflow = true;
             spill[k < TR_SPILL_STACK ? k : TR_SPILL_STACK - 1] = v;
         }
+    }
+    TR_DEV void push(int* spill, int v) {
+        store_row(spill, sp - 1, tos);
+        tos = v;
         sp++;
     }
-    TR_DEV int pop(const int* spill) {
-        sp--;
-        int v = lds[(sp < TR_LDS_STACK ? sp : 0) * TR_BLOCK];
-        asm volatile("" : "+v"(v));   // pin the ds_read: no select-of-pointers + flat_load
-        if (sp >= TR_LDS_STACK) v = spill[sp - TR_LDS_STACK < TR_SPILL_STACK ? sp - TR_LDS_STACK : TR_SPILL_STACK - 1];
-        return v;
+    // The hit children of a node phase other than the one the ray descends into, nearest last: `m` of (c3, c2, c1) are valid - the last m.
+    TR_DEV void push_sorted(int* spill, int m, int c1, int c2, int c3) {
+        if (sp + 2 <= TR_LDS_STACK) {     // rows sp - 1, sp, sp + 1 are LDS rows
+            int* row = lds + (sp - 1) * TR_BLOCK;
+            row[0] = tos;
+            row[TR_BLOCK] = m == 3 ? c3 : c2;
+            row[2 * TR_BLOCK] = c2;
+            tos = m > 0 ? c1 : tos;
+            sp += m;
+        } else {
+            if (m > 2) push(spill, c3);
+            if (m > 1) push(spill, c2);
+            if (m > 0) push(spill, c1);
+        }
     }
+    // ... in slot order, for the any-hit loop (which descends into the first hit child and keeps the others in the order of their slots):
+    // `n` valid entries among (a, b, c), packed to the front
+    TR_DEV void push_packed(int* spill, int n, int a, int b, int c) {
+        if (sp + 2 <= TR_LDS_STACK) {
+            // bottom to top: old top, a, b | top = c (n = 3);  old top, a | top = b (n = 2);  old top | top = a (n = 1)
+            int* row = lds + (sp - 1) * TR_BLOCK;
+            row[0] = tos;
+            row[TR_BLOCK] = a;
+            row[2 * TR_BLOCK] = b;
+            tos = n == 3 ? c : (n == 2 ? b : (n == 1 ? a : tos));
+            sp += n;
+        } else {
+            if (n > 0) push(spill, a);
+            if (n > 1) push(spill, b);
+            if (n > 2) push(spill, c);
+        }
+    }
+    TR_DEV int pop(const int* spill) {
+        const int out = tos;
+        sp--;
+        const int r = sp - 1;       // the row that becomes the top: -1 (junk, never handed out) when the stack is empty now
+        int v = lds[(r < TR_LDS_STACK ? r : 0) * TR_BLOCK];
+        asm volatile("" : "+v"(v));   // pin the ds_read: no select-of-pointers + flat_load
+        if (r >= TR_LDS_STACK) v = spill[r - TR_LDS_STACK < TR_SPILL_STACK ? r - TR_LDS_STACK : TR_SPILL_STACK - 1];
+        tos = v;
+        return out;
+    }
+    // every entry in memory (rows 0 .. sp - 1): what the re-deal to quads reads (trace_quad.h)
+    TR_DEV void flush(int* spill) { store_row(spill, sp - 1, tos); }
 };
 
 struct TraceStats {
@@ -172,30 +239,26 @@ struct Hit4 { float t[4]; int c[4]; };
 // one compare.  NaNs (0 * inf: origin on a plane of an axis the ray does not move along) are dropped by min / max, i.e.
 // that axis does not constrain the interval.  Empty slots hold an inverted infinite box: their near distance is +inf (or
 // their far distance -inf) for every ray, so they never pass and need no test of their own.
-TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h TL(, TlPhase* tlp = nullptr)) {
-    f4 nxv, fxv, nyv, fyv, nzv, fzv;
-    int c0, c1, c2, c3;
-    {
-        const char* base = reinterpret_cast<const char*>(nodes);
-        const uint t = (uint)node << 7;
-        uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
-        // opaque to the optimiser: once it splits the known +32 / +64 out of ay / az as immediate offsets, it addresses the far
-        // planes with 64-bit adds instead of the base + 32-bit offset form
-        asm volatile("" : "+v"(ay), "+v"(az));
-        nxv = *reinterpret_cast<const f4*>(base + (size_t)ax); fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
-        nyv = *reinterpret_cast<const f4*>(base + (size_t)ay); fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
-        nzv = *reinterpret_cast<const f4*>(base + (size_t)az); fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
-        const int4 ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
-        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
-    }
-    TL(if (tlp) tlp->loads_issued();)
-    const float nx[4] = {nxv.x, nxv.y, nxv.z, nxv.w}, ny[4] = {nyv.x, nyv.y, nyv.z, nyv.w}, nz[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
-    const float fx[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fy[4] = {fyv.x, fyv.y, fyv.z, fyv.w}, fz[4] = {fzv.x, fzv.y, fzv.z, fzv.w};
+struct Node4Data { f4 nxv, fxv, nyv, fyv, nzv, fzv; int4 ch; };      // near / far planes of the axes kx, ky, kz and the child references
+TR_DEV void box4_load(const RayPre& r, const Bvh4Node* nodes, int node, Node4Data& d) {
+    const char* base = reinterpret_cast<const char*>(nodes);
+    const uint t = (uint)node << 7;
+    const uint ax = t | r.nkx, ay = t | r.nky, az = t | r.nkz;
+    d.nxv = *reinterpret_cast<const f4*>(base + (size_t)ax); d.fxv = *reinterpret_cast<const f4*>(base + (size_t)(ax ^ 16u));
+    d.nyv = *reinterpret_cast<const f4*>(base + (size_t)ay); d.fyv = *reinterpret_cast<const f4*>(base + (size_t)(ay ^ 16u));
+    d.nzv = *reinterpret_cast<const f4*>(base + (size_t)az); d.fzv = *reinterpret_cast<const f4*>(base + (size_t)(az ^ 16u));
+    d.ch = *reinterpret_cast<const int4*>(base + (size_t)t + 96);
+}
+TR_DEV void box4_test(const RayPre& r, const Node4Data& d, float tmin, float tmax, Hit4& h) {
+    int c0 = d.ch.x, c1 = d.ch.y, c2 = d.ch.z, c3 = d.ch.w;
+    const float nx[4] = {d.nxv.x, d.nxv.y, d.nxv.z, d.nxv.w}, ny[4] = {d.nyv.x, d.nyv.y, d.nyv.z, d.nyv.w}, nz[4] = {d.nzv.x, d.nzv.y, d.nzv.z, d.nzv.w};
+    const float fx[4] = {d.fxv.x, d.fxv.y, d.fxv.z, d.fxv.w}, fy[4] = {d.fyv.x, d.fyv.y, d.fyv.z, d.fyv.w}, fz[4] = {d.fzv.x, d.fzv.y, d.fzv.z, d.fzv.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float tx0 = (nx[k] - r.org.x) * r.inv_dir.x, tx1 = (fx[k] - r.org.x) * r.inv_dir.x;
-        const float ty0 = (ny[k] - r.org.y) * r.inv_dir.y, ty1 = (fy[k] - r.org.y) * r.inv_dir.y;
-        const float tz0 = (nz[k] - r.org.z) * r.inv_dir.z, tz1 = (fz[k] - r.org.z) * r.inv_dir.z;
+        // the three slabs in the ray's axis order: max / min over them do not depend on the order
+        const float tx0 = (nx[k] - r.op.x) * r.ip.x, tx1 = (fx[k] - r.op.x) * r.ip.x;
+        const float ty0 = (ny[k] - r.op.y) * r.ip.y, ty1 = (fy[k] - r.op.y) * r.ip.y;
+        const float tz0 = (nz[k] - r.op.z) * r.ip.z, tz1 = (fz[k] - r.op.z) * r.ip.z;
         const float t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tmin));
         const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
         h.t[k] = t0 <= t1 ? t0 : __builtin_huge_valf();
@@ -205,7 +268,30 @@ TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, flo
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     h.c[0] = c0; h.c[1] = c1; h.c[2] = c2; h.c[3] = c3;
 }
+TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h TL(, TlPhase* tlp = nullptr)) {
+    Node4Data d;
+    box4_load(r, nodes, node, d);
+    TL(if (tlp) tlp->loads_issued();)
+    box4_test(r, d, tmin, tmax, h);
+}
 
+// What the any-hit loop does with the four slab tests of a node: the first hit child in slot order is where the ray goes next, the other
+// hit children go onto the stack in slot order (unordered descent: an occluder anywhere ends the ray).  Returns false without a hit.
+TR_DEV bool shadow_descend(const Hit4& h, LaneStack& stk, int* spill, int& node) {
+    const bool h0 = h.t[0] < __builtin_huge_valf(), h1 = h.t[1] < __builtin_huge_valf(), h2 = h.t[2] < __builtin_huge_valf(), h3 = h.t[3] < __builtin_huge_valf();
+    const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (n == 0) return false;
+    // registers, not elements of an array: a select between array elements is turned into a load at a selected address, which puts the array into scratch
+    int c0 = h.c[0], c1 = h.c[1], c2 = h.c[2], c3 = h.c[3];
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    const int first = h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3));
+    // the hit children behind the first, packed to the front: a = the second hit, b = the third, c = the fourth
+    const int a = (h0 && h1) ? c1 : ((h2 && (h0 != h1)) ? c2 : c3);
+    const int b = (h0 && h1 && h2) ? c2 : c3;
+    stk.push_packed(spill, n - 1, a, b, c3);
+    node = first;
+    return true;
+}
 
 #define TR_CE4(a, b) { const bool sw = h.t[b] < h.t[a]; const float ta = h.t[a], tb = h.t[b]; const int ca = h.c[a], cb = h.c[b]; \
                        h.t[a] = sw ? tb : ta; h.t[b] = sw ? ta : tb; h.c[a] = sw ? cb : ca; h.c[b] = sw ? ca : cb; }
@@ -246,19 +332,18 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                 if (COUNT) st.nodes++;
                 TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                 if (h.t[0] < __builtin_huge_valf()) {
-                    if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
-                    if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
-                    if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
+                    // sorted: the hit children come first, so the number of further hits says which of c[1..3] go onto the stack
+                    const int m = (int)(h.t[1] < __builtin_huge_valf()) + (int)(h.t[2] < __builtin_huge_valf()) + (int)(h.t[3] < __builtin_huge_valf());
+                    stk.push_sorted(spill, m, h.c[1], h.c[2], h.c[3]);
                     if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                     node = h.c[0];
                     continue;
                 }
             } else {
-                const TriRecord tr = sv.tris[~node];
+                TriHit tr;
                 if (COUNT) st.tris++;
-                float t, bu, bv;
-                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-                if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) {
+                if (tri_intersect(r, sv.tris, (uint)~node, tmin, __builtin_huge_valf(), tr)) {
+                    const float t = tr.t, bu = tr.bu, bv = tr.bv;
                     const uint inst = tr.inst_flags & 0x7FFFFFFFu;
                     const bool closer = t < best_t ||
                         (t == best_t && found && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
@@ -280,7 +365,7 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             if (stk.sp == 0) break;
             node = stk.pop(spill);
         }
-        overflow += stk.overflow;
+        overflow += stk.overflow ? 1 : 0;
     }
     if (include_lights && finite_ray) {
         for (uint i = 0; i < sv.point_light_count; ++i) {
@@ -316,29 +401,17 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
     int node = sv.node_count > 0 ? 0 : -1;   // single-triangle scene: leaf ~0 == -1
     while (true) {
         if (node >= 0) {
-            int next = 0x7FFFFFFF;
-            {
-                Hit4 h;
-                box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (h.t[k] < __builtin_huge_valf()) {
-                        if (next == 0x7FFFFFFF) next = h.c[k];
-                        else stk.push(spill, h.c[k]);
-                    }
-                }
-            }
+            Hit4 h;
+            box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
             if (COUNT) st.nodes++;
-            if (next != 0x7FFFFFFF) { node = next; continue; }
+            if (shadow_descend(h, stk, spill, node)) continue;
         } else {
-            const TriRecord tr = sv.tris[~node];
+            TriHit tr;
             if (COUNT) st.tris++;
-            float t, bu, bv;
-            f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+            if (tri_intersect(r, sv.tris, (uint)~node, tmin, tmax, tr)) {
                 if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
                 if (COUNT) st.alpha++;
-                float alpha = candidate_alpha(sv, tr.alpha, bu, bv);
+                float alpha = candidate_alpha(sv, tr.alpha, tr.bu, tr.bv);
                 visibility *= 1.0f - alpha;
                 if (visibility == 0.0f) break;
             }
@@ -346,11 +419,13 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
         if (stk.sp == 0) break;
         node = stk.pop(spill);
     }
-    overflow += stk.overflow;
+    overflow += stk.overflow ? 1 : 0;
     return visibility;
 }
 
-// LDS words per block for the per-lane stacks
-#define TR_STACK_WORDS (TR_LDS_STACK * TR_BLOCK)
+// LDS words per block for the per-lane stacks: TR_LDS_STACK rows and, in front of them, the row a store to "row -1" lands in (LaneStack).
+// Kernels declare `__shared__ int s_stack_rows[TR_STACK_WORDS]` and hand out `s_stack_rows + TR_STACK_ROW0`.
+#define TR_STACK_ROW0 TR_BLOCK
+#define TR_STACK_WORDS ((TR_LDS_STACK + 1) * TR_BLOCK)
 
 }  // namespace tr

@@ -66,8 +66,10 @@ TR_DEV QuadCtx make_quad_ctx(int* s_stack, int* s_owner, const PathBuffers& pb T
 
 // The shadow rays of slots base .. base + 63 of the bounce's shadow queue, one wave: contrib *= shadow_ray(...)
 // (path_tracer.glsl:35-52, 462-463) and add_demodulated_color of the result.  Every lane of the wave calls this.
-template <bool COUNT, typename LOBES>
-TR_DEV void shadow_ray(const SceneView& sv, const PtParams& P, const PathBuffers& pb, bool valid, f4 o, f4 d, f4 c, LOBES&& lobes, int* lds_stack, const QuadCtx& qc,
+// `contrib` and `lobes` are fetched behind the traversal, by the rays that turn out visible: four registers the traversal loop (64 in all for
+// the shadow kernel) does not have to carry, for one more round trip at the end of a chunk of 64 rays.
+template <bool COUNT, typename CONTRIB, typename LOBES>
+TR_DEV void shadow_ray(const SceneView& sv, const PtParams& P, const PathBuffers& pb, bool valid, f4 o, f4 d, CONTRIB&& contrib, LOBES&& lobes, int* lds_stack, const QuadCtx& qc,
                        TraceStats& st, int& overflow, uint& rays) {
 #if TR_QUAD_SWITCH > 0 && !defined(TR_NO_SHADOW_QUADS)
     float vis = trace_shadow_wave4<COUNT>(sv, valid, F3(o), F3(d), P.opt.min_ray_dist, o.w, lds_stack, qc, st, overflow);
@@ -78,6 +80,7 @@ TR_DEV void shadow_ray(const SceneView& sv, const PtParams& P, const PathBuffers
     if (!valid) return;
     const uint id = __float_as_uint(d.w);
     if (vis != 0.0f) {
+        const f4 c = contrib();
         // clamp_contribution_mul on the occluded radiance (path_tracer.glsl:462-463): c.w = luminance before visibility
         float m = c.w * vis;
         if (c.w > 0.0f && m > P.opt.indirect_clamping) vis *= P.opt.indirect_clamping / m;
@@ -93,9 +96,9 @@ template <bool COUNT>
 TR_DEV void shadow_lane(const SceneView& sv, const PtParams& P, const PathBuffers& pb, uint qi, uint n, int* lds_stack, const QuadCtx& qc,
                         TraceStats& st, int& overflow, uint& rays) {
     const bool valid = qi < n;
-    f4 o = F4(0), d = F4(0), c = F4(0);
-    if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; c = pb.sh_contrib[qi]; }
-    shadow_ray<COUNT>(sv, P, pb, valid, o, d, c, [&] { return pb.sh_lobes[qi]; }, lds_stack, qc, st, overflow, rays);
+    f4 o = F4(0), d = F4(0);
+    if (valid) { o = pb.sh_org_tmax[qi]; d = pb.sh_dir_id[qi]; }
+    shadow_ray<COUNT>(sv, P, pb, valid, o, d, [&] { return pb.sh_contrib[qi]; }, [&] { return pb.sh_lobes[qi]; }, lds_stack, qc, st, overflow, rays);
 }
 
 template <bool COUNT>

@@ -44,6 +44,14 @@ TR_DEV float qrot2f(float v) { return __int_as_float(qrot2(__float_as_int(v))); 
 TR_DEV int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 TR_DEV float bpermf(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
 
+// This lane's place in its quad, read off the hardware each time it is wanted: kept in a register across the quad loop it was the value the
+// allocator spilled, and every node phase of the tail began with a scratch load and a wait for it (three instructions here instead).
+TR_DEV int quad_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l & 3;
+}
+
 TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its other lanes afterwards (no other wave is involved)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -52,10 +60,7 @@ TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its ot
 
 // What the four lanes of a quad share about their ray (same values in all four) plus the lane's own candidate.
 struct QuadRay {
-    f3 org, inv_dir;
-    float Sx, Sy, Sz;
-    int kx, ky, kz;
-    uint nox, noy, noz;
+    RayPre r;        // the ray as its owner kept it (trace.h)
     float tmin;
 };
 
@@ -66,8 +71,7 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int
     {
         const char* base = reinterpret_cast<const char*>(nodes);
         const uint t = ((uint)node << 7) | ((uint)q << 2);
-        uint ax = t | r.nox, ay = t | r.noy, az = t | r.noz;
-        asm volatile("" : "+v"(ay), "+v"(az));
+        const uint ax = t | r.r.nkx, ay = t | r.r.nky, az = t | r.r.nkz;
         nx = *reinterpret_cast<const float*>(base + (size_t)ax); fx = *reinterpret_cast<const float*>(base + (size_t)(ax ^ 16u));
         ny = *reinterpret_cast<const float*>(base + (size_t)ay); fy = *reinterpret_cast<const float*>(base + (size_t)(ay ^ 16u));
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
@@ -75,9 +79,9 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int
     }
     TL(if (tlp) tlp->loads_issued();)
     // the arithmetic of box4_intersect for one child
-    const float tx0 = (nx - r.org.x) * r.inv_dir.x, tx1 = (fx - r.org.x) * r.inv_dir.x;
-    const float ty0 = (ny - r.org.y) * r.inv_dir.y, ty1 = (fy - r.org.y) * r.inv_dir.y;
-    const float tz0 = (nz - r.org.z) * r.inv_dir.z, tz1 = (fz - r.org.z) * r.inv_dir.z;
+    const float tx0 = (nx - r.r.op.x) * r.r.ip.x, tx1 = (fx - r.r.op.x) * r.r.ip.x;
+    const float ty0 = (ny - r.r.op.y) * r.r.ip.y, ty1 = (fy - r.r.op.y) * r.r.ip.y;
+    const float tz0 = (nz - r.r.op.z) * r.r.ip.z, tz1 = (fz - r.r.op.z) * r.r.ip.z;
     t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, r.tmin));
     const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
     hit = t0 <= t1;
@@ -123,7 +127,7 @@ struct QuadDeal {
     bool has_ray;         // this quad got a ray
 };
 TR_DEV QuadDeal quad_deal(unsigned long long act, bool live, const RayPre& r, float tmin, int node, const LaneStack& stk, const int* spill, const QuadCtx& qc,
-                          int& overflow, QuadRay& qr, RayPre& tr_ray, QuadStack& qs, int& qnode) {
+                          int& overflow, QuadRay& qr, QuadStack& qs, int& qnode) {
     QuadDeal d;
     const int lane = threadIdx.x & 63, n_act = __popcll(act);
     d.q = lane & 3; d.qd = lane >> 2;
@@ -142,14 +146,12 @@ TR_DEV QuadDeal quad_deal(unsigned long long act, bool live, const RayPre& r, fl
     d.src = owner << 2;
     d.back = d.my_rank << 4;
     const int src = d.src;
-    qr.org = F3(bpermf(src, r.org.x), bpermf(src, r.org.y), bpermf(src, r.org.z));
-    qr.inv_dir = F3(bpermf(src, r.inv_dir.x), bpermf(src, r.inv_dir.y), bpermf(src, r.inv_dir.z));
-    qr.Sx = bpermf(src, r.Sx); qr.Sy = bpermf(src, r.Sy); qr.Sz = bpermf(src, r.Sz);
-    const int packed = bperm(src, r.kx | (r.ky << 2) | (r.kz << 4) | (int)(r.nox << 8) | (int)(r.noy << 16) | (int)(r.noz << 24));
-    qr.kx = packed & 3; qr.ky = (packed >> 2) & 3; qr.kz = (packed >> 4) & 3;
-    qr.nox = ((uint)packed >> 8) & 0xFFu; qr.noy = ((uint)packed >> 16) & 0xFFu; qr.noz = ((uint)packed >> 24) & 0xFFu;
+    qr.r.op = F3(bpermf(src, r.op.x), bpermf(src, r.op.y), bpermf(src, r.op.z));
+    qr.r.ip = F3(bpermf(src, r.ip.x), bpermf(src, r.ip.y), bpermf(src, r.ip.z));
+    qr.r.Sx = bpermf(src, r.Sx); qr.r.Sy = bpermf(src, r.Sy);
+    const uint packed = (uint)bperm(src, (int)(r.nkx | (r.nky << 8) | (r.nkz << 16)));
+    qr.r.nkx = packed & 0xFFu; qr.r.nky = (packed >> 8) & 0xFFu; qr.r.nkz = (packed >> 16) & 0xFFu;
     qr.tmin = bpermf(src, tmin);
-    tr_ray.org = qr.org; tr_ray.kx = qr.kx; tr_ray.ky = qr.ky; tr_ray.kz = qr.kz; tr_ray.Sx = qr.Sx; tr_ray.Sy = qr.Sy; tr_ray.Sz = qr.Sz;   // what tri_intersect reads
     qnode = bperm(src, node);
     qs.lds = qc.wave_stack + owner;
     qs.glob = qc.spill + d.qd * TR_QSPILL;
@@ -202,7 +204,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     TL(const unsigned long long tl_enter = tl_now(), tl_wall0 = tl_wall();)
 
     // candidate of a triangle test against the lane's best so far (shader/rt_common.rahit:15-24 for non-opaque geometry)
-    auto consider = [&](const TriRecord& tr, float t, float bu, float bv) {
+    auto consider = [&](const TriHit& tr, float t, float bu, float bv) {
         const uint inst = tr.inst_flags & 0x7FFFFFFFu;
         const bool closer = t < best_t || (t == best_t && best_inst != 0xFFFFFFFFu && (inst < best_inst || (inst == best_inst && tr.prim < best_prim)));
         if (closer) {
@@ -247,26 +249,23 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     TR_CE4(0, 1) TR_CE4(2, 3) TR_CE4(0, 2) TR_CE4(1, 3) TR_CE4(1, 2)
                     TL(asm volatile("" : "+v"(h.t[0]), "+v"(h.t[1]), "+v"(h.t[2]), "+v"(h.t[3]), "+v"(h.c[0]), "+v"(h.c[1]), "+v"(h.c[2]), "+v"(h.c[3])); tlp.mark_a();)
                     if (h.t[0] < __builtin_huge_valf()) {
-                        if (h.t[3] < __builtin_huge_valf()) stk.push(spill, h.c[3]);
-                        if (h.t[2] < __builtin_huge_valf()) stk.push(spill, h.c[2]);
-                        if (h.t[1] < __builtin_huge_valf()) stk.push(spill, h.c[1]);
+                        // sorted: the hit children come first, so the number of further hits says which of c[1..3] go onto the stack
+                        const int m = (int)(h.t[1] < __builtin_huge_valf()) + (int)(h.t[2] < __builtin_huge_valf()) + (int)(h.t[3] < __builtin_huge_valf());
+                        stk.push_sorted(spill, m, h.c[1], h.c[2], h.c[3]);
                         if (COUNT) st.maxsp = max(st.maxsp, (uint)stk.sp);
                         node = h.c[0];
                         descend = true;
                     }
                 } else {
-                    const TriRecord tr = sv.tris[~node];
-                    TL(tlp.loads_issued();)
+                    TriHit tr;
                     if (COUNT) st.tris++;
-                    float t, bu, bv;
-                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
 #if TR_TIMELINE
-                    const bool tl_hit = tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv);
+                    const bool tl_hit = tri_intersect(r, sv.tris, (uint)~node, tmin, __builtin_huge_valf(), tr, &tlp);
                     tlp.mark_a();
-                    if (tl_hit) { tlp.alpha = (tr.inst_flags & 0x80000000u) != 0 && (t < best_t || t == best_t); consider(tr, t, bu, bv); }
+                    if (tl_hit) { tlp.alpha = (tr.inst_flags & 0x80000000u) != 0 && (tr.t < best_t || tr.t == best_t); consider(tr, tr.t, tr.bu, tr.bv); }
                     tlp.mark_b();
 #else
-                    if (tri_intersect(r, v0, v1, v2, tmin, __builtin_huge_valf(), t, bu, bv)) consider(tr, t, bu, bv);
+                    if (tri_intersect(r, sv.tris, (uint)~node, tmin, __builtin_huge_valf(), tr)) consider(tr, tr.t, tr.bu, tr.bv);
 #endif
                 }
                 if (!descend) {
@@ -285,10 +284,11 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     const float dbg_u = live ? (float)stk.sp : -1.0f, dbg_v = live ? (float)((node < 0 ? 1000 : 0) + n_act) : -1.0f;
 #endif
     if (n_act > 0) {
-        QuadRay qr; RayPre tr_ray; QuadStack qs; int qnode;
+        QuadRay qr; QuadStack qs; int qnode;
         TL(const unsigned long long tl_deal = tl_now();)
-        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, tr_ray, qs, qnode);
-        const int q = deal.q, src = deal.src;
+        if (live) stk.flush(spill);     // the quads read the stack from memory: the top entry leaves its register
+        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, qs, qnode);
+        const int src = deal.src;
         const uint qseed = (uint)bperm(src, (int)seed);
         // every lane of the quad starts from the owner's best candidate; the quad shares the culling bound
         float lt = bpermf(src, best_t), lu = bpermf(src, best_u), lv = bpermf(src, best_v);
@@ -308,12 +308,10 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             if (tri_phase) {
                 if (pend >= 0) {
                     TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)); tlp.begin();)
-                    const TriRecord tr = sv.tris[pend];
-                    TL(tlp.loads_issued();)
+                    TriHit tr;
                     if (COUNT) st.tris++;
-                    float t, bu, bv;
-                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-                    if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, __builtin_huge_valf(), t, bu, bv)) {
+                    if (tri_intersect(qr.r, sv.tris, (uint)pend, qr.tmin, __builtin_huge_valf(), tr TL(, &tlp))) {
+                        const float t = tr.t, bu = tr.bu, bv = tr.bv;
                         const uint inst = tr.inst_flags & 0x7FFFFFFFu;
                         bool accept = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
                         if (accept && (tr.inst_flags & 0x80000000u)) {
@@ -334,10 +332,11 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 float m = lt;
                 m = fminf(m, qrot1f(m)); m = fminf(m, qrot2f(m));
                 qbest = fminf(qbest, m);
-            } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
+            } else if (can_node && qnode < 0) quad_inherited_leaf(quad_lane(), pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
                 TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)) >> 2; tlp.begin();)
+                const int q = quad_lane();
                 const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0 TL(, &tlp));
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
@@ -366,7 +365,7 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         const int ro = bperm(back, qo);
         if (live) { best_t = rt; best_u = ru; best_v = rv; best_inst = ri; best_prim = rp; overflow += ro; }
     }
-    overflow += stk.overflow;
+    overflow += stk.overflow ? 1 : 0;
     TL(tl_misc(qc.tl, 0, 1); tl_misc(qc.tl, 1, tl_now() - tl_enter); tl_misc(qc.tl, 4, tl_wall() - tl_wall0);)
 
     bool found = best_inst != 0xFFFFFFFFu;
@@ -427,25 +426,15 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 Hit4 h;
                 box4_intersect(r, sv.nodes4, node, tmin, tmax, h);
                 if (COUNT) st.nodes++;
-                int next = 0x7FFFFFFF;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (h.t[k] < __builtin_huge_valf()) {
-                        if (next == 0x7FFFFFFF) next = h.c[k];
-                        else stk.push(spill, h.c[k]);
-                    }
-                }
-                if (next != 0x7FFFFFFF) { node = next; descend = true; }
+                descend = shadow_descend(h, stk, spill, node);
             } else {
-                const TriRecord tr = sv.tris[~node];
+                TriHit tr;
                 if (COUNT) st.tris++;
-                float t, bu, bv;
-                f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-                if (tri_intersect(r, v0, v1, v2, tmin, tmax, t, bu, bv)) {
+                if (tri_intersect(r, sv.tris, (uint)~node, tmin, tmax, tr)) {
                     if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
                     else {
                         if (COUNT) st.alpha++;
-                        const float alpha = candidate_alpha(sv, tr.alpha, bu, bv);
+                        const float alpha = candidate_alpha(sv, tr.alpha, tr.bu, tr.bv);
                         visibility *= 1.0f - alpha;
                         if (visibility == 0.0f) live = false;
                     }
@@ -460,8 +449,9 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
     const unsigned long long act = __ballot(live);
     const int n_act = __popcll(act);
     if (n_act > 0) {
-        QuadRay qr; RayPre tr_ray; QuadStack qs; int qnode;
-        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, tr_ray, qs, qnode);
+        QuadRay qr; QuadStack qs; int qnode;
+        if (live) stk.flush(spill);
+        const QuadDeal deal = quad_deal(act, live, r, tmin, node, stk, spill, qc, overflow, qr, qs, qnode);
         const int q = deal.q, src = deal.src;
         const float qtmax = bpermf(src, tmax);
         const float owner_vis = bpermf(src, visibility);
@@ -477,15 +467,13 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             const bool tri_phase = __popcll(__ballot(pend >= 0)) >= TR_QUAD_VOTE || __ballot(can_node) == 0;
             if (tri_phase) {
                 if (pend >= 0) {
-                    const TriRecord tr = sv.tris[pend];
+                    TriHit tr;
                     if (COUNT) st.tris++;
-                    float t, bu, bv;
-                    f3 v0 = F3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = F3(tr.v1[0], tr.v1[1], tr.v1[2]), v2 = F3(tr.v2[0], tr.v2[1], tr.v2[2]);
-                    if (tri_intersect(tr_ray, v0, v1, v2, qr.tmin, qtmax, t, bu, bv)) {
+                    if (tri_intersect(qr.r, sv.tris, (uint)pend, qr.tmin, qtmax, tr)) {
                         if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
                         else {
                             if (COUNT) st.alpha++;
-                            lvis *= 1.0f - candidate_alpha(sv, tr.alpha, bu, bv);
+                            lvis *= 1.0f - candidate_alpha(sv, tr.alpha, tr.bu, tr.bv);
                         }
                     }
                 }
@@ -493,9 +481,10 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 int z = lvis == 0.0f ? 1 : 0;
                 z |= qrot1(z); z |= qrot2(z);
                 if (z) qlive = false;      // occluded: nothing left to find
-            } else if (can_node && qnode < 0) quad_inherited_leaf(q, pend, qs, qnode, qlive);
+            } else if (can_node && qnode < 0) quad_inherited_leaf(quad_lane(), pend, qs, qnode, qlive);
             else if (can_node) {
                 bool hitb; float t0;
+                const int q = quad_lane();
                 const int c = quad_child_box(qr, sv.nodes4, qnode, q, qtmax, hitb, t0);
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
@@ -512,7 +501,7 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         const int ro = bperm(back, qo);
         if (live) { visibility = rv; overflow += ro; }
     }
-    overflow += stk.overflow;
+    overflow += stk.overflow ? 1 : 0;
     return visibility;
 }
 

@@ -448,6 +448,8 @@ class PathTracerStage:
         identity (what the ranks of a job compare), key (the pinned option fields as text)."""
         from ._lib import ProgramInfoC
         p = ProgramInfoC()
+        if not hasattr(_lib.lib(), "trhip_pt_get_program"):      # an older build named by TRHIP_LIB (A/B runs)
+            return {"kind": "general", "ieee": False, "identity": 0, "key": "unknown: the library predates trhip_pt_get_program"}
         check(_lib.lib().trhip_pt_get_program(self.h, C.byref(p)))
         return {"kind": ("general", "cli", "compiled")[p.kind], "ieee": bool(p.ieee), "identity": int(p.identity), "key": p.key.decode()}
 
@@ -710,11 +712,14 @@ class RtRenderer:
         return mine
 
     def sync(self):
-        """Waits for every frame in flight."""
+        """Waits for every frame in flight.  An exchange that can tell that a frame is incomplete (the copy-engine exchange: a device-side
+        wait for a peer that gave up) says so here, before anybody looks at the frame."""
         for slot in self.slots:
             if slot.stream is not None:
                 self.ctx.sync(slot.stream)
         self.ctx.sync()
+        if self.exchange is not None and hasattr(self.exchange, "check"):
+            self.exchange.check()
 
     def reset_accumulation(self, reset_sample_counter=False):
         for slot in self.slots:

@@ -170,15 +170,27 @@ def test_config3_full_size_accumulation_property(R, ctx):
 #   * Suzanne (glass): the same earlier model on the transmission lobe (albedo * transmission today): -4.8 %.
 #   * room faces: +0.2 ... +2.3 %, largest on the darkest wall (mean 0.07), whose light is all indirect off the objects above.
 #   * plane (alpha-blended): -0.2 %.
-GOLDEN_REGIONS = {0: ("room face 0", 0.025, 0.018), 1: ("room face 1", 0.01, 0.009), 2: ("room face 2", 0.05, 0.007), 3: ("room face 3", 0.01, 0.022),
-                  4: ("teapot", 0.14, 0.05), 5: ("suzanne", 0.105, 0.065), 6: ("torus", 0.20, 0.0), 7: ("plane", 0.01, 0.0135)}
+# Round 5: every region's mean is held to a WINDOW around its measured, explained residual (16 384 spp, seeds fixed: the residual is a number,
+# not a random variable), +- the larger of 0.4 % and three tenths of the residual - a bound of "less than two or three times the residual"
+# let a 5 % energy error in the metallic or the transmission lobe pass (teapot -6.5 % had a bound of 14 %); the windows do not
+# (teapot: -8.4 ... -4.5 %).  Block means: 1.5 x the measured figure.
+#        region: (name, measured relative offset of the mean, its window half-width, bound on the 16 x 16 block RMS)
+GOLDEN_REGIONS = {0: ("room face 0", 0.0113, 0.004, 0.0122), 1: ("room face 1", 0.0018, 0.004, 0.0059), 2: ("room face 2", 0.0229, 0.0069, 0.0047),
+                  3: ("room face 3", 0.0022, 0.004, 0.0152), 4: ("teapot", -0.0648, 0.0194, 0.0353), 5: ("suzanne", -0.0479, 0.0144, 0.044),
+                  6: ("torus", 0.1345, 0.04, 0.0), 7: ("plane", -0.0020, 0.004, 0.0092)}
 
 
-def test_l2_against_the_reference_golden_image(R, ctx):
+def test_mse_and_region_means_against_the_reference_golden_image(R, ctx):
     """validate_path-tracer.exr (test/references, 512x512 half, filmic + gamma 2.2) is the one image of the Vulkan path tracer
     that exists here.  HIP render with the CLI defaults it was made with (8 bounces, uniform-random sampler, point film) at
-    SPP_GPU * 4 samples per pixel, same tonemap, compared as the reference's own test does (MSE over the image, test/validate_render.py:
-    26-45), as its square root, and region by region (GOLDEN_REGIONS above: every systematic difference has a bound of its own)."""
+    SPP_GPU * 4 samples per pixel, same tonemap, compared
+      * as the reference's own test does: the MEAN SQUARED error over the image (ImageMagick `compare -metric mse`, test/validate_render.py:
+        26-45) - this is the figure held to 1e-3 below, and it is an MSE: its square root, the RMS (per-pixel L2), is 0.031 and is the
+        golden image's own one-sample-per-pixel-scale noise (this render's is 0.010), not an error of 3 %;
+      * region by region (GOLDEN_REGIONS above): the mean of every region inside a window around its explained residual, block means
+        bounded - the part of the comparison that says something about the integrator.
+    "Image L2 < 1e-3 against the Vulkan reference" of north_star cannot be shown against this golden, which predates the checkout's material
+    model, nor against a live Vulkan render (no ICD here): it is shown against the oracle (config 3: RMS 1.3e-5)."""
     from tauray_amd.gltf import load_glb
     W = H = 512
     N = SPP_GPU * 4
@@ -212,12 +224,12 @@ def test_l2_against_the_reference_golden_image(R, ctx):
         return float(np.sqrt((((bo - bg) / np.maximum(n, 1)[..., None])[valid] ** 2).mean()))
 
     regions = {}
-    for k, (name, max_offset, max_block) in GOLDEN_REGIONS.items():
+    for k, (name, residual, half_width, max_block) in GOLDEN_REGIONS.items():
         m = ids == k
         assert m.sum() > 4000, name
         off = float((ours[m].mean() - gold[m].mean()) / gold[m].mean())
-        regions[name] = {"pixels": int(m.sum()), "rel_mean_offset": off, "block16_rms": block_rms(m)}
-        assert abs(off) < max_offset, f"{name}: mean differs by {off:+.2%} (bound {max_offset:.1%})"
+        regions[name] = {"pixels": int(m.sum()), "rel_mean_offset": off, "block16_rms": block_rms(m), "window": [residual - half_width, residual + half_width]}
+        assert abs(off - residual) < half_width, f"{name}: mean differs by {off:+.2%}, outside {residual - half_width:+.2%} ... {residual + half_width:+.2%}"
         if max_block:
             assert regions[name]["block16_rms"] < max_block, f"{name}: block RMS {regions[name]['block16_rms']:.4f} (bound {max_block})"
     # the two differences with a known cause have the sign and size that cause gives them
@@ -229,9 +241,48 @@ def test_l2_against_the_reference_golden_image(R, ctx):
         "mse_without_visible_emitter": mse_keep, "rms_without_visible_emitter": mse_keep ** 0.5, "block16_rms": block_rms(keep),
         "emitter_pixels": int(torus.sum()), "mean_rel_err": abs(float(ours[keep].mean()) - float(gold[keep].mean())) / float(gold[keep].mean()),
         "regions": regions})
-    assert mse_keep < L2_BOUND, f"MSE {mse_keep:.3e} against the reference image"      # north_star's bound; the golden's own noise is 9e-4 of it
+    assert mse_keep < L2_BOUND, f"MSE {mse_keep:.3e} against the reference image"      # a mean SQUARED error (the reference's metric); 9.4e-4 of it is the golden's own noise
     assert block_rms(keep) < 0.02
     assert mse_all < 0.15       # the reference's own tolerance: 10000 on ImageMagick's Q16 scale (test/CMakeLists.txt)
+
+
+def test_config4_full_size_frame_vs_oracle(R, ctx, oracle):
+    """BASELINE config 4's frame at the size bench.py times it: sponza_teapots (1 M triangles), 1920 x 1080, 1 spp, 4 bounces - the oracle
+    renders it in a few seconds on the box's host cores.  Two frame indices (two sets of random streams), both shading arithmetics: IEEE fp32
+    against the oracle pixel by pixel (it follows the oracle expression by expression: bit-equal in all but a handful of pixels), the default
+    arithmetic within the per-pixel tolerance.  tests/test_gpu_parity.py compares the same scene at 480 x 272; this is the frame of the headline."""
+    from tauray_amd import scenes
+    W, H = 1920, 1080
+    scene = scenes.sponza_teapots(width=W, height=H)
+    assert scene.triangle_count > 900_000
+    ss = R.SceneStage(ctx, scene)
+    osc = oracle.OracleScene(scene)
+    kw = dict(max_bounces=4)
+    out = {}
+    for frame in (0, 3):
+        ref = osc.render_pt(oracle.options_for_scene(scene, **kw), W, H, frame_counter=frame)[0]
+        for mode, ieee in (("ieee", True), ("default", False)):
+            pt = R.PathTracerStage(ctx, ss, R.options_for_scene(scene, **kw), _dup((W, H)))
+            pt.set_shading_arithmetic(ieee)
+            pt.set_frame_counter(frame)
+            color = ctx.alloc(W * H * 16).zero()
+            pt.run(color)
+            img = color.download((H, W, 4))
+            assert pt.counters()["stack_overflows"] == 0
+            pt.close()
+            assert np.isfinite(img).all()
+            a, b = img[..., :3].astype(np.float64), ref[..., :3].astype(np.float64)
+            rel = np.abs(a - b) / (np.abs(b) + 1e-2)
+            outside = float((rel.max(-1) > 1e-2).mean())
+            bit_equal = float((img[..., :3] == ref[..., :3]).all(-1).mean())
+            mean_rel = abs(a.mean() - b.mean()) / b.mean()
+            out[f"frame {frame} {mode}"] = {"pixels_outside_1e-2": outside, "bit_equal_pixels": bit_equal, "mean_rel_err": float(mean_rel), "rms": _rms(a, b)}
+            assert outside < (2e-4 if ieee else 5e-3), f"frame {frame}, {mode}: {outside:.4%} of the pixels outside 1 %"
+            assert mean_rel < (1e-4 if ieee else 2e-3), f"frame {frame}, {mode}: image mean off by {mean_rel:.3e}"
+            if ieee:
+                assert bit_equal > 0.5, f"frame {frame}: only {bit_equal:.4%} of the pixels bit-equal to the oracle at IEEE fp32"      # 74 % measured: the rest differ in the last bits (libm against the device's sin / cos / pow)
+            assert np.array_equal(img[..., 3], ref[..., 3])
+    _report("config4_full_size_hip_vs_oracle", {"scene": "sponza_teapots", "triangles": int(scene.triangle_count), "size": [W, H], "bounces": 4, "spp": 1, **out})
 
 
 def test_config5_light_field_grid_full_size(R, ctx):

@@ -17,7 +17,7 @@ def test_comm_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trhip_comm.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(trhip_[a-z_0-9]+)\s*\(", text)))
     L = comm.lib()
-    assert len(names) == 14 and sorted(comm.SYMBOLS) == names
+    assert len(names) == 15 and sorted(comm.SYMBOLS) == names
     for n in names:
         assert hasattr(L, n), f"libtrhip_comm.so does not export {n}"
     # linked against RCCL, not against the path-tracing library
