@@ -580,7 +580,9 @@ def main():
         phases = {"frames": n_ph, "display_rank": every[0], "other_ranks_max": {k: max(e[k] for e in every[1:]) for k in mine},
                   "note": "one frame at a time with a host sync; transport_wait = whole frame - the same frame with nothing travelling"}
     # what DESIGN.md section 6 expects of this run from one-GPU probes (a rank's strip one frame at a time / with frames in flight, before the transport)
-    expected = {1: (1.0, 1.0), 2: (1.84, 1.9), 4: (3.4, 3.8), 8: (4.8, 6.8)}.get(world)
+    # what N ranks can reach before the transport costs anything: the whole frame's time over the time of one rank's share, rendered alone on
+    # one GPU under each of the three definitions (tools/shard_share_probe.py, profiles/r5/shard_share_probe_sponza_teapots.txt: balanced strips)
+    expected = {1: (1.0, 1.0, 1.0), 2: (1.64, 1.86, 1.90), 4: (2.96, 3.30, 3.52), 8: (3.55, 5.49, 6.48)}.get(world)
 
     result = {
         "metric": "Mray/s (closest-hit + shadow rays traced) @%dx%d, %d bounces, %d spp" % (W, H, args.bounces, args.spp),
@@ -612,8 +614,9 @@ def main():
                    "views": args.views, "frames_in_flight": 1, "frames_per_launch": 1, "prewarm_frames": args.prewarm, "exchange": exchange_name,
                    "scene_hash": scenes.scene_hash(scene)},
         **({"rank_phases": phases} if phases else {}),
-        **({"scaling_expected_vs_one_gpu": {"value": expected[0], "value_pipelined": expected[1],
-                                             "source": "DESIGN.md section 6: one-GPU probes of a rank's share, before the transport"}} if (expected and world > 1) else {}),
+        **({"scaling_expected_vs_one_gpu": {"value": expected[0], "value_two_in_flight": expected[1], "value_pipelined": expected[2],
+                                             "source": "profiles/r5/shard_share_probe_sponza_teapots.txt: one-GPU probes of a rank's share, before the transport (DESIGN.md section 6)"}}
+           if (expected and world > 1) else {}),
         "accel_build_ms": round(rr.scene_update.accel["build_ms"], 2),
         **({"load_balance": {k: v for k, v in balance.items() if k != "workloads_exact"}} if balance else {}),
         "rays_per_frame": rays_total // steps,

@@ -51,10 +51,15 @@ __global__ __launch_bounds__(KB, 4) void k_trace_closest(SceneView sv, PtParams 
     bool first = true;
     while (true) {
         uint base = 0;
-        if (first) base = wave_id * 128u;
+#ifdef TR_RAYS2_DEBUG_ONE_SLOT
+        const uint chunk = 64u;
+#else
+        const uint chunk = 128u;
+#endif
+        if (first) base = wave_id * chunk;
         else {
-            if (n <= n_waves * 128u) break;
-            if ((threadIdx.x & 63) == 0) base = n_waves * 128u + atomicAdd(&bc[BC_CUR_CLOSEST], 128u);
+            if (n <= n_waves * chunk) break;
+            if ((threadIdx.x & 63) == 0) base = n_waves * chunk + atomicAdd(&bc[BC_CUR_CLOSEST], chunk);
             base = __shfl(base, 0);
         }
         first = false;

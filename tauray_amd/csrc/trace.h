@@ -39,9 +39,9 @@ namespace tr {
 
 // A ray as the traversal keeps it: in the frame the watertight triangle test works in - components in the order (kx, ky, kz), kz the axis
 // the direction is largest along (Woop et al. 2013).  Round 5: the slab test does not care in which order it takes the axes (its
-// near / far planes are picked by per-lane byte offsets anyway), and the triangle test reads the vertex components it wants straight
-// from the record with per-lane offsets 4 kx / 4 ky / 4 kz - so nothing is ever picked out of a register by a run-time index, which the
-// compiler lowers to exec-mask branches: nine picks per triangle test were 150 of its 335 instructions
+// near / far planes are picked by per-lane byte offsets anyway), and the triangle test picks the vertex components it wants with explicit
+// selects on 4 kx / 4 ky / 4 kz (tri_intersect) - a component picked out of a vector by a run-time index is lowered to exec-mask branches:
+// nine such picks per triangle test were 150 of its 335 instructions
 // (profiles/r5/trace_phase_timeline.txt: a triangle phase spent 2 400 clocks there, twice a node phase's slab tests and sort).
 struct RayPre {
     f3 op;                // origin in the order (kx, ky, kz)
@@ -79,10 +79,25 @@ struct TriHit { float t, bu, bv; uint inst_flags, prim, alpha; };
 
 // Watertight test (Woop, Benthin, Wald 2013), no culling, of triangle record `index`.  Plain IEEE fp32 without
 // contraction: the shared-edge guarantee needs both products of each edge function
-// rounded, and the CPU oracle evaluates exactly the same expression tree.  The nine vertex components arrive in the ray's order:
-// nine dword loads at per-lane offsets into one or two cache lines.
+// rounded, and the CPU oracle evaluates exactly the same expression tree.  The nine vertex components are taken in the ray's order.
 TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, float tmin, float tmax, TriHit& o TL(, TlPhase* tlp = nullptr)) {
 #pragma clang fp contract(off)
+#ifndef TR_TRI_FETCH_DWORDS
+    // The record is three 16-byte loads - what a lane's L1 pays for is accesses, not bytes - and every component is picked out of the three
+    // registers of its vertex with two selects (18 selects per test).  Round 5 measured both ways of not branching over the axes
+    // (profiles/r5/triangle_fetch_ab.txt): nine 4-byte loads at per-lane offsets 4 kx / 4 ky / 4 kz cost no vector instruction at all and ten
+    // L1 accesses instead of three; the selects win by 4 % of the closest-hit kernel - the vector L1 is the busiest unit of these kernels
+    // (0.65 of its access rate), the VALUs are not (0.43).
+    const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(tris) + (size_t)index * 48u);
+    const f4 q0 = p[0], q1 = p[1], q2 = p[2];       // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 inst prim alpha
+    o.inst_flags = __float_as_uint(q2.y); o.prim = __float_as_uint(q2.z); o.alpha = __float_as_uint(q2.w);
+    const uint kx4 = tri_component_offset(r.nkx), ky4 = tri_component_offset(r.nky), kz4 = tri_component_offset(r.nkz);
+    auto pick = [](float x, float y, float z, uint k4) { const float xy = k4 == 4u ? y : x; return k4 == 8u ? z : xy; };
+    const float v0x = pick(q0.x, q0.y, q0.z, kx4), v1x = pick(q0.w, q1.x, q1.y, kx4), v2x = pick(q1.z, q1.w, q2.x, kx4);
+    const float v0y = pick(q0.x, q0.y, q0.z, ky4), v1y = pick(q0.w, q1.x, q1.y, ky4), v2y = pick(q1.z, q1.w, q2.x, ky4);
+    const float v0z = pick(q0.x, q0.y, q0.z, kz4), v1z = pick(q0.w, q1.x, q1.y, kz4), v2z = pick(q1.z, q1.w, q2.x, kz4);
+#else
+    // variant for the A/B: nine 4-byte loads at per-lane offsets, no select
     const char* base = reinterpret_cast<const char*>(tris);
     const uint rec = index * 48u;
     const uint ox = rec + tri_component_offset(r.nkx), oy = rec + tri_component_offset(r.nky), oz = rec + tri_component_offset(r.nkz);
@@ -91,6 +106,7 @@ TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, fl
     const float v0z = *reinterpret_cast<const float*>(base + (size_t)oz), v1z = *reinterpret_cast<const float*>(base + (size_t)oz + 12), v2z = *reinterpret_cast<const float*>(base + (size_t)oz + 24);
     const uint* tail = reinterpret_cast<const uint*>(base + (size_t)rec + 36);
     o.inst_flags = tail[0]; o.prim = tail[1]; o.alpha = tail[2];
+#endif
     TL(if (tlp) tlp->loads_issued();)
     const float Akz = v0z - r.op.z, Bkz = v1z - r.op.z, Ckz = v2z - r.op.z;
     const float Ax = (v0x - r.op.x) - r.Sx * Akz, Ay = (v0y - r.op.y) - r.Sy * Akz;

@@ -59,25 +59,65 @@ TR_DEV void wave_sync_lds() {   // LDS writes of this wave are visible to its ot
 }
 
 // What the four lanes of a quad share about their ray (same values in all four) plus the lane's own candidate.
+#ifndef TR_QUAD_FETCH
+#define TR_QUAD_FETCH 0
+#endif
 struct QuadRay {
     RayPre r;        // the ray as its owner kept it (trace.h)
     float tmin;
+#if TR_QUAD_FETCH
+    uint off_a, off_b;     // byte offsets inside a node of the two 16-byte chunks this lane fetches for its quad (quad_child_box)
+#endif
 };
 
+// 4 x 4 transpose inside a quad: lane i comes in with row i in (r0 .. r3) and leaves with column i.  Two butterfly stages of
+// quad-permute DPP reads (lane ^ 1, lane ^ 2), four selects + two reads per register pair: 16 vector instructions.
+TR_DEV void quad_transpose(int q, float& r0, float& r1, float& r2, float& r3) {
+    const bool odd = (q & 1) != 0, hi = (q & 2) != 0;
+    auto swap1 = [&](float& a, float& b) {      // with lane ^ 1
+        const float t = __int_as_float(quad_perm<0xB1>(__float_as_int(odd ? a : b)));
+        a = odd ? t : a; b = odd ? b : t;
+    };
+    auto swap2 = [&](float& a, float& b) {      // with lane ^ 2
+        const float t = __int_as_float(quad_perm<0x4E>(__float_as_int(hi ? a : b)));
+        a = hi ? t : a; b = hi ? b : t;
+    };
+    swap1(r0, r1); swap1(r2, r3);
+    swap2(r0, r2); swap2(r1, r3);
+}
+
 // Box of child q of `node` against the quad's ray; returns the child reference, `hit` and the entry distance.
+// A lane reads the seven words of its child out of seven different 16-byte chunks of the node: 28 L1 accesses per quad and node.
+// -DTR_QUAD_FETCH=1 (round 5, measured, not adopted: profiles/r5/quad_fetch_ab.txt) lets the quad fetch the node together instead - lane q
+// loads two whole chunks, eight accesses per quad, and two 4 x 4 transposes hand every lane the column of its child: 32 vector
+// instructions for 20 accesses.  Closest-hit +2 %, frames +1 %: the tail's phases serve few rays, its L1 accesses are few either way,
+// and the 32 instructions sit on the critical path of the last rays of a wave.  (The same trade in the triangle test - selects for
+// accesses - won, because those phases run with full waves.)
 TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0 TL(, TlPhase* tlp = nullptr)) {
     float nx, fx, ny, fy, nz, fz;
     int c;
     {
         const char* base = reinterpret_cast<const char*>(nodes);
+#if TR_QUAD_FETCH
+        const uint t = (uint)node << 7;
+        const f4 a = *reinterpret_cast<const f4*>(base + (size_t)(t | r.off_a));
+        const f4 b = *reinterpret_cast<const f4*>(base + (size_t)(t | r.off_b));
+        TL(if (tlp) tlp->loads_issued();)
+        float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+        quad_transpose(q, a0, a1, a2, a3);      // rows: near x, far x, near y, far y
+        quad_transpose(q, b0, b1, b2, b3);      // rows: near z, far z, references, references
+        nx = a0; fx = a1; ny = a2; fy = a3; nz = b0; fz = b1;
+        c = __float_as_int(b2);
+#else
         const uint t = ((uint)node << 7) | ((uint)q << 2);
         const uint ax = t | r.r.nkx, ay = t | r.r.nky, az = t | r.r.nkz;
         nx = *reinterpret_cast<const float*>(base + (size_t)ax); fx = *reinterpret_cast<const float*>(base + (size_t)(ax ^ 16u));
         ny = *reinterpret_cast<const float*>(base + (size_t)ay); fy = *reinterpret_cast<const float*>(base + (size_t)(ay ^ 16u));
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
         c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
+        TL(if (tlp) tlp->loads_issued();)
+#endif
     }
-    TL(if (tlp) tlp->loads_issued();)
     // the arithmetic of box4_intersect for one child
     const float tx0 = (nx - r.r.op.x) * r.r.ip.x, tx1 = (fx - r.r.op.x) * r.r.ip.x;
     const float ty0 = (ny - r.r.op.y) * r.r.ip.y, ty1 = (fy - r.r.op.y) * r.r.ip.y;
@@ -85,7 +125,9 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int
     t0 = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, r.tmin));
     const float t1 = fminf(fminf(fminf(tx1, ty1), tz1), tmax) * TR_SLAB_PAD;
     hit = t0 <= t1;
+#if !TR_QUAD_FETCH
     asm volatile("" : "+v"(c));
+#endif
     return c;
 }
 
@@ -152,6 +194,13 @@ TR_DEV QuadDeal quad_deal(unsigned long long act, bool live, const RayPre& r, fl
     const uint packed = (uint)bperm(src, (int)(r.nkx | (r.nky << 8) | (r.nkz << 16)));
     qr.r.nkx = packed & 0xFFu; qr.r.nky = (packed >> 8) & 0xFFu; qr.r.nkz = (packed >> 16) & 0xFFu;
     qr.tmin = bpermf(src, tmin);
+#if TR_QUAD_FETCH
+    {   // which two chunks of a node this lane fetches for its quad: lane 0 near x + near z, 1 far x + far z, 2 near y + references, 3 far y + references
+        const uint flip = (uint)(d.q & 1) << 4;
+        qr.off_a = ((d.q & 2) ? qr.r.nky : qr.r.nkx) ^ flip;
+        qr.off_b = (d.q & 2) ? 96u : (qr.r.nkz ^ flip);
+    }
+#endif
     qnode = bperm(src, node);
     qs.lds = qc.wave_stack + owner;
     qs.glob = qc.spill + d.qd * TR_QSPILL;

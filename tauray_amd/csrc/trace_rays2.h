@@ -63,10 +63,18 @@ TR_DEV void closest_lane2(const SceneView& sv, const PtParams& P, const PathBuff
     for (int k = 0; k < 2; ++k) {
         const uint qi = base + lane + 64u * (uint)k;
         valid[k] = qi < n;
+#ifdef TR_RAYS2_DEBUG_ONE_SLOT      // bisecting: only slot TR_RAYS2_DEBUG_ONE_SLOT carries rays (chunks of 64)
+        valid[k] = k == TR_RAYS2_DEBUG_ONE_SLOT && base + lane < n;
+#endif
         ids[k] = 0;
         u4 misc = {0, 0, 0, 1};
         f4 o = F4(0), d = F4(0, 0, 1, 0);
-        if (valid[k]) { ids[k] = queue ? queue[qi] : qi + P.id_offset; misc = pb.misc[ids[k]]; o = pb.org_pdf[ids[k]]; d = pb.dir_reg[ids[k]]; valid[k] = !(misc.w & 1u); }
+#ifdef TR_RAYS2_DEBUG_ONE_SLOT
+        const uint qj = base + lane;
+#else
+        const uint qj = qi;
+#endif
+        if (valid[k]) { ids[k] = queue ? queue[qj] : qj + P.id_offset; misc = pb.misc[ids[k]]; o = pb.org_pdf[ids[k]]; d = pb.dir_reg[ids[k]]; valid[k] = !(misc.w & 1u); }
         for (int b = 0; b < bounce; ++b) pcg(misc.x);
         org[k] = F3(o); dir[k] = F3(d);
         RaySlot& s = S[k];

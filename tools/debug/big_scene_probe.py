@@ -1,9 +1,9 @@
 """Scale check: the atrium generator at 4, 16 and 48 million triangles - upload, on-device build, one 1080p frame of 4 bounces with counters,
 a second build as a refit; prints triangles, build / refit / frame times, node visits per ray, device memory in use and the overflow
-flag.  usage (through gpurun): python tools/big_scene_probe.py [millions ...]"""
+flag.  usage (through gpurun): python tools/debug/big_scene_probe.py [millions ...]"""
 import os, sys, time
 import numpy as np
-root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, root)
 from tauray_amd import renderer as R, scenes
 from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE

@@ -1,9 +1,9 @@
 """On-device acceleration-structure times by scene size: the static build (PLOC + reinsertion + cost-based collapse; what a scene gets once), the
 fast rebuild of a dynamic scene (src/acceleration_structure.cc:129-131's ePreferFastBuild), a refit; wall time around the call with a
-device sync, best of five, and the frame the resulting tree gives.  usage (through gpurun): python tools/build_time_probe.py [millions ...]"""
+device sync, best of five, and the frame the resulting tree gives.  usage (through gpurun): python tools/debug/build_time_probe.py [millions ...]"""
 import os, sys, time
 import numpy as np
-root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, root)
 from tauray_amd import renderer as R, scenes
 from tauray_amd.distribution import DistributionParams, DISTRIBUTION_DUPLICATE

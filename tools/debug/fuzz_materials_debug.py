@@ -1,4 +1,4 @@
-"""Reproduces draw K of tests/test_gpu_parity.py::test_random_materials under fuzz seed S and prints the pixels where HIP (both shading\narithmetic modes) and the oracle differ most.  usage (through gpurun): python tools/fuzz_materials_debug.py S K"""
+"""Reproduces draw K of tests/test_gpu_parity.py::test_random_materials under fuzz seed S and prints the pixels where HIP (both shading\narithmetic modes) and the oracle differ most.  usage (through gpurun): python tools/debug/fuzz_materials_debug.py S K"""
 import copy, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc GPU bring-up check (run through gpurun): HIP path vs CPU oracle on test.glb."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from tauray_amd.gltf import load_glb

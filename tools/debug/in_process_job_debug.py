@@ -1,6 +1,6 @@
 """One in-process multi-rank job (tests/test_gpu_parity.py _in_process_job) against the single-rank frames, for a list of
 configurations W H world strategy F B: which frames differ and by how many pixels.  usage (through gpurun):
-python tools/in_process_job_debug.py "62 18 1 2 4 4" "62 18 1 2 1 1" ..."""
+python tools/debug/in_process_job_debug.py "62 18 1 2 4 4" "62 18 1 2 1 1" ..."""
 import os, sys
 import numpy as np
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -1,6 +1,6 @@
 """Concurrency of the kernels in a rocprofv3 kernel trace (t_kernel_trace.csv of `--kernel-trace`): for the timed region
 of a bench run (the stretch where k_trace_fused runs, i.e. profiling off), the wall-clock span, the sum of kernel
-durations and how many kernels were running on average and at most.  usage: python tools/kernel_overlap.py <csv>"""
+durations and how many kernels were running on average and at most.  usage: python tools/debug/kernel_overlap.py <csv>"""
 import csv
 import re
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Markdown table of the option-set bench lines of one profiling session (tools/profile_r4.sh):
-    python tools/option_sets_table.py profiles/r4 > profiles/r4/option_sets.md
+    python tools/debug/option_sets_table.py profiles/r4 > profiles/r4/option_sets.md
 Every row is one `python bench.py <flags> --steps 20 --warmup 5` line on sponza_teapots; the reference row is the command-line set
 (`sponza_teapots_bench.json`, the line the driver measures)."""
 import glob

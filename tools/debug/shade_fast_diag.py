@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Where do the two arithmetic modes of k_shade (csrc/shade_fast.hip vs IEEE, TRHIP_SHADE_FAST=0) part?  Renders the textured
 quad of tests/test_gpu_parity.py::test_texture_edge_cases in both modes (this process = the mode of the environment; the other
-mode in a child) and against the oracle, per bounce count.  usage (GPU box): python tools/shade_fast_diag.py"""
+mode in a child) and against the oracle, per bounce count.  usage (GPU box): python tools/debug/shade_fast_diag.py"""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
