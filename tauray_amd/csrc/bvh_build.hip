@@ -854,6 +854,117 @@ static int reorder_into_treelets(DeviceScene& ds, hipStream_t stream, uint n_nod
     return 0;
 }
 
+// Experiment (TRHIP_PAIR_LEAVES=1 with a library built -DTR_PAIR_LEAVES=1; profiles/r5/pair_leaves_ab.txt): leaves of two triangles.
+// A host pass over the finished 4-wide tree, bottom-up: the leaf slots of a node are paired (the two whose union box is smallest first), a
+// pair takes one slot - reference ~(first | 1 << 30), its triangles adjacent in the record array - and the slots that frees are filled by
+// adopting the children of inner children that fit, which removes those nodes and a level of the walk above them.  Nodes and records are
+// then renumbered in depth-first order.  Refit does not understand pair references: the experiment is for static scenes.
+static int pair_leaves_postpass(DeviceScene& ds, hipStream_t stream, uint n_nodes, uint n_tris) {
+    if (n_nodes == 0 || n_tris < 2) return 0;
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<Bvh4Node> nodes(n_nodes);
+    std::vector<TriRecord> tris(n_tris);
+    HIPCHK(hipMemcpy(nodes.data(), ds.nodes4, (size_t)n_nodes * sizeof(Bvh4Node), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tris.data(), ds.tris, (size_t)n_tris * sizeof(TriRecord), hipMemcpyDeviceToHost));
+    struct Slot { float lo[3], hi[3]; int kind; int a, b; };      // kind 0 inner node a, 1 triangle a, 2 pair (a, b)
+    std::vector<std::vector<Slot>> slots(n_nodes);
+    std::vector<char> live(n_nodes, 0), dead(n_nodes, 0);
+    {   // live nodes: reachable from the root
+        std::vector<uint> st = {0u};
+        while (!st.empty()) {
+            const uint nd = st.back(); st.pop_back();
+            live[nd] = 1;
+            for (int c = 0; c < 4; ++c) {
+                const int ch = nodes[nd].child[c];
+                if (ch == 0x7FFFFFFF) continue;
+                Slot sl;
+                sl.lo[0] = nodes[nd].lox[c]; sl.lo[1] = nodes[nd].loy[c]; sl.lo[2] = nodes[nd].loz[c];
+                sl.hi[0] = nodes[nd].hix[c]; sl.hi[1] = nodes[nd].hiy[c]; sl.hi[2] = nodes[nd].hiz[c];
+                sl.kind = ch >= 0 ? 0 : 1; sl.a = ch >= 0 ? ch : ~ch; sl.b = -1;
+                slots[nd].push_back(sl);
+                if (ch >= 0) st.push_back((uint)ch);
+            }
+        }
+    }
+    auto area_of = [](const float* lo, const float* hi) { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return dx * dy + dy * dz + dz * dx; };
+    size_t pairs = 0, adopted = 0;
+    for (uint k = n_nodes; k-- > 0;) {      // children sit behind their parents (depth-first order): bottom-up
+        if (!live[k]) continue;
+        std::vector<Slot>& S = slots[k];
+        while (true) {      // pair leaf slots, cheapest union first
+            int bi = -1, bj = -1; float best = __builtin_huge_valf();
+            for (size_t i = 0; i < S.size(); ++i) for (size_t j = i + 1; j < S.size(); ++j) {
+                if (S[i].kind != 1 || S[j].kind != 1) continue;
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(S[i].lo[a], S[j].lo[a]); hi[a] = std::max(S[i].hi[a], S[j].hi[a]); }
+                const float ar = area_of(lo, hi);
+                if (ar < best) { best = ar; bi = (int)i; bj = (int)j; }
+            }
+            if (bi < 0) break;
+            for (int a = 0; a < 3; ++a) { S[bi].lo[a] = std::min(S[bi].lo[a], S[bj].lo[a]); S[bi].hi[a] = std::max(S[bi].hi[a], S[bj].hi[a]); }
+            S[bi].kind = 2; S[bi].b = S[bj].a;
+            S.erase(S.begin() + bj);
+            pairs++;
+        }
+        while (true) {      // adopt the children of an inner child that fit into the free slots, largest box first
+            int pick = -1; float best = -1.0f;
+            for (size_t i = 0; i < S.size(); ++i) {
+                if (S[i].kind != 0) continue;
+                const std::vector<Slot>& C = slots[(size_t)S[i].a];
+                if (S.size() - 1 + C.size() > 4) continue;
+                const float ar = area_of(S[i].lo, S[i].hi);
+                if (ar > best) { best = ar; pick = (int)i; }
+            }
+            if (pick < 0) break;
+            const int child = S[pick].a;
+            const std::vector<Slot> C = slots[(size_t)child];
+            S.erase(S.begin() + pick);
+            S.insert(S.end(), C.begin(), C.end());
+            dead[(size_t)child] = 1;
+            adopted++;
+        }
+    }
+    // renumber depth-first
+    std::vector<int> new_id(n_nodes, -1);
+    std::vector<uint> order;
+    {
+        std::vector<uint> st = {0u};
+        while (!st.empty()) {
+            const uint nd = st.back(); st.pop_back();
+            new_id[nd] = (int)order.size(); order.push_back(nd);
+            for (size_t i = slots[nd].size(); i-- > 0;) if (slots[nd][i].kind == 0) st.push_back((uint)slots[nd][i].a);
+        }
+    }
+    std::vector<Bvh4Node> out_nodes(n_nodes, nodes[0]);
+    std::vector<TriRecord> out_tris(n_tris);
+    uint next_tri = 0;
+    for (size_t k = 0; k < order.size(); ++k) {
+        Bvh4Node nd;
+        const std::vector<Slot>& S = slots[order[k]];
+        for (int c = 0; c < 4; ++c) {
+            nd.pad[c] = 0;
+            if ((size_t)c >= S.size()) {
+                nd.lox[c] = nd.loy[c] = nd.loz[c] = __builtin_huge_valf(); nd.hix[c] = nd.hiy[c] = nd.hiz[c] = -__builtin_huge_valf(); nd.child[c] = 0x7FFFFFFF;
+                continue;
+            }
+            const Slot& sl = S[(size_t)c];
+            nd.lox[c] = sl.lo[0]; nd.loy[c] = sl.lo[1]; nd.loz[c] = sl.lo[2]; nd.hix[c] = sl.hi[0]; nd.hiy[c] = sl.hi[1]; nd.hiz[c] = sl.hi[2];
+            if (sl.kind == 0) nd.child[c] = new_id[(size_t)sl.a];
+            else {
+                out_tris[next_tri] = tris[(size_t)sl.a];
+                if (sl.kind == 2) { out_tris[next_tri + 1] = tris[(size_t)sl.b]; nd.child[c] = ~(int)(next_tri | 0x40000000u); next_tri += 2; }
+                else { nd.child[c] = ~(int)next_tri; next_tri += 1; }
+            }
+        }
+        out_nodes[k] = nd;
+    }
+    if (next_tri != n_tris) return set_error("pair leaves: " + std::to_string(next_tri) + " of " + std::to_string(n_tris) + " triangles referenced");
+    HIPCHK(hipMemcpy(ds.nodes4, out_nodes.data(), (size_t)n_nodes * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ds.tris, out_tris.data(), (size_t)n_tris * sizeof(TriRecord), hipMemcpyHostToDevice));
+    fprintf(stderr, "[trhip] pair leaves: %zu pairs, %zu nodes adopted away, %zu live nodes of %u\n", pairs, adopted, order.size(), n_nodes);
+    return 0;
+}
+
 int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
     const uint n_scene = ds.tri_count;
     hipEvent_t e0, e1;
@@ -1034,6 +1145,13 @@ int build_accel(DeviceScene& ds, hipStream_t stream, trhip_accel_info* info) {
             }
         }
         HIPCHK(hipGetLastError());
+        if (getenv("TRHIP_PAIR_LEAVES") && atoi(getenv("TRHIP_PAIR_LEAVES")) != 0 && n > 2) {
+#if TR_PAIR_LEAVES
+            if (int rc = pair_leaves_postpass(ds, stream, n - 1, n)) return rc;
+#else
+            return set_error("TRHIP_PAIR_LEAVES needs a library built with -DTR_PAIR_LEAVES=1 (the traversal has to know the pair references)");
+#endif
+        }
         if (const char* e = getenv("TRHIP_TREELET")) {
             if (n > 2 && atoi(e) > 0) if (int rc = reorder_into_treelets(ds, stream, n - 1, n, (uint)atoi(e), !getenv("TRHIP_TREELET_KEEP_TRIS"))) return rc;
         }

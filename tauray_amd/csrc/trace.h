@@ -74,6 +74,19 @@ TR_DEV bool ray_is_finite(f3 o, f3 d) {
            (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f);
 }
 
+// Experiment -DTR_PAIR_LEAVES=1 (bvh_build.hip pair_leaves_postpass): a leaf reference ~(index | 1 << 30) names two records, index and index + 1.
+#ifndef TR_PAIR_LEAVES
+#define TR_PAIR_LEAVES 0
+#endif
+TR_DEV uint leaf_index(uint complemented_ref) { return TR_PAIR_LEAVES ? (complemented_ref & 0x3FFFFFFFu) : complemented_ref; }
+TR_DEV bool leaf_is_pair(uint complemented_ref) { return TR_PAIR_LEAVES && (complemented_ref & 0x40000000u) != 0; }
+// in front of the `if (tri_intersect(... leaf_index(ref) + member ...))` of a leaf: once, or once per member of a pair
+#if TR_PAIR_LEAVES
+#define TR_LEAF_MEMBERS(ref, more) for (uint member = 0; member <= (leaf_is_pair(ref) ? 1u : 0u) && (more); ++member)
+#else
+#define TR_LEAF_MEMBERS(ref, more) constexpr uint member = 0;
+#endif
+
 // What a triangle test hands back: the candidate and the words of the record behind the vertices.
 struct TriHit { float t, bu, bv; uint inst_flags, prim, alpha; };
 
@@ -358,7 +371,8 @@ TR_DEV void trace_closest4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
             } else {
                 TriHit tr;
                 if (COUNT) st.tris++;
-                if (tri_intersect(r, sv.tris, (uint)~node, tmin, __builtin_huge_valf(), tr)) {
+                TR_LEAF_MEMBERS((uint)~node, true)
+                if (tri_intersect(r, sv.tris, leaf_index((uint)~node) + member, tmin, __builtin_huge_valf(), tr)) {
                     const float t = tr.t, bu = tr.bu, bv = tr.bv;
                     const uint inst = tr.inst_flags & 0x7FFFFFFFu;
                     const bool closer = t < best_t ||
@@ -424,6 +438,20 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
         } else {
             TriHit tr;
             if (COUNT) st.tris++;
+#if TR_PAIR_LEAVES
+            bool occluded = false;
+            for (uint member = 0; member <= (leaf_is_pair((uint)~node) ? 1u : 0u) && !occluded; ++member)
+            if (tri_intersect(r, sv.tris, leaf_index((uint)~node) + member, tmin, tmax, tr)) {
+                if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; occluded = true; }
+                else {
+                    if (COUNT) st.alpha++;
+                    float alpha = candidate_alpha(sv, tr.alpha, tr.bu, tr.bv);
+                    visibility *= 1.0f - alpha;
+                    if (visibility == 0.0f) occluded = true;
+                }
+            }
+            if (occluded) break;
+#else
             if (tri_intersect(r, sv.tris, (uint)~node, tmin, tmax, tr)) {
                 if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; break; }
                 if (COUNT) st.alpha++;
@@ -431,6 +459,7 @@ TR_DEV float trace_shadow4(const SceneView& sv, f3 org, f3 dir, float tmin, floa
                 visibility *= 1.0f - alpha;
                 if (visibility == 0.0f) break;
             }
+#endif
         }
         if (stk.sp == 0) break;
         node = stk.pop(spill);

@@ -314,7 +314,8 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     if (tl_hit) { tlp.alpha = (tr.inst_flags & 0x80000000u) != 0 && (tr.t < best_t || tr.t == best_t); consider(tr, tr.t, tr.bu, tr.bv); }
                     tlp.mark_b();
 #else
-                    if (tri_intersect(r, sv.tris, (uint)~node, tmin, __builtin_huge_valf(), tr)) consider(tr, tr.t, tr.bu, tr.bv);
+                    TR_LEAF_MEMBERS((uint)~node, true)
+                    if (tri_intersect(r, sv.tris, leaf_index((uint)~node) + member, tmin, __builtin_huge_valf(), tr)) consider(tr, tr.t, tr.bu, tr.bv);
 #endif
                 }
                 if (!descend) {
@@ -359,7 +360,8 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                     TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)); tlp.begin();)
                     TriHit tr;
                     if (COUNT) st.tris++;
-                    if (tri_intersect(qr.r, sv.tris, (uint)pend, qr.tmin, __builtin_huge_valf(), tr TL(, &tlp))) {
+                    TR_LEAF_MEMBERS((uint)pend, true)
+                    if (tri_intersect(qr.r, sv.tris, leaf_index((uint)pend) + member, qr.tmin, __builtin_huge_valf(), tr TL(, &tlp))) {
                         const float t = tr.t, bu = tr.bu, bv = tr.bv;
                         const uint inst = tr.inst_flags & 0x7FFFFFFFu;
                         bool accept = t < lt || (t == lt && linst != 0xFFFFFFFFu && (inst < linst || (inst == linst && tr.prim < lprim)));
@@ -479,7 +481,8 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
             } else {
                 TriHit tr;
                 if (COUNT) st.tris++;
-                if (tri_intersect(r, sv.tris, (uint)~node, tmin, tmax, tr)) {
+                TR_LEAF_MEMBERS((uint)~node, live)
+                if (tri_intersect(r, sv.tris, leaf_index((uint)~node) + member, tmin, tmax, tr)) {
                     if (!(tr.inst_flags & 0x80000000u)) { visibility = 0.0f; live = false; }
                     else {
                         if (COUNT) st.alpha++;
@@ -518,7 +521,8 @@ TR_DEV float trace_shadow_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 if (pend >= 0) {
                     TriHit tr;
                     if (COUNT) st.tris++;
-                    if (tri_intersect(qr.r, sv.tris, (uint)pend, qr.tmin, qtmax, tr)) {
+                    TR_LEAF_MEMBERS((uint)pend, true)
+                    if (tri_intersect(qr.r, sv.tris, leaf_index((uint)pend) + member, qr.tmin, qtmax, tr)) {
                         if (!(tr.inst_flags & 0x80000000u)) lvis = 0.0f;
                         else {
                             if (COUNT) st.alpha++;
