@@ -391,6 +391,7 @@ public:
     void set_frame_batch(uint32_t frames) { check(trhip_pt_set_frame_batch(pt, frames)); frame_batch = frames; }
     // slices of a frame run concurrently inside the stage: 0 = automatic, 1 = none (several frames in flight instead)
     void set_lanes(int lanes) { check(trhip_pt_set_lanes(pt, lanes)); }
+    void set_frame_slots(int slots) { check(trhip_pt_set_frame_slots(pt, slots)); }
     // which shading program renders this stage (general kernels / the command-line set's ahead-of-time instances / compiled for the option
     // set), resolved now, and its identity - what the devices of a job compare before the first frame (trhip_pt_get_program)
     trhip_program_info program() const { trhip_program_info p; check(trhip_pt_get_program(pt, &p)); return p; }
@@ -550,7 +551,7 @@ public:
                 path_tracer_stage::options po = this->opt;
                 po.distribution = d.dist;
                 sl.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, sl.color, po);
-                if(n_slots > 1) sl.ray_tracer->set_lanes(1);          // the frames in flight fill the chip between them
+                if(n_slots > 1) { sl.ray_tracer->set_lanes(1); sl.ray_tracer->set_frame_slots(n_slots); }   // the frames in flight fill the chip between them
                 if(batch > 1) sl.ray_tracer->set_frame_batch(batch);
                 if(i != 0) sl.gbuffer_copy = per_device[0].dev->alloc(d.max_bytes);   // receive buffer on the display device
             }

@@ -230,6 +230,11 @@ int trhip_pt_set_frame_batch(trhip_pt* pt, uint32_t frames);
  * (four for frames of >= 1.5 M paths), 1 = everything on the caller's stream - the right choice with several frames in
  * flight, which fill the chip between them. */
 int trhip_pt_set_lanes(trhip_pt* pt, int lanes);
+/* A hint from a renderer with frame slots (MAX_FRAMES_IN_FLIGHT stages of the same scene, src/context.hh:26): how many stages render
+ * next to this one on the device.  The stage sizes its persistent launches by it - with two or three frames in flight a trace launch of
+ * three blocks per CU leaves the room the neighbours need (two slots: -0 ... 5 %, three: -3 ... 5 %), with four or more the larger grids
+ * stay (profiles/r5/frame_slot_grids.txt).  0 (the default) = unknown.  Frames are the same bits whatever the hint. */
+int trhip_pt_set_frame_slots(trhip_pt* pt, int slots);
 /* View and sample sharding across devices (the reference itself only shards pixels,
  * src/distribution_strategy.cc).  Local layer l of the target shows viewport viewport_base + l * viewport_stride: that
  * viewport's camera (shader/scene.glsl:176-185) and its RNG stream (the viewport index seeds the sampler,

@@ -122,6 +122,7 @@ SYMBOLS = {
     "trhip_stream_wait_peer": (_i, [_vp, _vp, _vp, _vp]),
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
+    "trhip_pt_set_frame_slots": (_i, [_vp, C.c_int]),
     "trhip_pt_set_shading_arithmetic": (_i, [_vp, C.c_int]),
     "trhip_pt_set_specialization": (_i, [_vp, C.c_int]),
     "trhip_pt_precompile": (_i, [C.POINTER(PtOptionsC), C.c_int, C.c_int, C.c_int, C.c_char_p]),

@@ -693,6 +693,12 @@ int trhip_pt_set_lanes(trhip_pt* pt, int lanes) {
     pt->stage->lanes = lanes;
     return 0;
 }
+int trhip_pt_set_frame_slots(trhip_pt* pt, int slots) {
+    if (!pt) return set_error("null trhip_pt");
+    if (slots < 0) return set_error("trhip_pt_set_frame_slots: slots must be >= 0");
+    pt->stage->frame_slots = slots;
+    return 0;
+}
 int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee) {
     if (!pt) return set_error("null trhip_pt");
     pt->stage->ieee_shading = ieee ? 1 : 0;

@@ -718,7 +718,14 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // other three lanes of their own frame - get four blocks per CU instead of eight, which leaves room for the launches next
     // to them (four slots: sponza_teapots 4.33 -> 4.18 ms per frame, sponza_class 3.59 -> 3.44; four lanes of a lone frame:
     // 4.78 -> 4.52 ms, profiles/r2/schedule_sweep.txt).  Only a kernel that is timed alone wants the whole chip.
-    const uint grid_cap = (!timing && !getenv("TRHIP_GRID_BLOCKS")) ? 1024u : trace_grid_cap();
+    // Round 5 (profiles/r5/sync_schedule_sweep.txt, lone_frame_grids.txt): with the round's faster traversal the four pixel lanes of a lone frame want
+    // smaller grids still - three blocks per CU for the trace launches and for k_shade (768 / 768 instead of 1024 / 2048): a lane's launch
+    // then leaves half the chip to the other lanes' launches, which is what lanes are for; one frame at a time 4.06 -> 3.72 ms on
+    // sponza_teapots.  Frame slots (one lane per frame, whole frames per launch) and sample lanes keep the larger grids: pipelined 3.29 ms
+    // against 3.37 with the small ones.
+    const bool pixel_lanes = n_lanes >= 3 && !sample_lanes;
+    const bool few_slots = n_lanes == 1 && (frame_slots == 2 || frame_slots == 3);      // trhip_pt_set_frame_slots: trace launches of three blocks per CU
+    const uint grid_cap = (!timing && !getenv("TRHIP_GRID_BLOCKS")) ? ((pixel_lanes || few_slots) ? 768u : 1024u) : trace_grid_cap();
     // A trace kernel that is timed alone gets exactly the blocks that are resident at its register budget (persistent waves: a
     // block that has to wait for a slot only lengthens the tail): 1536 for the closest-hit kernel, 0.544 -> 0.527 ms per launch
     // on sponza_teapots against the 2048 both used to get; the shadow kernel's budget is 8 per CU, i.e. 2048.
@@ -872,7 +879,8 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     timed(T_SHADE, ls, [&] {
                         // k_shade holds three waves per SIMD (768 resident blocks) and strides over the queue; 2048 blocks since the
                         // trace launches of a frame slot shrank to 1024 (round 2 sweep: profiles/r2/schedule_sweep.txt)
-                        static const uint shade_cap = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 2048u;
+                        static const uint shade_cap_env = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 0u;
+                        const uint shade_cap = shade_cap_env ? shade_cap_env : (pixel_lanes ? 768u : 2048u);
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
                         static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
                         const bool last = last_variant && bounce == opt.max_bounces - 1;

@@ -26,6 +26,7 @@ public:
     int count_work = 0, detailed_timing = 0;
     // trhip_pt_set_shard: which viewports / samples of the whole job this stage renders (view and sample sharding)
     uint shard_vp_base = 0, shard_vp_stride = 1, shard_sample_base = 0, shard_sample_stride = 1;
+    int frame_slots = 0;             // trhip_pt_set_frame_slots: stages rendering next to this one (0 = unknown)
     int lanes = 0;                   // trhip_pt_set_lanes: 0 = automatic
     uint frame_batch = 1;            // trhip_pt_set_frame_batch: consecutive frames per render() call
     int ieee_shading = -1;           // trhip_pt_set_shading_arithmetic: 1 = k_shade at IEEE fp32 for every option set, 0 = Vulkan-grade arithmetic for the command-line set, -1 = TRHIP_SHADE_FAST decides

@@ -399,6 +399,11 @@ class PathTracerStage:
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 
+    def set_frame_slots(self, slots: int):
+        """Hint: how many stages render next to this one (a renderer's frames in flight); trhip_pt_set_frame_slots."""
+        if hasattr(_lib.lib(), "trhip_pt_set_frame_slots"):      # an older build named by TRHIP_LIB (A/B runs) has no such hint
+            check(_lib.lib().trhip_pt_set_frame_slots(self.h, slots))
+
     def reset_accumulated_samples(self):
         check(_lib.lib().trhip_pt_reset_accumulation(self.h, 0))
 
@@ -640,6 +645,7 @@ class RtRenderer:
                 slot.pt.set_frame_batch(frames_per_launch)
             if frames_in_flight > 1:
                 slot.pt.set_lanes(1)             # the frames in flight fill the chip between them
+                slot.pt.set_frame_slots(frames_in_flight)
                 slot.stream = ctx.create_stream()
             slot.color = self._alloc_color(viewports, tw, th)
             self.slots.append(slot)

@@ -13,9 +13,9 @@ import json, sys
 l = [x for x in open(sys.argv[1]) if x.startswith("{")]
 if not l:
     print(sys.argv[2], sys.argv[3], "FAILED"); sys.exit(0)
-r = json.loads(l[-1]); k = r["roofline"]
-print(sys.argv[2], sys.argv[3], "| sync ms", r["ms_per_step"], "Mray/s", r["value"], "| pipelined ms", r["pipelined"]["ms_per_frame"], "Mray/s", r["value_pipelined"],
-      "| kernel ms/frame", {a: b for a, b in k["kernel_ms_per_frame"].items() if a in ("trace_closest", "trace_shadow", "shade")})
+r = json.loads(l[-1]); k = r.get("roofline") or {}
+print(sys.argv[2], sys.argv[3], "| sync ms", r["ms_per_step"], "Mray/s", r["value"], "| two in flight ms", (r.get("two_in_flight") or {}).get("ms_per_frame"), "| pipelined ms", r["pipelined"]["ms_per_frame"], "Mray/s", r["value_pipelined"],
+      "| kernel ms/frame", {a: b for a, b in (k.get("kernel_ms_per_frame") or {}).items() if a in ("trace_closest", "trace_shadow", "shade")})
 PY
   done
 done
