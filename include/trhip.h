@@ -43,6 +43,12 @@ int trhip_sync(trhip_device* dev, void* stream);
 int trhip_stream_create(trhip_device* dev, void** stream_out);
 int trhip_stream_destroy(trhip_device* dev, void* stream);
 int trhip_stream_wait(trhip_device* dev, void* stream, void* on);
+/* Streams are kept for the life of the process and handed out by the hardware pipe their queue sits on (csrc/stream_pool.hip: queues
+ * of one pipe do not overlap launches larger than the chip, so the slots of a renderer and the lanes of a stage are spread over the
+ * pipes).  trhip_stream_create returns an idle stream of the pipe with the fewest takers; trhip_stream_destroy hands it back.
+ * `pipe_class_out`: the pipe of any stream of this process, the caller's own included (small integers from 0 in the order pipes
+ * were seen; -1 with TRHIP_PIPE_PROBE=0): two streams of one class serialise chip-filling launches. */
+int trhip_stream_pipe_class(trhip_device* dev, void* stream, int32_t* pipe_class_out);
 /* The same dependency between streams of two devices of one process (the timeline semaphores the reference exports
  * between devices, src/device_transfer.cc:318-347, src/rt_renderer.cc:98-127): work enqueued on `stream` of `dev` after
  * the call starts only when everything enqueued on `on` of `on_dev` before the call has finished. */

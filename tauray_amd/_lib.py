@@ -118,6 +118,7 @@ SYMBOLS = {
     "trhip_stitch_batch": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, C.c_float, _vp]),
     "trhip_stream_create": (_i, [_vp, C.POINTER(C.c_void_p)]),
     "trhip_stream_destroy": (_i, [_vp, _vp]),
+    "trhip_stream_pipe_class": (_i, [_vp, _vp, C.POINTER(C.c_int32)]),
     "trhip_stream_wait": (_i, [_vp, _vp, _vp]),
     "trhip_stream_wait_peer": (_i, [_vp, _vp, _vp, _vp]),
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),

@@ -364,13 +364,21 @@ int trhip_stream_create(trhip_device* dev, void** stream_out) {
     DEVCHK(dev);
     if (!stream_out) return set_error("trhip_stream_create: null argument");
     hipStream_t st = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (int rc = stream_pool_acquire(&st)) return rc;
     *stream_out = st;
     return 0;
 }
 int trhip_stream_destroy(trhip_device* dev, void* stream) {
     DEVCHK(dev);
-    if (stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipStreamDestroy((hipStream_t)stream)); }
+    if (stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); stream_pool_release((hipStream_t)stream); }
+    return 0;
+}
+int trhip_stream_pipe_class(trhip_device* dev, void* stream, int32_t* pipe_class_out) {
+    DEVCHK(dev);
+    if (!pipe_class_out) return set_error("trhip_stream_pipe_class: null argument");
+    int c = -1;
+    if (int rc = stream_pool_class((hipStream_t)stream, &c)) return rc;
+    *pipe_class_out = c;
     return 0;
 }
 int trhip_stream_wait(trhip_device* dev, void* stream, void* on) {

@@ -449,6 +449,10 @@ static uint trace_grid_cap() {   // most blocks a persistent trace launch gets (
     static const uint cap = getenv("TRHIP_GRID_BLOCKS") ? (uint)atoi(getenv("TRHIP_GRID_BLOCKS")) : 256u * 8u;
     return cap;
 }
+static uint fused_grid_factor() {   // blocks of a fused launch per block of paths of its lane (two queues: 2 gives every chunk of both a wave)
+    static const uint f = getenv("TRHIP_FUSED_GRID_FACTOR") ? (uint)std::max(1, atoi(getenv("TRHIP_FUSED_GRID_FACTOR"))) : 2u;
+    return f;
+}
 // words of the quad-tail spill buffer one trace launch of `blocks` blocks needs: a slice per wave
 static size_t qspill_words(size_t blocks) { return std::max<size_t>(blocks, 1) * (KB / 64) * 16u * TR_QSPILL; }
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -490,8 +494,8 @@ PtStage::~PtStage() {
     if (impl->ev_init) for (auto& e : impl->ev) (void)hipEventDestroy(e);
     for (auto& sp : impl->pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto& e : impl->pool) (void)hipEventDestroy(e);
-    if (impl->side) { (void)hipStreamDestroy(impl->side); (void)hipEventDestroy(impl->ev_fork); (void)hipEventDestroy(impl->ev_join); }
-    for (int l = 2; l < PT_LANES; ++l) if (impl->lane_stream[l]) { (void)hipStreamDestroy(impl->lane_stream[l]); (void)hipEventDestroy(impl->lane_join[l]); }
+    if (impl->side) { stream_pool_release(impl->side); (void)hipEventDestroy(impl->ev_fork); (void)hipEventDestroy(impl->ev_join); }
+    for (int l = 2; l < PT_LANES; ++l) if (impl->lane_stream[l]) { stream_pool_release(impl->lane_stream[l]); (void)hipEventDestroy(impl->lane_join[l]); }
     for (auto& e : impl->pass_done) if (e) (void)hipEventDestroy(e);
     delete impl;
 }
@@ -691,12 +695,12 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // Per-kernel timing (trhip_pt_set_profiling) wants kernels that own the chip: one lane, one stream.
     static const int lanes_env = getenv("TRHIP_LANES") ? atoi(getenv("TRHIP_LANES")) : PT_LANES;
     static const bool overlap_enabled = !(getenv("TRHIP_OVERLAP") && atoi(getenv("TRHIP_OVERLAP")) == 0);
-    // Small frames (the shards of a multi-GPU job) are bound by the latency of one ray's dependent fetches per kernel, not
-    // by throughput, and below ~200 k paths extra hardware queues only add dispatch latency (130 k paths: 0.74 ms on one lane, 0.75 on
-    // two, 0.79 on four).  Above that lanes pay again since the round-3 kernels and grids (one frame at a time, sponza_teapots:
-    // 261 k paths 1.07 -> 0.90 ms on two lanes, 518 k 1.61 -> 1.28 ms on four, 1.04 M 2.71 -> 2.36 ms on four;
-    // profiles/r3/small_frame_lanes.txt) - round 2's threshold of 1.5 M paths had outlived the kernels it was measured on.
-    static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)200000;
+    // Small frames (the shards of a multi-GPU job) are bound by the latency of one ray's dependent fetches per kernel, not by
+    // throughput; extra lanes pay as long as a lane still has a few hundred blocks.  One frame at a time, sponza_teapots, lanes
+    // 1 / 2 / 4 (profiles/r5/lanes_by_share.txt, every lane on a hardware pipe of its own - stream_pool.hip; round 3's
+    // thresholds were measured with whatever pipes the streams had landed on): 65 k paths 0.50 / 0.52 / 0.55 ms, 130 k
+    // 0.60 / 0.57 / 0.61, 261 k 0.94 / 0.79 / 0.74, 518 k 1.49 / 1.40 / 1.17, 1.04 M 2.52 / 2.30 / 2.16, 2.07 M 4.48 / 3.96 / 3.70.
+    static const size_t lanes_min_paths = getenv("TRHIP_LANES_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_LANES_MIN_PATHS")) : (size_t)100000;
     //  * sample lanes (a frame of two or more one-sample passes, the offline case - BASELINE config 3 is 4096 of them): the lanes
     //    take turns with whole samples instead of sharing one, each with path state of its own, so that up to four samples are
     //    in flight like the frames of a renderer with frame slots (3.4 instead of 4.0 ms per sample on sponza_class).  A pass
@@ -710,7 +714,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     const bool fused = fused_enabled && !timing && !count;
     const bool overlap = overlap_enabled && !timing && !fused && n_lanes == 1;
     if ((overlap || n_lanes > 1) && !impl->side) {
-        HIPCHK(hipStreamCreateWithFlags(&impl->side, hipStreamNonBlocking));
+        if (int rc = stream_pool_acquire(&impl->side, &stream, 1)) return rc;      // on another hardware pipe than the caller's stream
         HIPCHK(hipEventCreateWithFlags(&impl->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&impl->ev_join, hipEventDisableTiming));
     }
@@ -735,7 +739,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     {   // spill regions: one per lane; a single lane whose shadow launches overlap the next closest-hit launch on the side stream
         // needs a second one (both kernels index their slices by block and wave)
         const size_t lane_paths = sample_lanes ? n : (n + (size_t)n_lanes - 1) / (size_t)n_lanes;
-        const size_t lane_blocks = std::min<size_t>(std::max(std::max(closest_cap, shadow_cap), grid_cap), (lane_paths + KB - 1) / KB + 1);
+        const size_t lane_blocks = std::min<size_t>(std::max(std::max(closest_cap, shadow_cap), grid_cap), fused_grid_factor() * ((lane_paths + KB - 1) / KB) + 1);
         if (int rc = ensure_qspill(impl->pb, impl->qspill_lane_words, impl->qspill_regions, (size_t)std::max(n_lanes, overlap ? 2 : 1), lane_blocks)) return rc;
     }
     auto& ev = impl->ev;
@@ -794,7 +798,9 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         return 0;
     }
     for (int l = 2; l < n_lanes; ++l) if (!impl->lane_stream[l]) {
-        HIPCHK(hipStreamCreateWithFlags(&impl->lane_stream[l], hipStreamNonBlocking));
+        hipStream_t taken[PT_LANES] = {stream, impl->side};
+        for (int k = 2; k < l; ++k) taken[k] = impl->lane_stream[k];
+        if (int rc = stream_pool_acquire(&impl->lane_stream[l], taken, l)) return rc;       // every lane on a pipe of its own
         HIPCHK(hipEventCreateWithFlags(&impl->lane_join[l], hipEventDisableTiming));
     }
     if (n_lanes > 1) {   // fork
@@ -811,7 +817,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         P.L.tiles_per_lane = even ? (uint)(tiles / (size_t)n_lanes) : 0u;
     }
     if (sample_lanes) for (int l = 0; l < n_lanes; ++l) if (!impl->pass_done[l]) HIPCHK(hipEventCreateWithFlags(&impl->pass_done[l], hipEventDisableTiming));
-    struct LaneCtx { hipStream_t ls; PtParams LP; PathBuffers lb; uint blocks_all, blocks_q; bool shadow_in_flight; };
+    struct LaneCtx { hipStream_t ls; PtParams LP; PathBuffers lb; uint blocks_all, blocks_q, blocks_f; bool shadow_in_flight; };
     LaneCtx lane_ctx[PT_LANES];
     int lanes_used = 0;
     for (int lane = 0; lane < n_lanes; ++lane) {
@@ -838,6 +844,10 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         c.blocks_all = (c.LP.n_ids + KB - 1) / KB;
         // persistent-style launch for the queue kernels: enough blocks to fill the chip, grid-stride over the queue
         c.blocks_q = c.blocks_all < grid_cap ? c.blocks_all : grid_cap;
+        // The fused launch carries two queues (closest-hit rays of this bounce, shadow rays of the last one): a small frame - a rank's share
+        // of a multi-GPU job - leaves the chip room for a wave per chunk of both, and then the launch lasts as long as the longer of the two
+        // traversals instead of their sum (a 1/8 strip of sponza_teapots: 165 -> 12x us per fused launch, profiles/r5/strip_timeline.txt)
+        c.blocks_f = std::min(grid_cap, c.blocks_all * fused_grid_factor());
         c.shadow_in_flight = false;
         lanes_used = lane + 1;
     }
@@ -850,7 +860,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         const hipStream_t ls = c.ls;
         PtParams& LP = c.LP;
         PathBuffers& lb = c.lb;
-        const uint blocks_all = c.blocks_all, blocks_q = c.blocks_q;
+        const uint blocks_all = c.blocks_all, blocks_q = c.blocks_q, blocks_f = c.blocks_f;
         bool& shadow_in_flight = c.shadow_in_flight;
         {
             LP.previous_samples = (uint)pass * (uint)opt.samples_per_pass;
@@ -867,7 +877,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                     uint* bc = lb.bounce + BC_STRIDE * bounce;
                     if (fused && bounce > 0) {
                         // closest(b) together with shadow(b - 1): one launch, one tail
-                        hipLaunchKernelGGL(wide ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_q), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
+                        hipLaunchKernelGGL(wide ? k_trace_fused<true> : k_trace_fused<false>, dim3(blocks_f), dim3(KB), 0, ls, sv, LP, lb, bounce, q, bc, bc - BC_STRIDE);
                     } else {
                         timed(T_CLOSEST, ls, [&] {
                             auto kc = count ? k_trace_closest<true, false> : (timing ? (wide ? k_trace_closest<false, true, true> : k_trace_closest<false, true, false>)

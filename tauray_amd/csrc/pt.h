@@ -7,6 +7,12 @@ namespace tr {
 
 void get_ray_count(const trhip_distribution& d, uint& w, uint& h);
 
+// Streams of the current device, kept for the life of the process and classified by hardware pipe (stream_pool.hip): a new stream
+// for a taker whose launches must overlap those of `overlap_with` (streams of any origin, the null stream included).
+int stream_pool_acquire(hipStream_t* out, const hipStream_t* overlap_with = nullptr, int n_overlap = 0);
+void stream_pool_release(hipStream_t s);
+int stream_pool_class(hipStream_t s, int* cls);     // -1: unknown (TRHIP_PIPE_PROBE=0)
+
 class PtStage {
 public:
     PtStage(DeviceScene* scene, const trhip_pt_options& opt);

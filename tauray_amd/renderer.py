@@ -146,6 +146,13 @@ class Context:
     def destroy_stream(self, stream):
         check(_lib.lib().trhip_stream_destroy(self.h, stream))
 
+    def stream_pipe_class(self, stream=None) -> int:
+        """The hardware pipe (a small integer) the queue of `stream` sits on (None = the default stream); launches that fill the chip
+        overlap only between streams of different pipes (csrc/stream_pool.hip)."""
+        c = C.c_int32(-1)
+        check(_lib.lib().trhip_stream_pipe_class(self.h, stream, C.byref(c)))
+        return c.value
+
     def stream_wait(self, stream, on):
         """Work enqueued on `stream` from now on waits for what is on `on` now (None = the default stream)."""
         check(_lib.lib().trhip_stream_wait(self.h, stream, on))

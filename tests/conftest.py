@@ -24,6 +24,8 @@ def _usable_cpus():
 
 # the oracle's OpenMP loops: as many threads as there are CPUs to run them (256 threads on 16 CPUs cost more than they compute)
 os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cpus()))
+# what tauray_amd/_lib.py sets on import - but _has_gpu() below starts the HIP runtime first, and the runtime reads it once
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):
