@@ -582,7 +582,7 @@ def main():
     # what DESIGN.md section 6 expects of this run from one-GPU probes (a rank's strip one frame at a time / with frames in flight, before the transport)
     # what N ranks can reach before the transport costs anything: the whole frame's time over the time of one rank's share, rendered alone on
     # one GPU under each of the three definitions (tools/shard_share_probe.py, profiles/r5/shard_share_probe_sponza_teapots.txt: balanced strips)
-    expected = {1: (1.0, 1.0, 1.0), 2: (1.72, 1.85, 1.87), 4: (3.13, 3.22, 3.54), 8: (4.96, 5.60, 6.30)}.get(world)
+    expected = {1: (1.0, 1.0, 1.0), 2: (1.72, 1.78, 1.87), 4: (3.13, 3.29, 3.54), 8: (4.96, 6.24, 6.30)}.get(world)
 
     result = {
         "metric": "Mray/s (closest-hit + shadow rays traced) @%dx%d, %d bounces, %d spp" % (W, H, args.bounces, args.spp),

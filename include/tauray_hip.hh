@@ -551,7 +551,7 @@ public:
                 path_tracer_stage::options po = this->opt;
                 po.distribution = d.dist;
                 sl.ray_tracer = std::make_unique<Pipeline>(*d.dev, *d.scene_update, sl.color, po);
-                if(n_slots > 1) { sl.ray_tracer->set_lanes(1); sl.ray_tracer->set_frame_slots(n_slots); }   // the frames in flight fill the chip between them
+                if(n_slots > 1) { sl.ray_tracer->set_frame_slots(n_slots); }   // the frames in flight fill the chip between them
                 if(batch > 1) sl.ray_tracer->set_frame_batch(batch);
                 if(i != 0) sl.gbuffer_copy = per_device[0].dev->alloc(d.max_bytes);   // receive buffer on the display device
             }

@@ -162,7 +162,7 @@ public:
             path_tracer_stage::options po = this->opt;
             po.distribution = dists[(size_t)rank];
             sl.ray_tracer = std::make_unique<Pipeline>(dev, scene_update, sl.color, po);
-            if(n_slots > 1) { sl.ray_tracer->set_lanes(1); sl.ray_tracer->set_frame_slots(n_slots); }
+            if(n_slots > 1) { sl.ray_tracer->set_frame_slots(n_slots); }
             if(rank == 0)
             {
                 sl.display = dev.alloc(size_t(size.x) * size.y * 16 * layers);

@@ -706,8 +706,14 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     //    in flight like the frames of a renderer with frame slots (3.4 instead of 4.0 ms per sample on sponza_class).  A pass
     //    ends in k_resolve, which blends into the targets and therefore runs in pass order: each one waits for the previous
     //    pass's, on whatever lane that ran.
-    const int n_lanes = sample_lanes ? sample_lane_count
-                                     : (timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : (n < lanes_min_paths ? 1 : std::max(1, std::min(n < 2 * lanes_min_paths ? std::min(lanes_env, 2) : lanes_env, PT_LANES)))));
+    //  * a stage of a renderer with frames in flight (trhip_pt_set_frame_slots): the frames overlap each other, so one lane per frame -
+    //    except with two slots, where two lanes each put the pair on all four hardware pipes (two in flight, one frame per launch:
+    //    3.57 -> 3.43 ms on sponza_teapots, 3.05 -> 2.92 sponza_class, 1.80 -> 1.66 test.glb; profiles/r5/two_in_flight_lanes.txt)
+    static const size_t slots2_min_paths = getenv("TRHIP_SLOTS2_MIN_PATHS") ? (size_t)atol(getenv("TRHIP_SLOTS2_MIN_PATHS")) : (size_t)50000;
+    const int auto_lanes = frame_slots >= 3 ? 1
+                         : frame_slots == 2 ? (n < slots2_min_paths ? 1 : std::min(lanes_env, 2))
+                         : (n < lanes_min_paths ? 1 : std::max(1, std::min(n < 2 * lanes_min_paths ? std::min(lanes_env, 2) : lanes_env, PT_LANES)));
+    const int n_lanes = sample_lanes ? sample_lane_count : (timing ? 1 : (lanes > 0 ? std::min(lanes, PT_LANES) : auto_lanes));
     // shadow(b) rides in the launch of closest(b + 1) unless kernels are being timed or counted one by one
     static const bool fused_enabled = !(getenv("TRHIP_FUSED") && atoi(getenv("TRHIP_FUSED")) == 0);
     const bool first_hit_targets = targets.albedo || targets.material || targets.normal || targets.pos || targets.instance_id || targets.screen_motion;
@@ -728,7 +734,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     // sponza_teapots.  Frame slots (one lane per frame, whole frames per launch) and sample lanes keep the larger grids: pipelined 3.29 ms
     // against 3.37 with the small ones.
     const bool pixel_lanes = n_lanes >= 3 && !sample_lanes;
-    const bool few_slots = n_lanes == 1 && (frame_slots == 2 || frame_slots == 3);      // trhip_pt_set_frame_slots: trace launches of three blocks per CU
+    const bool few_slots = (n_lanes == 1 && (frame_slots == 2 || frame_slots == 3)) || (n_lanes == 2 && frame_slots == 2);      // trhip_pt_set_frame_slots: trace launches of three blocks per CU
     const uint grid_cap = (!timing && !getenv("TRHIP_GRID_BLOCKS")) ? ((pixel_lanes || few_slots) ? 768u : 1024u) : trace_grid_cap();
     // A trace kernel that is timed alone gets exactly the blocks that are resident at its register budget (persistent waves: a
     // block that has to wait for a slot only lengthens the tail): 1536 for the closest-hit kernel, 0.544 -> 0.527 ms per launch
@@ -890,7 +896,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
                         // k_shade holds three waves per SIMD (768 resident blocks) and strides over the queue; 2048 blocks since the
                         // trace launches of a frame slot shrank to 1024 (round 2 sweep: profiles/r2/schedule_sweep.txt)
                         static const uint shade_cap_env = getenv("TRHIP_SHADE_BLOCKS") ? (uint)atoi(getenv("TRHIP_SHADE_BLOCKS")) : 0u;
-                        const uint shade_cap = shade_cap_env ? shade_cap_env : (pixel_lanes ? 768u : 2048u);
+                        const uint shade_cap = shade_cap_env ? shade_cap_env : ((pixel_lanes || (n_lanes == 2 && frame_slots == 2)) ? 768u : 2048u);
                         const uint blocks_s = timing ? blocks_q : (blocks_all < shade_cap ? blocks_all : shade_cap);   // alone on the chip it wants the full grid
                         static const bool last_variant = !(getenv("TRHIP_SHADE_LAST") && atoi(getenv("TRHIP_SHADE_LAST")) == 0);
                         const bool last = last_variant && bounce == opt.max_bounces - 1;

@@ -651,8 +651,7 @@ class RtRenderer:
             if frames_per_launch > 1:
                 slot.pt.set_frame_batch(frames_per_launch)
             if frames_in_flight > 1:
-                slot.pt.set_lanes(1)             # the frames in flight fill the chip between them
-                slot.pt.set_frame_slots(frames_in_flight)
+                slot.pt.set_frame_slots(frames_in_flight)    # the frames in flight fill the chip between them: the stage picks one lane (two with two slots)
                 slot.stream = ctx.create_stream()
             slot.color = self._alloc_color(viewports, tw, th)
             self.slots.append(slot)
