@@ -814,23 +814,28 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));
         for (int l = 2; l < n_lanes; ++l) HIPCHK(hipStreamWaitEvent(impl->lane_stream[l], impl->ev_fork, 0));
     }
-    const uint per_lane = sample_lanes ? (uint)n : (uint)((((n + n_lanes - 1) / n_lanes + 63) / 64) * 64);   // whole 8x8 tiles per lane
-    {   // interleave the lanes' tiles when the image is whole tiles and divides evenly (always true for 1080p / 4 lanes)
+    // Slices: a lane may render its pixels as several slices one after the other (TRHIP_LANE_SLICES, an experiment: the frame ends with
+    // the tails of smaller slices).  Slice i runs on the stream of lane i mod n_lanes and reuses that lane's counters and spill region.
+    static const int slices_env = getenv("TRHIP_LANE_SLICES") ? std::max(1, std::min(atoi(getenv("TRHIP_LANE_SLICES")), 4)) : 1;
+    const int n_slices = (sample_lanes || n_lanes < 2) ? n_lanes : n_lanes * slices_env;
+    const uint per_lane = sample_lanes ? (uint)n : (uint)((((n + n_slices - 1) / n_slices + 63) / 64) * 64);   // whole 8x8 tiles per slice
+    {   // interleave the slices' tiles when the image is whole tiles and divides evenly (always true for 1080p / 4 lanes)
         const size_t tiles = n / 64;
-        const bool even = !sample_lanes && viewports == 1 && (lw & 7u) == 0 && (lh & 7u) == 0 && n_lanes > 1 && tiles % (size_t)n_lanes == 0 &&
-                          (size_t)per_lane * (size_t)n_lanes == n;
-        P.L.tile_lanes = even ? (uint)n_lanes : 1u;
-        P.L.tiles_per_lane = even ? (uint)(tiles / (size_t)n_lanes) : 0u;
+        const bool even = !sample_lanes && viewports == 1 && (lw & 7u) == 0 && (lh & 7u) == 0 && n_slices > 1 && tiles % (size_t)n_slices == 0 &&
+                          (size_t)per_lane * (size_t)n_slices == n;
+        P.L.tile_lanes = even ? (uint)n_slices : 1u;
+        P.L.tiles_per_lane = even ? (uint)(tiles / (size_t)n_slices) : 0u;
     }
     if (sample_lanes) for (int l = 0; l < n_lanes; ++l) if (!impl->pass_done[l]) HIPCHK(hipEventCreateWithFlags(&impl->pass_done[l], hipEventDisableTiming));
     struct LaneCtx { hipStream_t ls; PtParams LP; PathBuffers lb; uint blocks_all, blocks_q, blocks_f; bool shadow_in_flight; };
-    LaneCtx lane_ctx[PT_LANES];
+    LaneCtx lane_ctx[PT_LANES * 4];
     int lanes_used = 0;
-    for (int lane = 0; lane < n_lanes; ++lane) {
-        LaneCtx& c = lane_ctx[lane];
+    for (int slice = 0; slice < n_slices; ++slice) {
+        const int lane = slice % n_lanes;      // the stream, the counters and the spill region
+        LaneCtx& c = lane_ctx[slice];
         c.ls = lane == 0 ? stream : (lane == 1 ? impl->side : impl->lane_stream[lane]);
         c.LP = P;
-        c.LP.id_offset = sample_lanes ? 0u : (uint)lane * per_lane;
+        c.LP.id_offset = sample_lanes ? 0u : (uint)slice * per_lane;
         if (c.LP.id_offset >= n) break;
         c.LP.n_ids = std::min(per_lane, (uint)n - c.LP.id_offset);
         PathBuffers& lb = c.lb;
@@ -855,7 +860,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         // traversals instead of their sum (a 1/8 strip of sponza_teapots: 165 -> 12x us per fused launch, profiles/r5/strip_timeline.txt)
         c.blocks_f = std::min(grid_cap, c.blocks_all * fused_grid_factor());
         c.shadow_in_flight = false;
-        lanes_used = lane + 1;
+        lanes_used = slice + 1;
     }
     const int passes = passes_total;
     // every launch of one pass of one lane
@@ -947,12 +952,15 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         // TRHIP_ENQUEUE=skew<k>: lane l runs k steps behind lane l - 1 (0 = all lanes in step)
         static const int skew = (order_env && !strncmp(order_env, "skew", 4)) ? atoi(order_env + 4) : 0;
         const int n_steps = opt.max_bounces + 2;
-        for (int t = 0; t < n_steps + skew * (lanes_used - 1); ++t)
-            for (int lane = 0; lane < lanes_used; ++lane) {
-                const int step = t - skew * lane;
-                if (step < 0 || step >= n_steps) continue;
-                if (int rc = enqueue_pass(lane, 0, step - 1)) return rc;
-            }
+        for (int first = 0; first < lanes_used; first += n_lanes) {      // slices of one stream one after the other (they share its counters)
+            const int here = std::min(n_lanes, lanes_used - first);
+            for (int t = 0; t < n_steps + skew * (here - 1); ++t)
+                for (int lane = 0; lane < here; ++lane) {
+                    const int step = t - skew * lane;
+                    if (step < 0 || step >= n_steps) continue;
+                    if (int rc = enqueue_pass(first + lane, 0, step - 1)) return rc;
+                }
+        }
     } else {
         for (int lane = 0; lane < lanes_used; ++lane)
             for (int pass = 0; pass < passes; ++pass) if (int rc = enqueue_pass(lane, pass, -2)) return rc;
