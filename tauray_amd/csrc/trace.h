@@ -93,8 +93,25 @@ struct TriHit { float t, bu, bv; uint inst_flags, prim, alpha; };
 // Watertight test (Woop, Benthin, Wald 2013), no culling, of triangle record `index`.  Plain IEEE fp32 without
 // contraction: the shared-edge guarantee needs both products of each edge function
 // rounded, and the CPU oracle evaluates exactly the same expression tree.  The nine vertex components are taken in the ray's order.
+// Wave priority around the fetch of a phase (an experiment, -DTR_SETPRIO=1: low while a phase issues its loads, high from there to the
+// next phase's loads; =2: the other way round; profiles/r5/setprio_ab.txt).  Off: no instruction.
+#ifndef TR_SETPRIO
+#define TR_SETPRIO 0
+#endif
+#if TR_SETPRIO == 1
+#define TR_PRIO_BEGIN() __builtin_amdgcn_s_setprio(0)
+#define TR_PRIO_ISSUED() __builtin_amdgcn_s_setprio(2)
+#elif TR_SETPRIO == 2
+#define TR_PRIO_BEGIN() __builtin_amdgcn_s_setprio(2)
+#define TR_PRIO_ISSUED() __builtin_amdgcn_s_setprio(0)
+#else
+#define TR_PRIO_BEGIN()
+#define TR_PRIO_ISSUED()
+#endif
+
 TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, float tmin, float tmax, TriHit& o TL(, TlPhase* tlp = nullptr)) {
 #pragma clang fp contract(off)
+    TR_PRIO_BEGIN();
 #ifndef TR_TRI_FETCH_DWORDS
     // The record is three 16-byte loads - what a lane's L1 pays for is accesses, not bytes - and every component is picked out of the three
     // registers of its vertex with two selects (18 selects per test).  Round 5 measured both ways of not branching over the axes
@@ -103,6 +120,7 @@ TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, fl
     // (0.65 of its access rate), the VALUs are not (0.43).
     const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(tris) + (size_t)index * 48u);
     const f4 q0 = p[0], q1 = p[1], q2 = p[2];       // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 inst prim alpha
+    TR_PRIO_ISSUED();
     o.inst_flags = __float_as_uint(q2.y); o.prim = __float_as_uint(q2.z); o.alpha = __float_as_uint(q2.w);
     const uint kx4 = tri_component_offset(r.nkx), ky4 = tri_component_offset(r.nky), kz4 = tri_component_offset(r.nkz);
     auto pick = [](float x, float y, float z, uint k4) { const float xy = k4 == 4u ? y : x; return k4 == 8u ? z : xy; };
@@ -299,7 +317,9 @@ TR_DEV void box4_test(const RayPre& r, const Node4Data& d, float tmin, float tma
 }
 TR_DEV void box4_intersect(const RayPre& r, const Bvh4Node* nodes, int node, float tmin, float tmax, Hit4& h TL(, TlPhase* tlp = nullptr)) {
     Node4Data d;
+    TR_PRIO_BEGIN();
     box4_load(r, nodes, node, d);
+    TR_PRIO_ISSUED();
     TL(if (tlp) tlp->loads_issued();)
     box4_test(r, d, tmin, tmax, h);
 }

