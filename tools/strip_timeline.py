@@ -24,7 +24,7 @@ if sys.argv[1] == "render":
         if i == 10:
             t0 = time.perf_counter()
         rr.reset_accumulation(); rr.render_partial(); rr.sync()
-    print(f"{wname} 1/{world}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per frame under the tracer", file=sys.stderr)
+    print(f"{wname} 1/{world}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per frame (host wall time, with or without the tracer around it)", file=sys.stderr)
     rr.close()
     sys.exit(0)
 
