@@ -518,6 +518,7 @@ def main():
     sync_all(lone)
     elapsed = time.perf_counter() - t0
     rays_total, elapsed, _ = total_rays(lone, elapsed)
+    lone_lanes, lone_pipes = lone.slots[0].pt.lane_pipes()      # the schedule the timed frames ran with (trhip_pt_get_lane_pipes)
     ms_per_step = elapsed / steps * 1e3
     frame_times.sort()
 
@@ -608,6 +609,8 @@ def main():
                    "shading_program": {"general": "general kernels (or unknown: see identity)", "cli": "command-line set, ahead of time", "compiled": "compiled for the option set (hipRTC / kernel cache)"}[program["kind"]]
                                       + (", IEEE fp32" if program["ieee"] else ", Vulkan-grade arithmetic"),
                    "shading_program_identity": "%016x" % program["identity"],
+                   # lanes of a timed frame and the hardware pipe of each lane's stream: lanes on one pipe would run one after the other
+                   "lanes": lone_lanes, "lane_pipe_classes": lone_pipes,
                    "parallelism": ({"pixels": ("shuffled strips x%d, balanced shares + RCCL gather" if balance else "shuffled strips x%d + RCCL gather") if strips
                                     else "scanline-sharded x%d + RCCL gather", "views": "view-sharded x%d, no exchange",
                                     "samples": "sample-sharded x%d + RCCL reduce"}[args.shard] % world) if world > 1 else "single GPU",

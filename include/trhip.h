@@ -233,14 +233,17 @@ int trhip_pt_set_frame_counter(trhip_pt* pt, uint32_t frame_counter);
  * that are too small to fill the chip; four frames per launch cost 12 % less per frame. */
 int trhip_pt_set_frame_batch(trhip_pt* pt, uint32_t frames);
 /* How many slices of a frame the stage runs concurrently on its own streams: 0 = automatic
- * (four for frames of >= 1.5 M paths), 1 = everything on the caller's stream - the right choice with several frames in
- * flight, which fill the chip between them. */
+ * (by frame size: four lanes from 200 k paths, two from 100 k, each on a hardware pipe of its own - and by trhip_pt_set_frame_slots:
+ * two lanes per stage with two slots, one with more), 1 = everything on the caller's stream. */
 int trhip_pt_set_lanes(trhip_pt* pt, int lanes);
 /* A hint from a renderer with frame slots (MAX_FRAMES_IN_FLIGHT stages of the same scene, src/context.hh:26): how many stages render
  * next to this one on the device.  The stage sizes its persistent launches by it - with two or three frames in flight a trace launch of
  * three blocks per CU leaves the room the neighbours need (two slots: -0 ... 5 %, three: -3 ... 5 %), with four or more the larger grids
  * stay (profiles/r5/frame_slot_grids.txt).  0 (the default) = unknown.  Frames are the same bits whatever the hint. */
 int trhip_pt_set_frame_slots(trhip_pt* pt, int slots);
+/* The schedule of the stage's last render: how many lanes it ran (1 ... 4) and the hardware pipe class (trhip_stream_pipe_class) of each
+ * lane's stream, the caller's stream first.  Lanes on one pipe would have run one after the other. */
+int trhip_pt_get_lane_pipes(trhip_pt* pt, int32_t* lanes_out, int32_t pipe_classes_out[4]);
 /* View and sample sharding across devices (the reference itself only shards pixels,
  * src/distribution_strategy.cc).  Local layer l of the target shows viewport viewport_base + l * viewport_stride: that
  * viewport's camera (shader/scene.glsl:176-185) and its RNG stream (the viewport index seeds the sampler,

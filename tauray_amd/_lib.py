@@ -124,6 +124,7 @@ SYMBOLS = {
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
     "trhip_pt_set_frame_slots": (_i, [_vp, C.c_int]),
+    "trhip_pt_get_lane_pipes": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "trhip_pt_set_shading_arithmetic": (_i, [_vp, C.c_int]),
     "trhip_pt_set_specialization": (_i, [_vp, C.c_int]),
     "trhip_pt_precompile": (_i, [C.POINTER(PtOptionsC), C.c_int, C.c_int, C.c_int, C.c_char_p]),

@@ -707,6 +707,12 @@ int trhip_pt_set_frame_slots(trhip_pt* pt, int slots) {
     pt->stage->frame_slots = slots;
     return 0;
 }
+int trhip_pt_get_lane_pipes(trhip_pt* pt, int32_t* lanes_out, int32_t pipe_classes_out[4]) {
+    if (!pt || !lanes_out || !pipe_classes_out) return set_error("trhip_pt_get_lane_pipes: null argument");
+    *lanes_out = pt->stage->last_lanes;
+    for (int l = 0; l < 4; ++l) pipe_classes_out[l] = l < pt->stage->last_lanes ? pt->stage->last_lane_pipes[l] : -1;
+    return 0;
+}
 int trhip_pt_set_shading_arithmetic(trhip_pt* pt, int ieee) {
     if (!pt) return set_error("null trhip_pt");
     pt->stage->ieee_shading = ieee ? 1 : 0;

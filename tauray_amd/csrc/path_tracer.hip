@@ -809,6 +809,14 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         if (int rc = stream_pool_acquire(&impl->lane_stream[l], taken, l)) return rc;       // every lane on a pipe of its own
         HIPCHK(hipEventCreateWithFlags(&impl->lane_join[l], hipEventDisableTiming));
     }
+    if (n_lanes != last_lanes || stream != last_main) {     // what trhip_pt_get_lane_pipes reports (looked up when the schedule changes)
+        last_lanes = n_lanes; last_main = stream;
+        for (int l = 0; l < n_lanes && l < 4; ++l) {
+            int c = -1;
+            (void)stream_pool_class(l == 0 ? stream : (l == 1 ? impl->side : impl->lane_stream[l]), &c);
+            last_lane_pipes[l] = c;
+        }
+    }
     if (n_lanes > 1) {   // fork
         HIPCHK(hipEventRecord(impl->ev_fork, stream));
         HIPCHK(hipStreamWaitEvent(impl->side, impl->ev_fork, 0));

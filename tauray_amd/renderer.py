@@ -406,6 +406,15 @@ class PathTracerStage:
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 
+    def lane_pipes(self):
+        """(lanes, [hardware pipe class of each lane's stream]) of the last render; trhip_pt_get_lane_pipes."""
+        if not hasattr(_lib.lib(), "trhip_pt_get_lane_pipes"):
+            return 0, []
+        n = C.c_int32(0)
+        cls = (C.c_int32 * 4)()
+        check(_lib.lib().trhip_pt_get_lane_pipes(self.h, C.byref(n), cls))
+        return n.value, [cls[i] for i in range(n.value)]
+
     def set_frame_slots(self, slots: int):
         """Hint: how many stages render next to this one (a renderer's frames in flight); trhip_pt_set_frame_slots."""
         if hasattr(_lib.lib(), "trhip_pt_set_frame_slots"):      # an older build named by TRHIP_LIB (A/B runs) has no such hint

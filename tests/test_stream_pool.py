@@ -69,6 +69,16 @@ def test_a_renderer_is_as_fast_after_other_renderers_as_before(R, ctx):
         rr.close()
         return best
 
+    # a whole frame runs as four lanes, each on a pipe of its own, whatever streams exist already
+    whole = R.RtRenderer(ctx, sc, opt, (W, H), use_torch=False)
+    whole.render_partial(); whole.sync()
+    lanes, pipes = whole.slots[0].pt.lane_pipes()
+    whole.close()
+    probe = [ctx.create_stream() for _ in range(8)]
+    known = len({ctx.stream_pipe_class(s) for s in probe} | {ctx.stream_pipe_class(None)})      # pipes this process can reach: four on gfx950
+    for s in probe:
+        ctx.destroy_stream(s)
+    assert lanes == 4 and -1 not in pipes and len(set(pipes)) == min(4, known), (lanes, pipes, known)
     before = {l: strip_ms(l) for l in (2, 4)}
     held = [ctx.create_stream() for _ in range(3)]            # an application's own streams, idle
     slots = R.RtRenderer(ctx, sc, opt, (W, H), use_torch=False, frames_in_flight=4, frames_per_launch=2)
