@@ -35,40 +35,6 @@ namespace {
 // kernel running alone (the roofline measurement) apart from the overlapped launches of normal frames.
 // WIDE: the scene has RGBA16 textures.  The instances for scenes without (nearly all) pin SceneView::wide_textures to 0, and the
 // any-hit alpha test compiles to the one-dword fetch it always was (texture.h; profiles/r4/texture_format_ab.txt).
-#if TR_RAYS2
-// Experiment: two rays per lane, four waves per SIMD (trace_rays2.h).  Same launch interface; a chunk is 128 queue slots.
-template <bool COUNT, bool SOLO, bool WIDE = true>
-__global__ __launch_bounds__(KB, 4) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue, uint* bc) {
-    if (!WIDE) sv.wide_textures = 0;
-    __shared__ int s_rows[2 * TR_STACK_WORDS];
-    int* const lds_a = s_rows + TR_STACK_ROW0 + threadIdx.x;
-    int* const lds_b = s_rows + TR_STACK_WORDS + TR_STACK_ROW0 + threadIdx.x;
-    const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
-    TraceStats st = {};
-    uint rays = 0;
-    int overflow = 0;
-    const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
-    bool first = true;
-    while (true) {
-        uint base = 0;
-#ifdef TR_RAYS2_DEBUG_ONE_SLOT
-        const uint chunk = 64u;
-#else
-        const uint chunk = 128u;
-#endif
-        if (first) base = wave_id * chunk;
-        else {
-            if (n <= n_waves * chunk) break;
-            if ((threadIdx.x & 63) == 0) base = n_waves * chunk + atomicAdd(&bc[BC_CUR_CLOSEST], chunk);
-            base = __shfl(base, 0);
-        }
-        first = false;
-        if (base >= n) break;
-        closest_lane2<COUNT>(sv, P, pb, bounce, queue, base, n, lds_a, lds_b, st, overflow, rays);
-    }
-    flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, 0u);
-}
-#else
 template <bool COUNT, bool SOLO, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                       uint* bc) {
@@ -99,7 +65,6 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_closest(SceneVie
     flush_trace_counters<COUNT>(P, pb, overflow, 1000 + bounce, rays, 0u, st, max_vis);
     TL(__syncthreads(); for (uint i = threadIdx.x; i < (KB / 64) * TL_WORDS; i += KB) if (s_tl[i]) atomicAdd(&g_timeline[i % TL_WORDS], (unsigned long long)s_tl[i]);)
 }
-#endif
 
 template <bool COUNT, bool WIDE = true>
 __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView sv, PtParams P, PathBuffers pb, uint* bc) {

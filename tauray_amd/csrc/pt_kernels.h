@@ -8,9 +8,3 @@
 #include "pt_state.h"
 #include "shade_kernel.h"
 #include "trace_lanes.h"
-#ifndef TR_RAYS2
-#define TR_RAYS2 0
-#endif
-#if TR_RAYS2
-#include "trace_rays2.h"
-#endif
