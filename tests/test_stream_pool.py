@@ -91,3 +91,38 @@ def test_a_renderer_is_as_fast_after_other_renderers_as_before(R, ctx):
     for l in (2, 4):
         assert after[l] < before[l] * 1.12, (before, after)
     assert before[4] < before[2] * 1.05, before               # four lanes on four pipes are no slower than two (0.61 against 0.70 ms)
+
+
+@pytest.mark.gpu
+def test_two_slots_run_two_lanes_each_and_render_the_same_frames(R, ctx):
+    """A renderer with the reference's two frames in flight (MAX_FRAMES_IN_FLIGHT, src/context.hh:26) runs two lanes per slot, the four
+    on four pipes (above 50 k paths); three slots run one lane each.  Frames are the one-frame-at-a-time renderer's, bit for bit."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from tauray_amd.gltf import load_glb
+    W, H = 384, 256
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    opt = R.options_for_scene(scene, max_bounces=3)
+    serial = R.RtRenderer(ctx, scene, opt, (W, H), use_torch=False)
+    want = []
+    for _ in range(5):
+        serial.render()
+        want.append(serial.download("color"))
+    serial.close()
+    for F, lanes_expected in ((2, 2), (3, 1)):
+        rr = R.RtRenderer(ctx, scene, opt, (W, H), use_torch=False, frames_in_flight=F)
+        for i in range(5):
+            rr.render()
+        rr.sync()
+        pipes = []
+        for slot in rr.slots:
+            lanes, p = slot.pt.lane_pipes()
+            assert lanes == lanes_expected, (F, lanes)
+            pipes += p
+        if -1 not in pipes and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8:
+            assert len(set(pipes)) == min(len(pipes), 4), (F, pipes)      # no two lanes of the renderer on one pipe
+        for back in range(F):
+            i = 4 - back
+            assert np.array_equal(rr.slots[i % F].color.download((1, H, W, 4)), want[i]), f"F={F}: frame {i}"
+        rr.close()
