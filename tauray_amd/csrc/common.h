@@ -179,11 +179,16 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node layout");
 //   itself - the material has no albedo texture, alpha = albedo_factor.a for every point of the triangle, no fetch at all.  Bit 31 set:
 //   index of the triangle's AlphaTri record.  (Round 5: the test used to walk instance -> span -> three indices -> three vertices ->
 //   texture table -> texels, four dependent round trips inside a triangle phase that every other lane of the wave waits through.)
-struct alignas(16) TriRecord {
+// -DTR_TRI_STRIDE64=1 (an experiment, profiles/r5/tri_stride_ab.txt): records padded to 64 bytes, so that none straddles a 128-byte line
+// (three of eight 48-byte records do)
+#ifndef TR_TRI_STRIDE64
+#define TR_TRI_STRIDE64 0
+#endif
+struct alignas(TR_TRI_STRIDE64 ? 64 : 16) TriRecord {
     float v0[3], v1[3], v2[3];
     uint inst_flags, prim, alpha;
 };
-static_assert(sizeof(TriRecord) == 48, "tri layout");
+static_assert(sizeof(TriRecord) == (TR_TRI_STRIDE64 ? 64 : 48), "tri layout");
 // One per triangle of a non-opaque instance, at alpha_base[instance] + primitive: texture coordinates of the three vertices,
 // albedo_factor.a and the albedo texture (get_interpolated_vertex_light + the alpha tap of shader/rt_common.rahit:15-24 in one 32-byte fetch).
 struct alignas(16) AlphaTri { f2 uv0, uv1, uv2; float factor; int tex; };

@@ -118,7 +118,7 @@ TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, fl
     // (profiles/r5/triangle_fetch_ab.txt): nine 4-byte loads at per-lane offsets 4 kx / 4 ky / 4 kz cost no vector instruction at all and ten
     // L1 accesses instead of three; the selects win by 4 % of the closest-hit kernel - the vector L1 is the busiest unit of these kernels
     // (0.65 of its access rate), the VALUs are not (0.43).
-    const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(tris) + (size_t)index * 48u);
+    const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(tris) + (size_t)index * (uint)sizeof(TriRecord));
     const f4 q0 = p[0], q1 = p[1], q2 = p[2];       // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 inst prim alpha
     TR_PRIO_ISSUED();
     o.inst_flags = __float_as_uint(q2.y); o.prim = __float_as_uint(q2.z); o.alpha = __float_as_uint(q2.w);
@@ -130,7 +130,7 @@ TR_DEV bool tri_intersect(const RayPre& r, const TriRecord* tris, uint index, fl
 #else
     // variant for the A/B: nine 4-byte loads at per-lane offsets, no select
     const char* base = reinterpret_cast<const char*>(tris);
-    const uint rec = index * 48u;
+    const uint rec = index * (uint)sizeof(TriRecord);
     const uint ox = rec + tri_component_offset(r.nkx), oy = rec + tri_component_offset(r.nky), oz = rec + tri_component_offset(r.nkz);
     const float v0x = *reinterpret_cast<const float*>(base + (size_t)ox), v1x = *reinterpret_cast<const float*>(base + (size_t)ox + 12), v2x = *reinterpret_cast<const float*>(base + (size_t)ox + 24);
     const float v0y = *reinterpret_cast<const float*>(base + (size_t)oy), v1y = *reinterpret_cast<const float*>(base + (size_t)oy + 12), v2y = *reinterpret_cast<const float*>(base + (size_t)oy + 24);
