@@ -17,12 +17,14 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #ifdef TAURAY_HIP_WITH_ZLIB
@@ -392,6 +394,8 @@ public:
     // slices of a frame run concurrently inside the stage: 0 = automatic, 1 = none (several frames in flight instead)
     void set_lanes(int lanes) { check(trhip_pt_set_lanes(pt, lanes)); }
     void set_frame_slots(int slots) { check(trhip_pt_set_frame_slots(pt, slots)); }
+    // the last pass of a frame also writes tonemap(colour) into `display` (a renderer with nothing between this stage and its tonemap stage)
+    void set_fused_tonemap(void* display, const trhip_tonemap_info* info) { check(trhip_pt_set_fused_tonemap(pt, display, info)); }
     // which shading program renders this stage (general kernels / the command-line set's ahead-of-time instances / compiled for the option
     // set), resolved now, and its identity - what the devices of a job compare before the first frame (trhip_pt_get_program)
     trhip_program_info program() const { trhip_program_info p; check(trhip_pt_get_program(pt, &p)); return p; }
@@ -448,10 +452,11 @@ public:
         bool alpha_grid_background = false;
     };
     tonemap_stage(device& dev, const options& opt): dev(&dev), opt(opt) {}
+    trhip_tonemap_info info() const { return {(int32_t)opt.tonemap_operator, opt.exposure, opt.gamma, opt.alpha_grid_background ? 16 : 0}; }
     void run(const void* in, void* out, uvec2 size, uint32_t layers, void* stream = nullptr)
     {
-        trhip_tonemap_info info = {(int32_t)opt.tonemap_operator, opt.exposure, opt.gamma, opt.alpha_grid_background ? 16 : 0};
-        check(trhip_tonemap(dev->h, in, out, size.x, size.y, layers, &info, stream));
+        const trhip_tonemap_info i = info();
+        check(trhip_tonemap(dev->h, in, out, size.x, size.y, layers, &i, stream));
     }
     device* dev;
     options opt;
@@ -561,6 +566,15 @@ public:
         for(frame_slot& fs: frame_slots) fs.display = per_device[0].dev->alloc(display_bytes);
         display = frame_slots[0].display;
         tonemap = std::make_unique<tonemap_stage>(*per_device[0].dev, this->opt.tonemap);
+        // One device: nothing sits between the path tracer and the tonemap stage (no transfer, no stitch), and the stage writes the slot's
+        // display image while it writes its colour target - the same bits without a second pass over the frame.  TRHIP_FUSED_TONEMAP=0: off.
+        const char* fe = getenv("TRHIP_FUSED_TONEMAP");
+        fused_tonemap = std::is_same<Pipeline, path_tracer_stage>::value && per_device.size() == 1 && !(fe && atoi(fe) == 0);
+        if(fused_tonemap)
+        {
+            const trhip_tonemap_info ti = tonemap->info();
+            for(size_t k = 0; k < frame_slots.size(); ++k) per_device[0].slots[k].ray_tracer->set_fused_tonemap(frame_slots[k].display, &ti);
+        }
     }
 
     ~basic_rt_renderer()
@@ -642,7 +656,7 @@ public:
             stitch_blend_ratio = 1.0f;      // src/rt_renderer.cc:122
         }
         display = frame_slots[k].display;
-        tonemap->run(per_device[0].slots[k].color, display, size, layers, display_stream);
+        if(!fused_tonemap) tonemap->run(per_device[0].slots[k].color, display, size, layers, display_stream);
         frame_index += batch;
         accumulated_frames++;
     }
@@ -706,6 +720,7 @@ public:
     void* display = nullptr;          // frame_slots[current_slot].display
     size_t display_bytes = 0;
     std::unique_ptr<tonemap_stage> tonemap;
+    bool fused_tonemap = false;
     unsigned accumulated_frames = 0;
     float stitch_blend_ratio = 1.0f;
 };

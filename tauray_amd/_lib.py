@@ -124,6 +124,7 @@ SYMBOLS = {
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),
     "trhip_pt_set_lanes": (_i, [_vp, C.c_int]),
     "trhip_pt_set_frame_slots": (_i, [_vp, C.c_int]),
+    "trhip_pt_set_fused_tonemap": (_i, [_vp, _vp, _vp]),
     "trhip_pt_get_lane_pipes": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "trhip_pt_set_shading_arithmetic": (_i, [_vp, C.c_int]),
     "trhip_pt_set_specialization": (_i, [_vp, C.c_int]),

@@ -10,6 +10,7 @@
 #include "trace.h"
 #include "trace_quad.h"
 #include "specialize.h"
+#include "tonemap.h"
 #include "../../include/tauray_image.hh"
 #include "../../include/tauray_exr.hh"
 
@@ -213,31 +214,7 @@ __global__ __launch_bounds__(KB) void k_tonemap(const f4* in, f4* out, uint w, u
     size_t i = (size_t)blockIdx.x * KB + threadIdx.x;
     size_t n = (size_t)w * h * layers;
     if (i >= n) return;
-    f4 col = in[i];
-    f3 c;
-    if (op <= 1) c = F3(col) * exposure;
-    else if (op == 2) {
-        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
-        c = max3(F3(0.0f), c - 0.004f);
-        f3 q = (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
-        c = F3(powf(q.x, 2.2f), powf(q.y, 2.2f), powf(q.z, 2.2f));
-    } else if (op == 3) {
-        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
-        c = c / (F3(1.0f) + c);
-    } else {
-        c = min3(max3(F3(col) * exposure, F3(0)), F3(1000));
-        float lum = rgb_to_luminance(c);
-        float new_lum = lum / (1.0f + lum);
-        c = c / fmax2(lum, 1e-4f) * new_lum;
-    }
-    if (gamma != 1.0f) { float ig = 1.0f / gamma; c = F3(powf(c.x, ig), powf(c.y, ig), powf(c.z, ig)); }
-    if (grid != 0) {
-        uint x = (uint)(i % w), y = (uint)((i / w) % h);
-        int gx = (int)(x / (uint)grid) & 1, gy = (int)(y / (uint)grid) & 1;
-        f3 ac = (gx ^ gy) == 0 ? F3(0.4f) : F3(0.6f);
-        c = mix3(ac, c, col.w);
-    }
-    out[i] = F4(c, col.w);
+    out[i] = tonemap_pixel(in[i], op, exposure, gamma, grid, (uint)(i % w), (uint)((i / w) % h));
 }
 
 template <typename T>
@@ -705,6 +682,14 @@ int trhip_pt_set_frame_slots(trhip_pt* pt, int slots) {
     if (!pt) return set_error("null trhip_pt");
     if (slots < 0) return set_error("trhip_pt_set_frame_slots: slots must be >= 0");
     pt->stage->frame_slots = slots;
+    return 0;
+}
+int trhip_pt_set_fused_tonemap(trhip_pt* pt, void* display_dev, const trhip_tonemap_info* info) {
+    if (!pt) return set_error("null trhip_pt");
+    if (display_dev && !info) return set_error("trhip_pt_set_fused_tonemap: null info");
+    if (display_dev && pt->stage->direct) return set_error("trhip_pt_set_fused_tonemap: the direct stage resolves its samples in a kernel of its own; run trhip_tonemap");
+    pt->stage->tm_display = display_dev;
+    if (info) { pt->stage->tm_info = *info; if (info->op == 0) pt->stage->tm_info.gamma = 1.0f; }   // src/tonemap_stage.cc:159
     return 0;
 }
 int trhip_pt_get_lane_pipes(trhip_pt* pt, int32_t* lanes_out, int32_t pipe_classes_out[4]) {

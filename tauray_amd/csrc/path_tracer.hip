@@ -601,6 +601,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
     P.bounce_words = (uint)BC_STRIDE * ((uint)opt.max_bounces + 2u);
     P.fused_resolve = opt.samples_per_pass == 1;
     P.T = targets;
+    P.tm_display = nullptr; P.tm_op = tm_info.op; P.tm_exposure = tm_info.exposure; P.tm_gamma = tm_info.gamma; P.tm_grid = tm_info.alpha_grid_background;
     const bool timing = detailed_timing != 0;
     // A frame of several one-sample passes can keep whole samples in flight instead of slices of one (see "sample lanes" below):
     // every lane then needs path state for all n paths.
@@ -907,6 +908,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
             if (only != -2 && only != opt.max_bounces) return 0;
             // sample lanes: the targets have seen pass - 1 before this pass blends into them
             if (sample_lanes && pass > 0) HIPCHK(hipStreamWaitEvent(ls, impl->pass_done[(pass - 1) % n_lanes], 0));
+            LP.tm_display = (pass == passes - 1 && !direct) ? reinterpret_cast<f4*>(tm_display) : nullptr;      // the frame's last pass leaves the final colour
             timed(T_RESOLVE, ls, [&] { hipLaunchKernelGGL(k_resolve, dim3(blocks_all), dim3(KB), 0, ls, LP, lb); });
             if (sample_lanes && pass + 1 < passes) HIPCHK(hipEventRecord(impl->pass_done[lane], ls));
         }

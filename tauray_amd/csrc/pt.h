@@ -36,6 +36,8 @@ public:
     int lanes = 0;                   // trhip_pt_set_lanes: 0 = automatic
     int last_lanes = 0, last_lane_pipes[4] = {-1, -1, -1, -1};      // trhip_pt_get_lane_pipes
     hipStream_t last_main = nullptr;
+    void* tm_display = nullptr;      // trhip_pt_set_fused_tonemap
+    trhip_tonemap_info tm_info{};
     uint frame_batch = 1;            // trhip_pt_set_frame_batch: consecutive frames per render() call
     int ieee_shading = -1;           // trhip_pt_set_shading_arithmetic: 1 = k_shade at IEEE fp32 for every option set, 0 = Vulkan-grade arithmetic for the command-line set, -1 = TRHIP_SHADE_FAST decides
     int specialize = -1;             // trhip_pt_set_specialization: 1 = a shading program compiled for this stage's option set (hipRTC / kernel cache), 0 = the general kernels, -1 = TRHIP_SPECIALIZE decides (default on)

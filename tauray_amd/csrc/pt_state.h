@@ -70,6 +70,8 @@ struct PtParams {
     uint bounce_words;            // size of PathBuffers::bounce for one lane
     int fused_resolve;            // samples_per_pass == 1: k_resolve forms the sample's colour itself
     trhip_pt_targets T;           // device images; null = target not requested
+    f4* tm_display;               // trhip_pt_set_fused_tonemap: the last pass's k_resolve also writes tonemap(colour) here (null = off)
+    int tm_op; float tm_exposure, tm_gamma; int tm_grid;
 };
 
 

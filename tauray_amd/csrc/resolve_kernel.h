@@ -2,6 +2,7 @@
 // into the targets (write_all_outputs, shader/path_tracer.glsl:535-576; shader/gbuffer.glsl:18-28).  Device-only.
 #pragma once
 #include "pt_state.h"
+#include "tonemap.h"
 
 namespace tr {
 
@@ -46,6 +47,7 @@ TR_DEV void resolve_path(const PtParams& P, const PathBuffers& pb, uint i) {   /
         f4* target = reinterpret_cast<f4*>(image);
         if (prev_samples != 0) value = mix4(value, target[idx], keep);
         target[idx] = value;
+        if (P.tm_display && image == P.T.color) P.tm_display[idx] = tonemap_pixel(value, P.tm_op, P.tm_exposure, P.tm_gamma, P.tm_grid, (uint)wx, (uint)wy);
     };
     if (P.fused_resolve) {
         // one sample per pass: the sums are the sample itself (0 + x and x / 1 are exact), k_accumulate_sample is not launched.

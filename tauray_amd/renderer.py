@@ -16,6 +16,7 @@ TrhipError where the reference throws std::runtime_error):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -406,6 +407,10 @@ class PathTracerStage:
     def set_lanes(self, lanes: int):
         check(_lib.lib().trhip_pt_set_lanes(self.h, lanes))
 
+    def set_fused_tonemap(self, display, info):
+        """The stage's last pass writes tonemap(colour) into `display` as it writes the colour target (None: off); trhip_pt_set_fused_tonemap."""
+        check(_lib.lib().trhip_pt_set_fused_tonemap(self.h, None if display is None else _ptr(display), None if info is None else C.byref(info)))
+
     def lane_pipes(self):
         """(lanes, [hardware pipe class of each lane's stream]) of the last render; trhip_pt_get_lane_pipes."""
         if not hasattr(_lib.lib(), "trhip_pt_get_lane_pipes"):
@@ -649,6 +654,11 @@ class RtRenderer:
             import torch
             self._torch = torch
         self.frames_in_flight = frames_in_flight
+        self.tonemap = TonemapStage(ctx, **(tonemap or {}))
+        # rt_renderer on one device has nothing between path_tracer_stage and tonemap_stage: the stage writes the display image itself
+        # (trhip_pt_set_fused_tonemap: the same bits without the second pass over the frame); TRHIP_FUSED_TONEMAP=0 keeps the stage
+        self.fused_tonemap = (world_size == 1 and (stage_cls is None or stage_cls is PathTracerStage) and viewports > 0
+                              and hasattr(_lib.lib(), "trhip_pt_set_fused_tonemap") and os.environ.get("TRHIP_FUSED_TONEMAP", "1") != "0")
         self.slots = []
         for k in range(frames_in_flight):
             slot = _FrameSlot()
@@ -663,11 +673,13 @@ class RtRenderer:
                 slot.pt.set_frame_slots(frames_in_flight)    # the frames in flight fill the chip between them: the stage picks one lane (two with two slots)
                 slot.stream = ctx.create_stream()
             slot.color = self._alloc_color(viewports, tw, th)
+            if self.fused_tonemap:
+                slot.display = self._alloc_display(viewports)
+                slot.pt.set_fused_tonemap(slot.display, self.tonemap.info)
             self.slots.append(slot)
         self.current = self.slots[0]
         self.stitch = StitchStage(ctx, self.size) if (world_size > 1 and self.shard == "pixels") else None
         self.all_views = None
-        self.tonemap = TonemapStage(ctx, **(tonemap or {}))
         self.recv_buffers = {}
         self.accumulated_frames = 0
         self.frame_index = 0
@@ -689,6 +701,12 @@ class RtRenderer:
         if self.use_torch:
             return self._torch.zeros((viewports, th, tw, 4), dtype=self._torch.float32, device=f"cuda:{self.ctx.hip_device}")
         return self.ctx.alloc(max(viewports * tw * th, 1) * 16).zero()
+
+    def _alloc_display(self, viewports):
+        w, h = self.size
+        if self.use_torch:
+            return self._torch.empty((viewports, h, w, 4), dtype=self._torch.float32, device=f"cuda:{self.ctx.hip_device}")
+        return self.ctx.alloc(viewports * w * h * 16)
 
     def _device_dists(self, ratios) -> List[DistributionParams]:
         out, cumulative = [], 0.0
@@ -849,7 +867,7 @@ class RtRenderer:
         self.render_partial()
         slot = self.current
         if self.world_size == 1:
-            if tonemap:
+            if tonemap and not self.fused_tonemap:
                 self.post_process(slot.stream)       # the whole frame stays on its slot's stream
             self.accumulated_frames += 1
             return
@@ -889,10 +907,7 @@ class RtRenderer:
             return
         slot = self.current
         if slot.display is None:
-            if self.use_torch:
-                slot.display = self._torch.empty((self.viewports, h, w, 4), dtype=self._torch.float32, device=slot.color.device)
-            else:
-                slot.display = self.ctx.alloc(self.viewports * w * h * 16)
+            slot.display = self._alloc_display(self.viewports)
         self.tonemap.run(slot.color, slot.display, w, h, self.viewports, stream)
 
     def download(self, which="color") -> np.ndarray:

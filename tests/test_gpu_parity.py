@@ -2451,3 +2451,44 @@ def test_schedule_and_experiment_switches_render_the_same_frame(tmp_path):
         base = ieee if tag.startswith("ieee_") else ref
         assert np.array_equal(f, base), f"{tag}: {int((f != base).any(-1).sum())} pixels differ from the {'IEEE' if base is ieee else 'default'} frame"
     _compare(ref[None], ieee[None], "default shading arithmetic vs IEEE fp32")
+
+
+@pytest.mark.gpu
+def test_display_written_by_the_resolve_equals_the_tonemap_stage(R, ctx, monkeypatch):
+    """A one-device renderer has nothing between path_tracer_stage and tonemap_stage (src/rt_renderer.cc), and the stage's last pass
+    writes the display image while it writes the colour target (trhip_pt_set_fused_tonemap).  Same bits as the tonemap stage run
+    afterwards: every operator, the alpha grid over a transparent background, progressive accumulation, several passes per frame,
+    frames in flight."""
+    from tauray_amd.gltf import load_glb
+    W, H = 160, 96
+    scene = load_glb(os.path.join(GOLDEN, "test.glb"), W, H)
+    cases = [
+        (dict(max_bounces=3), dict(), dict()),
+        (dict(max_bounces=2, transparent_background=1), dict(tonemap=dict(op=R.TONEMAP_FILMIC, alpha_grid_background=True)), dict()),
+        (dict(max_bounces=2), dict(tonemap=dict(op=1, exposure=1.7, gamma=2.4)), dict(accumulate=True)),
+        (dict(max_bounces=2, samples_per_pixel=4, samples_per_pass=2), dict(tonemap=dict(op=3)), dict()),
+        (dict(max_bounces=2), dict(tonemap=dict(op=4, exposure=0.6)), dict(frames_in_flight=2)),
+        (dict(max_bounces=2), dict(tonemap=dict(op=0, exposure=2.0)), dict(frames_in_flight=3, frames_per_launch=2, viewports=1)),
+    ]
+    for okw, tkw, rkw in cases:
+        opt = R.options_for_scene(scene, **okw)
+        frames = {}
+        for fused in ("0", "1"):
+            monkeypatch.setenv("TRHIP_FUSED_TONEMAP", fused)
+            rr = R.RtRenderer(ctx, scene, opt, (W, H), use_torch=False, **tkw, **rkw)
+            assert rr.fused_tonemap == (fused == "1")
+            out = []
+            for _ in range(4):
+                rr.render()
+                if rr.frames_in_flight == 1:
+                    out.append((rr.download("color"), rr.download("display")))
+            rr.sync()
+            if rr.frames_in_flight > 1:
+                layers = rr.viewports
+                out = [(s.color.download((layers, H, W, 4)), s.display.download((layers, H, W, 4))) for s in rr.slots]
+            frames[fused] = out
+            rr.close()
+        for k, ((c0, d0), (c1, d1)) in enumerate(zip(frames["0"], frames["1"])):
+            assert np.array_equal(c0, c1), f"{okw} {tkw} {rkw}: colour {k}"
+            assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), f"{okw} {tkw} {rkw}: display {k}"
+            assert not np.array_equal(d0, c0)
