@@ -98,6 +98,15 @@ __global__ __launch_bounds__(KB, TR_SHADOW_WAVES) void k_trace_shadow(SceneView 
 // state arrays), and in the lane schedule a launch lasts as long as its slowest wave: one launch with one tail instead of
 // two launches with two.  Chunk g of the launch is a closest-hit chunk while g < chunks_c (the longer rays go first), a
 // shadow chunk afterwards.
+#ifndef TR_TAIL_PIECES
+#define TR_TAIL_PIECES 0
+#endif
+#ifndef TR_TAIL16_DIV
+#define TR_TAIL16_DIV 8
+#endif
+#ifndef TR_TAIL32_DIV
+#define TR_TAIL32_DIV 8
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView sv, PtParams P, PathBuffers pb, int bounce, const uint* queue,
                                                                       uint* bc, uint* bc_prev) {
@@ -112,19 +121,40 @@ __global__ __launch_bounds__(KB, TR_CLOSEST_WAVES) void k_trace_fused(SceneView 
     uint closest_rays = 0, shadow_rays = 0, max_vis = 0;
     int overflow = 0;
     const uint wave_id = (blockIdx.x * KB + threadIdx.x) >> 6, n_waves = (gridDim.x * KB) >> 6;
+#if TR_TAIL_PIECES
+    // The end of the launch in smaller pieces (an experiment, profiles/r5/tail_pieces_ab.txt): the last chunks behind the static ones are
+    // handed out as halves (32 rays) and then quarters (16 rays, which a wave traces one ray per quad from the start), so that the waves
+    // still running when the queue drains hold less each.  Piece p -> chunk g, offset, size: the same function in every wave.
+    const uint dyn = total > n_waves ? total - n_waves : 0u;
+    const uint tail16 = dyn < n_waves / TR_TAIL16_DIV ? dyn : n_waves / TR_TAIL16_DIV;                          // chunks cut into four
+    const uint tail32 = dyn - tail16 < n_waves / TR_TAIL32_DIV ? dyn - tail16 : n_waves / TR_TAIL32_DIV;        // chunks cut into two
+    const uint full = total - tail16 - tail32, pieces = full + 2u * tail32 + 4u * tail16;
+#else
+    const uint pieces = total;
+#endif
     bool first = true;
     while (true) {
-        uint g = 0;
-        if (first) g = wave_id;
+        uint p = 0;
+        if (first) p = wave_id;
         else {
-            if (total <= n_waves) break;   // the static first chunks covered both queues
-            if ((threadIdx.x & 63) == 0) g = n_waves + atomicAdd(&bc[BC_CUR_CLOSEST], 1u);
-            g = __shfl(g, 0);
+            if (pieces <= n_waves) break;   // the static first chunks covered both queues
+            if ((threadIdx.x & 63) == 0) p = n_waves + atomicAdd(&bc[BC_CUR_CLOSEST], 1u);
+            p = __shfl(p, 0);
         }
         first = false;
-        if (g >= total) break;
-        if (g < chunks_c) closest_lane<false>(sv, P, pb, bounce, queue, (g << 6) + (threadIdx.x & 63), nc, s_stack + threadIdx.x, qc, st, overflow, max_vis, closest_rays);
-        else shadow_lane<false>(sv, P, pb, ((g - chunks_c) << 6) + (threadIdx.x & 63), ns, s_stack + threadIdx.x, qc, st, overflow, shadow_rays);
+        if (p >= pieces) break;
+        uint g = p, off = 0u, size = 64u;
+#if TR_TAIL_PIECES
+        if (p >= full) {
+            const uint q = p - full;
+            if (q < 2u * tail32) { g = full + (q >> 1); off = (q & 1u) << 5; size = 32u; }
+            else { const uint r = q - 2u * tail32; g = full + tail32 + (r >> 2); off = (r & 3u) << 4; size = 16u; }
+        }
+#endif
+        const uint lane = threadIdx.x & 63;
+        const uint slot = lane < size ? off + lane : 0xFFFFFFFFu;      // lanes beyond the piece hold no ray
+        if (g < chunks_c) closest_lane<false>(sv, P, pb, bounce, queue, slot == 0xFFFFFFFFu ? slot : (g << 6) + slot, nc, s_stack + threadIdx.x, qc, st, overflow, max_vis, closest_rays);
+        else shadow_lane<false>(sv, P, pb, slot == 0xFFFFFFFFu ? slot : ((g - chunks_c) << 6) + slot, ns, s_stack + threadIdx.x, qc, st, overflow, shadow_rays);
     }
     flush_trace_counters<false>(P, pb, overflow, 3000 + bounce, closest_rays, shadow_rays, st, max_vis);
 }
