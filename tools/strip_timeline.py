@@ -1,6 +1,6 @@
 """The kernels of one rank's share of a frame, one frame at a time, as a timeline: which launch runs when on which hardware queue.
   render:  rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python tools/strip_timeline.py render [workload] [world] [frames]
-  report:  python tools/strip_timeline.py report DIR/.../t_kernel_trace.csv > profiles/r5/strip_timeline.txt
+  report:  python tools/strip_timeline.py report DIR/.../t_kernel_trace.csv > profiles/r5/strip_timeline_1_8.txt
 The render leg draws the last rank's share of a job of `world` ranks (shuffled strips) `frames` times with a host sync after every
 frame; the report leg takes the median frame of the trace and prints its launches per queue with start offsets and durations."""
 import os
