@@ -861,7 +861,7 @@ int PtStage::render(const trhip_pt_targets& targets, uint target_w, uint target_
         c.blocks_q = c.blocks_all < grid_cap ? c.blocks_all : grid_cap;
         // The fused launch carries two queues (closest-hit rays of this bounce, shadow rays of the last one): a small frame - a rank's share
         // of a multi-GPU job - leaves the chip room for a wave per chunk of both, and then the launch lasts as long as the longer of the two
-        // traversals instead of their sum (a 1/8 strip of sponza_teapots: 165 -> 12x us per fused launch, profiles/r5/strip_timeline_1_8.txt)
+        // traversals instead of their sum (a 1/8 strip of sponza_teapots: 165 -> 130 us per fused launch, profiles/r5/strip_timeline_1_8.txt)
         c.blocks_f = std::min(grid_cap, c.blocks_all * fused_grid_factor());
         c.shadow_in_flight = false;
         lanes_used = slice + 1;
