@@ -52,6 +52,9 @@ double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::
 // true when a launch on `b` cannot start while a launch on `a` is still placing its workgroups
 bool same_pipe(DevicePool& P, hipStream_t a, hipStream_t b) {
     if (a == b) return true;
+    // both idle first: work already queued on either (a caller's stream seen for the first time in the middle of its frame) would be
+    // taken for the other launch holding the pipe
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
     int slow = 0;
     for (int trial = 0; trial < 2; ++trial) {
         *(volatile int*)P.flag = 0;
