@@ -2492,3 +2492,15 @@ def test_display_written_by_the_resolve_equals_the_tonemap_stage(R, ctx, monkeyp
             assert np.array_equal(c0, c1), f"{okw} {tkw} {rkw}: colour {k}"
             assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), f"{okw} {tkw} {rkw}: display {k}"
             assert not np.array_equal(d0, c0)
+    # the direct stage resolves its samples in a kernel of its own: the renderer keeps the tonemap stage, the library says why
+    dopt = R.options_for_scene(scene, max_bounces=2, samples_per_pixel=2, samples_per_pass=2)
+    monkeypatch.setenv("TRHIP_FUSED_TONEMAP", "1")
+    d = R.RtRenderer(ctx, scene, dopt, (W, H), use_torch=False, stage_cls=R.DirectStage)
+    assert not d.fused_tonemap
+    d.render()
+    shown = d.download("display")
+    assert np.isfinite(shown).all() and shown[..., :3].max() > 0
+    with pytest.raises(RuntimeError, match="direct stage"):
+        d.slots[0].pt.set_fused_tonemap(d.slots[0].display, d.tonemap.info)
+    d.close()
+
