@@ -570,11 +570,7 @@ public:
         // display image while it writes its colour target - the same bits without a second pass over the frame.  TRHIP_FUSED_TONEMAP=0: off.
         const char* fe = getenv("TRHIP_FUSED_TONEMAP");
         fused_tonemap = std::is_same<Pipeline, path_tracer_stage>::value && per_device.size() == 1 && !(fe && atoi(fe) == 0);
-        if(fused_tonemap)
-        {
-            const trhip_tonemap_info ti = tonemap->info();
-            for(size_t k = 0; k < frame_slots.size(); ++k) per_device[0].slots[k].ray_tracer->set_fused_tonemap(frame_slots[k].display, &ti);
-        }
+        fused_info.assign(frame_slots.size(), trhip_tonemap_info{-1, 0.0f, 0.0f, 0});     // what each slot's stage was last told: render() keeps it current
     }
 
     ~basic_rt_renderer()
@@ -628,6 +624,16 @@ public:
         const uint32_t layers = (uint32_t)opt.active_viewport_count * batch;
         device& display_device = *per_device[0].dev;
         void* const display_stream = per_device[0].slots[k].stream;
+        if(fused_tonemap)
+        {   // the stage's copy of the tonemap parameters follows tonemap->opt: an edit between frames takes effect on the next frame,
+            // as it does when the tonemap stage itself runs (several devices)
+            const trhip_tonemap_info ti = tonemap->info();
+            if(std::memcmp(&ti, &fused_info[k], sizeof(ti)) != 0)
+            {
+                per_device[0].slots[k].ray_tracer->set_fused_tonemap(frame_slots[k].display, &ti);
+                fused_info[k] = ti;
+            }
+        }
         for(size_t i = 0; i < per_device.size(); ++i)
         {
             per_device_data& d = per_device[i];
@@ -721,6 +727,7 @@ public:
     size_t display_bytes = 0;
     std::unique_ptr<tonemap_stage> tonemap;
     bool fused_tonemap = false;
+    std::vector<trhip_tonemap_info> fused_info;
     unsigned accumulated_frames = 0;
     float stitch_blend_ratio = 1.0f;
 };

@@ -49,6 +49,36 @@ int trhip_stream_wait(trhip_device* dev, void* stream, void* on);
  * `pipe_class_out`: the pipe of any stream of this process, the caller's own included (small integers from 0 in the order pipes
  * were seen; -1 with TRHIP_PIPE_PROBE=0): two streams of one class serialise chip-filling launches. */
 int trhip_stream_pipe_class(trhip_device* dev, void* stream, int32_t* pipe_class_out);
+/* ---- Process requirements (what the library needs from the process it is loaded into; nothing in the reference corresponds -
+ * the Vulkan driver owns its queues, src/context.hh:26, src/stage.cc:35-76).
+ *  1. GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the first HIP call of the process (the HIP runtime reads it once).  A lone
+ *     frame is cut into four lanes on four streams that must sit on four different hardware pipes to overlap; with the runtime's
+ *     default of four hardware queues the streams of one process share fewer pipes: sponza_teapots 1920x1080 renders in 4.55 ms
+ *     instead of 3.69, a 1/8 strip in 1.0 instead of 0.75.  Frames are the same bits either way.  The
+ *     Python mirror (tauray_amd/_lib.py), bench.py, the tests and the CLI (tauray_amd/host/tauray_hip_cli.cc) set it with
+ *     setenv(.., overwrite = 0) before they touch HIP; an embedding application must do the same in its main() or launcher.
+ *  2. Streams: create the streams you render on with trhip_stream_create (they come classified by pipe).  A stream of your own
+ *     (or NULL - the default stream is classified by trhip_device_create) works too; the first stage that renders on it classifies it with a ~1 ms experiment if - and only if - the stream
+ *     is idle and not capturing at that moment; otherwise its pipe stays unknown (-1) and the stage's lanes may share it.
+ *     trhip_stream_pipe_class is the explicit form: it SYNCHRONISES `stream`, runs the experiment and remembers the result for
+ *     that stream identity.  The library never synchronises a caller's stream anywhere else.
+ *  3. trhip_device_get_info tells how many distinct pipes the process reaches (4 on MI355X with requirement 1 met; fewer = the
+ *     -19 % case); with TRHIP_DEBUG=1 it and trhip_pt_render warn once on stderr when lanes share a pipe.
+ *  4. TRHIP_PIPE_CLASSES=0,1,2,3 pins the classes of the library's streams in creation order and skips every experiment (for
+ *     hosts that cannot afford the ~10 ms of probing at start-up or run under a tool that serialises queues);
+ *     TRHIP_PIPE_PROBE=0 switches classification off altogether (every stream -1). */
+typedef struct trhip_device_info {
+    uint32_t struct_size;
+    int32_t hip_device;
+    char name[64];                    /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    char pci_bus_id[24];              /* "0000:05:00.0" */
+    uint8_t uuid[16];
+    int32_t compute_units;
+    int32_t pipe_classes;             /* distinct hardware pipes the library's streams landed on (0: TRHIP_PIPE_PROBE=0) */
+    int32_t pool_streams;             /* streams the library holds on this device (never destroyed) */
+    int32_t hw_queues_env;            /* GPU_MAX_HW_QUEUES as this process sees it; 0 = unset (the runtime's default of 4) */
+} trhip_device_info;
+int trhip_device_get_info(trhip_device* dev, trhip_device_info* out);
 /* The same dependency between streams of two devices of one process (the timeline semaphores the reference exports
  * between devices, src/device_transfer.cc:318-347, src/rt_renderer.cc:98-127): work enqueued on `stream` of `dev` after
  * the call starts only when everything enqueued on `on` of `on_dev` before the call has finished. */
@@ -306,11 +336,14 @@ int trhip_pt_precompile(const trhip_pt_options* opt, int shade_tris, int ieee, i
  *   kind: 0 = the general kernels (every option read from the parameter block), 1 = the ahead-of-time instances of the reference's
  *         command-line option set, 2 = a program compiled for this option set (hipRTC / kernel cache);
  *   ieee: 1 = IEEE fp32 shading, 0 = Vulkan-grade arithmetic;
- *   identity: FNV-1a over kind, arithmetic, the pinned option fields, the embedded device sources of this build of the library and,
- *         for kind 2, the bytes of the code objects that were loaded;
+ *   identity: FNV-1a over kind, arithmetic, the pinned option fields, the embedded device sources of this build of the library, the
+ *         build's id (trhip_build_id: every source of csrc/ and the compile flags, so two builds whose ahead-of-time kernels differ - kinds
+ *         0 and 1 live in path_tracer.o / shade_fast.o, not in the embedded sources - differ here too) and, for kind 2, the bytes of the
+ *         code objects that were loaded;
  *   key: the pinned fields as text (what TRHIP_DEBUG prints). */
 typedef struct trhip_program_info { int32_t kind, ieee; uint64_t identity; char key[240]; } trhip_program_info;
 int trhip_pt_get_program(trhip_pt* pt, trhip_program_info* out);
+uint64_t trhip_build_id(void);              /* 64 bits of SHA-256 over the library's sources and compile flags, fixed when it was built */
 const char* trhip_kernel_cache_dir(void);   /* TRHIP_KERNEL_CACHE, else kernel_cache/ next to libtrhip.so, else ~/.cache/trhip; "" = none writable */
 int trhip_pt_set_profiling(trhip_pt* pt, int count_work, int detailed_timing);
 int trhip_pt_get_counters(trhip_pt* pt, trhip_counters* out);     /* synchronises the stream */

@@ -33,6 +33,14 @@ int trhip_comm_create(int hip_device, int nranks, int rank, const void* id, trhi
 void trhip_comm_destroy(trhip_comm* comm);
 int trhip_comm_rank(const trhip_comm* comm);
 int trhip_comm_size(const trhip_comm* comm);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion) - the
+ * arguments of trhip_comm_create are not echoed: a job's log can show that the library saw N ranks on N devices. */
+typedef struct trhip_comm_info {
+    uint32_t struct_size;
+    int32_t nranks, rank, hip_device;
+    int32_t rccl_version;              /* NCCL_VERSION_CODE of the linked librccl, e.g. 22204 */
+} trhip_comm_info;
+int trhip_comm_get_info(const trhip_comm* comm, trhip_comm_info* out);
 /* device_transfer of one frame: every rank but `root` sends `send_bytes` bytes at `send_dev` (its partial colour target),
  * `root` receives recv_bytes[r] bytes into recv_dev[r] for every r != root (entries of index root are ignored; the arrays
  * may be NULL on the other ranks).  Sizes may differ from rank to rank (shuffled strips with balanced shares,

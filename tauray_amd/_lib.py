@@ -119,6 +119,8 @@ SYMBOLS = {
     "trhip_stream_create": (_i, [_vp, C.POINTER(C.c_void_p)]),
     "trhip_stream_destroy": (_i, [_vp, _vp]),
     "trhip_stream_pipe_class": (_i, [_vp, _vp, C.POINTER(C.c_int32)]),
+    "trhip_device_get_info": (_i, [_vp, _vp]),
+    "trhip_build_id": (C.c_uint64, []),
     "trhip_stream_wait": (_i, [_vp, _vp, _vp]),
     "trhip_stream_wait_peer": (_i, [_vp, _vp, _vp, _vp]),
     "trhip_pt_set_frame_counter": (_i, [_vp, _u32]),

@@ -24,6 +24,7 @@ SYMBOLS = {
     "trhip_comm_destroy": (None, [_vp]),
     "trhip_comm_rank": (_i, [_vp]),
     "trhip_comm_size": (_i, [_vp]),
+    "trhip_comm_get_info": (_i, [_vp, _vp]),
     "trhip_gather_partials": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _vp]),
     "trhip_reduce_samples": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     "trhip_ipc_create": (_i, [_i, _i, _i, _i, _sz, _i, C.POINTER(_vp)]),
@@ -83,6 +84,14 @@ class Comm:
             _check(lib().trhip_gather_partials(self.h, root, None, 0, ptrs, sizes, stream))
         else:
             _check(lib().trhip_gather_partials(self.h, root, send_ptr, send_bytes, None, None, stream))
+
+    def info(self) -> dict:
+        """trhip_comm_get_info: what RCCL says about this communicator (ranks, this rank, its HIP device, the library's version)."""
+        class Info(C.Structure):
+            _fields_ = [("struct_size", C.c_uint32), ("nranks", C.c_int32), ("rank", C.c_int32), ("hip_device", C.c_int32), ("rccl_version", C.c_int32)]
+        i = Info()
+        _check(lib().trhip_comm_get_info(self.h, C.byref(i)))
+        return {"nranks": i.nranks, "rank": i.rank, "hip_device": i.hip_device, "rccl_version": i.rccl_version}
 
     def reduce_samples(self, root: int, send_ptr, recv_ptr, float_count: int, stream=None):
         _check(lib().trhip_reduce_samples(self.h, root, send_ptr, recv_ptr, float_count, stream))

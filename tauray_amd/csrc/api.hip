@@ -315,6 +315,9 @@ int trhip_device_create(int hip_device, trhip_device** out) {
     d->hip_device = hip_device;
     HIPCHK(hipMalloc(&d->overflow_flag, 4));
     HIPCHK(hipMemset(d->overflow_flag, 0, 4));
+    // the pipe of the default stream, once, while nothing of ours is in flight on this device: NULL is the stream most callers render on,
+    // and a stage may not synchronise a caller's stream to find out later (stream_pool.hip; include/trhip.h "process requirements")
+    { int cls = -1; (void)stream_pool_class(nullptr, &cls, true); }
     *out = d;
     return 0;
 }
@@ -354,8 +357,33 @@ int trhip_stream_pipe_class(trhip_device* dev, void* stream, int32_t* pipe_class
     DEVCHK(dev);
     if (!pipe_class_out) return set_error("trhip_stream_pipe_class: null argument");
     int c = -1;
-    if (int rc = stream_pool_class((hipStream_t)stream, &c)) return rc;
+    if (int rc = stream_pool_class((hipStream_t)stream, &c, true)) return rc;      // the caller asked: `stream` may be synchronised
     *pipe_class_out = c;
+    return 0;
+}
+int trhip_device_get_info(trhip_device* dev, trhip_device_info* out) {
+    DEVCHK(dev);
+    if (!out) return set_error("trhip_device_get_info: null argument");
+    memset(out, 0, sizeof(*out));
+    out->struct_size = (uint32_t)sizeof(*out);
+    out->hip_device = dev->hip_device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev->hip_device));
+    snprintf(out->name, sizeof(out->name), "%s", prop.gcnArchName);
+    out->compute_units = prop.multiProcessorCount;
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), dev->hip_device) != hipSuccess) { (void)hipGetLastError(); out->pci_bus_id[0] = 0; }
+    hipUUID uuid;
+    if (hipDeviceGetUuid(&uuid, dev->hip_device) == hipSuccess) memcpy(out->uuid, uuid.bytes, 16); else (void)hipGetLastError();
+    out->hw_queues_env = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 0;
+    int classes = 0, streams = 0;
+    if (int rc = stream_pool_pipe_classes(&classes, &streams)) return rc;
+    out->pipe_classes = classes; out->pool_streams = streams;
+    static bool warned = false;
+    if (!warned && classes > 0 && classes < 4 && getenv("TRHIP_DEBUG") && atoi(getenv("TRHIP_DEBUG")) != 0) {
+        warned = true;
+        fprintf(stderr, "trhip: this process reaches %d hardware pipe%s (GPU_MAX_HW_QUEUES=%s); the four lanes of a frame want four - "
+                        "see include/trhip.h, \"process requirements\"\n", classes, classes == 1 ? "" : "s", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
+    }
     return 0;
 }
 int trhip_stream_wait(trhip_device* dev, void* stream, void* on) {

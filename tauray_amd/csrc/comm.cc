@@ -59,6 +59,17 @@ void trhip_comm_destroy(trhip_comm* comm) {
 
 int trhip_comm_rank(const trhip_comm* comm) { return comm ? comm->rank : -1; }
 int trhip_comm_size(const trhip_comm* comm) { return comm ? comm->nranks : 0; }
+int trhip_comm_get_info(const trhip_comm* comm, trhip_comm_info* out) {
+    if (!comm || !out) return fail("trhip_comm_get_info: null argument");
+    memset(out, 0, sizeof(*out));
+    out->struct_size = (uint32_t)sizeof(*out);
+    // asked of the communicator, not echoed from the arguments it was created with
+    NCHK(ncclCommCount(comm->comm, &out->nranks));
+    NCHK(ncclCommUserRank(comm->comm, &out->rank));
+    NCHK(ncclCommCuDevice(comm->comm, &out->hip_device));
+    NCHK(ncclGetVersion(&out->rccl_version));
+    return 0;
+}
 
 int trhip_gather_partials(trhip_comm* comm, int root, const void* send_dev, size_t send_bytes, void* const* recv_dev, const size_t* recv_bytes,
                           void* stream) {

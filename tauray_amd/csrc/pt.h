@@ -11,7 +11,11 @@ void get_ray_count(const trhip_distribution& d, uint& w, uint& h);
 // for a taker whose launches must overlap those of `overlap_with` (streams of any origin, the null stream included).
 int stream_pool_acquire(hipStream_t* out, const hipStream_t* overlap_with = nullptr, int n_overlap = 0);
 void stream_pool_release(hipStream_t s);
-int stream_pool_class(hipStream_t s, int* cls);     // -1: unknown (TRHIP_PIPE_PROBE=0)
+// The pipe class of any stream (-1: unknown).  A stream the pool did not create is classified by the experiment the first time it is
+// seen: with `blocking` the stream is synchronised for it (trhip_stream_pipe_class: the caller asked); without, only a stream that is
+// idle and not capturing is probed, anything else is -1 for now.
+int stream_pool_class(hipStream_t s, int* cls, bool blocking = false);
+int stream_pool_pipe_classes(int* classes_out, int* streams_out);      // distinct classes this process reaches on the current device
 
 class PtStage {
 public:
@@ -45,7 +49,7 @@ public:
     hipStream_t last_stream = nullptr;
 
     // which kernels shade this stage (render() and get_program() decide it the same way)
-    struct Program { bool cli_set, shade_fast, wide; const struct SpecKernels *shade, *raygen; std::string key; };
+    struct Program { bool cli_set, shade_fast, wide; const struct SpecKernels *shade, *raygen; };
     Program choose_program();
 
 private:

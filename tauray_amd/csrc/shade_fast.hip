@@ -33,3 +33,13 @@ void launch_shade_fast(bool cli, bool count, bool last, uint blocks, hipStream_t
 }
 
 }  // namespace tr
+
+#if TR_SHADE_TIMELINE
+// the phase timeline of the shade kernels of this translation unit (shade_timeline.h): read out / reset, instrument builds only
+extern "C" int trhip_debug_shade_timeline(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(tr::g_shade_tl), sizeof(unsigned long long) * tr::STL_WORDS) != hipSuccess) return 1;
+    if (reset) { static unsigned long long zero[tr::STL_WORDS]; if (hipMemcpyToSymbol(HIP_SYMBOL(tr::g_shade_tl), zero, sizeof(zero)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

@@ -39,15 +39,18 @@ TR_DEV float clamp_contribution_mul(const PtParams& P, f3 contrib) {   // path_t
     return 1;
 }
 
-// sample_environment_map (rt.glsl:251-285)
-TR_DEV f3 sample_environment_map(const SceneView& sv, u4 rnd, f3& dir, float& length, float& pdf) {
+// sample_environment_map (rt.glsl:251-285), in two halves: which entry of the alias table the sample reads, and the sample once
+// that entry is there (sample_explicit_light fetches it together with whatever records the other lanes of the wave chose)
+TR_DEV int environment_alias_index(const SceneView& sv, u4 rnd) {
+    const uint sx = sv.env_w, sy = sv.env_h;
+    const uint ipx = clampu(rnd.x / (0xFFFFFFFFu / sx), 0u, sx - 1u), ipy = clampu(rnd.y / (0xFFFFFFFFu / sy), 0u, sy - 1u);
+    return (int)(ipx + ipy * sx);
+}
+TR_DEV f3 sample_environment_map(const SceneView& sv, u4 rnd, int i, const AliasEntry at, f3& dir, float& length, float& pdf) {
     f3 color = F3(sv.environment_factor);
     if (sv.environment_proj >= 0) {
         uint sx = sv.env_w, sy = sv.env_h;
         const uint pixel_count = sx * sy;
-        uint ipx = clampu(rnd.x / (0xFFFFFFFFu / sx), 0u, sx - 1u), ipy = clampu(rnd.y / (0xFFFFFFFFu / sy), 0u, sy - 1u);
-        int i = (int)(ipx + ipy * sx);
-        AliasEntry at = sv.alias_table[i];
         pdf = at.pdf;
         if (rnd.z > at.probability) { i = (int)at.alias_id; pdf = at.alias_pdf; }
         int ppx = (int)((uint)i % sx), ppy = (int)((uint)i / sx);
@@ -72,25 +75,57 @@ TR_DEV float sample_environment_map_pdf(const SceneView& sv, f3 dir) {   // rt.g
     return 1.0f / (4.0f * TR_PI);
 }
 
-// sample_explicit_light (path_tracer.glsl:203-289)
+// sample_explicit_light (path_tracer.glsl:203-289).
+// Round 6: select, fetch, compute.  The reference's chain of `(u.w -= probability) < 0` tests picks one kind of light per path, so the
+// lanes of a wave sample different kinds, and with a fetch inside every branch a wave paid the round trips of all of them one after
+// the other - point light record, triangle light record (+ its texture), alias table entry (+ envmap texels), directional light
+// record: half of the 16 000 clocks the light sample took of a shade wave's 50 000 (profiles/r6/shade_phase_timeline.txt).  Now every
+// lane first decides its kind and its record - a PointLight, a TriLight (64 bytes each), an AliasEntry (16) or a DirectionalLight
+// (32) - then all lanes fetch theirs at once through one per-lane pointer into the same four 16-byte registers, and the branches that
+// follow only compute (the environment's texels and an emissive triangle's texture remain fetches of their own).  Same tests in the
+// same order, same arithmetic on the same values.
 TR_DEV f3 sample_explicit_light(const SceneView& sv, const PtParams& P, u4 rnd, f3 pos, f3& out_dir, float& out_length, float& pdf) {
     f4 u = u4_to_unit(rnd);
-    if (P.nee_point && (u.w -= P.prob_point) < 0) {
-        const int light_count = (int)sv.point_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);   // random_sample_point_light
+    enum { NONE = 0, POINT, TRI, ENV, DIR };
+    int kind = NONE;
+    if (P.nee_point && (u.w -= P.prob_point) < 0) kind = POINT;
+    else if (P.nee_tri && (u.w -= P.prob_tri) < 0) kind = TRI;
+    else if (P.nee_env && (u.w -= P.prob_env) < 0) kind = ENV;
+    else if (P.nee_dir && (u.w -= P.prob_dir) < 0) kind = DIR;
+    // (opaque to the optimiser: it would otherwise thread every test above straight into its branch below and put a copy of the fetch
+    // back into each - the structure this function was rewritten to get rid of)
+    asm volatile("" : "+v"(kind));
+    // the lane's record: address and size in 16-byte words
+    // (the counts by value first: a conditional expression over members of the view would select between their addresses and pin the view in memory)
+    const int n_point = (int)sv.point_light_count, n_tri = (int)sv.tri_light_count, n_dir = (int)sv.directional_light_count;
+    const int light_count = kind == POINT ? n_point : kind == TRI ? n_tri : n_dir;
+    const int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);   // random_sample_point_light and its siblings
+    // (four masked fetches into the same registers, not one fetch through a selected pointer: a pointer chosen among the arrays of
+    // the scene view makes the compiler keep the whole view in scratch memory and every load of the kernel a flat one)
+    u4 r0 = {0u, 0u, 0u, 0u}, r1 = r0, r2 = r0, r3 = r0;
+    int alias_i = 0;
+    if (kind == POINT) { const u4* rec = reinterpret_cast<const u4*>(sv.point_lights + light_index); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+    if (kind == TRI) { const u4* rec = reinterpret_cast<const u4*>(sv.tri_lights + light_index); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+    if (kind == DIR) { const u4* rec = reinterpret_cast<const u4*>(sv.directional_lights + light_index); r0 = rec[0]; r1 = rec[1]; }
+    if (kind == ENV && sv.environment_proj >= 0) { alias_i = environment_alias_index(sv, rnd); r0 = *reinterpret_cast<const u4*>(sv.alias_table + alias_i); }
+#define TR_F(x) __uint_as_float(x)
+    STL(STL_L_SELECT);
+
+    if (kind == POINT) {
         float weight = (float)max(light_count, 1);
-        const PointLight pl = sv.point_lights[light_index];
+        PointLight pl;
+        pl.color = F3(TR_F(r0.x), TR_F(r0.y), TR_F(r0.z)); pl.dir = F3(TR_F(r0.w), TR_F(r1.x), TR_F(r1.y)); pl.pos = F3(TR_F(r1.z), TR_F(r1.w), TR_F(r2.x));
+        pl.radius = TR_F(r2.y); pl.dir_cutoff = TR_F(r2.z); pl.dir_falloff = TR_F(r2.w);
+        pl.cutoff_radius = TR_F(r3.x); pl.spot_radius = TR_F(r3.y); pl.shadow_map_index = (int)r3.z; pl.padding = (int)r3.w;
         f3 color;
         sample_point_light(pl, F2(u.x, u.y), pos, out_dir, out_length, color, pdf);
         pdf *= P.prob_point / weight;
         return color;
     }
-    if (P.nee_tri && (u.w -= P.prob_tri) < 0) {
-        const int light_count = (int)sv.tri_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
-        const TriLight tl = sv.tri_lights[light_index];
-        f3 A = tl.pos[0] - pos, B = tl.pos[1] - pos, C = tl.pos[2] - pos;
-        f3 color = r9g9b9e5_to_rgb(tl.emission_factor);
+    if (kind == TRI) {
+        f3 A = F3(TR_F(r0.x), TR_F(r0.y), TR_F(r0.z)) - pos, B = F3(TR_F(r0.w), TR_F(r1.x), TR_F(r1.y)) - pos, C = F3(TR_F(r1.z), TR_F(r1.w), TR_F(r2.x)) - pos;
+        f3 color = r9g9b9e5_to_rgb(r2.y);
+        const int emission_tex_id = (int)r3.w;
         float tri_pdf = 0.0f;
         out_dir = sample_triangle_light(P.opt.tri_light_mode, F2(u.x, u.y), A, B, C, tri_pdf);
         out_length = ray_plane_intersection_dist(out_dir, A, B, C);
@@ -98,31 +133,35 @@ TR_DEV f3 sample_explicit_light(const SceneView& sv, const PtParams& P, u4 rnd, 
             pdf = 1.0f; out_dir = F3(0);
             return F3(0);
         }
-        if (tl.emission_tex_id >= 0) {
+        if (emission_tex_id >= 0) {
             f3 bary = get_barycentric_coords(out_dir * out_length, A, B, C);
-            f2 uv = bary.x * unpack_half2x16(tl.uv[0]) + bary.y * unpack_half2x16(tl.uv[1]) + bary.z * unpack_half2x16(tl.uv[2]);
-            color = color * F3(sample_texture(sv, tl.emission_tex_id, uv));
+            f2 uv = bary.x * unpack_half2x16(r3.x) + bary.y * unpack_half2x16(r3.y) + bary.z * unpack_half2x16(r3.z);
+            color = color * F3(sample_texture(sv, emission_tex_id, uv));
         }
         out_length -= P.opt.min_ray_dist;
         pdf = P.prob_tri * tri_pdf / light_count;
+        STL(STL_L_TRI);
         return color;
     }
-    if (P.nee_env && (u.w -= P.prob_env) < 0) {
-        f3 color = sample_environment_map(sv, rnd, out_dir, out_length, pdf);
+    if (kind == ENV) {
+        const AliasEntry at = {r0.x, r0.y, TR_F(r0.z), TR_F(r0.w)};
+        f3 color = sample_environment_map(sv, rnd, alias_i, at, out_dir, out_length, pdf);
         pdf *= P.prob_env;
+        STL(STL_L_ENV);
         return color;
     }
-    if (P.nee_dir && (u.w -= P.prob_dir) < 0) {
-        const int light_count = (int)sv.directional_light_count;
-        int light_index = clampi((int)(u.z * light_count), 0, light_count - 1);
-        const DirectionalLight dl = sv.directional_lights[light_index];
+    if (kind == DIR) {
+        DirectionalLight dl;
+        dl.color = F3(TR_F(r0.x), TR_F(r0.y), TR_F(r0.z)); dl.shadow_map_index = (int)r0.w; dl.dir = F3(TR_F(r1.x), TR_F(r1.y), TR_F(r1.z)); dl.dir_cutoff = TR_F(r1.w);
         out_length = __builtin_huge_valf();
         out_dir = sample_cone(F2(u.x, u.y), -dl.dir, dl.dir_cutoff);   // sample_directional_light (light.glsl:119-129)
         pdf = dl.dir_cutoff >= 1.0f ? -1.0f : 1.0f / (2.0f * TR_PI * (1.0f - dl.dir_cutoff));
         f3 color = pdf > 0 ? dl.color * pdf : dl.color;
         pdf *= P.prob_dir / light_count;
+        STL(STL_L_DIR);
         return color;
     }
+#undef TR_F
     out_dir = F3(0); out_length = 0; pdf = 1.0f;
     return F3(0);
 }
@@ -219,6 +258,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
         bool have = bounce == 0;
         f2 pl = bounce == 0 ? F2(0.0f, 1.0f) : pb.plobes[id];   // primary_lobes = (0,0,0,1) (path_tracer.glsl:383)
         u4 rs = pb.rng[id];
+        STL(STL_STATE);
         // (payload.random_seed advances once per closest-hit trace: closest_lane derives the seed of its bounce from the one k_raygen
         // stored, so no kernel rewrites misc)
 
@@ -274,6 +314,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
                 env_pdf = sv.environment_proj >= 0 ? sample_environment_map_pdf(sv, view) : 0.0f;
             } else mat.emission += F3(c);
         }
+        if (!surface) { STL(STL_NOSURFACE); }
         const bool terminal = LAST || !surface || bounce == P.opt.max_bounces - 1;
 
         // ---- emission with MIS (path_tracer.glsl:413-435)
@@ -294,6 +335,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
             pb.first_emis[id] = F4(light, mat.albedo.w);
         }
 
+        STL(STL_EMIT_MIS);
         if (P.opt.regularization_gamma != 0.0f) {   // PATH_SPACE_REGULARIZATION (path_tracer.glsl:437-444)
             if (bsdf_pdf != 0.0f) regularization *= fmax2(1 - P.opt.regularization_gamma / tpow(bsdf_pdf, 0.25f), 0.0f);
             mat.roughness = 1.0f - ((1.0f - mat.roughness) * regularization);
@@ -319,6 +361,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
                 f3 out_dir;
                 float out_length = 0.0f, light_pdf;
                 f3 contrib = sample_explicit_light(sv, P, rnd, v.pos, out_dir, out_length, light_pdf);
+                STL(STL_LIGHT);
                 f3 shading_light = mulT(out_dir, tbn);
                 float nee_bsdf_pdf = material_bsdf_pdf(P.opt.bounce_mode, shading_light, shading_view, mat, lobes);
                 correct_lobes_for_normal_map(out_dir, v.hard_normal, lobes);
@@ -345,6 +388,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
                     ref.x += r.x * pl.y; ref.y += r.y * pl.y; ref.z += r.z * pl.y;
                 }
             }
+            STL(STL_NEE_EVAL);
             if (bounce == 1) {   // diffuse.a = reflection.a = 1 / length(v.pos - pos) (path_tracer.glsl:470-471)
                 const float inv_len = 1.0f / length(v.pos - pos);
                 if (have) { dif.w = inv_len; ref.w = inv_len; }
@@ -367,6 +411,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
             }
             if (fmax2(attenuation.x, fmax2(attenuation.y, attenuation.z)) <= 0.0f) alive = false;
         }
+        STL(STL_BSDF);
         // ---- write back
         if (have) { pb.diffuse[id] = dif; pb.reflection[id] = ref; }
         if (alive) {
@@ -376,6 +421,7 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
             if (bounce == 0) pb.plobes[id] = pl;
             pb.rng[id] = rs;
         }
+        STL(STL_WRITEBACK);
 }
 
 template <bool COUNT, bool LAST, typename S>
@@ -389,7 +435,12 @@ TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuf
     const uint n = queue ? bc[BC_QUEUE] : P.n_ids;
     const uint n_round = LAST ? n : ((n + (uint)KB - 1u) & ~((uint)KB - 1u));   // whole blocks take part in the appends
     uint surf = 0;
+#if TR_SHADE_TIMELINE
+    stl_begin();
+#endif
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
+        STL(STL_ITER);
+        STL(STL_CALIBRATION);
         bool active = qi < n;
         uint id = 0;
         u4 misc = {0, 0, 0, 1};
@@ -401,6 +452,7 @@ TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuf
             if (!misc_needed && queue) misc = u4{0u, 0u, id, 0u};
             else { misc = pb.misc[id]; active = !(misc.w & 1u); }
         }
+        STL(STL_ID);
         ShadeOut o;
         if (active) shade_path<COUNT, LAST, S>(sv, P, pb, bounce, id, misc, o, surf);
         const bool alive = o.alive, want_shadow = o.want_shadow;
@@ -408,6 +460,7 @@ TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuf
         if (LAST) continue;     // nothing survives the last bounce
         uint sslot, nslot;
         block_append2(&bc[BC_SHADOW], want_shadow, sslot, &bc[BC_STRIDE + BC_QUEUE], alive, nslot);
+        STL(STL_APPEND);
         if (want_shadow) {
             pb.sh_org_tmax[sslot] = F4(o.sh_o, o.sh_tmax);
             pb.sh_dir_id[sslot] = F4(o.sh_d, __uint_as_float(id));
@@ -415,7 +468,11 @@ TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuf
             pb.sh_lobes[sslot] = o.sh_w;
         }
         if (alive) next_queue[nslot] = id;
+        STL(STL_QUEUE);
     }
+#if TR_SHADE_TIMELINE
+    stl_end(bounce);
+#endif
     if (COUNT && P.count_work) {
         for (int off = 32; off > 0; off >>= 1) surf += __shfl_xor(surf, off);
         if ((threadIdx.x & 63) == 0) add64(pb.counters, CNT_SURF, surf);

@@ -5,6 +5,14 @@
 #include "common.h"
 #include "rng.h"
 #include "texture.h"
+#ifndef TR_SHADE_TIMELINE
+#define TR_SHADE_TIMELINE 0
+#endif
+#if TR_SHADE_TIMELINE
+#include "shade_timeline.h"     // the phase timeline of k_shade: an instrument of variant builds only
+#else
+#define STL(seg)
+#endif
 
 namespace tr {
 
@@ -587,6 +595,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
                           bool want_tri_pdf, int tri_light_mode, bool pre, SurfacePoint& sp, SampledMaterial& res, bool rec = false) {
     const Instance& o = sv.instances[instance_id];
     const MeshSpan span = sv.spans[instance_id];
+    STL(STL_INSTANCE);
     f3 q0, q1, q2, n0, n1, n2;
     f2 t0, t1, t2;
     f4 g0 = F4(0, 0, 0, 0), g1 = g0, g2 = g0;      // tangents: with the vertices (no records), or fetched where they are used
@@ -625,6 +634,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
     sp.hard_normal = hard_normal;
     sp.smooth_normal = smooth_normal;
     sp.mapped_normal = smooth_normal;
+    STL(STL_SHADETRI);
 
     const Material& mat = o.mat;
     res.albedo = mat.albedo_factor;
@@ -633,6 +643,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
         f3 lin = inverse_srgb_correction(F3(tex_col));
         res.albedo = res.albedo * F4(lin, tex_col.w);
     }
+    STL(STL_ALBEDO);
     f2 mr = F2(mat.metallic_roughness_factor.x, mat.metallic_roughness_factor.y);
     if (mat.metallic_roughness_tex_id >= 0) {
         f4 t = sample_texture(sv, mat.metallic_roughness_tex_id, uv);
@@ -640,6 +651,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
     }
     res.metallic = mr.x;
     res.roughness = mr.y * mr.y;
+    STL(STL_MR);
     if (mat.normal_tex_id >= 0) {
         // the bitangent comes from the interpolated normal BEFORE the back-face flip (the order the vertex is assembled in, and the
         // oracle's): `front` undoes the flip, exactly
@@ -654,6 +666,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
         f3 mapped = normalize(mul(tbn, ts_normal * F3(mat.normal_factor, mat.normal_factor, 1.0f)));
         sp.mapped_normal = any_nan(mapped) ? smooth_normal : mapped;
     }
+    STL(STL_NORMALMAP);
     res.emission = F3(mat.emission_factor);
     if (mat.emission_tex_id >= 0) res.emission = res.emission * F3(sample_texture(sv, mat.emission_tex_id, uv));
     res.transmittance = mat.transmittance;
@@ -661,6 +674,7 @@ TR_DEV void shade_surface(const SceneView& sv, int instance_id, int primitive_id
     else { res.ior_in = 1.0f; res.ior_out = mat.ior; }
     float f0 = (res.ior_out - res.ior_in) / (res.ior_out + res.ior_in);
     res.f0 = f0 * f0;
+    STL(STL_EMISSION);
 }
 
 }  // namespace tr

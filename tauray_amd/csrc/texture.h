@@ -94,13 +94,21 @@ TR_DEV float sample_texture_alpha(const SceneView& sv, int tex_id, f2 uv) {
     return top * (1.0f - t.fy) + bot * t.fy;
 }
 
+// i mod n for a coordinate one period away at most: what a uv in [0, 1] produces (texel -1 ... n), i.e. every environment lookup - the uv of
+// a direction (asin / atan2 over pi) or of an alias-table sample.  A 32-bit remainder is ~35 instructions here (no integer divider), an
+// environment tap used four, and a shade wave spends a fifth of its clocks in the two environment lookups of a bounce
+// (profiles/r6/shade_phase_timeline.txt).  Any other coordinate takes the remainder as before: the same integer either way.
+TR_DEV int wrap_repeat_near(int i, int n) {
+    if (__builtin_expect((uint)(i + n) < 3u * (uint)n, 1)) return i < 0 ? i + n : (i >= n ? i - n : i);
+    return wrap_repeat(i, n);
+}
 TR_DEV f4 sample_envmap(const SceneView& sv, f2 uv) {
     int w = (int)sv.env_w, h = (int)sv.env_h;
     float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
-    int x0 = wrap_repeat((int)fx0, w), y0 = wrap_repeat((int)fy0, h);
-    int x1 = wrap_repeat((int)fx0 + 1, w), y1 = wrap_repeat((int)fy0 + 1, h);
+    int x0 = wrap_repeat_near((int)fx0, w), y0 = wrap_repeat_near((int)fy0, h);
+    int x1 = wrap_repeat_near((int)fx0 + 1, w), y1 = wrap_repeat_near((int)fy0 + 1, h);
     const f4* e = sv.envmap;
     return bilerp(e[(size_t)y0 * w + x0], e[(size_t)y0 * w + x1], e[(size_t)y1 * w + x0], e[(size_t)y1 * w + x1], fx, fy);
 }

@@ -154,6 +154,19 @@ class Context:
         check(_lib.lib().trhip_stream_pipe_class(self.h, stream, C.byref(c)))
         return c.value
 
+    def info(self) -> dict:
+        """trhip_device_get_info: which device this is (arch, PCI bus id, UUID) and how many hardware pipes the process reaches on it
+        (include/trhip.h, "process requirements": 4 on MI355X with GPU_MAX_HW_QUEUES >= 8)."""
+        class Info(C.Structure):
+            _fields_ = [("struct_size", C.c_uint32), ("hip_device", C.c_int32), ("name", C.c_char * 64), ("pci_bus_id", C.c_char * 24),
+                        ("uuid", C.c_uint8 * 16), ("compute_units", C.c_int32), ("pipe_classes", C.c_int32), ("pool_streams", C.c_int32),
+                        ("hw_queues_env", C.c_int32)]
+        i = Info()
+        check(_lib.lib().trhip_device_get_info(self.h, C.byref(i)))
+        return {"hip_device": i.hip_device, "name": i.name.decode("ascii", "replace"), "pci_bus_id": i.pci_bus_id.decode("ascii", "replace"),
+                "uuid": bytes(i.uuid).hex(), "compute_units": i.compute_units, "pipe_classes": i.pipe_classes, "pool_streams": i.pool_streams,
+                "hw_queues_env": i.hw_queues_env}
+
     def stream_wait(self, stream, on):
         """Work enqueued on `stream` from now on waits for what is on `on` now (None = the default stream)."""
         check(_lib.lib().trhip_stream_wait(self.h, stream, on))
@@ -573,6 +586,7 @@ class _FrameSlot:
         self.color = None
         self.display = None
         self.stream = None
+        self.fused_info = None
 
 
 class RtRenderer:
@@ -675,7 +689,7 @@ class RtRenderer:
             slot.color = self._alloc_color(viewports, tw, th)
             if self.fused_tonemap:
                 slot.display = self._alloc_display(viewports)
-                slot.pt.set_fused_tonemap(slot.display, self.tonemap.info)
+                slot.fused_info = None       # what the stage was last told (bytes of the tonemap info), None = off
             self.slots.append(slot)
         self.current = self.slots[0]
         self.stitch = StitchStage(ctx, self.size) if (world_size > 1 and self.shard == "pixels") else None
@@ -833,10 +847,21 @@ class RtRenderer:
             # the other devices start over with one sample: blend it into what has accumulated (src/rt_renderer.cc:176-181)
             self.stitch.set_blend_ratio(1.0 / (self.accumulated_frames + 1))
 
-    def render_partial(self, stream=None):
+    def _sync_fused_tonemap(self, slot, want: bool):
+        """The stage's copy of the tonemap parameters follows self.tonemap.info: an edit of exposure / operator / gamma between frames
+        takes effect on the next frame, as it does with the tonemap stage of a multi-device renderer; render(tonemap=False) switches
+        the display write off for that frame."""
+        now = bytes(self.tonemap.info) if want else None
+        if now != slot.fused_info:
+            slot.pt.set_fused_tonemap(slot.display if want else None, self.tonemap.info if want else None)
+            slot.fused_info = now
+
+    def render_partial(self, stream=None, tonemap=True):
         """The path-tracing part of the next frame on its slot (`stream` overrides the slot's stream)."""
         slot = self.slots[(self.frame_index // self.frames_per_launch) % self.frames_in_flight]
         self.current = slot
+        if self.fused_tonemap:
+            self._sync_fused_tonemap(slot, tonemap)
         if not self.accumulate:
             slot.pt.reset_accumulated_samples()
         if self.frames_in_flight > 1 or self.frames_per_launch > 1:
@@ -864,7 +889,7 @@ class RtRenderer:
             self.stitch.set_blend_ratio(1.0)
 
     def render(self, tonemap=True, gather_views=False):
-        self.render_partial()
+        self.render_partial(tonemap=tonemap)
         slot = self.current
         if self.world_size == 1:
             if tonemap and not self.fused_tonemap:

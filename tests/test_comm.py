@@ -17,7 +17,7 @@ def test_comm_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trhip_comm.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(trhip_[a-z_0-9]+)\s*\(", text)))
     L = comm.lib()
-    assert len(names) == 15 and sorted(comm.SYMBOLS) == names
+    assert len(names) == 16 and sorted(comm.SYMBOLS) == names
     for n in names:
         assert hasattr(L, n), f"libtrhip_comm.so does not export {n}"
     # linked against RCCL, not against the path-tracing library
@@ -35,6 +35,8 @@ def test_one_rank_communicator():
     assert len(uid) == comm.ID_BYTES
     c = comm.Comm(0, 1, 0, uid)
     assert c.rank == 0 and c.nranks == 1 and comm.lib().trhip_comm_size(c.h) == 1
+    info = c.info()      # asked of RCCL, not echoed (trhip_comm_get_info): what the N > 1 bench line prints
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["hip_device"] == 0 and info["rccl_version"] > 20000
     n = 1920 * 136 * 4
     src = ctx.alloc(n * 4).upload(np.arange(n, dtype=np.float32))
     dst = ctx.alloc(n * 4).zero()

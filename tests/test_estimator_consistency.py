@@ -332,12 +332,16 @@ def test_metal_furnace_second_bounce_is_the_metallic_lobe(R, ctx):
 def test_glass_partition_in_a_furnace(R, ctx):
     """The transmission lobe (shader/ggx.glsl:200-209, 240-388).  A pane of glass across the furnace, seen along its normal, two bounces: every
     direction the first hit can go - reflected or refracted - ends on an emitter, so the pixel is Le times the sum over the lobes,
-    Le (rho_s + albedo rho_t) by quadrature of ggx_bsdf.  There is no figure to hold the integrator to more tightly than a few per cent:
-    the checkout's own estimators disagree on this lobe - its sampling weights (ggx_bsdf_sample_core's pre-divided terms) and its
-    evaluation (ggx_bsdf, what next-event estimation calls) are not the same function, and MIS mixes them; the CPU oracle gives 0.872 ...
-    0.926 of Le for the six configurations below where the quadrature says 0.894 (profiles/r5/estimator_consistency.json).  What is asserted:
-    every configuration within 5 % of the quadrature (a lobe that is wrong by a factor, a missing (1 - F) or eta shows up in tens of per cent),
-    and HIP equal to the oracle on the same seeds is tests/test_gpu_parity.py's business."""
+    Le (rho_s + albedo rho_t) by quadrature of ggx_bsdf.  Round 6: the lobe is held by its two PURE estimators, each to about one per cent -
+      * BSDF sampling alone (no next-event estimation): the mean of ggx_bsdf_sample_core's pre-divided weights, i.e. the sampling side of
+        shader/ggx.glsl:240-388 - measured +0.02 % off the quadrature;
+      * next-event estimation alone (mis_mode 0: a sampled direction that lands on an emitter weighs nothing), i.e. the evaluation ggx_bsdf
+        integrated over the twelve wall triangles - measured -0.5 ... -0.9 %; and cosine-hemisphere bounces (bounce_mode 1), -0.2 %.
+    A 4 % energy error in the glass lobe - a missing (1 - F), a wrong eta^2, a clipped masking term - fails either of them.  The three
+    configurations that MIX the two through MIS stay at 5 %: the checkout's sampling pdf and the pdf its MIS weights use are not the same
+    function (ggx_bsdf_pdf vs the pre-divided terms), which biases the mixture by +2.4 ... +4.2 % - the reference's behaviour, kept
+    (profiles/r5/estimator_closed_forms.json, profiles/r6/estimator_closed_forms.json); HIP equal to the oracle on the same seeds is
+    tests/test_gpu_parity.py's business."""
     from tauray_amd import scene as S
     Le = np.array([1.0, 0.7, 0.4])
     glass = np.array([0.9, 0.8, 0.95])
@@ -352,12 +356,18 @@ def test_glass_partition_in_a_furnace(R, ctx):
         quads = [(*_quad(S, *w), wall) for w in walls] + [(*_quad(S, (-1, -1, 0), (2, 0, 0), (0, 2, 0)), pane)]
         sc = _scene(S, quads, [_ortho_camera(S, (0, 0, 0.5), (0, 0, -1), 0.4)])
         ss = R.SceneStage(ctx, sc)
-        for kw in (dict(), dict(nee_triangles=0.0), dict(mis_mode=0), dict(mis_mode=1), dict(bounce_mode=1), dict(tri_light_mode=0)):
+        # (options, bound relative to the quadrature): pure estimators first, MIS mixtures after
+        cases = ((dict(nee_triangles=0.0), 0.004), (dict(mis_mode=0), 0.012), (dict(bounce_mode=1, mis_mode=0), 0.012),
+                 (dict(), 0.05), (dict(mis_mode=1), 0.05), (dict(bounce_mode=1), 0.05), (dict(tri_light_mode=0), 0.05))
+        for kw, bound in cases:
             b = _batches(R, ctx, ss, sc, (64, 64), 8, 64, max_bounces=2, projection=S.PROJ_ORTHOGRAPHIC, **kw)
-            mean = b.mean((0, 1, 2))
-            rows[f"roughness {roughness} {kw}"] = dict(relative_to_quadrature=[round(float(x), 4) for x in (mean - want) / want], rho_s=round(rho[1], 5), rho_t=round(rho[3], 5))
-            assert (np.abs(mean - want) < 0.05 * want).all(), f"glass pane, roughness {roughness}, {kw}: {mean} instead of {want} ({(mean - want) / want} relative)"
-    _report("glass pane in a furnace: Le (rho_s + albedo rho_t), the checkout's estimators disagree by +-3 %", rows)
+            per_batch = b.mean((1, 2))
+            mean, se = per_batch.mean(0), per_batch.std(0, ddof=1) / math.sqrt(len(per_batch))
+            rows[f"roughness {roughness} {kw}"] = dict(relative_to_quadrature=[round(float(x), 4) for x in (mean - want) / want], bound=bound,
+                                                        standard_error=[round(float(x), 5) for x in se / want], rho_s=round(rho[1], 5), rho_t=round(rho[3], 5))
+            assert (np.abs(mean - want) <= 4 * se + bound * want).all(), f"glass pane, roughness {roughness}, {kw}: {mean} +- {se} instead of {want} ({(mean - want) / want} relative, bound {bound})"
+            assert (se < 0.01 * want).all(), f"glass pane, {kw}: too noisy to say anything ({se / want})"
+    _report("glass pane in a furnace: Le (rho_s + albedo rho_t); pure estimators within ~1 %, MIS mixtures within 5 %", rows)
 
 
 def _room(S):

@@ -42,7 +42,7 @@ rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Nam
 rows.sort()
 stretches = []
 for s, e, k, q, g, b in rows:
-    if stretches and s <= stretches[-1][1] + 8_000:
+    if stretches and s <= stretches[-1][1] + 30_000:      # a frame starts host-bound: up to ~25 us between its first kernel and the next
         stretches[-1][1] = max(stretches[-1][1], e); stretches[-1][2].append((s, e, k, q, g, b))
     else:
         stretches.append([s, e, [(s, e, k, q, g, b)]])
