@@ -615,7 +615,7 @@ def main():
     # who rendered: every rank's device as the library sees it, its pipes and its shading program; what RCCL says about the communicator
     try:
         dev_info = ctx.info()
-    except AttributeError:      # an older library selected with TRHIP_LIB for an A/B (tools/r6_ab_libs.sh): no trhip_device_get_info
+    except AttributeError:      # an older library selected with TRHIP_LIB for an A/B (tools/ab_libs.sh): no trhip_device_get_info
         dev_info = {"hip_device": local_rank, "pci_bus_id": "", "uuid": "", "name": "", "pipe_classes": -1, "hw_queues_env": int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))}
     me = {"rank": rank, "hip_device": dev_info["hip_device"], "pci_bus_id": dev_info["pci_bus_id"], "uuid": dev_info["uuid"], "arch": dev_info["name"],
           "pipe_classes_reachable": dev_info["pipe_classes"], "hw_queues_env": dev_info["hw_queues_env"],

@@ -174,7 +174,7 @@ def lib():
                 fn = getattr(L, name)
             except AttributeError:
                 # the tree's own library exports everything (tests/test_abi_and_host.py); a library named by TRHIP_LIB may be an older
-                # build kept for an A/B (tools/ab_two_libs.sh): calls it does not have fail when they are made
+                # build kept for an A/B (tools/ab_libs.sh): calls it does not have fail when they are made
                 if "TRHIP_LIB" not in os.environ:
                     raise
                 continue

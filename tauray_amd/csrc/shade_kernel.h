@@ -172,8 +172,11 @@ TR_DEV void correct_lobes_for_normal_map(f3 sample_dir, f3 geometric_normal, Lob
 }
 
 // One bounce of evaluate_ray (path_tracer.glsl:385-498) for every live path of the queue.
+#ifndef TR_SHADE_NOLOOP
+#define TR_SHADE_NOLOOP 0       // 1: one pass per thread instead of the persistent loop (an experiment: profiles/r6/shade_noloop_ab.txt)
+#endif
 #ifndef TR_SHADE_WAVES
-#define TR_SHADE_WAVES 3
+#define TR_SHADE_WAVES (TR_SHADE_NOLOOP ? 4 : 3)
 #endif
 #ifndef TR_SHADE_LAST_WAVES
 #define TR_SHADE_LAST_WAVES 5   // the last bounce only collects emission: no light or BSDF sampling, no queue appends
@@ -424,6 +427,21 @@ TR_DEV void shade_path(const SceneView& sv, const PtParams& P, const PathBuffers
         STL(STL_WRITEBACK);
 }
 
+// The arguments of k_shade / trhip_spec_shade as they lie in the kernel-argument segment (by-value arguments in order, each at its
+// natural alignment: the layout of this struct).  shade_bounce reads the scene view and the parameters through it (below).
+struct ShadeKernArgs { SceneView sv; PtParams P; PathBuffers pb; int bounce; const uint* queue; uint* bc; uint* next_queue; };
+#ifndef TR_SHADE_FRESH_ARGS
+#define TR_SHADE_FRESH_ARGS 1
+#endif
+template <typename T>
+TR_DEV void load_kernarg(T& dst, const T __attribute__((address_space(4)))* src) {      // word by word out of the constant address space
+    static_assert(sizeof(T) % 4 == 0, "kernel arguments are whole words");
+    uint* d = reinterpret_cast<uint*>(&dst);
+    const uint __attribute__((address_space(4)))* s = (const uint __attribute__((address_space(4)))*)src;
+#pragma unroll
+    for (uint i = 0; i < sizeof(T) / 4; ++i) d[i] = s[i];
+}
+
 template <bool COUNT, bool LAST, typename S>
 TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuffers& pb, int bounce, const uint* queue, uint* bc, uint* next_queue) {
     PtParams P = P_;
@@ -438,7 +456,34 @@ TR_DEV void shade_bounce(const SceneView& sv_, const PtParams& P_, const PathBuf
 #if TR_SHADE_TIMELINE
     stl_begin();
 #endif
+    // A persistent grid that strides over the queue.  -DTR_SHADE_NOLOOP=1 (an experiment, profiles/r6/shade_noloop_ab.txt): one pass per thread,
+    // launched with a thread per queue slot - the kernel alone is 28 % faster (126 registers, nothing hoisted, nothing spilled), but a grid of
+    // one-pass blocks gives its slots away to the other lanes' persistent trace kernels as its blocks finish, and whole frames lose 1-5 %.
+#if TR_SHADE_NOLOOP
+    for (uint qi = blockIdx.x * KB + threadIdx.x, once = 1; once && qi < n_round; once = 0) {
+#else
     for (uint qi = blockIdx.x * KB + threadIdx.x; qi < n_round; qi += gridDim.x * KB) {
+#endif
+#if TR_SHADE_FRESH_ARGS && !TR_SHADE_NOLOOP
+        // Every pass of the loop reads the scene view and the parameters afresh, through a pointer to the kernel-argument segment the
+        // optimiser cannot see through.  Round 6 (profiles/r6/shade_phase_timeline.txt, shade_noloop_ab.txt): around this loop the compiler
+        // hoisted everything invariant - reciprocals of the light counts and of the environment's size, the pieces of uniform divisions -
+        // into registers that stay live around the back edge, and spilled six of the kernel's 168 to scratch, each reload behind a full
+        // `s_waitcnt vmcnt(0)` in the middle of the body's gathers.  With nothing to hoist the kernel needs 158 registers and no scratch:
+        // k_shade 0.89 -> 0.795 ms per frame on sponza_teapots, frames -2 ... -4 % (profiles/r6/shade_fresh_args_ab.txt).  The loop itself
+        // stays: a persistent grid keeps the slots it has while the other lanes' trace kernels run.  The argument layout this relies on
+        // (by-value arguments in order at their natural alignment = struct ShadeKernArgs) is the AMDGPU kernel ABI; every parity test
+        // renders through it.
+        typedef const ShadeKernArgs __attribute__((address_space(4)))* KernArgPtr;      // the constant address space: scalar loads
+        KernArgPtr ka = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        PtParams P;
+        load_kernarg(P, &ka->P);
+        S::pin(P);
+        SceneView sv;
+        load_kernarg(sv, &ka->sv);
+        if (!S::wide_textures) sv.wide_textures = 0;
+#endif
         STL(STL_ITER);
         STL(STL_CALIBRATION);
         bool active = qi < n;

@@ -87,7 +87,8 @@ def test_build_warmed_the_cache_for_the_named_option_sets():
     t = time.perf_counter()
     for kw, ieee, count in presets.warm_up_jobs()[:6]:
         assert presets.precompile(kw, True, ieee, count) < 0.5, f"{kw} was not in {d}: run __graft_entry__.build()"
-    assert time.perf_counter() - t < 3.0
+    # six look-ups, not six compilations (4-8 s each); the bound leaves room for a loaded machine and the first load of libhiprtc
+    assert time.perf_counter() - t < 12.0
 
 
 def test_reference_presets_are_what_the_cfg_files_say():

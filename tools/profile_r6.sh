@@ -1,11 +1,13 @@
 #!/bin/bash
-# usage (through gpurun): bash tools/profile_r5.sh     -> gpurun_out/r5_summary/ (copy into profiles/r5/)
+# usage (through gpurun): bash tools/profile_r6.sh     -> gpurun_out/r6_summary/ (copy into profiles/r6/)
 # (a) per workload: rocprofv3 --kernel-trace --stats of the bench command without its own counter passes, and the bench command as the
-#     driver runs it, with --pmc-dump (as tools/profile_r4.sh);
+#     driver runs it, with --pmc-dump;
 # (b) a Sobol sampler and a preset through the programs compiled for them (round 4's table, two rows of it, at this round's kernels);
 # (c) the phase timeline of the closest-hit kernel at the final kernels (variant library, tools/trace_timeline.py);
-# (d) the lone frame's kernel timeline.
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5_summary; mkdir -p $OUT
+# (d) the lone frame's kernel timeline;
+# (e) round 6: the phase timeline of k_shade (variant library libtrhip_shadetl.so, tools/shade_timeline.py) for the whole frame and a 1/8 strip,
+#     the strip's kernel timeline (tools/strip_timeline.py) and what a rank's share costs (tools/shard_share_probe.py).
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r6_summary; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for W in ${@:-sponza_teapots test_glb sponza_class}; do
   D=/tmp/prof_$W; rm -rf $D
@@ -24,6 +26,13 @@ for a in "--sampler 1" "--preset quality"; do
   timeout 300 python bench.py $a --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --sustained-frames 0 > $OUT/option_set_$n.json 2> $OUT/option_set_$n.err || echo "failed: $a"
 done
 [ -f $R/tauray_amd/libtrhip_timeline.so ] && TRHIP_LIB=$R/tauray_amd/libtrhip_timeline.so timeout 300 python tools/trace_timeline.py sponza_teapots 8 > $OUT/trace_phase_timeline_final_kernels.txt 2> $OUT/timeline.err
+if [ -f $R/tauray_amd/libtrhip_shadetl.so ]; then
+  TRHIP_LIB=$R/tauray_amd/libtrhip_shadetl.so timeout 300 python tools/shade_timeline.py sponza_teapots 1 8 > $OUT/shade_phase_timeline.txt 2>> $OUT/timeline.err
+  TRHIP_LIB=$R/tauray_amd/libtrhip_shadetl.so timeout 300 python tools/shade_timeline.py sponza_teapots 8 8 > $OUT/shade_phase_timeline_strip_1_8.txt 2>> $OUT/timeline.err
+fi
+timeout 600 python tools/shard_share_probe.py sponza_teapots > $OUT/shard_share_probe_sponza_teapots.txt 2> $OUT/share.err
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace8 -o t -- python $R/tools/strip_timeline.py render sponza_teapots 8 40 > $OUT/trace8.log 2>&1;
+ python $R/tools/strip_timeline.py report $(find /tmp/trace8 -name 't_kernel_trace.csv' | head -1) > $OUT/strip_timeline_1_8.txt 2>&1; rm -rf /tmp/trace8)
 python - $OUT <<'PY'
 import glob, json, os, sys
 out = sys.argv[1]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, session 6: schedule sweeps.  (a) a lone frame: enqueue order / lane skew, and more lanes than pipes (libtrhip_lanes8.so);
+# schedule sweeps (round 6: profiles/r6/lone_frame_phase_ab.txt, strip_schedule_ab.txt); usage through gpurun: bash tools/schedule_sweep.sh.  (a) a lone frame: enqueue order / lane skew, and more lanes than pipes (libtrhip_lanes8.so);
 # (b) a 1/8 strip one frame at a time: lanes, enqueue order
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/s6; mkdir -p $OUT; cd $R
 export GPU_MAX_HW_QUEUES=8
