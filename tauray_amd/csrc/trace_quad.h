@@ -93,7 +93,13 @@ TR_DEV void quad_transpose(int q, float& r0, float& r1, float& r2, float& r3) {
 // instructions for 20 accesses.  Closest-hit +2 %, frames +1 %: the tail's phases serve few rays, its L1 accesses are few either way,
 // and the 32 instructions sit on the critical path of the last rays of a wave.  (The same trade in the triangle test - selects for
 // accesses - won, because those phases run with full waves.)
-TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0 TL(, TlPhase* tlp = nullptr)) {
+// -DTR_TAIL_PREFETCH=1 (an experiment of round 6, profiles/r6/tail_prefetch_ab.txt): a quad lane whose child is an inner node that was hit
+// touches that child's cache line right away (one dword, `pf`), so that the line is on its way while the quad sorts its hits and updates its
+// stack; the value is consumed here, behind the next phase's own loads (older loads return first: no extra wait).
+#ifndef TR_TAIL_PREFETCH
+#define TR_TAIL_PREFETCH 0
+#endif
+TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int q, float tmax, bool& hit, float& t0 TL(, TlPhase* tlp = nullptr), int pf = 0) {
     float nx, fx, ny, fy, nz, fz;
     int c;
     {
@@ -115,6 +121,9 @@ TR_DEV int quad_child_box(const QuadRay& r, const Bvh4Node* nodes, int node, int
         ny = *reinterpret_cast<const float*>(base + (size_t)ay); fy = *reinterpret_cast<const float*>(base + (size_t)(ay ^ 16u));
         nz = *reinterpret_cast<const float*>(base + (size_t)az); fz = *reinterpret_cast<const float*>(base + (size_t)(az ^ 16u));
         c = *reinterpret_cast<const int*>(base + (size_t)t + 96);
+#if TR_TAIL_PREFETCH
+        asm volatile("" : : "v"(pf));
+#endif
         TL(if (tlp) tlp->loads_issued();)
 #endif
     }
@@ -346,6 +355,9 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
         float qbest = lt;
         bool qlive = deal.has_ray;
         int pend = -1;      // triangle this lane has to test
+#if TR_TAIL_PREFETCH
+        int qpf = 0;
+#endif
         TL(tl_misc(qc.tl, 2, tl_now() - tl_deal);)
         while (true) {
             int w = pend >= 0 ? 1 : 0;
@@ -388,9 +400,16 @@ TR_DEV void trace_closest_wave4(const SceneView& sv, bool valid, f3 org, f3 dir,
                 bool hitb; float t0;
                 TL(TlPhase tlp; const int tl_units = __popcll(__ballot(true)) >> 2; tlp.begin();)
                 const int q = quad_lane();
+#if TR_TAIL_PREFETCH
+                const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0 TL(, &tlp), qpf);
+#else
                 const int c = quad_child_box(qr, sv.nodes4, qnode, q, qbest, hitb, t0 TL(, &tlp));
+#endif
                 if (COUNT && q == 0) st.nodes++;
                 const bool inner = hitb && c >= 0;
+#if TR_TAIL_PREFETCH
+                if (inner) qpf = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sv.nodes4) + ((size_t)(uint)c << 7) + 96);
+#endif
                 if (hitb && c < 0) pend = ~c;
                 // order of the inner children that were hit: entry distance, ties by slot (two low mantissa bits carry the slot)
                 quad_descend(inner, inner ? ((__float_as_uint(t0) & ~3u) | (uint)q) : 0xFFFFFFFFu, c, qs, qnode, qlive);
