@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, "python binding and header disagree on the entry points"
 
 
+def test_build_id_is_the_one_the_makefile_generated():
+    """trhip_build_id: 64 bits of SHA-256 over the library's sources and compile flags (csrc/Makefile -> build_id.inc), mixed into a
+    stage's program identity so that the ranks of a job notice two different builds of libtrhip.so (include/trhip.h)."""
+    from tauray_amd import _lib
+    inc = os.path.join(ROOT, "tauray_amd", "csrc", "build_id.inc")
+    got = _lib.lib().trhip_build_id()
+    assert got != 0
+    if os.path.exists(inc) and os.path.getmtime(inc) <= os.path.getmtime(_lib.LIB_PATH):
+        want = int(re.search(r"0x([0-9a-f]+)ull", open(inc).read()).group(1), 16)
+        assert got == want, "libtrhip.so is not the build build_id.inc describes"
+
+
 def test_struct_layouts_match_header():
     from tauray_amd import _lib
     assert C.sizeof(_lib.PtOptionsC) == 24 * 4
