@@ -2492,6 +2492,30 @@ def test_display_written_by_the_resolve_equals_the_tonemap_stage(R, ctx, monkeyp
             assert np.array_equal(c0, c1), f"{okw} {tkw} {rkw}: colour {k}"
             assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), f"{okw} {tkw} {rkw}: display {k}"
             assert not np.array_equal(d0, c0)
+    # the tonemap parameters are the renderer's to edit between frames (tonemap_stage's options in the reference): an edit takes effect on
+    # the next frame with the fused write as it does with the stage, and render(tonemap=False) leaves the display image alone
+    opt = R.options_for_scene(scene, max_bounces=2)
+    shown = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("TRHIP_FUSED_TONEMAP", fused)
+        rr = R.RtRenderer(ctx, scene, opt, (W, H), use_torch=False, tonemap=dict(op=R.TONEMAP_FILMIC, exposure=1.0))
+        rr.render()
+        first = rr.download("display")
+        rr.tonemap.info.exposure = 2.5
+        rr.tonemap.info.op = 3
+        rr.render()
+        second = rr.download("display")
+        rr.render(tonemap=False)
+        third = rr.download("display")
+        rr.render()
+        fourth = rr.download("display")
+        rr.close()
+        shown[fused] = (first, second, third, fourth)
+        assert not np.array_equal(first, second)
+        assert np.array_equal(third, second), "render(tonemap=False) wrote the display image"
+        assert not np.array_equal(fourth, second)
+    for k in range(4):
+        assert np.array_equal(shown["0"][k].view(np.uint32), shown["1"][k].view(np.uint32)), f"edited tonemap parameters, frame {k}"
     # the direct stage resolves its samples in a kernel of its own: the renderer keeps the tonemap stage, the library says why
     dopt = R.options_for_scene(scene, max_bounces=2, samples_per_pixel=2, samples_per_pass=2)
     monkeypatch.setenv("TRHIP_FUSED_TONEMAP", "1")
